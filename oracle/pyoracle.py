@@ -1,0 +1,230 @@
+"""ctypes front-end of the C oracle (oracle/libfixedl_oracle.so) -- TEST INFRASTRUCTURE ONLY.
+
+Thin, one method per C entry point of oracle/fixedl_oracle.h.  numpy arrays cross the boundary
+in ITensor order (first index fastest): A_j[a,s,r(,L)], B[a,s,t,r(,L)] as Fortran-ordered
+arrays; environments [m(,L)].
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+NL = 10
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libfixedl_oracle.so")
+    src = os.path.join(_HERE, "fixedl_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+class CgTrace(C.Structure):
+    _fields_ = [("npass_done", C.c_int), ("converged", C.c_int), ("cost", C.c_double * 64),
+                ("rnorm", C.c_double * 64), ("pAp", C.c_double * 64), ("alpha", C.c_double * 64)]
+
+
+class BondReport(C.Structure):
+    _fields_ = [("sweep", C.c_int), ("half", C.c_int), ("bond", C.c_int), ("c", C.c_int),
+                ("origm", C.c_int), ("newm", C.c_int), ("truncerr", C.c_double),
+                ("norm_newB", C.c_double), ("diff_B_newB", C.c_double),
+                ("cost_after_svd", C.c_double), ("label_cost", C.c_double * NL),
+                ("reg_cost", C.c_double), ("ncorrect", C.c_long), ("cg", CgTrace)]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.c_int, C.c_int, dp, ip, C.c_int, C.c_int]
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_last_error.restype = C.c_char_p
+        L.orc_features_series.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_ubyte), dp]
+        L.orc_set_site.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, dp]
+        L.orc_site_dims.argtypes = [C.c_void_p, C.c_int, ip, ip, ip]
+        L.orc_get_site.argtypes = [C.c_void_p, C.c_int, dp]
+        L.orc_init.argtypes = [C.c_void_p]
+        L.orc_set_bond.argtypes = [C.c_void_p, C.c_int]
+        L.orc_shiftE.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_env_dims.argtypes = [C.c_void_p, C.c_int, ip, ip]
+        L.orc_get_env.argtypes = [C.c_void_p, C.c_int, C.c_int, dp]
+        L.orc_bond_dims.argtypes = [C.c_void_p, C.c_int, ip, ip, ip]
+        L.orc_bond_tensor.argtypes = [C.c_void_p, C.c_int, dp]
+        L.orc_forward.argtypes = [C.c_void_p, dp, dp]
+        L.orc_gradient.argtypes = [C.c_void_p, dp, dp]
+        L.orc_quadcost.restype = C.c_double
+        L.orc_quadcost.argtypes = [C.c_void_p, dp, C.c_double, dp, dp, C.POINTER(C.c_long)]
+        L.orc_cgrad.argtypes = [C.c_void_p, dp, C.c_int, C.c_double, C.c_double, C.POINTER(CgTrace)]
+        L.orc_truncate.argtypes = [dp, C.c_int, C.c_int, C.c_int, C.c_double, dp]
+        L.orc_svd_split.argtypes = [C.c_void_p, dp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
+                                    dp, ip, dp, ip]
+        L.orc_sweepnext.argtypes = [ip, ip, C.c_int]
+        L.orc_mldmrg.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double,
+                                 C.c_double, C.c_int, C.POINTER(BondReport), C.c_int]
+        L.orc_toverlap.argtypes = [C.c_void_p, C.c_int, dp]
+        _LIB = L
+    return _LIB
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _f(a):
+    """flatten in ITensor (first-index-fastest) order"""
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64).ravel(order="F"))
+
+
+class Oracle:
+    """One TrainStates + W pair of the reference (fixedL.cc:64-274, :669-728)."""
+
+    def __init__(self, phi, labels, W=None, nthread=1, nbatch=1):
+        phi = np.ascontiguousarray(phi, dtype=np.float64)          # [NT,N,2]
+        self.NT, self.N, d = phi.shape
+        assert d == 2
+        lab = np.ascontiguousarray(labels, dtype=np.int32)
+        self.labels = lab
+        self.c0 = self.N // 2
+        self._L = lib()
+        self._h = self._L.orc_create(self.N, self.NT, _dp(phi), lab.ctypes.data_as(C.POINTER(C.c_int)),
+                                     nthread, nbatch)
+        if not self._h:
+            raise ValueError(self._L.orc_last_error().decode())
+        if W is not None:
+            self.set_mps(W)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.orc_destroy(self._h)
+            self._h = None
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise RuntimeError(self._L.orc_last_error().decode())
+
+    def set_mps(self, W):
+        for j, A in enumerate(W, start=1):
+            A = np.asarray(A, dtype=np.float64)
+            self._ck(self._L.orc_set_site(self._h, j, A.shape[0], A.shape[2], int(A.ndim == 4), _dp(_f(A))))
+
+    def get_site(self, j):
+        ml, mr, hl = C.c_int(), C.c_int(), C.c_int()
+        self._ck(self._L.orc_site_dims(self._h, j, ml, mr, hl))
+        shape = (ml.value, 2, mr.value) + ((NL,) if hl.value else ())
+        buf = np.empty(int(np.prod(shape)))
+        self._ck(self._L.orc_get_site(self._h, j, _dp(buf)))
+        return buf.reshape(shape, order="F")
+
+    def get_mps(self):
+        return [self.get_site(j) for j in range(1, self.N + 1)]
+
+    def init(self):
+        self._ck(self._L.orc_init(self._h))
+
+    def set_bond(self, b):
+        self._ck(self._L.orc_set_bond(self._h, b))
+
+    def shiftE(self, b, from_left):
+        self._ck(self._L.orc_shiftE(self._h, b, int(bool(from_left))))
+
+    def env(self, j):
+        m, hl = C.c_int(), C.c_int()
+        self._ck(self._L.orc_env_dims(self._h, j, m, hl))
+        shape = (m.value,) + ((NL,) if hl.value else ())
+        out = np.empty((self.NT,) + shape)
+        buf = np.empty(int(np.prod(shape)))
+        for i in range(self.NT):
+            self._ck(self._L.orc_get_env(self._h, j, i, _dp(buf)))
+            out[i] = buf.reshape(shape, order="F")
+        return out
+
+    def bond_shape(self, b):
+        mL, mR, lab = C.c_int(), C.c_int(), C.c_int()
+        self._ck(self._L.orc_bond_dims(self._h, b, mL, mR, lab))
+        return (mL.value, 2, 2, mR.value) + ((NL,) if lab.value else ())
+
+    def bond_tensor(self, b):
+        shape = self.bond_shape(b)
+        buf = np.empty(int(np.prod(shape)))
+        self._ck(self._L.orc_bond_tensor(self._h, b, _dp(buf)))
+        return buf.reshape(shape, order="F")
+
+    def forward(self, B):
+        P = np.empty((self.NT, NL))
+        self._ck(self._L.orc_forward(self._h, _dp(_f(B)), _dp(P)))
+        return P
+
+    def gradient(self, B):
+        G = np.empty(B.size)
+        self._ck(self._L.orc_gradient(self._h, _dp(_f(B)), _dp(G)))
+        return G.reshape(B.shape, order="F")
+
+    def quadcost(self, B, lam):
+        lc = np.empty(NL)
+        cr, nc = C.c_double(), C.c_long()
+        Cst = self._L.orc_quadcost(self._h, _dp(_f(B)), lam, _dp(lc), C.byref(cr), C.byref(nc))
+        return Cst, lc, cr.value, nc.value
+
+    def cgrad(self, B, npass, lam, cconv):
+        buf = _f(B).copy()                                         # cgrad updates B in place
+        tr = CgTrace()
+        self._ck(self._L.orc_cgrad(self._h, _dp(buf), npass, lam, cconv, C.byref(tr)))
+        n = tr.npass_done
+        trace = dict(npass_done=n, converged=bool(tr.converged), cost=list(tr.cost[:max(n - 1, 0) if not tr.converged else n]),
+                     rnorm=list(tr.rnorm[:max(n - 1, 0) if not tr.converged else n]),
+                     pAp=list(tr.pAp[:n]), alpha=list(tr.alpha[:n]))
+        return buf.reshape(B.shape, order="F"), trace
+
+    def svd_split(self, B, b, ha, cutoff, maxm, minm):
+        te, m, nsv = C.c_double(), C.c_int(), C.c_int()
+        sv = np.empty(B.size)
+        self._ck(self._L.orc_svd_split(self._h, _dp(_f(B)), b, ha, cutoff, maxm, minm, C.byref(te), C.byref(m),
+                                       _dp(sv), C.byref(nsv)))
+        return m.value, te.value, sv[:nsv.value].copy()
+
+    def mldmrg(self, nsweep, maxm, minm, cutoff, npass, lam, cconv, max_bonds=0, verbose=False):
+        cap = max_bonds if max_bonds > 0 else nsweep * 2 * (self.N - 1)
+        reps = (BondReport * cap)()
+        n = self._L.orc_mldmrg(self._h, nsweep, maxm, minm, cutoff, npass, lam, cconv, max_bonds, reps, int(verbose))
+        if n < 0:
+            raise RuntimeError(self._L.orc_last_error().decode())
+        out = []
+        for r in reps[:n]:
+            k = r.cg.npass_done
+            out.append(dict(sweep=r.sweep, half=r.half, bond=r.bond, c=r.c, origm=r.origm, newm=r.newm,
+                            truncerr=r.truncerr, norm_newB=r.norm_newB, diff=r.diff_B_newB, cost=r.cost_after_svd,
+                            label_cost=np.array(r.label_cost[:]), reg_cost=r.reg_cost, ncorrect=r.ncorrect,
+                            cg=dict(npass_done=k, converged=bool(r.cg.converged), cost=list(r.cg.cost[:k]),
+                                    rnorm=list(r.cg.rnorm[:k]), pAp=list(r.cg.pAp[:k]), alpha=list(r.cg.alpha[:k]))))
+        return out
+
+    def toverlap(self, i):
+        out = np.empty(NL)
+        self._ck(self._L.orc_toverlap(self._h, i, _dp(out)))
+        return out
+
+
+def truncate(p, maxm, minm, cutoff):
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    te = C.c_double()
+    m = lib().orc_truncate(_dp(p), len(p), maxm, minm, cutoff, C.byref(te))
+    return m, te.value
+
+
+def sweepnext(b, ha, N):
+    bb, hh = C.c_int(b), C.c_int(ha)
+    lib().orc_sweepnext(C.byref(bb), C.byref(hh), N)
+    return bb.value, hh.value
+
+
+def features_series(pixels):
+    pixels = np.ascontiguousarray(pixels, dtype=np.uint8)
+    NT, N = pixels.shape
+    phi = np.empty((NT, N, 2))
+    lib().orc_features_series(N, NT, pixels.ctypes.data_as(C.POINTER(C.c_ubyte)), _dp(phi))
+    return phi
