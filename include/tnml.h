@@ -1,0 +1,165 @@
+/*
+ * tnml.h -- C-ABI of the MI355X-native fixedL hot path (libtnml.so).
+ *
+ * The reference (emstoudenmire/TNML) has no plugin/FFI surface: fixedL.cc is one translation unit
+ * whose functions take ITensor objects.  This ABI is the seam cut exactly where
+ * mldmrg() (fixedL.cc:451-570) calls into TrainStates / cgrad / quadcost / ITensor svd, so a host
+ * driver that keeps the reference's CLI and sweep loop binds these entry points instead.  Each
+ * function cites the reference interface it replaces.
+ *
+ * Conventions
+ *  - every call returns 0 on success, non-zero on error; tnml_last_error(ctx) gives the message
+ *    (the reference's Error()/EXIT become status codes -- nothing throws across the ABI);
+ *  - tensors cross the ABI as raw fp64 (the reference's Real) column-major arrays in ITensor index
+ *    order, first index fastest:
+ *        site tensor  A_j [ml][2][mr]     (+[10] last, only on the label site c0 = N/2)
+ *        bond tensor  B   [mL][2][2][mR]  (+[10] last, only when c0 is b or b+1)
+ *        environment  E_j [m] or [m][10]  per image
+ *    sites/bonds are 1-indexed as in the reference;
+ *  - one context per GPU / per rank; calls on a context are serialised by the caller; the
+ *    collective calls (tnml_gradient, tnml_quadcost, tnml_cgrad, tnml_bond_update) must be entered
+ *    by every rank of the communicator;
+ *  - the context owns all device memory (features, labels, environments, W replica, workspaces),
+ *    its HIP stream, rocBLAS/rocSOLVER handles and the RCCL communicator.  There is no CPU
+ *    fallback: without a usable HIP device tnml_create fails.
+ */
+#ifndef TNML_H
+#define TNML_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TNML_NL 10           /* label dimension, fixedL.cc:15 */
+#define TNML_MAX_PASS 64
+
+typedef struct tnml_ctx tnml_ctx;
+
+/* arithmetic type of the per-image bond contractions (environments are stored in fp32 either way):
+   TNML_F64  v_mfma_f64_16x16x4_f64, fp64 operands/accumulation -- the default: the reference computes
+             in fp64 and its CG is not reproducible below that (DESIGN.md "why fp64 MFMA")
+   TNML_F32  v_mfma_f32_16x16x4_f32, exact-fp32 -- 2x the MFMA rate, for the tolerance study only */
+enum { TNML_F32 = 0, TNML_F64 = 1 };
+enum { TNML_SVD_SYEVD = 0, TNML_SVD_GESVDJ = 1 };   /* rocSOLVER back-end of tnml_svd_split */
+
+typedef struct {
+    int device;          /* HIP device ordinal */
+    int rank, nranks;    /* data-parallel rank / world size (images are sharded by rank) */
+    int N;               /* number of sites (fixedL.cc:615) */
+    int NT_local;        /* training images owned by this rank */
+    int64_t NT_total;    /* training images over all ranks (costs are reported un-normalised) */
+    int maxm;            /* largest bond dimension that will occur (workspace sizing) */
+    int dtype;           /* TNML_F64 (default choice) or TNML_F32 */
+    int svd_backend;     /* TNML_SVD_* */
+} tnml_config;
+
+/* mirrors the prints of fixedL.cc:391,429-439 */
+typedef struct {
+    int npass_done;
+    int converged;                         /* |r| < cconv hit (fixedL.cc:432) */
+    double cost[TNML_MAX_PASS];            /* un-normalised C printed at :429 (index pass-1) */
+    double rnorm[TNML_MAX_PASS];           /* |r| printed at :434/:439 */
+    double pAp[TNML_MAX_PASS];
+    double alpha[TNML_MAX_PASS];
+} tnml_cg_trace;
+
+/* knobs of one bond update: Sweeps(Nsweep,minm,maxm,cutoff) fixedL.cc:749 + Args :751-759 */
+typedef struct {
+    int maxm, minm;
+    double cutoff;
+    int npass;
+    double lambda;       /* used by cgrad (fixedL.cc:356) */
+    double lambda_cost;  /* used by the "After SVD" quadcost (cargs copy, fixedL.cc:467) */
+    double cconv;
+} tnml_sweep_params;
+
+/* mirrors the prints of fixedL.cc:490,523-533,341-342 */
+typedef struct {
+    int bond, half, c;
+    int origm, newm;
+    double truncerr;
+    double norm_newB, diff_B_newB;
+    double cost_after_svd;                 /* un-normalised */
+    double label_cost[TNML_NL];
+    double reg_cost;
+    int64_t ncorrect;
+    tnml_cg_trace cg;
+} tnml_bond_report;
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+int tnml_create(tnml_ctx** out, const tnml_config* cfg);
+int tnml_destroy(tnml_ctx* ctx);
+const char* tnml_last_error(const tnml_ctx* ctx);      /* ctx may be NULL: error of the failed create */
+
+/* RCCL communicator over xGMI.  Rank 0 obtains a 128-byte unique id, the host transports it to
+   the other ranks (any channel), every rank then calls tnml_comm_init.  Replaces the host-side
+   stdx::accumulate over per-thread partials, fixedL.cc:333,339,385,402,421,427. */
+int tnml_comm_unique_id(void* id128);
+int tnml_comm_init(tnml_ctx* ctx, const void* id128);
+
+/* ---- training set: TState ctor fixedL.cc:28-47 + feature map :637-642 -------------------- */
+/* raw bytes [NT_local][N] with the reference's feature map phi = [1, byte/(255*255*4)] */
+int tnml_set_data_u8(tnml_ctx* ctx, const uint8_t* pixels, const int32_t* labels);
+/* arbitrary d=2 local features phi[NT_local][N][2] (TState::data layout) */
+int tnml_set_data_phi(tnml_ctx* ctx, const double* phi, const int32_t* labels);
+
+/* ---- weight MPS replica (W.A(j) / W.Aref(j)) ------------------------------------------- */
+int tnml_set_site(tnml_ctx* ctx, int j, int ml, int mr, int has_label, const double* A);
+int tnml_site_dims(tnml_ctx* ctx, int j, int* ml, int* mr, int* has_label);
+int tnml_get_site(tnml_ctx* ctx, int j, double* A);
+
+/* ---- TrainStates::init / setBond / shiftE  (fixedL.cc:122-157, :159-190, :192-233) ------- */
+int tnml_env_init(tnml_ctx* ctx);
+int tnml_set_bond(tnml_ctx* ctx, int b);               /* selects env buffers; t.v is never formed */
+int tnml_shift_env(tnml_ctx* ctx, int b, int from_left);
+int tnml_env_dims(tnml_ctx* ctx, int j, int* m, int* has_label);
+int tnml_get_env(tnml_ctx* ctx, int j, double* E);     /* [NT_local][m(*10)], for parity tests */
+
+/* ---- bond tensor oB = W.A(b)*W.A(b+1)  (fixedL.cc:494,527,745) --------------------------- */
+int tnml_bond_dims(tnml_ctx* ctx, int b, int* mL, int* mR, int* label_on_B);
+int tnml_bond_tensor(tnml_ctx* ctx, int b, double* B);
+
+/* ---- per-image contractions of the current bond ------------------------------------------ */
+/* P_n = B*t.v (fixedL.cc:318,377,399,416): P[NT_local][10] */
+int tnml_forward(tnml_ctx* ctx, const double* B, double* P);
+/* sum_n dP_n*dag(t.v) over ALL ranks (fixedL.cc:375-385): G has the layout of B */
+int tnml_gradient(tnml_ctx* ctx, const double* B, double* G);
+/* quadcost (fixedL.cc:280-344): *cost = sum_l C_l + lambda|B|^2, un-normalised, over all ranks */
+int tnml_quadcost(tnml_ctx* ctx, const double* B, double lambda, double* cost,
+                  double label_cost[TNML_NL], double* reg_cost, int64_t* ncorrect);
+/* cgrad (fixedL.cc:349-445): B is updated in place */
+int tnml_cgrad(tnml_ctx* ctx, double* B, int npass, double lambda, double cconv, tnml_cg_trace* trace);
+
+/* ---- svd(B, W.Aref(c), S, W.Aref(c+dc)); W.Aref(c+dc) *= S  (fixedL.cc:519-521) ---------- */
+/* ha = 1: c = b (sweeping right), ha = 2: c = b+1 (sweeping left).  Updates the W replica.
+   sv (nullable, capacity >= min(rows,cols)) receives all singular values, descending. */
+int tnml_svd_split(tnml_ctx* ctx, const double* B, int b, int ha, double cutoff, int maxm, int minm,
+                   double* truncerr, int* newm, double* sv, int* nsv);
+
+/* ---- one iteration of the mldmrg loop body, device resident (fixedL.cc:478-540) ----------- */
+/* setBond -> oB -> cgrad -> svd -> newB -> quadcost -> shiftE without tensors leaving the GPU */
+int tnml_bond_update(tnml_ctx* ctx, int b, int ha, const tnml_sweep_params* p, tnml_bond_report* rep);
+
+/* ---- host-side rules (no GPU needed) ------------------------------------------------------ */
+/* ITensor truncate(): p = sigma^2 descending; returns kept m */
+int tnml_truncate(const double* p, int n, int maxm, int minm, double cutoff, double* truncerr);
+/* ITensor sweepnext (fixedL.cc:478) */
+void tnml_sweepnext(int* b, int* ha, int N);
+/* contiguous image shard of `rank`: ParallelDo's chunking with GPUs as threads (paralleldo.h:32-43) */
+void tnml_shard_bounds(int64_t NT_total, int nranks, int rank, int64_t* begin, int64_t* end);
+
+/* ---- measurement -------------------------------------------------------------------------- */
+/* per-kernel-class HIP-event timing on the context's stream (bench.py roofline figures) */
+int tnml_profile_enable(tnml_ctx* ctx, int on);
+int tnml_profile_count(tnml_ctx* ctx);
+int tnml_profile_get(tnml_ctx* ctx, int idx, char* name64, int64_t* launches, double* total_ms);
+int tnml_profile_reset(tnml_ctx* ctx);
+int tnml_synchronize(tnml_ctx* ctx);
+int64_t tnml_device_bytes(tnml_ctx* ctx);              /* device memory currently owned by ctx */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

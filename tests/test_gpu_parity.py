@@ -1,0 +1,208 @@
+"""GPU parity tests: the HIP path (through the C-ABI, tnml_amd.fixedl) against the CPU oracle on
+identical seeded inputs.  Default arithmetic (dtype "f64"): fp64 MFMA contractions over fp32-stored
+environments, fp64 CG/SVD algebra -- the tolerances below are set by the fp32 environment storage
+(~1e-7 per site, accumulated along the chain).  The "f32" study mode gets the looser figures of
+SURVEY.md 8(d)."""
+import numpy as np
+import pytest
+
+from conftest import make_problem
+
+pytestmark = pytest.mark.gpu
+
+P_RTOL = 5e-6        # P_n, ||.||inf relative to max|P|
+G_RTOL = 2e-5        # gradient, relative to max|G| (a cancelled sum over images)
+C_RTOL = 2e-6        # costs
+E_RTOL = 5e-6        # environments (fp32 MFMA chain)
+
+
+def _pair(N=12, NT=60, m=4, seed=3, boost=200.0, use_u8=False, maxm=None, dtype="f64"):
+    from oracle import pyoracle
+    from tnml_amd.fixedl import TrainStates
+    pixels, labels, phi, W = make_problem(N, NT, m, seed, pixel_boost=boost)
+    if use_u8:
+        ts = TrainStates(labels, N, maxm or m, pixels=pixels, dtype=dtype)
+        phi = pyoracle.features_series(pixels)
+    else:
+        ts = TrainStates(labels, N, maxm or m, phi=phi, dtype=dtype)
+    o = pyoracle.Oracle(phi, labels, W)
+    ts.set_mps(W)
+    o.init()
+    ts.init()
+    return ts, o
+
+
+def _relmax(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def _walk(ts, o, b):
+    for bb in range(1, b):
+        ts.shiftE(bb, True)
+        o.shiftE(bb, True)
+    ts.setBond(b)
+    o.set_bond(b)
+
+
+@pytest.mark.parametrize("use_u8", [False, True])
+def test_envs_after_init(use_u8):
+    ts, o = _pair(use_u8=use_u8, boost=1.0 if use_u8 else 200.0)
+    for j in range(3, o.N + 1):
+        Eg, Eo = ts.env(j), o.env(j)
+        assert Eg.shape == Eo.shape
+        assert _relmax(Eg, Eo) < E_RTOL, f"site {j}"
+
+
+@pytest.mark.parametrize("b", [1, 2, 5, 6, 7, 11])
+def test_forward_gradient_quadcost_each_bond_kind(b):
+    ts, o = _pair()
+    _walk(ts, o, b)
+    B = o.bond_tensor(b)
+    assert _relmax(ts.bond_tensor(b), B) < 1e-12
+    B = B + 0.1 * np.random.default_rng(b).standard_normal(B.shape)
+    assert _relmax(ts.forward(B), o.forward(B)) < P_RTOL
+    assert _relmax(ts.gradient(B), o.gradient(B)) < G_RTOL
+    Cg, lg, crg, ng = ts.quadcost(B, 1e-3)
+    Co, lo, cro, no = o.quadcost(B, 1e-3)
+    assert Cg == pytest.approx(Co, rel=C_RTOL)
+    np.testing.assert_allclose(lg, lo, rtol=1e-5, atol=1e-7 * Co)
+    assert crg == pytest.approx(cro, rel=1e-12)
+    assert ng == no
+
+
+@pytest.mark.parametrize("b,lam", [(1, 0.0), (3, 1e-3), (6, 1e-3), (9, 1e-3)])
+def test_cgrad_matches_oracle(b, lam):
+    ts, o = _pair()
+    _walk(ts, o, b)
+    B0 = o.bond_tensor(b)
+    Bg, tg = ts.cgrad(B0, 4, lam, 1e-10)
+    Bo, to = o.cgrad(B0, 4, lam, 1e-10)
+    assert tg["npass_done"] == to["npass_done"] == 4
+    np.testing.assert_allclose(tg["cost"], to["cost"], rtol=1e-5)
+    np.testing.assert_allclose(tg["alpha"], to["alpha"], rtol=1e-3)
+    np.testing.assert_allclose(tg["rnorm"], to["rnorm"], rtol=1e-3)
+    assert _relmax(Bg, Bo) < 1e-3
+    assert all(x >= y * (1 - 1e-6) for x, y in zip(tg["cost"], tg["cost"][1:]))      # CG monotone
+
+
+@pytest.mark.parametrize("b,ha", [(1, 1), (3, 1), (3, 2), (5, 1), (5, 2), (6, 1), (6, 2), (8, 2), (11, 2)])
+def test_svd_split_matches_oracle(b, ha):
+    ts, o = _pair(N=12, NT=60, m=6)
+    _walk(ts, o, b)
+    B = o.bond_tensor(b)
+    B = B + 0.3 * np.random.default_rng(10 * b + ha).standard_normal(B.shape)
+    mg, teg, svg = ts.svd_split(B, b, ha, 1e-10, 5, 2)
+    mo, teo, svo = o.svd_split(B, b, ha, 1e-10, 5, 2)
+    assert mg == mo
+    np.testing.assert_allclose(svg, svo, rtol=1e-8, atol=1e-10 * svo[0])
+    assert teg == pytest.approx(teo, rel=1e-6, abs=1e-18)
+    # gauge invariant: the re-formed bond tensor, and isometry of the site the sweep leaves
+    assert _relmax(ts.bond_tensor(b), o.bond_tensor(b)) < 1e-9
+    A = ts.get_site(b if ha == 1 else b + 1)
+    if ha == 1:
+        M = np.moveaxis(A, 2, -1).reshape(-1, A.shape[2])
+    else:
+        M = A.reshape(A.shape[0], -1).T
+    np.testing.assert_allclose(M.T @ M, np.eye(M.shape[1]), atol=1e-9)
+
+
+def test_full_sweep_reports_match_oracle():
+    ts, o = _pair(N=10, NT=40, m=4)
+    from tnml_amd.fixedl import mldmrg
+    rg = mldmrg(ts, 1, 4, 2, 1e-10, 3, 1e-3, 1e-10)
+    ro = o.mldmrg(1, 4, 2, 1e-10, 3, 1e-3, 1e-10)
+    assert len(rg) == len(ro) == 2 * (o.N - 1)
+    for a, b in zip(rg, ro):
+        assert (a["bond"], a["half"], a["origm"], a["newm"]) == (b["bond"], b["half"], b["origm"], b["newm"])
+        assert a["cost"] == pytest.approx(b["cost"], rel=1e-4)
+        assert abs(a["ncorrect"] - b["ncorrect"]) <= 1
+    # first bond: identical (W, data) state -> tight tolerance
+    assert rg[0]["cost"] == pytest.approx(ro[0]["cost"], rel=1e-5)
+    assert rg[0]["truncerr"] == pytest.approx(ro[0]["truncerr"], rel=1e-3, abs=1e-12)
+    for j, A in enumerate(ts.get_mps(), start=1):
+        assert (A.ndim == 4) == (j == ts.c0)
+
+
+def test_m120_shapes_forward_gradient():
+    """the maxm=120 specialisations (240-column feature GEMM, 80x80 gradient tiles) vs the oracle"""
+    ts, o = _pair(N=20, NT=64, m=120, maxm=120)
+    _walk(ts, o, 8)          # bond 8: 120 x 120, Label on RE (c0 = 10)
+    B = o.bond_tensor(8)
+    B = B + 0.05 * np.random.default_rng(1).standard_normal(B.shape)
+    assert B.shape == (120, 2, 2, 120)
+    assert _relmax(ts.forward(B), o.forward(B)) < P_RTOL
+    assert _relmax(ts.gradient(B), o.gradient(B)) < G_RTOL
+    ts.shiftE(8, True); o.shiftE(8, True)
+    ts.setBond(9); o.set_bond(9)     # bond 9: Label on B
+    B = o.bond_tensor(9)
+    assert B.shape == (120, 2, 2, 120, 10)
+    assert _relmax(ts.forward(B), o.forward(B)) < P_RTOL
+    assert _relmax(ts.gradient(B), o.gradient(B)) < G_RTOL
+    for bb in (9, 10, 11):
+        ts.shiftE(bb, True); o.shiftE(bb, True)
+    ts.setBond(12); o.set_bond(12)   # bond 12: Label on LE
+    B = o.bond_tensor(12)
+    assert _relmax(ts.forward(B), o.forward(B)) < P_RTOL
+    assert _relmax(ts.gradient(B), o.gradient(B)) < G_RTOL
+    assert _relmax(ts.env(11), o.env(11)) < E_RTOL
+
+
+def test_ragged_image_count_and_padding():
+    """NT not a multiple of any tile size: padding images must not contribute"""
+    ts, o = _pair(N=8, NT=37, m=3)
+    B = o.bond_tensor(1)
+    assert _relmax(ts.gradient(B), o.gradient(B)) < G_RTOL
+    assert ts.quadcost(B, 0.0)[3] == o.quadcost(B, 0.0)[3]
+
+
+def test_properties_at_scale():
+    """size-independent properties at a BASELINE-config-2-like shape (N=784 is exercised by bench.py;
+    here N=64, NT=10000, m=20): linearity of the forward map in B, gradient additivity over image
+    shards, cost independent of the bond it is evaluated at (4-2/4-5)."""
+    from tnml_amd import synth
+    from tnml_amd.fixedl import TrainStates
+    N, NT, m = 64, 10000, 20
+    labels = synth.synthetic_labels(NT, per_label=NT // 10)
+    pixels = synth.synthetic_images(N, labels)
+    W = synth.random_mps(N, m, seed=5)
+    ts = TrainStates(labels, N, m, pixels=pixels)
+    ts.set_mps(W)
+    ts.init()
+    B1 = ts.bond_tensor(1)
+    rng = np.random.default_rng(0)
+    B2 = rng.standard_normal(B1.shape)
+    P1, P2, P12 = ts.forward(B1), ts.forward(B2), ts.forward(B1 + 2.0 * B2)
+    assert _relmax(P12, P1 + 2.0 * P2) < 1e-4
+    G = ts.gradient(B1)
+    half = NT // 2
+    parts = []
+    for sl in (slice(0, half), slice(half, NT)):
+        t2 = TrainStates(labels[sl], N, m, pixels=pixels[sl])
+        t2.set_mps(W)
+        t2.init()
+        parts.append(t2.gradient(B1))
+        t2.close()
+    assert _relmax(parts[0] + parts[1], G) < 1e-4
+    c1 = ts.quadcost(B1, 0.0)[0]
+    for b in range(1, 6):
+        ts.shiftE(b, True)
+    ts.setBond(6)
+    c6 = ts.quadcost(ts.bond_tensor(6), 0.0)[0]
+    assert c6 == pytest.approx(c1, rel=1e-4)
+
+
+def test_f32_study_mode_forward_gradient():
+    """TNML_F32 (exact-fp32 MFMA): per-image contractions agree to fp32 round-off; its CG is NOT
+    expected to track the fp64 reference (DESIGN.md "why fp64 MFMA"), so only single evaluations
+    are checked, with the looser tolerances of SURVEY.md 8(d)."""
+    ts, o = _pair(dtype="f32")
+    for b in (1, 6, 9):
+        if b > 1:
+            for bb in range(ts._walked if hasattr(ts, "_walked") else 1, b):
+                ts.shiftE(bb, True); o.shiftE(bb, True)
+        ts._walked = b
+        ts.setBond(b); o.set_bond(b)
+        B = o.bond_tensor(b) + 0.1 * np.random.default_rng(b).standard_normal(o.bond_shape(b))
+        assert _relmax(ts.forward(B), o.forward(B)) < 1e-4
+        assert _relmax(ts.gradient(B), o.gradient(B)) < 2e-4
+        assert ts.quadcost(B, 1e-3)[0] == pytest.approx(o.quadcost(B, 1e-3)[0], rel=1e-5)

@@ -1,0 +1,518 @@
+// kernels_gemm.hip -- the two MFMA kernels of the bond contraction (gfx950, exact-fp32 MFMA).
+//
+// k_fgemm  ("feature GEMM", forward):   replaces B*t.v (fixedL.cc:318,377,399,416) and the
+//          per-image (t.A(c)*W.A(c))*E products of init/shiftE (fixedL.cc:144-148,223-227).
+//   out[l][q][n] = sum_t phiO[t][n] * sum_{a,s} phiI[s][n] * EI[l?][a][n] * M[l?][2a+s][2q+t]
+//   i.e. T = X*M with X_n = EI_n (x) phiI_n built on the fly in LDS (the dense t.v of the
+//   reference is never formed), followed by the contraction with the output-site feature.
+//   GEMM shape: (NTp images) x (Np = 2*mO) x (Kp = 2*mI);  MFMA = v_mfma_f32_16x16x4_f32,
+//   rows = images, so each lane's 4 accumulator values are 4 consecutive images -> float4 stores
+//   into the image-fastest output.
+//
+// k_bgemm  ("gradient GEMM", backward): replaces tensors[nt] += dP*dag(t.v) (fixedL.cc:379,418)
+//   G[l][2a+s][2q+t] = sum_n (phiI[s][n] EI[a][n]) * (w[l][n] phiO[t][n] Zq[q][n])
+//   GEMM shape: Kp x Np with the reduction over images (split-K over image ranges; fp32 partial
+//   slabs reduced in a fixed order in fp64 -> deterministic).
+//
+// Each kernel exists in two arithmetic flavours over the same fp32 environment storage:
+//   *64 : v_mfma_f64_16x16x4_f64 (fp64 operands + accumulation, 77.4 TF measured ceiling) -- default;
+//   f32 : v_mfma_f32_16x16x4_f32 (exact fp32, 154.5 TF) -- env shifts, and the TNML_F32 study mode.
+// The f64 forms put the IMAGES on the MFMA column index: the f64 C fragment is
+// col = lane&15, row = (lane>>4) + 4*reg, so 16 consecutive lanes hold 16 consecutive images of one
+// output row -> 128-byte coalesced stores into the image-fastest output.
+#include "tnml_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static __device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+
+// ------------------------------------------------------------------------------------------
+template <int RT, int CT, int WR, int WC, int TO>
+__global__ __launch_bounds__(64 * WR * WC) void k_fgemm(FgemmArgs A) {
+    constexpr int T = 64 * WR * WC, BM = 16 * RT * WR, BN = 16 * CT * WC, KT = 16;
+    constexpr int XS = BM + 16;                         // row stride == 16 (mod 32): conflict-free fragment reads
+    constexpr int MS = BN + ((BN % 32 == 16) ? 0 : 16);
+    __shared__ __attribute__((aligned(16))) float lds[KT * XS + KT * MS];
+    float* Xs = lds;
+    float* Ms = lds + KT * XS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid / WC, wc = wid % WC;
+    const int n0 = blockIdx.x * BM, j0 = blockIdx.y * BN, l = blockIdx.z;
+    const float* E = A.EI + (size_t)l * A.EI_lstride;
+    const float* M = A.M + (size_t)l * A.M_lstride;
+    const int NTp = A.NTp;
+
+    f32x4 acc[RT][CT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < A.Kp; k0 += KT) {
+        // stage X: KT/2 environment rows, each expanded to its two site-index rows
+        for (int idx = tid; idx < (KT / 2) * (BM / 4); idx += T) {
+            const int ar = idx / (BM / 4), c4 = idx % (BM / 4);
+            const int a = k0 / 2 + ar, n = n0 + c4 * 4;
+            float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a < A.mI) e = *reinterpret_cast<const float4*>(E + (size_t)a * NTp + n);
+            const float4 p0 = *reinterpret_cast<const float4*>(A.phiI + n);
+            const float4 p1 = *reinterpret_cast<const float4*>(A.phiI + NTp + n);
+            *reinterpret_cast<float4*>(&Xs[(2 * ar) * XS + c4 * 4]) = mul4(e, p0);
+            *reinterpret_cast<float4*>(&Xs[(2 * ar + 1) * XS + c4 * 4]) = mul4(e, p1);
+        }
+        // stage M: KT rows of the (zero padded) bond matrix
+        for (int idx = tid; idx < KT * (BN / 4); idx += T) {
+            const int r = idx / (BN / 4), c4 = idx % (BN / 4);
+            const int j = j0 + c4 * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < A.Np) v = *reinterpret_cast<const float4*>(M + (size_t)(k0 + r) * A.Np + j);
+            *reinterpret_cast<float4*>(&Ms[r * MS + c4 * 4]) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < KT; kk += 4) {
+            float a[RT], b[CT];
+            const int krow = kk + (lane >> 4);
+#pragma unroll
+            for (int r = 0; r < RT; ++r) a[r] = Xs[krow * XS + (wr * RT + r) * 16 + (lane & 15)];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) b[c] = Ms[krow * MS + (wc * CT + c) * 16 + (lane & 15)];
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int c = 0; c < CT; ++c) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], b[c], acc[r][c], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C fragment = 4 consecutive images (rows) x 1 column per lane
+    float* out = A.out + (size_t)l * A.out_lstride;
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        const int n = n0 + (wr * RT + r) * 16 + (lane >> 4) * 4;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const int j = j0 + (wc * CT + c) * 16 + (lane & 15);
+            if (TO == 2) {
+                const int t = j & 1, q = j >> 1;
+                const float4 ph = *reinterpret_cast<const float4*>(A.phiO + (size_t)t * NTp + n);
+                float4 v = make_float4(acc[r][c][0] * ph.x, acc[r][c][1] * ph.y, acc[r][c][2] * ph.z, acc[r][c][3] * ph.w);
+                v.x += __shfl_xor(v.x, 1); v.y += __shfl_xor(v.y, 1);
+                v.z += __shfl_xor(v.z, 1); v.w += __shfl_xor(v.w, 1);
+                if (t == 0 && q < A.mO) *reinterpret_cast<float4*>(out + (size_t)q * NTp + n) = v;
+            } else {
+                if (j < A.mO)
+                    *reinterpret_cast<float4*>(out + (size_t)j * NTp + n) = make_float4(acc[r][c][0], acc[r][c][1], acc[r][c][2], acc[r][c][3]);
+            }
+        }
+    }
+}
+
+template <int RT, int CT, int WR, int WC>
+static void fgemm_go(tnml_ctx* c, const FgemmArgs& a) {
+    constexpr int BM = 16 * RT * WR, BN = 16 * CT * WC;
+    dim3 grid(a.NTp / BM, (a.Np + BN - 1) / BN, a.L);
+    dim3 block(64 * WR * WC);
+    if (a.phiO) hipLaunchKernelGGL((k_fgemm<RT, CT, WR, WC, 2>), grid, block, 0, c->stream, a);
+    else        hipLaunchKernelGGL((k_fgemm<RT, CT, WR, WC, 1>), grid, block, 0, c->stream, a);
+}
+
+int launch_fgemm(tnml_ctx* c, const FgemmArgs& a) {
+    ProfScope ps(c, a.phiO ? KC_FGEMM_FWD : KC_FGEMM_SHIFT);
+    if (a.NTp % TNML_NTPAD) return tnml_fail(c, "fgemm: NTp not padded");
+    if (a.Np == 240)      fgemm_go<4, 5, 2, 3>(c, a);      // m = 120: exactly 15 column tiles, no padding waste
+    else if (a.Np > 64)   fgemm_go<4, 4, 2, 2>(c, a);      // 128 x 128 tiles
+    else if (a.Np > 32)   fgemm_go<4, 2, 2, 2>(c, a);      // 128 x 64
+    else                  fgemm_go<4, 1, 2, 2>(c, a);      // 128 x 32
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+struct BgemmKArgs {
+    BgemmArgs a;
+    float* slab;
+    int nsplit, imgs_per_split;
+};
+
+template <int RT, int CT, int WR, int WC>
+__global__ __launch_bounds__(64 * WR * WC) void k_bgemm(BgemmKArgs K) {
+    constexpr int T = 64 * WR * WC, BMr = 16 * RT * WR, BNc = 16 * CT * WC, KTn = 32, ST = KTn + 4;
+    __shared__ __attribute__((aligned(16))) float lds[(BMr + BNc) * ST];
+    float* As = lds;
+    float* Bs = lds + BMr * ST;
+    const BgemmArgs& A = K.a;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid / WC, wc = wid % WC;
+    const int i0 = blockIdx.x * BMr, j0 = blockIdx.y * BNc;
+    const int split = blockIdx.z % K.nsplit, l = blockIdx.z / K.nsplit;
+    const int NTp = A.NTp;
+    const int nbeg = split * K.imgs_per_split;
+    const int nend = min(nbeg + K.imgs_per_split, NTp);
+    const float* w = A.w ? A.w + (size_t)l * A.w_lstride : nullptr;
+
+    f32x4 acc[RT][CT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int nb = nbeg; nb < nend; nb += KTn) {
+        for (int idx = tid; idx < (BMr / 2) * (KTn / 4); idx += T) {
+            const int ar = idx / (KTn / 4), c4 = idx % (KTn / 4);
+            const int a = i0 / 2 + ar, n = nb + c4 * 4;
+            float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a < A.mI) e = *reinterpret_cast<const float4*>(A.EI + (size_t)a * NTp + n);
+            const float4 p0 = *reinterpret_cast<const float4*>(A.phiI + n);
+            const float4 p1 = *reinterpret_cast<const float4*>(A.phiI + NTp + n);
+            *reinterpret_cast<float4*>(&As[(2 * ar) * ST + c4 * 4]) = mul4(e, p0);
+            *reinterpret_cast<float4*>(&As[(2 * ar + 1) * ST + c4 * 4]) = mul4(e, p1);
+        }
+        for (int idx = tid; idx < (BNc / 2) * (KTn / 4); idx += T) {
+            const int qr = idx / (KTn / 4), c4 = idx % (KTn / 4);
+            const int q = j0 / 2 + qr, n = nb + c4 * 4;
+            float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < A.mO) z = *reinterpret_cast<const float4*>(A.Zq + (size_t)q * NTp + n);
+            if (w) z = mul4(z, *reinterpret_cast<const float4*>(w + n));
+            const float4 p0 = *reinterpret_cast<const float4*>(A.phiO + n);
+            const float4 p1 = *reinterpret_cast<const float4*>(A.phiO + NTp + n);
+            *reinterpret_cast<float4*>(&Bs[(2 * qr) * ST + c4 * 4]) = mul4(z, p0);
+            *reinterpret_cast<float4*>(&Bs[(2 * qr + 1) * ST + c4 * 4]) = mul4(z, p1);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < KTn; kk += 16) {
+            // lane group g = lane>>4 owns images kk+4g..kk+4g+3; MFMA step e uses element e of every
+            // group (a permutation of the reduction index, identical for A and B)
+            float4 a[RT], b[CT];
+            const int ko = kk + 4 * (lane >> 4);
+#pragma unroll
+            for (int r = 0; r < RT; ++r) a[r] = *reinterpret_cast<const float4*>(&As[((wr * RT + r) * 16 + (lane & 15)) * ST + ko]);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) b[c] = *reinterpret_cast<const float4*>(&Bs[((wc * CT + c) * 16 + (lane & 15)) * ST + ko]);
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].x, b[c].x, acc[r][c], 0, 0, 0);
+                    acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].y, b[c].y, acc[r][c], 0, 0, 0);
+                    acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].z, b[c].z, acc[r][c], 0, 0, 0);
+                    acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].w, b[c].w, acc[r][c], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+    float* slab = K.slab + ((size_t)split * A.L + l) * A.Kp * A.Np;
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const int j = j0 + (wc * CT + c) * 16 + (lane & 15);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = i0 + (wr * RT + r) * 16 + (lane >> 4) * 4 + e;
+                if (i < A.Kp && j < A.Np) slab[(size_t)i * A.Np + j] = acc[r][c][e];
+            }
+        }
+}
+
+__global__ void k_slab_reduce(const float* __restrict__ slab, double* __restrict__ G, size_t n, int nsplit) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.;
+    for (int k = 0; k < nsplit; ++k) s += (double)slab[(size_t)k * n + i];
+    G[i] = s;
+}
+
+template <int RT, int CT, int WR, int WC>
+static int bgemm_go(tnml_ctx* c, const BgemmArgs& a, double* G) {
+    constexpr int BMr = 16 * RT * WR, BNc = 16 * CT * WC;
+    const int tiles = ((a.Kp + BMr - 1) / BMr) * ((a.Np + BNc - 1) / BNc) * a.L;
+    int nsplit = (1024 + tiles - 1) / tiles;
+    const int chunks = a.NTp / 32;
+    if (nsplit > chunks) nsplit = chunks;
+    if (nsplit < 1) nsplit = 1;
+    const size_t n = (size_t)a.L * a.Kp * a.Np;
+    const size_t cap = c->slab_bytes / sizeof(float);
+    while (nsplit > 1 && (size_t)nsplit * n > cap) --nsplit;
+    if ((size_t)nsplit * n > cap) return tnml_fail(c, "bgemm: slab workspace too small");
+    int per = ((chunks + nsplit - 1) / nsplit) * 32;
+    nsplit = (a.NTp + per - 1) / per;
+    BgemmKArgs K{a, (float*)c->slab, nsplit, per};
+    {
+        ProfScope ps(c, KC_BGEMM);
+        dim3 grid((a.Kp + BMr - 1) / BMr, (a.Np + BNc - 1) / BNc, nsplit * a.L);
+        hipLaunchKernelGGL((k_bgemm<RT, CT, WR, WC>), grid, dim3(64 * WR * WC), 0, c->stream, K);
+    }
+    {
+        ProfScope ps(c, KC_SLABRED);
+        hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const float*)c->slab, G, n, nsplit);
+    }
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
+
+int launch_bgemm(tnml_ctx* c, const BgemmArgs& a, double* G) {
+    if (a.Kp % 80 == 0 && a.Np % 80 == 0) return bgemm_go<1, 5, 5, 1>(c, a, G);   // 80 x 80 tiles (m = 40k: 240 = 3*80)
+    if (a.Kp > 32 && a.Np > 32) return bgemm_go<2, 2, 2, 2>(c, a, G);             // 64 x 64
+    return bgemm_go<1, 1, 2, 2>(c, a, G);                                         // 32 x 32
+}
+
+// ==========================================================================================
+// fp64 MFMA flavour
+// ==========================================================================================
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// RT: image tiles per wave, CT: output-column tiles per wave
+template <int RT, int CT, int WR, int WC>
+__global__ __launch_bounds__(64 * WR * WC) void k_fgemm64(Fgemm64Args A) {
+    constexpr int T = 64 * WR * WC, BM = 16 * RT * WR, BN = 16 * CT * WC, KT = 16;
+    constexpr int XS = BM + 16;                          // doubles; (XS*2) % 64 == 32 -> conflict-free ds_read_b64
+    constexpr int MS = BN + ((BN % 32 == 16) ? 0 : 16);
+    __shared__ __attribute__((aligned(16))) double lds[KT * XS + KT * MS];
+    double* Xs = lds;
+    double* Ms = lds + KT * XS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid / WC, wc = wid % WC;
+    const int n0 = blockIdx.x * BM, j0 = blockIdx.y * BN, l = blockIdx.z;
+    const float* E = A.EI + (size_t)l * A.EI_lstride;
+    const double* M = A.M + (size_t)l * A.M_lstride;
+    const int NTp = A.NTp;
+
+    f64x4 acc[CT][RT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < RT; ++r) acc[c][r] = f64x4{0., 0., 0., 0.};
+
+    for (int k0 = 0; k0 < A.Kp; k0 += KT) {
+        for (int idx = tid; idx < (KT / 2) * (BM / 4); idx += T) {
+            const int ar = idx / (BM / 4), c4 = idx % (BM / 4);
+            const int a = k0 / 2 + ar, n = n0 + c4 * 4;
+            float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a < A.mI) e = *reinterpret_cast<const float4*>(E + (size_t)a * NTp + n);
+            const float4 p0 = *reinterpret_cast<const float4*>(A.phiI + n);
+            const float4 p1 = *reinterpret_cast<const float4*>(A.phiI + NTp + n);
+            double* x0 = &Xs[(2 * ar) * XS + c4 * 4];
+            double* x1 = &Xs[(2 * ar + 1) * XS + c4 * 4];
+            *reinterpret_cast<double2*>(x0) = make_double2((double)e.x * p0.x, (double)e.y * p0.y);
+            *reinterpret_cast<double2*>(x0 + 2) = make_double2((double)e.z * p0.z, (double)e.w * p0.w);
+            *reinterpret_cast<double2*>(x1) = make_double2((double)e.x * p1.x, (double)e.y * p1.y);
+            *reinterpret_cast<double2*>(x1 + 2) = make_double2((double)e.z * p1.z, (double)e.w * p1.w);
+        }
+        for (int idx = tid; idx < KT * (BN / 2); idx += T) {
+            const int r = idx / (BN / 2), c2 = idx % (BN / 2);
+            const int j = j0 + c2 * 2;
+            double2 v = make_double2(0., 0.);
+            if (j < A.Np) v = *reinterpret_cast<const double2*>(M + (size_t)(k0 + r) * A.Np + j);
+            *reinterpret_cast<double2*>(&Ms[r * MS + c2 * 2]) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < KT; kk += 4) {
+            double x[RT], m[CT];
+            const int krow = kk + (lane >> 4);
+#pragma unroll
+            for (int r = 0; r < RT; ++r) x[r] = Xs[krow * XS + (wr * RT + r) * 16 + (lane & 15)];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) m[c] = Ms[krow * MS + (wc * CT + c) * 16 + (lane & 15)];
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int r = 0; r < RT; ++r)      // D[i = column j of M][j = image]
+                    acc[c][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(m[c], x[r], acc[c][r], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: lane (g = lane>>4, i = lane&15) holds rows g+4e of column-tile c for image i of tile r;
+    // rows 2q, 2q+1 (site index t = 0,1 of output link q) sit on lane groups g and g^1
+    double* out = A.out + (size_t)l * A.out_lstride;
+    const int g = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        const int n = n0 + (wr * RT + r) * 16 + (lane & 15);
+        const double ph = (double)A.phiO[(size_t)(g & 1) * NTp + n];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = j0 + (wc * CT + c) * 16 + g + 4 * e;
+                double v = acc[c][r][e] * ph;
+                v += __shfl_xor(v, 16);
+                const int q = j >> 1;
+                if ((g & 1) == 0 && q < A.mO) out[(size_t)q * NTp + n] = v;
+            }
+        }
+    }
+}
+
+template <int RT, int CT, int WR, int WC>
+static void fgemm64_go(tnml_ctx* c, const Fgemm64Args& a) {
+    constexpr int BM = 16 * RT * WR, BN = 16 * CT * WC;
+    dim3 grid(a.NTp / BM, (a.Np + BN - 1) / BN, a.L);
+    hipLaunchKernelGGL((k_fgemm64<RT, CT, WR, WC>), grid, dim3(64 * WR * WC), 0, c->stream, a);
+}
+
+int launch_fgemm64(tnml_ctx* c, const Fgemm64Args& a) {
+    ProfScope ps(c, KC_FGEMM_FWD);
+    if (a.NTp % TNML_NTPAD) return tnml_fail(c, "fgemm64: NTp not padded");
+    if (!a.phiO) return tnml_fail(c, "fgemm64: output-site features required");
+    if (a.Np == 240)      fgemm64_go<2, 5, 2, 3>(c, a);     // m = 120: 64 images x 240 columns, 6 waves
+    else if (a.Np > 64)   fgemm64_go<2, 4, 2, 2>(c, a);     // 64 x 128
+    else if (a.Np > 32)   fgemm64_go<2, 2, 2, 2>(c, a);     // 64 x 64
+    else                  fgemm64_go<2, 1, 2, 2>(c, a);     // 64 x 32
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
+
+struct Bgemm64KArgs {
+    Bgemm64Args a;
+    double* slab;
+    int nsplit, imgs_per_split;
+};
+
+template <int RT, int CT, int WR, int WC>
+__global__ __launch_bounds__(64 * WR * WC) void k_bgemm64(Bgemm64KArgs K) {
+    constexpr int T = 64 * WR * WC, BMr = 16 * RT * WR, BNc = 16 * CT * WC, KTn = 32, ST = KTn + 2;   // doubles
+    __shared__ __attribute__((aligned(16))) double lds[(BMr + BNc) * ST];
+    double* As = lds;
+    double* Bs = lds + BMr * ST;
+    const Bgemm64Args& A = K.a;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid / WC, wc = wid % WC;
+    const int i0 = blockIdx.x * BMr, j0 = blockIdx.y * BNc;
+    const int split = blockIdx.z % K.nsplit, l = blockIdx.z / K.nsplit;
+    const int NTp = A.NTp;
+    const int nbeg = split * K.imgs_per_split;
+    const int nend = min(nbeg + K.imgs_per_split, NTp);
+    const double* w = A.w ? A.w + (size_t)l * A.w_lstride : nullptr;
+
+    f64x4 acc[RT][CT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[r][c] = f64x4{0., 0., 0., 0.};
+
+    for (int nb = nbeg; nb < nend; nb += KTn) {
+        for (int idx = tid; idx < (BMr / 2) * (KTn / 4); idx += T) {
+            const int ar = idx / (KTn / 4), c4 = idx % (KTn / 4);
+            const int a = i0 / 2 + ar, n = nb + c4 * 4;
+            float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a < A.mI) e = *reinterpret_cast<const float4*>(A.EI + (size_t)a * NTp + n);
+            const float4 p0 = *reinterpret_cast<const float4*>(A.phiI + n);
+            const float4 p1 = *reinterpret_cast<const float4*>(A.phiI + NTp + n);
+            double* x0 = &As[(2 * ar) * ST + c4 * 4];
+            double* x1 = &As[(2 * ar + 1) * ST + c4 * 4];
+            *reinterpret_cast<double2*>(x0) = make_double2((double)e.x * p0.x, (double)e.y * p0.y);
+            *reinterpret_cast<double2*>(x0 + 2) = make_double2((double)e.z * p0.z, (double)e.w * p0.w);
+            *reinterpret_cast<double2*>(x1) = make_double2((double)e.x * p1.x, (double)e.y * p1.y);
+            *reinterpret_cast<double2*>(x1 + 2) = make_double2((double)e.z * p1.z, (double)e.w * p1.w);
+        }
+        for (int idx = tid; idx < (BNc / 2) * (KTn / 4); idx += T) {
+            const int qr = idx / (KTn / 4), c4 = idx % (KTn / 4);
+            const int q = j0 / 2 + qr, n = nb + c4 * 4;
+            double z0 = 0., z1 = 0., z2 = 0., z3 = 0.;
+            if (q < A.mO) {
+                if (A.Zq64) {
+                    const double2 za = *reinterpret_cast<const double2*>(A.Zq64 + (size_t)q * NTp + n);
+                    const double2 zb = *reinterpret_cast<const double2*>(A.Zq64 + (size_t)q * NTp + n + 2);
+                    z0 = za.x; z1 = za.y; z2 = zb.x; z3 = zb.y;
+                } else {
+                    const float4 zf = *reinterpret_cast<const float4*>(A.Zq32 + (size_t)q * NTp + n);
+                    z0 = zf.x; z1 = zf.y; z2 = zf.z; z3 = zf.w;
+                }
+            }
+            if (w) {
+                const double2 wa = *reinterpret_cast<const double2*>(w + n);
+                const double2 wb = *reinterpret_cast<const double2*>(w + n + 2);
+                z0 *= wa.x; z1 *= wa.y; z2 *= wb.x; z3 *= wb.y;
+            }
+            const float4 p0 = *reinterpret_cast<const float4*>(A.phiO + n);
+            const float4 p1 = *reinterpret_cast<const float4*>(A.phiO + NTp + n);
+            double* b0 = &Bs[(2 * qr) * ST + c4 * 4];
+            double* b1 = &Bs[(2 * qr + 1) * ST + c4 * 4];
+            *reinterpret_cast<double2*>(b0) = make_double2(z0 * p0.x, z1 * p0.y);
+            *reinterpret_cast<double2*>(b0 + 2) = make_double2(z2 * p0.z, z3 * p0.w);
+            *reinterpret_cast<double2*>(b1) = make_double2(z0 * p1.x, z1 * p1.y);
+            *reinterpret_cast<double2*>(b1 + 2) = make_double2(z2 * p1.z, z3 * p1.w);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < KTn; kk += 8) {
+            // lane group g owns images kk+2g, kk+2g+1; MFMA step e uses element e of every group
+            double2 a[RT], b[CT];
+            const int ko = kk + 2 * (lane >> 4);
+#pragma unroll
+            for (int r = 0; r < RT; ++r) a[r] = *reinterpret_cast<const double2*>(&As[((wr * RT + r) * 16 + (lane & 15)) * ST + ko]);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) b[c] = *reinterpret_cast<const double2*>(&Bs[((wc * CT + c) * 16 + (lane & 15)) * ST + ko]);
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r].x, b[c].x, acc[r][c], 0, 0, 0);
+                    acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r].y, b[c].y, acc[r][c], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+    double* slab = K.slab + ((size_t)split * A.L + l) * A.Kp * A.Np;
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const int j = j0 + (wc * CT + c) * 16 + (lane & 15);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = i0 + (wr * RT + r) * 16 + (lane >> 4) + 4 * e;     // f64 C map: row = g + 4*reg
+                if (i < A.Kp && j < A.Np) slab[(size_t)i * A.Np + j] = acc[r][c][e];
+            }
+        }
+}
+
+__global__ void k_slab_reduce64(const double* __restrict__ slab, double* __restrict__ G, size_t n, int nsplit) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.;
+    for (int k = 0; k < nsplit; ++k) s += slab[(size_t)k * n + i];
+    G[i] = s;
+}
+
+template <int RT, int CT, int WR, int WC>
+static int bgemm64_go(tnml_ctx* c, const Bgemm64Args& a, double* G) {
+    constexpr int BMr = 16 * RT * WR, BNc = 16 * CT * WC;
+    const int tiles = ((a.Kp + BMr - 1) / BMr) * ((a.Np + BNc - 1) / BNc) * a.L;
+    int nsplit = (768 + tiles - 1) / tiles;
+    const int chunks = a.NTp / 32;
+    if (nsplit > chunks) nsplit = chunks;
+    if (nsplit < 1) nsplit = 1;
+    const size_t n = (size_t)a.L * a.Kp * a.Np;
+    const size_t cap = c->slab_bytes / sizeof(double);
+    while (nsplit > 1 && (size_t)nsplit * n > cap) --nsplit;
+    if ((size_t)nsplit * n > cap) return tnml_fail(c, "bgemm64: slab workspace too small");
+    int per = ((chunks + nsplit - 1) / nsplit) * 32;
+    nsplit = (a.NTp + per - 1) / per;
+    Bgemm64KArgs K{a, (double*)c->slab, nsplit, per};
+    {
+        ProfScope ps(c, KC_BGEMM);
+        dim3 grid((a.Kp + BMr - 1) / BMr, (a.Np + BNc - 1) / BNc, nsplit * a.L);
+        hipLaunchKernelGGL((k_bgemm64<RT, CT, WR, WC>), grid, dim3(64 * WR * WC), 0, c->stream, K);
+    }
+    {
+        ProfScope ps(c, KC_SLABRED);
+        hipLaunchKernelGGL(k_slab_reduce64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const double*)c->slab, G, n, nsplit);
+    }
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
+
+int launch_bgemm64(tnml_ctx* c, const Bgemm64Args& a, double* G) {
+    if (a.Kp % 80 == 0 && a.Np % 80 == 0) return bgemm64_go<1, 5, 5, 1>(c, a, G);
+    if (a.Kp > 32 && a.Np > 32) return bgemm64_go<2, 2, 2, 2>(c, a, G);
+    return bgemm64_go<1, 1, 2, 2>(c, a, G);
+}

@@ -1,0 +1,180 @@
+// kernels_stream.hip -- HBM-bound streaming kernels of the bond contraction (gfx950).
+//
+// k_labeldot : P[l][n] = sum_q A[l][q][n] * Bv[q][n]  -- the contraction of the feature-GEMM
+//              output with the Label-carrying environment (second half of B*t.v,
+//              fixedL.cc:318,377,399,416), fused with dP = delta_{l_n} - P (:319,378,417), the
+//              per-label cost partials (:320,419), the argmax|P| count (:321-326, util.h:42-57)
+//              or |P|^2 for pAp (:400).  Image-fastest layout: every lane owns 2 images, every
+//              load is an 8-byte-per-lane fully coalesced stream; no cross-lane reduction.
+// k_zprime   : Z'[q][n] = sum_l EL[l][q][n] * dP[l][n]  (first half of dP*dag(t.v), :379,418)
+// k_features : TState ctor (fixedL.cc:28-47) with phi of :637-642 from raw bytes.
+#include "tnml_internal.h"
+
+#define LD_IMGS 128     // images per workgroup (2 per lane)
+
+template <typename T> struct vec2;
+template <> struct vec2<float> { typedef float2 type; };
+template <> struct vec2<double> { typedef double2 type; };
+
+// TA: element type of the label-carrying operand, TB: of the label-free one, TC: arithmetic type
+template <int NW, typename TA, typename TB, typename TC>
+__global__ __launch_bounds__(64 * NW) void k_labeldot(LdotArgs A, double* __restrict__ partials) {
+    __shared__ __attribute__((aligned(16))) TC red[NW * TNML_NL * LD_IMGS];
+    __shared__ TC s_val[LD_IMGS];
+    __shared__ int s_lab[LD_IMGS];
+    __shared__ int s_cor[LD_IMGS];
+    typedef typename vec2<TA>::type TA2;
+    typedef typename vec2<TB>::type TB2;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int NTp = A.NTp;
+    const int n = blockIdx.x * LD_IMGS + lane * 2;
+    const TA* Ap = static_cast<const TA*>(A.A);
+    const TB* Bp = static_cast<const TB*>(A.Bv);
+
+    TC px[TNML_NL], py[TNML_NL];
+#pragma unroll
+    for (int l = 0; l < TNML_NL; ++l) { px[l] = 0; py[l] = 0; }
+    for (int q = w; q < A.mq; q += NW) {
+        const TB2 u = *reinterpret_cast<const TB2*>(Bp + (size_t)q * NTp + n);
+        const TA* ap = Ap + (size_t)q * NTp + n;
+#pragma unroll
+        for (int l = 0; l < TNML_NL; ++l) {
+            const TA2 e = *reinterpret_cast<const TA2*>(ap + (size_t)l * A.A_lstride);
+            px[l] = fma((TC)e.x, (TC)u.x, px[l]);
+            py[l] = fma((TC)e.y, (TC)u.y, py[l]);
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < TNML_NL; ++l) {
+        red[(w * TNML_NL + l) * LD_IMGS + lane * 2] = px[l];
+        red[(w * TNML_NL + l) * LD_IMGS + lane * 2 + 1] = py[l];
+    }
+    __syncthreads();
+
+    if (tid < LD_IMGS) {
+        const int ni = blockIdx.x * LD_IMGS + tid;
+        TC P[TNML_NL];
+#pragma unroll
+        for (int l = 0; l < TNML_NL; ++l) {
+            TC s = 0;
+            for (int ww = 0; ww < NW; ++ww) s += red[(ww * TNML_NL + l) * LD_IMGS + tid];   // fixed order
+            P[l] = s;
+        }
+        const int lab = A.label[ni];
+        TC val = 0; int cor = 0;
+        TC* Pout = static_cast<TC*>(A.P);
+        TC* dPout = static_cast<TC*>(A.dP);
+        if (A.mode == LD_MODE_PAP) {
+#pragma unroll
+            for (int l = 0; l < TNML_NL; ++l) val = fma(P[l], P[l], val);             // sqr(norm(pv)), :400
+            if (lab < 0) val = 0;
+        } else {
+            TC best = fabs(P[0]); int arg = 0;
+#pragma unroll
+            for (int l = 0; l < TNML_NL; ++l) {
+                const TC d = (lab >= 0) ? ((l == lab ? (TC)1 : (TC)0) - P[l]) : (TC)0;   // deltas[t.l] - P
+                val = fma(d, d, val);
+                if (dPout) dPout[(size_t)l * NTp + ni] = d;
+                if (Pout) Pout[(size_t)l * NTp + ni] = P[l];
+                const TC wgt = fabs(P[l]);
+                if (wgt > best) { best = wgt; arg = l; }                               // first maximum
+            }
+            cor = (lab >= 0 && arg == lab) ? 1 : 0;
+        }
+        s_val[tid] = val; s_lab[tid] = lab; s_cor[tid] = cor;
+    }
+    __syncthreads();
+    // deterministic per-workgroup partial sums: thread l sums its label bucket in image order
+    if (tid < 12) {
+        double s = 0.;
+        if (A.mode == LD_MODE_PAP) {
+            if (tid == 11) for (int i = 0; i < LD_IMGS; ++i) s += (double)s_val[i];
+        } else if (tid < TNML_NL) {
+            for (int i = 0; i < LD_IMGS; ++i) if (s_lab[i] == tid) s += (double)s_val[i];
+        } else if (tid == 10) {
+            for (int i = 0; i < LD_IMGS; ++i) s += (double)s_cor[i];
+        }
+        partials[(size_t)blockIdx.x * 12 + tid] = s;
+    }
+}
+
+__global__ void k_reduce_partials(const double* __restrict__ partials, int nblk, double* __restrict__ out) {
+    // one wave; lane t < 12 sums column t over all workgroups in order
+    const int t = threadIdx.x;
+    if (t < 12) {
+        double s = 0.;
+        for (int b = 0; b < nblk; ++b) s += partials[(size_t)b * 12 + t];
+        out[t] = s;
+    }
+}
+
+int launch_labeldot(tnml_ctx* c, const LdotArgs& a, double* scal_out) {
+    ProfScope ps(c, KC_LABELDOT);
+    const int nblk = a.NTp / LD_IMGS;
+    if (nblk > c->partial_cap) return tnml_fail(c, "labeldot: partial buffer too small");
+    if (c->f64()) {
+        if (a.a_is_env) hipLaunchKernelGGL((k_labeldot<4, float, double, double>), dim3(nblk), dim3(256), 0, c->stream, a, c->partials);
+        else            hipLaunchKernelGGL((k_labeldot<4, double, float, double>), dim3(nblk), dim3(256), 0, c->stream, a, c->partials);
+    } else {
+        hipLaunchKernelGGL((k_labeldot<8, float, float, float>), dim3(nblk), dim3(512), 0, c->stream, a, c->partials);
+    }
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(64), 0, c->stream, c->partials, nblk, scal_out);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
+
+template <typename T>
+__global__ void k_zprime_t(const float* __restrict__ EL, size_t lstride, const T* __restrict__ dP,
+                           T* __restrict__ Z, int mq, int NTp) {
+    const size_t n2 = (size_t)NTp / 2;
+    const size_t total = (size_t)mq * n2;
+    typedef typename vec2<T>::type T2;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t q = idx / n2, n = (idx % n2) * 2;
+        T zx = 0, zy = 0;
+#pragma unroll
+        for (int l = 0; l < TNML_NL; ++l) {
+            const float2 e = *reinterpret_cast<const float2*>(EL + (size_t)l * lstride + q * NTp + n);
+            const T2 d = *reinterpret_cast<const T2*>(dP + (size_t)l * NTp + n);
+            zx = fma((T)e.x, d.x, zx); zy = fma((T)e.y, d.y, zy);
+        }
+        T2 z; z.x = zx; z.y = zy;
+        *reinterpret_cast<T2*>(Z + q * NTp + n) = z;
+    }
+}
+
+int launch_zprime(tnml_ctx* c, const float* EL, size_t lstride, const void* dP, void* Z, int mq, int NTp) {
+    ProfScope ps(c, KC_ZPRIME);
+    const size_t total = (size_t)mq * (NTp / 2);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    if (c->f64()) hipLaunchKernelGGL(k_zprime_t<double>, dim3(blocks), dim3(256), 0, c->stream, EL, lstride, (const double*)dP, (double*)Z, mq, NTp);
+    else          hipLaunchKernelGGL(k_zprime_t<float>, dim3(blocks), dim3(256), 0, c->stream, EL, lstride, (const float*)dP, (float*)Z, mq, NTp);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
+
+__global__ void k_features_u8(const uint8_t* __restrict__ pix, int N, int NT, int NTp, float* __restrict__ phi) {
+    // pix [NT][N] -> phi [N][2][NTp]; one thread per (site, image)
+    const size_t total = (size_t)N * NTp;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(idx / NTp), n = (int)(idx % NTp);
+        float f0 = 0.f, f1 = 0.f;
+        if (n < NT) {
+            // g = byte/255. (mllib/mnist.h:495); x = g/255.; phi = pow(x/4., n-1) (fixedL.cc:640-641),
+            // evaluated in fp64 then rounded once to fp32
+            const double g = (double)pix[(size_t)n * N + j] / 255.;
+            f0 = 1.f;
+            f1 = (float)((g / 255.) / 4.);
+        }
+        phi[((size_t)j * 2 + 0) * NTp + n] = f0;
+        phi[((size_t)j * 2 + 1) * NTp + n] = f1;
+    }
+}
+
+int launch_features_u8(tnml_ctx* c, const uint8_t* d_pix, int N, int NT, int NTp, float* phi) {
+    ProfScope ps(c, KC_PACK);
+    hipLaunchKernelGGL(k_features_u8, dim3(4096), dim3(256), 0, c->stream, d_pix, N, NT, NTp, phi);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,139 @@
+// svd.hip -- truncated SVD that re-splits the optimised bond tensor (fixedL.cc:519-521) on rocSOLVER.
+//
+// ITensor v2 computes the SVD of the matricised bond tensor through the eigen-decomposition of
+// M M^T; this back-end does the same on the device in fp64:
+//   M (nl x nr): rows = (a,s[,l]) indices of site b, columns = (t,beta[,l]) indices of site b+1
+//   rho = M M^T or M^T M on the smaller side  (rocBLAS dgemm)
+//   rho = Q diag(lambda) Q^T                  (rocSOLVER dsyevd, measured 5.9 ms at n=240 vs
+//                                              29 ms dgesvdj / 153 ms dgesvd, profiles/r01_probe_*)
+//   sigma = sqrt(lambda), truncation rule on the host (tnml_truncate), kept factors by dgemm:
+//   the site the sweep leaves gets the orthonormal factor, the site it moves to gets S*V
+//   ("W.Aref(c+dc) *= S", fixedL.cc:521).
+#include <cmath>
+
+#include "tnml_internal.h"
+
+static inline int nblk(size_t n) { size_t b = (n + 255) / 256; return (int)(b > 2048 ? 2048 : (b ? b : 1)); }
+
+// B_it [a][s][t][be][l] with Label on the LEFT site -> M[(a,s,l)][(t,be)]
+__global__ void k_perm_labL_fwd(const double* __restrict__ B, double* __restrict__ M, int mL2, int nr) {
+    const size_t total = (size_t)mL2 * TNML_NL * nr;
+    const int nl = mL2 * TNML_NL;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int il = (int)(idx % nl), ir = (int)(idx / nl);
+        const int as = il % mL2, l = il / mL2;
+        M[idx] = B[as + (size_t)mL2 * ir + (size_t)mL2 * nr * l];
+    }
+}
+// Lfac[(a,s,l)][g] -> A_b[a][s][g][l]
+__global__ void k_perm_labL_back(const double* __restrict__ Lf, double* __restrict__ A, int mL2, int m) {
+    const int nl = mL2 * TNML_NL;
+    const size_t total = (size_t)nl * m;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int il = (int)(idx % nl), g = (int)(idx / nl);
+        const int as = il % mL2, l = il / mL2;
+        A[as + (size_t)mL2 * (g + (size_t)m * l)] = Lf[idx];
+    }
+}
+// Q[:, g] = G[:, n-1-g]  (dsyevd returns ascending eigenvalues), optional column scale
+__global__ void k_take_top(const double* __restrict__ G, double* __restrict__ Q, int n, int m, const double* __restrict__ colscale) {
+    const size_t total = (size_t)n * m;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(idx % n), g = (int)(idx / n);
+        double v = G[i + (size_t)n * (n - 1 - g)];
+        if (colscale) v *= colscale[g];
+        Q[idx] = v;
+    }
+}
+// out[g + m*i] = scale[g] * Q[i + n*g]   (transpose of the kept columns, optional row scale)
+__global__ void k_transpose_scale(const double* __restrict__ Q, double* __restrict__ out, int n, int m, const double* __restrict__ rowscale) {
+    const size_t total = (size_t)n * m;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int g = (int)(idx % m), i = (int)(idx / m);
+        double v = Q[i + (size_t)n * g];
+        if (rowscale) v *= rowscale[g];
+        out[idx] = v;
+    }
+}
+__global__ void k_scale_rows(double* __restrict__ X, int m, size_t cols, const double* __restrict__ rowscale) {
+    const size_t total = (size_t)m * cols;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) X[idx] *= rowscale[idx % m];
+}
+__global__ void k_scale_cols(double* __restrict__ X, size_t rows, int m, const double* __restrict__ colscale) {
+    const size_t total = rows * m;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) X[idx] *= colscale[idx / rows];
+}
+
+#define RBCK(c, expr) do { rocblas_status s_ = (expr); if (s_ != rocblas_status_success) return tnml_fail((c), "%s failed: rocblas status %d (%s:%d)", #expr, (int)s_, __FILE__, __LINE__); } while (0)
+
+int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cutoff, int maxm, int minm,
+                     double* truncerr, int* newm, double* sv_host, int* nsv) {
+    ProfScope ps(c, KC_SVD);
+    SiteT& Sl = c->W[b];
+    SiteT& Sr = c->W[b + 1];
+    const int mL = Sl.ml, mR = Sr.mr;
+    const bool labL = (c->c0 == b), labR = (c->c0 == b + 1);
+    const int nl = 2 * mL * (labL ? TNML_NL : 1), nr = 2 * mR * (labR ? TNML_NL : 1);
+    const int n = nl < nr ? nl : nr;
+    if (n > c->svd_n) return tnml_fail(c, "svd_split: matrix side %d exceeds workspace %d (raise maxm)", n, c->svd_n);
+    hipStream_t st = c->stream;
+
+    const double* M = B_it;
+    if (labL) {
+        hipLaunchKernelGGL(k_perm_labL_fwd, dim3(nblk((size_t)nl * nr)), dim3(256), 0, st, B_it, c->sM, 2 * mL, nr);
+        M = c->sM;
+    }
+    const bool left = (nl < nr) || (nl == nr && ha == 1);
+    const double one = 1.0, zero = 0.0;
+    if (left) RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_transpose, nl, nl, nr, &one, M, nl, M, nl, &zero, c->sG, nl));
+    else      RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, nr, nr, nl, &one, M, nl, M, nl, &zero, c->sG, nr));
+    RBCK(c, rocsolver_dsyevd(c->blas, rocblas_evect_original, rocblas_fill_upper, n, c->sG, n, c->sD, c->sE, c->sInfo));
+    // eigenvalues -> host: the truncation decision (ITensor truncate()) fixes the new bond dimension
+    double* h = c->h_scal;          // pinned, capacity >= 2*svd_n + 64
+    HIPCK(c, hipMemcpyAsync(h, c->sD, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+    HIPCK(c, hipStreamSynchronize(st));
+    std::vector<double> p(n), sig(n);
+    for (int g = 0; g < n; ++g) { double lam = h[n - 1 - g]; if (!(lam > 0.)) lam = 0.; p[g] = lam; sig[g] = std::sqrt(lam); }
+    double te = 0.;
+    const int m = tnml_truncate(p.data(), n, maxm, minm, cutoff, &te);
+    if (truncerr) *truncerr = te;
+    if (newm) *newm = m;
+    if (nsv) *nsv = n;
+    if (sv_host) for (int g = 0; g < n; ++g) sv_host[g] = sig[g];
+    if (m > c->maxm) return tnml_fail(c, "svd_split: new bond dimension %d exceeds maxm %d of the context", m, c->maxm);
+
+    // scale vectors sigma / 1/sigma for the kept columns (device copies live behind the eigenvalues)
+    double* hs = h + c->svd_n;
+    for (int g = 0; g < m; ++g) { hs[g] = sig[g]; hs[m + g] = sig[g] > 1e-300 ? 1.0 / sig[g] : 0.0; }
+    double* d_sig = c->sE;              // sE is free after dsyevd; capacity >= 2*svd_n
+    double* d_isig = c->sE + m;
+    HIPCK(c, hipMemcpyAsync(d_sig, hs, sizeof(double) * 2 * m, hipMemcpyHostToDevice, st));
+
+    double* Q = c->sF;                                   // kept eigenvectors, n x m
+    double* Lf = c->sF + (size_t)c->svd_n * c->maxm;     // left factor when a permutation is still needed
+    hipLaunchKernelGGL(k_take_top, dim3(nblk((size_t)n * m)), dim3(256), 0, st, c->sG, Q, n, m, (const double*)nullptr);
+    double* Aleft = labL ? Lf : Sl.a;      // left factor target, (nl x m), ld = nl
+    double* Aright = Sr.a;                 // right factor (m x nr), ld = m  == A_{b+1}[g][t][be](,[l])
+    if (left) {
+        // Q = U_m
+        RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, m, nr, nl, &one, Q, nl, M, nl, &zero, Aright, m));   // U^T M = S V^T
+        HIPCK(c, hipMemcpyAsync(Aleft, Q, sizeof(double) * (size_t)nl * m, hipMemcpyDeviceToDevice, st));
+        if (ha == 2) {   // orthonormal factor goes right: V^T = S^-1 U^T M ; left gets U S
+            hipLaunchKernelGGL(k_scale_rows, dim3(nblk((size_t)m * nr)), dim3(256), 0, st, Aright, m, (size_t)nr, d_isig);
+            hipLaunchKernelGGL(k_scale_cols, dim3(nblk((size_t)nl * m)), dim3(256), 0, st, Aleft, (size_t)nl, m, d_sig);
+        }
+    } else {
+        // Q = V_m
+        RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, nl, m, nr, &one, M, nl, Q, nr, &zero, Aleft, nl));        // M V = U S
+        if (ha == 2) {
+            hipLaunchKernelGGL(k_transpose_scale, dim3(nblk((size_t)nr * m)), dim3(256), 0, st, Q, Aright, nr, m, (const double*)nullptr);
+        } else {         // orthonormal factor goes left: U = M V S^-1 ; right gets S V^T
+            hipLaunchKernelGGL(k_scale_cols, dim3(nblk((size_t)nl * m)), dim3(256), 0, st, Aleft, (size_t)nl, m, d_isig);
+            hipLaunchKernelGGL(k_transpose_scale, dim3(nblk((size_t)nr * m)), dim3(256), 0, st, Q, Aright, nr, m, d_sig);
+        }
+    }
+    if (labL) hipLaunchKernelGGL(k_perm_labL_back, dim3(nblk((size_t)nl * m)), dim3(256), 0, st, Lf, Sl.a, 2 * mL, m);
+    HIPCK(c, hipGetLastError());
+    Sl.mr = m; Sr.ml = m;
+    return 0;
+}

@@ -1,0 +1,610 @@
+// tnml_abi.hip -- C-ABI entry points (include/tnml.h) and the device-resident orchestration of
+// one bond update of the reference's mldmrg loop (fixedL.cc:478-540).
+//
+// No CPU fallback lives here: every contraction is a HIP kernel launch on the context's stream.
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+
+#include "tnml_internal.h"
+
+static std::string g_create_err;
+
+int tnml_fail(tnml_ctx* c, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (c) c->err = buf; else g_create_err = buf;
+    return 1;
+}
+const char* tnml_last_error(const tnml_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+// ---- profiling ------------------------------------------------------------------------------
+static hipEvent_t prof_event(tnml_ctx* c) {
+    if (!c->prof_free.empty()) { hipEvent_t e = c->prof_free.back(); c->prof_free.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+void prof_begin(tnml_ctx* c, int, hipEvent_t* e0) { *e0 = prof_event(c); (void)hipEventRecord(*e0, c->stream); }
+void prof_end(tnml_ctx* c, int kc, hipEvent_t e0) {
+    hipEvent_t e1 = prof_event(c); (void)hipEventRecord(e1, c->stream);
+    c->prof_pending.push_back({e0, e1, kc});
+    if (c->prof_pending.size() > 8192) prof_resolve(c);
+}
+void prof_resolve(tnml_ctx* c) {
+    if (c->prof_pending.empty()) return;
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& p : c->prof_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) { c->prof_ms[p.kc] += ms; c->prof_launches[p.kc] += 1; }
+        c->prof_free.push_back(p.e0); c->prof_free.push_back(p.e1);
+    }
+    c->prof_pending.clear();
+}
+int tnml_profile_enable(tnml_ctx* c, int on) { prof_resolve(c); c->prof = on != 0; return 0; }
+int tnml_profile_count(tnml_ctx*) { return KC_COUNT; }
+int tnml_profile_get(tnml_ctx* c, int idx, char* name64, int64_t* launches, double* total_ms) {
+    if (idx < 0 || idx >= KC_COUNT) return tnml_fail(c, "profile index out of range");
+    prof_resolve(c);
+    if (name64) { strncpy(name64, kclass_names[idx], 63); name64[63] = 0; }
+    if (launches) *launches = c->prof_launches[idx];
+    if (total_ms) *total_ms = c->prof_ms[idx];
+    return 0;
+}
+int tnml_profile_reset(tnml_ctx* c) {
+    prof_resolve(c);
+    for (int i = 0; i < KC_COUNT; ++i) { c->prof_launches[i] = 0; c->prof_ms[i] = 0.; }
+    return 0;
+}
+int tnml_synchronize(tnml_ctx* c) { HIPCK(c, hipStreamSynchronize(c->stream)); return 0; }
+int64_t tnml_device_bytes(tnml_ctx* c) { return c->bytes; }
+
+// ---- host-side rules ------------------------------------------------------------------------
+// ITensor v2 truncate() as recalled in SURVEY.md 8(a9): always cut to maxm; then with
+// scale = sum(p) (DoRelCutoff) discard while (discarded + p_n) < cutoff*scale and kept > minm.
+int tnml_truncate(const double* P, int origm, int maxm, int minm, double cutoff, double* truncerr) {
+    if (origm <= 1) { if (truncerr) *truncerr = 0.; return origm; }
+    int n = origm - 1;
+    double te = 0.;
+    while (n >= maxm) { te += P[n]; --n; }
+    double scale = 0.;
+    for (int j = 0; j < origm; ++j) scale += P[j];
+    if (scale == 0.) scale = 1.;
+    while (n >= 0 && te + P[n] < cutoff * scale && n >= minm) { te += P[n]; --n; }
+    if (n < 0) n = 0;
+    if (truncerr) *truncerr = te / scale;
+    return n + 1;
+}
+// ITensor sweepnext: b = 1..N-1 (ha=1) then N-1..1 (ha=2); ha==3 ends the sweep
+void tnml_sweepnext(int* b, int* ha, int N) {
+    const int inc = (*ha == 1) ? +1 : -1;
+    *b += inc;
+    if (*b == ((*ha == 1) ? N : 0)) { *b -= inc; ++*ha; }
+}
+// ParallelDo's static chunking (paralleldo.h:32-43) with ranks in place of threads: equal chunks,
+// the last rank takes the remainder
+void tnml_shard_bounds(int64_t NT_total, int nranks, int rank, int64_t* begin, int64_t* end) {
+    const int64_t th = NT_total / nranks;
+    *begin = th * rank;
+    *end = (rank == nranks - 1) ? NT_total : th * (rank + 1);
+}
+
+// ---- allocation helpers ---------------------------------------------------------------------
+template <typename T>
+static int dmalloc(tnml_ctx* c, T** p, size_t n) {
+    if (n == 0) n = 1;
+    hipError_t e = hipMalloc((void**)p, n * sizeof(T));
+    if (e != hipSuccess) return tnml_fail(c, "hipMalloc of %zu bytes failed: %s", n * sizeof(T), hipGetErrorString(e));
+    c->bytes += (int64_t)(n * sizeof(T));
+    return 0;
+}
+static inline int ru16(int x) { return (x + 15) / 16 * 16; }
+
+int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
+    if (!out || !cfg) return tnml_fail(nullptr, "tnml_create: null argument");
+    *out = nullptr;
+    if (cfg->N < 4) return tnml_fail(nullptr, "tnml_create: need N >= 4 sites");
+    if (cfg->NT_local < 1 || cfg->maxm < 1) return tnml_fail(nullptr, "tnml_create: NT_local and maxm must be positive");
+    if (cfg->dtype != TNML_F32 && cfg->dtype != TNML_F64) return tnml_fail(nullptr, "tnml_create: dtype must be TNML_F64 or TNML_F32");
+    if (cfg->nranks < 1 || cfg->rank < 0 || cfg->rank >= cfg->nranks) return tnml_fail(nullptr, "tnml_create: bad rank/nranks");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return tnml_fail(nullptr, "tnml_create: no HIP device available (the HIP path is the only path; there is no CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= ndev) return tnml_fail(nullptr, "tnml_create: device %d out of range (%d visible)", cfg->device, ndev);
+    if (hipSetDevice(cfg->device) != hipSuccess) return tnml_fail(nullptr, "tnml_create: hipSetDevice failed");
+    tnml_ctx* c = new tnml_ctx();
+    c->cfg = *cfg;
+    c->N = cfg->N; c->NT = cfg->NT_local; c->maxm = cfg->maxm; c->c0 = cfg->N / 2;      // fixedL.cc:616
+    c->NTp = (cfg->NT_local + TNML_NTPAD - 1) / TNML_NTPAD * TNML_NTPAD;
+    int rc = 0;
+    auto bail = [&](int r) { g_create_err = c->err; tnml_destroy(c); return r; };
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(tnml_fail(c, "hipStreamCreate failed"));
+    if (rocblas_create_handle(&c->blas) != rocblas_status_success) return bail(tnml_fail(c, "rocblas_create_handle failed"));
+    rocblas_set_stream(c->blas, c->stream);
+    const size_t NTp = c->NTp;
+    const int Kmax = ru16(2 * c->maxm);
+    c->mcap = (size_t)TNML_NL * Kmax * Kmax;
+    c->small_elems = (size_t)c->maxm * NTp;
+    c->big_elems = (size_t)TNML_NL * c->maxm * NTp;
+    c->svd_n = 2 * c->maxm;
+    c->slab_bytes = (size_t)128 * Kmax * Kmax * 4 * (cfg->dtype == TNML_F64 ? 2 : 1);
+    c->partial_cap = (int)(NTp / 128);
+    c->W.resize(c->N + 2);
+    c->env.resize(c->N + 2);
+    if ((rc = dmalloc(c, &c->phi, (size_t)c->N * 2 * NTp))) return bail(rc);
+    if ((rc = dmalloc(c, &c->label, NTp))) return bail(rc);
+    if ((rc = dmalloc(c, &c->ones, NTp))) return bail(rc);
+    const size_t esz = c->esz();
+    if ((rc = dmalloc(c, (char**)&c->U, c->big_elems * esz))) return bail(rc);
+    if ((rc = dmalloc(c, (char**)&c->P, (size_t)TNML_NL * NTp * esz))) return bail(rc);
+    if ((rc = dmalloc(c, (char**)&c->dP, (size_t)TNML_NL * NTp * esz))) return bail(rc);
+    if ((rc = dmalloc(c, (char**)&c->Zp, c->small_elems * esz))) return bail(rc);
+    if ((rc = dmalloc(c, &c->Mf, c->mcap))) return bail(rc);
+    if ((rc = dmalloc(c, (char**)&c->slab, c->slab_bytes))) return bail(rc);
+    if ((rc = dmalloc(c, &c->partials, (size_t)c->partial_cap * 12))) return bail(rc);
+    if ((rc = dmalloc(c, &c->vB, c->mcap))) return bail(rc);
+    if ((rc = dmalloc(c, &c->vR, c->mcap))) return bail(rc);
+    if ((rc = dmalloc(c, &c->vP, c->mcap))) return bail(rc);
+    if ((rc = dmalloc(c, &c->vG, c->mcap + TNML_NSCAL_AR))) return bail(rc);
+    if ((rc = dmalloc(c, &c->scal, SC_N))) return bail(rc);
+    if ((rc = dmalloc(c, &c->tB, c->mcap))) return bail(rc);
+    if ((rc = dmalloc(c, &c->tB2, c->mcap))) return bail(rc);
+    if ((rc = dmalloc(c, &c->sM, (size_t)40 * c->maxm * c->maxm))) return bail(rc);
+    if ((rc = dmalloc(c, &c->sG, (size_t)c->svd_n * c->svd_n))) return bail(rc);
+    if ((rc = dmalloc(c, &c->sD, (size_t)c->svd_n))) return bail(rc);
+    if ((rc = dmalloc(c, &c->sE, (size_t)2 * c->svd_n))) return bail(rc);
+    if ((rc = dmalloc(c, &c->sF, (size_t)c->svd_n * c->maxm + (size_t)2 * TNML_NL * c->maxm * c->maxm))) return bail(rc);
+    if ((rc = dmalloc(c, &c->sInfo, 4))) return bail(rc);
+    if (hipHostMalloc((void**)&c->h_scal, sizeof(double) * (2 * c->svd_n + 64 + SC_N)) != hipSuccess) return bail(tnml_fail(c, "hipHostMalloc failed"));
+    for (int j = 1; j <= c->N; ++j) {
+        const size_t cap = (size_t)2 * c->maxm * c->maxm * (j == c->c0 ? TNML_NL : 1);
+        if ((rc = dmalloc(c, &c->W[j].a, cap))) return bail(rc);
+    }
+    if (hipMemsetAsync(c->vG, 0, sizeof(double) * (c->mcap + TNML_NSCAL_AR), c->stream) != hipSuccess) return bail(tnml_fail(c, "memset failed"));
+    if (hipMemsetAsync(c->scal, 0, sizeof(double) * SC_N, c->stream) != hipSuccess) return bail(tnml_fail(c, "memset failed"));
+    if ((rc = launch_fill_f32(c, c->ones, 1.0f, NTp))) return bail(rc);
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return bail(tnml_fail(c, "sync failed"));
+    *out = c;
+    return 0;
+}
+
+int tnml_destroy(tnml_ctx* c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm) ncclCommDestroy(c->comm);
+    for (auto& p : c->prof_pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
+    for (auto e : c->prof_free) (void)hipEventDestroy(e);
+    void* ptrs[] = {c->phi, c->label, c->ones, c->U, c->P, c->dP, c->Zp, c->Mf, c->slab, c->partials, c->vB, c->vR, c->vP,
+                    c->vG, c->scal, c->tB, c->tB2, c->sM, c->sG, c->sD, c->sE, c->sF, c->sInfo};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& s : c->W) if (s.a) (void)hipFree(s.a);
+    for (auto& e : c->env) if (e.ptr) (void)hipFree(e.ptr);
+    for (auto p : c->pool_small) (void)hipFree(p);
+    for (auto p : c->pool_big) (void)hipFree(p);
+    if (c->h_scal) (void)hipHostFree(c->h_scal);
+    if (c->blas) rocblas_destroy_handle(c->blas);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+// ---- RCCL -----------------------------------------------------------------------------------
+int tnml_comm_unique_id(void* id128) {
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return tnml_fail(nullptr, "ncclGetUniqueId failed");
+    memcpy(id128, &id, sizeof id);
+    return 0;
+}
+int tnml_comm_init(tnml_ctx* c, const void* id128) {
+    if (c->cfg.nranks == 1) return 0;
+    ncclUniqueId id; memcpy(&id, id128, sizeof id);
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    ncclResult_t r = ncclCommInitRank(&c->comm, c->cfg.nranks, id, c->cfg.rank);
+    if (r != ncclSuccess) return tnml_fail(c, "ncclCommInitRank failed: %s", ncclGetErrorString(r));
+    return 0;
+}
+// sum over ranks of a fp64 device buffer, in stream order (replaces stdx::accumulate, fixedL.cc:385,402,421,427)
+static int allreduce(tnml_ctx* c, double* buf, size_t count) {
+    if (c->cfg.nranks == 1) return 0;
+    if (!c->comm) return tnml_fail(c, "nranks > 1 but tnml_comm_init was not called");
+    ProfScope ps(c, KC_ALLREDUCE);
+    ncclResult_t r = ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, c->comm, c->stream);
+    if (r != ncclSuccess) return tnml_fail(c, "ncclAllReduce failed: %s", ncclGetErrorString(r));
+    return 0;
+}
+
+// ---- training set -----------------------------------------------------------------------------
+static int set_labels(tnml_ctx* c, const int32_t* labels) {
+    std::vector<int> lab(c->NTp, -1);
+    for (int i = 0; i < c->NT; ++i) {
+        if (labels[i] < 0 || labels[i] >= TNML_NL) return tnml_fail(c, "label %d of image %d out of range", labels[i], i);
+        lab[i] = labels[i];
+    }
+    HIPCK(c, hipMemcpy(c->label, lab.data(), sizeof(int) * c->NTp, hipMemcpyHostToDevice));
+    return 0;
+}
+int tnml_set_data_u8(tnml_ctx* c, const uint8_t* pixels, const int32_t* labels) {
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    TCK(set_labels(c, labels));
+    uint8_t* d_pix = nullptr;
+    const size_t nb = (size_t)c->NT * c->N;
+    HIPCK(c, hipMalloc((void**)&d_pix, nb));
+    HIPCK(c, hipMemcpy(d_pix, pixels, nb, hipMemcpyHostToDevice));
+    int rc = launch_features_u8(c, d_pix, c->N, c->NT, c->NTp, c->phi);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(d_pix);
+    if (rc) return rc;
+    c->data_set = true; c->currb = -1;
+    return 0;
+}
+int tnml_set_data_phi(tnml_ctx* c, const double* phi, const int32_t* labels) {
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    TCK(set_labels(c, labels));
+    // TState::data[(j-1)*d + (n-1)] (fixedL.cc:39-46) -> [N][2][NTp], rounded once to fp32
+    std::vector<float> h((size_t)c->N * 2 * c->NTp, 0.f);
+    for (int i = 0; i < c->NT; ++i)
+        for (int j = 0; j < c->N; ++j)
+            for (int s = 0; s < 2; ++s) h[((size_t)j * 2 + s) * c->NTp + i] = (float)phi[((size_t)i * c->N + j) * 2 + s];
+    HIPCK(c, hipMemcpy(c->phi, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice));
+    c->data_set = true; c->currb = -1;
+    return 0;
+}
+
+// ---- weight MPS replica -------------------------------------------------------------------------
+int tnml_set_site(tnml_ctx* c, int j, int ml, int mr, int has_label, const double* A) {
+    if (j < 1 || j > c->N) return tnml_fail(c, "tnml_set_site: site %d out of range", j);
+    if ((j == c->c0) != (has_label != 0)) return tnml_fail(c, "Label Index not on site %d", c->c0);     // fixedL.cc:734
+    if (ml < 1 || mr < 1 || ml > c->maxm || mr > c->maxm) return tnml_fail(c, "tnml_set_site: bond dimension outside 1..maxm");
+    if ((j == 1 && ml != 1) || (j == c->N && mr != 1)) return tnml_fail(c, "tnml_set_site: edge sites must have outer dimension 1");
+    SiteT& s = c->W[j];
+    s.ml = ml; s.mr = mr; s.L = has_label ? TNML_NL : 1; s.set = true;
+    HIPCK(c, hipMemcpy(s.a, A, sizeof(double) * (size_t)ml * 2 * mr * s.L, hipMemcpyHostToDevice));
+    c->currb = -1;
+    return 0;
+}
+int tnml_site_dims(tnml_ctx* c, int j, int* ml, int* mr, int* has_label) {
+    if (j < 1 || j > c->N || !c->W[j].set) return tnml_fail(c, "tnml_site_dims: site %d not set", j);
+    *ml = c->W[j].ml; *mr = c->W[j].mr; *has_label = c->W[j].L == TNML_NL;
+    return 0;
+}
+int tnml_get_site(tnml_ctx* c, int j, double* A) {
+    if (j < 1 || j > c->N || !c->W[j].set) return tnml_fail(c, "tnml_get_site: site %d not set", j);
+    const SiteT& s = c->W[j];
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    HIPCK(c, hipMemcpy(A, s.a, sizeof(double) * (size_t)s.ml * 2 * s.mr * s.L, hipMemcpyDeviceToHost));
+    return 0;
+}
+static int check_W(tnml_ctx* c) {
+    for (int j = 1; j <= c->N; ++j) {
+        if (!c->W[j].set) return tnml_fail(c, "W: site %d not set", j);
+        if (j > 1 && c->W[j].ml != c->W[j - 1].mr) return tnml_fail(c, "W: bond dimension mismatch between sites %d and %d", j - 1, j);
+    }
+    return 0;
+}
+
+// ---- environments -------------------------------------------------------------------------------
+static int env_alloc(tnml_ctx* c, int j, int m, int L) {
+    EnvSlot& e = c->env[j];
+    if (e.ptr) { (e.big ? c->pool_big : c->pool_small).push_back(e.ptr); e.ptr = nullptr; }
+    const int big = (L == TNML_NL);
+    auto& pool = big ? c->pool_big : c->pool_small;
+    if (!pool.empty()) { e.ptr = pool.back(); pool.pop_back(); }
+    else TCK(dmalloc(c, &e.ptr, big ? c->big_elems : c->small_elems));
+    e.m = m; e.L = L; e.big = big;
+    return 0;
+}
+static const float* phi_site(const tnml_ctx* c, int j) { return c->phi + (size_t)(j - 1) * 2 * c->NTp; }
+
+// new env at site cs from the env at ps (0: chain end): nextE = prevE*(t.A(c)*W.A(c)), fixedL.cc:142-149,221-228
+static int shift_site(tnml_ctx* c, int cs, int ps, bool from_left) {
+    const SiteT& A = c->W[cs];
+    const bool has_prev = ps >= 1 && ps <= c->N;
+    if (has_prev && !c->env[ps].ptr) return tnml_fail(c, "shift: environment of site %d missing", ps);
+    const int m_in = from_left ? A.ml : A.mr, m_out = from_left ? A.mr : A.ml;
+    const int Le = has_prev ? c->env[ps].L : 1;
+    if (has_prev && c->env[ps].m != m_in) return tnml_fail(c, "shift: env dim %d != site dim %d at site %d", c->env[ps].m, m_in, cs);
+    if (!has_prev && m_in != 1) return tnml_fail(c, "shift: chain-end site %d has outer dimension %d", cs, m_in);
+    if (Le == TNML_NL && A.L == TNML_NL) return tnml_fail(c, "shift: Label index on both env and site");
+    const int Lout = A.L > Le ? A.L : Le;
+    PackDesc d;
+    d.TO = 1; d.L = A.L; d.st = 0; d.ss = A.ml; d.sl = (long)2 * A.ml * A.mr;
+    if (from_left) { d.nx = A.ml; d.sx = 1; d.ny = A.mr; d.sy = 2 * A.ml; }
+    else           { d.nx = A.mr; d.sx = 2 * A.ml; d.ny = A.ml; d.sy = 1; }
+    d.Kp = ru16(2 * d.nx); d.Np = ru16(d.ny);
+    TCK(launch_pack(c, d, A.a, nullptr, c->Mf));
+    TCK(env_alloc(c, cs, m_out, Lout));
+    FgemmArgs f;
+    f.EI = has_prev ? c->env[ps].ptr : c->ones;
+    f.EI_lstride = (Le == TNML_NL) ? (size_t)m_in * c->NTp : 0;
+    f.mI = m_in; f.phiI = phi_site(c, cs);
+    f.M = c->Mf; f.M_lstride = (A.L == TNML_NL) ? (size_t)d.Kp * d.Np : 0; f.Kp = d.Kp; f.Np = d.Np;
+    f.phiO = nullptr;
+    f.out = c->env[cs].ptr; f.out_lstride = (size_t)m_out * c->NTp; f.mO = m_out;
+    f.NTp = c->NTp; f.L = Lout;
+    return launch_fgemm(c, f);
+}
+
+int tnml_env_init(tnml_ctx* c) {       // TrainStates::init, fixedL.cc:122-157
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    if (!c->data_set) return tnml_fail(c, "tnml_env_init: training data not set");
+    TCK(check_W(c));
+    for (int n = c->N; n >= 3; --n) TCK(shift_site(c, n, n == c->N ? 0 : n + 1, false));   // :136-153
+    c->currb = -1;
+    return tnml_set_bond(c, 1);                                                            // :156
+}
+int tnml_shift_env(tnml_ctx* c, int b, int from_left) {   // TrainStates::shiftE, fixedL.cc:192-233
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    if (b < 1 || b > c->N - 1) return tnml_fail(c, "tnml_shift_env: bond %d out of range", b);
+    const int cs = from_left ? b : b + 1;              // :196
+    const int prevc = from_left ? b - 1 : b + 2;       // :199
+    TCK(shift_site(c, cs, (prevc >= 1 && prevc <= c->N) ? prevc : 0, from_left != 0));
+    return 0;
+}
+int tnml_env_dims(tnml_ctx* c, int j, int* m, int* has_label) {
+    if (j < 1 || j > c->N || !c->env[j].ptr) return tnml_fail(c, "tnml_env_dims: environment of site %d not built", j);
+    *m = c->env[j].m; *has_label = c->env[j].L == TNML_NL;
+    return 0;
+}
+int tnml_get_env(tnml_ctx* c, int j, double* E) {
+    if (j < 1 || j > c->N || !c->env[j].ptr) return tnml_fail(c, "tnml_get_env: environment of site %d not built", j);
+    const EnvSlot& e = c->env[j];
+    std::vector<float> h((size_t)e.L * e.m * c->NTp);
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    HIPCK(c, hipMemcpy(h.data(), e.ptr, sizeof(float) * h.size(), hipMemcpyDeviceToHost));
+    for (int i = 0; i < c->NT; ++i)
+        for (int l = 0; l < e.L; ++l)
+            for (int q = 0; q < e.m; ++q) E[(size_t)i * e.m * e.L + q + (size_t)e.m * l] = h[((size_t)l * e.m + q) * c->NTp + i];
+    return 0;
+}
+
+// ---- bond plan (TrainStates::setBond, fixedL.cc:159-190: pointer selection only) ---------------
+static PackDesc bond_pack_desc(const BondPlan& p) {
+    PackDesc d;
+    d.TO = 2; d.L = p.LB;
+    const long mL = p.mL, mR = p.mR;
+    if (p.kind == 1) { d.nx = p.mR; d.sx = 4 * mL; d.ss = 2 * mL; d.ny = p.mL; d.sy = 1; d.st = mL; }
+    else             { d.nx = p.mL; d.sx = 1; d.ss = mL; d.ny = p.mR; d.sy = 4 * mL; d.st = 2 * mL; }
+    d.sl = 4 * mL * mR;
+    d.Kp = p.Kp; d.Np = p.Np;
+    return d;
+}
+int tnml_set_bond(tnml_ctx* c, int b) {
+    if (b < 1 || b > c->N - 1) return tnml_fail(c, "tnml_set_bond: bond %d out of range", b);
+    TCK(check_W(c));
+    const int lc = b - 1, rc = b + 2;                         // :164-165
+    const bool useL = lc > 0, useR = rc < c->N + 1;           // :166-167
+    if (useL && !c->env[lc].ptr) return tnml_fail(c, "setBond: left environment (site %d) missing", lc);
+    if (useR && !c->env[rc].ptr) return tnml_fail(c, "setBond: right environment (site %d) missing", rc);
+    BondPlan p;
+    p.b = b; p.mL = c->W[b].ml; p.mR = c->W[b + 1].mr;
+    if ((useL ? c->env[lc].m : 1) != p.mL || (useR ? c->env[rc].m : 1) != p.mR) return tnml_fail(c, "setBond: env dims do not match W at bond %d", b);
+    const int LL = useL ? c->env[lc].L : 1, LR = useR ? c->env[rc].L : 1;
+    const bool onB = (c->c0 == b || c->c0 == b + 1);
+    const float* LE = useL ? c->env[lc].ptr : c->ones;
+    const float* RE = useR ? c->env[rc].ptr : c->ones;
+    if (onB) {
+        if (LL != 1 || LR != 1) return tnml_fail(c, "setBond: Label index on an environment and on B at bond %d", b);
+        p.kind = 2; p.LB = TNML_NL; p.mI = p.mL; p.mO = p.mR; p.EI = LE; p.phiI = phi_site(c, b); p.EX = RE; p.phiO = phi_site(c, b + 1);
+    } else if (LR == TNML_NL && LL == 1) {
+        p.kind = 0; p.LB = 1; p.mI = p.mL; p.mO = p.mR; p.EI = LE; p.phiI = phi_site(c, b); p.EX = RE; p.phiO = phi_site(c, b + 1);
+    } else if (LL == TNML_NL && LR == 1) {
+        p.kind = 1; p.LB = 1; p.mI = p.mR; p.mO = p.mL; p.EI = RE; p.phiI = phi_site(c, b + 1); p.EX = LE; p.phiO = phi_site(c, b);
+    } else {
+        return tnml_fail(c, "Couldn't find Label index at bond %d", b);       // fixedL.cc:291-296,362
+    }
+    p.Kp = ru16(2 * p.mI); p.Np = ru16(2 * p.mO);
+    c->plan = p; c->currb = b;
+    return 0;
+}
+int tnml_bond_dims(tnml_ctx* c, int b, int* mL, int* mR, int* label_on_B) {
+    if (b < 1 || b > c->N - 1 || !c->W[b].set || !c->W[b + 1].set) return tnml_fail(c, "tnml_bond_dims: bad bond %d", b);
+    *mL = c->W[b].ml; *mR = c->W[b + 1].mr; *label_on_B = (c->c0 == b || c->c0 == b + 1);
+    return 0;
+}
+static size_t bond_elems(const tnml_ctx* c, int b) {
+    return (size_t)c->W[b].ml * 4 * c->W[b + 1].mr * ((c->c0 == b || c->c0 == b + 1) ? TNML_NL : 1);
+}
+int tnml_bond_tensor(tnml_ctx* c, int b, double* B) {
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    int mL, mR, lab; TCK(tnml_bond_dims(c, b, &mL, &mR, &lab));
+    if (c->W[b].mr != c->W[b + 1].ml) return tnml_fail(c, "bond %d: link dimensions differ", b);
+    TCK(launch_bond_form(c, c->W[b], c->W[b + 1], c->tB));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    HIPCK(c, hipMemcpy(B, c->tB, sizeof(double) * bond_elems(c, b), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- per-image contractions -----------------------------------------------------------------------
+// forward pass with the M-layout fp64 vector `vec` as bond tensor: P = vec*t.v, then mode-specific
+// reductions into tail[0..11] (device)
+static int forward_pass(tnml_ctx* c, const double* vec, int mode, double* tail, bool want_P) {
+    const BondPlan& p = c->plan;
+    const size_t ustride = (size_t)p.mO * c->NTp;
+    if (c->f64()) {
+        Fgemm64Args f;
+        f.EI = p.EI; f.EI_lstride = 0; f.mI = p.mI; f.phiI = p.phiI;
+        f.M = vec; f.M_lstride = p.kind == 2 ? (size_t)p.Kp * p.Np : 0; f.Kp = p.Kp; f.Np = p.Np;
+        f.phiO = p.phiO;
+        f.out = (double*)c->U; f.out_lstride = ustride; f.mO = p.mO;
+        f.NTp = c->NTp; f.L = p.LB;
+        TCK(launch_fgemm64(c, f));
+    } else {
+        TCK(launch_cvt(c, vec, c->Mf, p.msize()));
+        FgemmArgs f;
+        f.EI = p.EI; f.EI_lstride = 0; f.mI = p.mI; f.phiI = p.phiI;
+        f.M = c->Mf; f.M_lstride = p.kind == 2 ? (size_t)p.Kp * p.Np : 0; f.Kp = p.Kp; f.Np = p.Np;
+        f.phiO = p.phiO;
+        f.out = (float*)c->U; f.out_lstride = ustride; f.mO = p.mO;
+        f.NTp = c->NTp; f.L = p.LB;
+        TCK(launch_fgemm(c, f));
+    }
+    LdotArgs a;
+    if (p.kind == 2) { a.A = c->U; a.A_lstride = ustride; a.Bv = p.EX; a.a_is_env = 0; }
+    else             { a.A = p.EX; a.A_lstride = ustride; a.Bv = c->U; a.a_is_env = 1; }
+    a.mq = p.mO; a.NTp = c->NTp; a.label = c->label;
+    a.P = want_P ? c->P : nullptr; a.dP = (mode == LD_MODE_PAP) ? nullptr : c->dP; a.mode = mode;
+    return launch_labeldot(c, a, tail);
+}
+// G = sum_n dP_n*dag(t.v) over all ranks for the bond tensor in vB; cost partials ride in the tail
+static int grad_eval(tnml_ctx* c) {
+    const BondPlan& p = c->plan;
+    const size_t n = p.msize();
+    TCK(forward_pass(c, c->vB, LD_MODE_COST, c->vG + n, false));
+    if (p.kind != 2) TCK(launch_zprime(c, p.EX, (size_t)p.mO * c->NTp, c->dP, c->Zp, p.mO, c->NTp));
+    if (c->f64()) {
+        Bgemm64Args g;
+        g.EI = p.EI; g.mI = p.mI; g.phiI = p.phiI; g.phiO = p.phiO; g.mO = p.mO;
+        g.Kp = p.Kp; g.Np = p.Np; g.NTp = c->NTp; g.L = p.LB;
+        if (p.kind == 2) { g.Zq64 = nullptr; g.Zq32 = p.EX; g.w = (const double*)c->dP; g.w_lstride = c->NTp; }
+        else             { g.Zq64 = (const double*)c->Zp; g.Zq32 = nullptr; g.w = nullptr; g.w_lstride = 0; }
+        TCK(launch_bgemm64(c, g, c->vG));
+    } else {
+        BgemmArgs g;
+        g.EI = p.EI; g.mI = p.mI; g.phiI = p.phiI; g.phiO = p.phiO; g.mO = p.mO;
+        g.Kp = p.Kp; g.Np = p.Np; g.NTp = c->NTp; g.L = p.LB;
+        if (p.kind == 2) { g.Zq = p.EX; g.w = (const float*)c->dP; g.w_lstride = c->NTp; }
+        else             { g.Zq = (const float*)c->Zp; g.w = nullptr; g.w_lstride = 0; }
+        TCK(launch_bgemm(c, g, c->vG));
+    }
+    return allreduce(c, c->vG, n + TNML_NSCAL_AR);
+}
+static int read_scal(tnml_ctx* c, const double* dev, int count, double* host_out) {
+    double* h = c->h_scal + 2 * c->svd_n + 64;
+    HIPCK(c, hipMemcpyAsync(h, dev, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    memcpy(host_out, h, sizeof(double) * count);
+    return 0;
+}
+
+// cgrad, fixedL.cc:349-445, on the bond tensor in vB (M-layout)
+static int cgrad_device(tnml_ctx* c, int npass, double lambda, double cconv, tnml_cg_trace* tr) {
+    if (npass < 1 || npass > TNML_MAX_PASS) return tnml_fail(c, "cgrad: Npass must be in 1..%d", TNML_MAX_PASS);
+    const size_t n = c->plan.msize();
+    if (tr) memset(tr, 0, sizeof *tr);
+    double s[SC_N];
+    TCK(grad_eval(c));                                   // :374-385
+    TCK(launch_cg_init(c, n, lambda));                   // :386-388
+    for (int pass = 1; pass <= npass; ++pass) {          // :389
+        TCK(forward_pass(c, c->vP, LD_MODE_PAP, c->vG + n, false));   // :394-401
+        TCK(allreduce(c, c->vG + n, TNML_NSCAL_AR));                  // :402
+        TCK(launch_cg_step(c, n, lambda));               // :403-407
+        if (tr) tr->npass_done = pass;
+        if (pass == npass) {                             // :409
+            if (tr) { TCK(read_scal(c, c->scal, SC_N, s)); tr->pAp[pass - 1] = s[SC_PAP]; tr->alpha[pass - 1] = s[SC_ALPHA]; }
+            break;
+        }
+        TCK(grad_eval(c));                               // :412-421
+        TCK(launch_cg_resid(c, n, lambda, cconv));       // :422-428, :442
+        TCK(read_scal(c, c->scal, SC_N, s));
+        if (tr) {
+            tr->pAp[pass - 1] = s[SC_PAP]; tr->alpha[pass - 1] = s[SC_ALPHA];
+            tr->cost[pass - 1] = s[SC_COST]; tr->rnorm[pass - 1] = s[SC_RNORM];
+        }
+        if (s[SC_CONV] != 0.) { if (tr) tr->converged = 1; break; }   // :432-436
+    }
+    return 0;
+}
+// quadcost, fixedL.cc:280-344, on the bond tensor in vB
+static int quadcost_device(tnml_ctx* c, double lambda, double* cost, double* label_cost, double* reg_cost, int64_t* ncorrect, bool want_P) {
+    const size_t n = c->plan.msize();
+    double* tail = c->vG + n;
+    TCK(forward_pass(c, c->vB, LD_MODE_COST, tail, want_P));
+    TCK(allreduce(c, tail, TNML_NSCAL_AR));
+    TCK(launch_sqnorm(c, c->vB, n, c->scal + SC_BNORM2));
+    double t[12], bn2;
+    TCK(read_scal(c, tail, 12, t));
+    TCK(read_scal(c, c->scal + SC_BNORM2, 1, &bn2));
+    const double CR = lambda * bn2;                       // :329
+    double C = 0.;
+    for (int l = 0; l < TNML_NL; ++l) { if (label_cost) label_cost[l] = t[l]; C += t[l]; }   // :331-336
+    C += CR;                                              // :338
+    if (cost) *cost = C;
+    if (reg_cost) *reg_cost = CR;
+    if (ncorrect) *ncorrect = (int64_t)llround(t[SC_NCORR]);
+    return 0;
+}
+
+static int upload_bond(tnml_ctx* c, const double* B) {     // host ITensor layout -> tB, vB
+    if (c->currb < 1) return tnml_fail(c, "setBond has not been called");
+    const BondPlan& p = c->plan;
+    const size_t ne = (size_t)p.mL * 4 * p.mR * p.LB;
+    HIPCK(c, hipMemcpyAsync(c->tB, B, sizeof(double) * ne, hipMemcpyHostToDevice, c->stream));
+    return launch_pack(c, bond_pack_desc(p), c->tB, c->vB, nullptr);
+}
+static int download_bond(tnml_ctx* c, const double* Mvec, double* B) {   // M-layout -> host ITensor layout
+    const BondPlan& p = c->plan;
+    const size_t ne = (size_t)p.mL * 4 * p.mR * p.LB;
+    TCK(launch_unpack(c, bond_pack_desc(p), Mvec, c->tB2));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    HIPCK(c, hipMemcpy(B, c->tB2, sizeof(double) * ne, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int tnml_forward(tnml_ctx* c, const double* B, double* P) {
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    TCK(upload_bond(c, B));
+    TCK(forward_pass(c, c->vB, LD_MODE_COST, c->vG + c->plan.msize(), true));
+    const size_t ne = (size_t)TNML_NL * c->NTp;
+    std::vector<char> h(ne * c->esz());
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    HIPCK(c, hipMemcpy(h.data(), c->P, h.size(), hipMemcpyDeviceToHost));
+    for (int i = 0; i < c->NT; ++i)
+        for (int l = 0; l < TNML_NL; ++l)
+            P[(size_t)i * TNML_NL + l] = c->f64() ? ((const double*)h.data())[(size_t)l * c->NTp + i] : (double)((const float*)h.data())[(size_t)l * c->NTp + i];
+    return 0;
+}
+int tnml_gradient(tnml_ctx* c, const double* B, double* G) {
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    TCK(upload_bond(c, B));
+    TCK(grad_eval(c));
+    return download_bond(c, c->vG, G);
+}
+int tnml_quadcost(tnml_ctx* c, const double* B, double lambda, double* cost, double label_cost[TNML_NL], double* reg_cost, int64_t* ncorrect) {
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    TCK(upload_bond(c, B));
+    return quadcost_device(c, lambda, cost, label_cost, reg_cost, ncorrect, false);
+}
+int tnml_cgrad(tnml_ctx* c, double* B, int npass, double lambda, double cconv, tnml_cg_trace* trace) {
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    TCK(upload_bond(c, B));
+    TCK(cgrad_device(c, npass, lambda, cconv, trace));
+    return download_bond(c, c->vB, B);
+}
+int tnml_svd_split(tnml_ctx* c, const double* B, int b, int ha, double cutoff, int maxm, int minm,
+                   double* truncerr, int* newm, double* sv, int* nsv) {
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    if (b < 1 || b > c->N - 1 || (ha != 1 && ha != 2)) return tnml_fail(c, "tnml_svd_split: bad bond/half");
+    HIPCK(c, hipMemcpyAsync(c->tB, B, sizeof(double) * bond_elems(c, b), hipMemcpyHostToDevice, c->stream));
+    TCK(svd_split_device(c, c->tB, b, ha, cutoff, maxm, minm, truncerr, newm, sv, nsv));
+    c->currb = -1;
+    return 0;
+}
+
+// ---- one iteration of the mldmrg loop body (fixedL.cc:478-540) ------------------------------------
+int tnml_bond_update(tnml_ctx* c, int b, int ha, const tnml_sweep_params* sp, tnml_bond_report* rep) {
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    if (ha != 1 && ha != 2) return tnml_fail(c, "tnml_bond_update: half must be 1 or 2");
+    tnml_bond_report local;
+    if (!rep) rep = &local;
+    memset(rep, 0, sizeof *rep);
+    TCK(tnml_set_bond(c, b));                                         // :488
+    const BondPlan p = c->plan;
+    const size_t ne = (size_t)p.mL * 4 * p.mR * p.LB;
+    rep->bond = b; rep->half = ha; rep->c = (ha == 1) ? b : b + 1;    // :482
+    rep->origm = c->W[b].mr;                                          // :493
+    const PackDesc pd = bond_pack_desc(p);
+    TCK(launch_bond_form(c, c->W[b], c->W[b + 1], c->tB));            // :494
+    TCK(launch_pack(c, pd, c->tB, c->vB, nullptr));
+    TCK(cgrad_device(c, sp->npass, sp->lambda, sp->cconv, &rep->cg)); // :504
+    TCK(launch_unpack(c, pd, c->vB, c->tB));
+    TCK(svd_split_device(c, c->tB, b, ha, sp->cutoff, sp->maxm, sp->minm, &rep->truncerr, &rep->newm, nullptr, nullptr));   // :519-522
+    TCK(launch_bond_form(c, c->W[b], c->W[b + 1], c->tB2));           // :527
+    TCK(launch_diffnorm(c, c->tB2, c->tB, ne, c->scal + SC_N - 2));   // :528,:530
+    TCK(launch_pack(c, pd, c->tB2, c->vB, nullptr));
+    TCK(quadcost_device(c, sp->lambda_cost, &rep->cost_after_svd, rep->label_cost, &rep->reg_cost, &rep->ncorrect, false));   // :532
+    double d2[2];
+    TCK(read_scal(c, c->scal + SC_N - 2, 2, d2));
+    rep->norm_newB = std::sqrt(d2[0]); rep->diff_B_newB = std::sqrt(d2[1]);
+    TCK(tnml_shift_env(c, b, ha == 1));                               // :540
+    return 0;
+}

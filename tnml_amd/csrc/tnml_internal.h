@@ -1,0 +1,212 @@
+// tnml_internal.h -- context and kernel-launch declarations shared by the libtnml.so sources.
+//
+// Device data layout (all per rank, "image-fastest" structure of arrays, fp32):
+//   phi    [N][2][NTp]            local features of every image, site-major
+//   label  [NTp]                  int32, -1 for padding images
+//   env_j  [L][m_j][NTp]          environment of site j (L = 10 when it carries the Label index)
+//   U      [L][mO][NTp]           workspace: feature-GEMM output
+//   P, dP  [10][NTp]
+//   Zp     [mO][NTp]
+// NTp = NT_local rounded up to 256; padding images have zero features, so they contribute
+// nothing to any contraction.
+//
+// Bond tensors / CG vectors live in "M-layout" (fp64 master, fp32 GEMM operand):
+//   M[l][k][j], k = 2*x + s  (x = link of the label-free "input" env, s = its site index)
+//               j = 2*y + t  (y = link of the "output" side, t = its site index)
+//   zero padded to Kp x Np (multiples of 16).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+#include <rccl/rccl.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/tnml.h"
+
+#define TNML_NTPAD 256
+
+enum KClass {
+    KC_FGEMM_FWD = 0, KC_FGEMM_SHIFT, KC_LABELDOT, KC_ZPRIME, KC_BGEMM, KC_SLABRED, KC_PACK, KC_VEC,
+    KC_SMALLGEMM, KC_SVD, KC_ALLREDUCE, KC_COUNT
+};
+static const char* const kclass_names[KC_COUNT] = {
+    "fgemm_fwd", "fgemm_shift", "labeldot", "zprime", "bgemm", "slab_reduce", "pack", "cg_vec",
+    "small_gemm", "svd", "allreduce"};
+
+struct EnvSlot {
+    float* ptr = nullptr;   // [L][cap_m][NTp] (rows beyond m unused)
+    int m = 0, L = 0;
+    int big = 0;            // allocated from the label-carrying pool
+};
+
+struct SiteT {
+    double* a = nullptr;    // ITensor layout [ml][2][mr]([10]), capacity fixed at create
+    int ml = 0, mr = 0, L = 1;
+    bool set = false;
+};
+
+// scalar slots of the device-side CG state (doubles)
+enum { SC_COST0 = 0, /* ..9 */ SC_NCORR = 10, SC_PP = 11, SC_RR = 12, SC_ALPHA = 13, SC_BETA = 14,
+       SC_PNORM2 = 15, SC_BNORM2 = 16, SC_PAP = 17, SC_RNORM = 18, SC_COST = 19, SC_CONV = 20, SC_N = 32 };
+#define TNML_NSCAL_AR 16   /* scalars that ride behind G in the all-reduce buffer */
+
+struct BondPlan {
+    int b = -1;
+    int kind = 0;              // 0: Label on RE, 1: Label on LE, 2: Label on B
+    int mL = 0, mR = 0;
+    int mI = 0, mO = 0;        // link dims of input (label-free GEMM side) and output side
+    int Kp = 0, Np = 0, LB = 1;
+    const float* EI = nullptr; const float* phiI = nullptr;   // input env [mI][NTp], its features
+    const float* EX = nullptr; const float* phiO = nullptr;   // other env: [10][mO][NTp] (kind 0/1) or [mO][NTp] (kind 2)
+    size_t msize() const { return (size_t)LB * Kp * Np; }
+};
+
+struct ProfPending { hipEvent_t e0, e1; int kc; };
+
+struct tnml_ctx {
+    tnml_config cfg;
+    int N = 0, NT = 0, NTp = 0, c0 = 0, maxm = 0;
+    hipStream_t stream = nullptr;
+    rocblas_handle blas = nullptr;
+    ncclComm_t comm = nullptr;
+    std::string err;
+    int64_t bytes = 0;
+
+    float* phi = nullptr;      // [N][2][NTp]
+    int* label = nullptr;      // [NTp]
+    float* ones = nullptr;     // [NTp] of 1.0f: the "environment" beyond the chain ends
+    bool data_set = false;
+
+    std::vector<SiteT> W;      // 1..N
+    std::vector<EnvSlot> env;  // 1..N
+    std::vector<float*> pool_small, pool_big;
+    size_t small_elems = 0, big_elems = 0;
+
+    // workspaces
+    // element type of U/P/dP/Zp/slab follows cfg.dtype (double for TNML_F64, float for TNML_F32)
+    void* U = nullptr;         // [10][maxm][NTp]
+    void* P = nullptr;         // [10][NTp]
+    void* dP = nullptr;        // [10][NTp]
+    void* Zp = nullptr;        // [maxm][NTp]
+    float* Mf = nullptr;       // fp32 GEMM operand, M-layout, capacity 10*Kmax*Kmax (env shifts, F32 mode)
+    void* slab = nullptr;      // split-K partial slabs
+    size_t slab_bytes = 0;
+    bool f64() const { return cfg.dtype == TNML_F64; }
+    size_t esz() const { return cfg.dtype == TNML_F64 ? 8 : 4; }
+    double* partials = nullptr;  // [nblk][16]
+    int partial_cap = 0;
+    double *vB = nullptr, *vR = nullptr, *vP = nullptr, *vG = nullptr;   // CG vectors, M-layout fp64 (vG has TNML_NSCAL_AR tail)
+    double* scal = nullptr;    // device scalars [SC_N]
+    double* h_scal = nullptr;  // pinned host mirror
+    double *tB = nullptr, *tB2 = nullptr;   // bond tensors in ITensor layout (fp64)
+    size_t mcap = 0;           // capacity (elements) of M-layout vectors / bond tensors
+    // svd workspaces (fp64)
+    double *sM = nullptr, *sG = nullptr, *sD = nullptr, *sE = nullptr, *sF = nullptr;
+    int* sInfo = nullptr;
+    int svd_n = 0;
+
+    BondPlan plan;
+    int currb = -1;
+
+    // profiling
+    bool prof = false;
+    int64_t prof_launches[KC_COUNT] = {0};
+    double prof_ms[KC_COUNT] = {0};
+    std::vector<ProfPending> prof_pending;
+    std::vector<hipEvent_t> prof_free;
+};
+
+int tnml_fail(tnml_ctx* c, const char* fmt, ...);
+void prof_begin(tnml_ctx* c, int kc, hipEvent_t* e0);
+void prof_end(tnml_ctx* c, int kc, hipEvent_t e0);
+void prof_resolve(tnml_ctx* c);
+
+#define HIPCK(c, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return tnml_fail((c), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+#define TCK(expr) do { int r_ = (expr); if (r_) return r_; } while (0)
+
+// RAII-less profiling bracket around a group of launches of one kernel class
+struct ProfScope {
+    tnml_ctx* c; int kc; hipEvent_t e0 = nullptr;
+    ProfScope(tnml_ctx* c_, int kc_) : c(c_), kc(kc_) { if (c->prof) prof_begin(c, kc, &e0); }
+    ~ProfScope() { if (c->prof) prof_end(c, kc, e0); }
+};
+
+// ---- kernels_gemm.hip ---------------------------------------------------------------------
+struct FgemmArgs {
+    const float* EI; size_t EI_lstride; int mI;      // input env [L?][mI][NTp]
+    const float* phiI;                                // [2][NTp]
+    const float* M; size_t M_lstride; int Kp, Np;     // [L?][Kp][Np] row-major
+    const float* phiO;                                // [2][NTp], null when the output has no site index
+    float* out; size_t out_lstride; int mO;           // [L][mO][NTp]
+    int NTp; int L;
+};
+int launch_fgemm(tnml_ctx* c, const FgemmArgs& a);
+
+struct BgemmArgs {
+    const float* EI; int mI; const float* phiI;      // A operand rows: X[n][2a+s]
+    const float* Zq; int mO; const float* phiO;      // B operand rows: w[n]*phiO[t][n]*Zq[q][n]
+    const float* w; size_t w_lstride;                // per-image weight [L][NTp] or null
+    int Kp, Np, NTp, L;
+};
+// writes split-K partial slabs then reduces them (fixed order, fp64) into G[L][Kp][Np]
+int launch_bgemm(tnml_ctx* c, const BgemmArgs& a, double* G);
+
+// fp64-MFMA flavour (operands converted/expanded to fp64 while staging into LDS)
+struct Fgemm64Args {
+    const float* EI; size_t EI_lstride; int mI;
+    const float* phiI;
+    const double* M; size_t M_lstride; int Kp, Np;    // the fp64 CG vector itself (M-layout)
+    const float* phiO;
+    double* out; size_t out_lstride; int mO;
+    int NTp; int L;
+};
+int launch_fgemm64(tnml_ctx* c, const Fgemm64Args& a);
+struct Bgemm64Args {
+    const float* EI; int mI; const float* phiI;
+    const double* Zq64; const float* Zq32; int mO; const float* phiO;   // exactly one of Zq64 / Zq32
+    const double* w; size_t w_lstride;
+    int Kp, Np, NTp, L;
+};
+int launch_bgemm64(tnml_ctx* c, const Bgemm64Args& a, double* G);
+
+// ---- kernels_stream.hip -------------------------------------------------------------------
+enum { LD_MODE_COST = 0, LD_MODE_PAP = 1, LD_MODE_FWD = 2 };
+struct LdotArgs {
+    const void* A; size_t A_lstride;    // label-carrying operand [10][mq][NTp] (elements)
+    const void* Bv;                     // label-free operand [mq][NTp]
+    int a_is_env;                       // 1: A is an fp32 environment and Bv the GEMM output; 0: the reverse
+    int mq, NTp;
+    const int* label;
+    void* P; void* dP;                  // [10][NTp] in the context's arithmetic type
+    int mode;
+};
+// partial sums -> scal_out[0..11] (device); deterministic
+int launch_labeldot(tnml_ctx* c, const LdotArgs& a, double* scal_out);
+int launch_zprime(tnml_ctx* c, const float* EL, size_t lstride, const void* dP, void* Z, int mq, int NTp);
+int launch_features_u8(tnml_ctx* c, const uint8_t* d_pix, int N, int NT, int NTp, float* phi);
+
+// ---- kernels_small.hip --------------------------------------------------------------------
+struct PackDesc {       // M[l][2x+s][TO==2 ? 2y+t : y] <-> T[off + x*sx + s*ss + y*sy + t*st + l*sl]
+    int nx, ny, TO, L;
+    long sx, ss, sy, st, sl;
+    int Kp, Np;
+};
+int launch_pack(tnml_ctx* c, const PackDesc& d, const double* T, double* Md, float* Mf);   // either output may be null
+int launch_unpack(tnml_ctx* c, const PackDesc& d, const double* Md, double* T);
+int launch_cvt(tnml_ctx* c, const double* src, float* dst, size_t n);
+int launch_bond_form(tnml_ctx* c, const SiteT& A1, const SiteT& A2, double* B);            // B = A1*A2, ITensor layout
+// CG vector algebra on device scalars (single-block kernels)
+int launch_cg_init(tnml_ctx* c, size_t n, double lambda);          // r = G - lambda B ; p = r ; RR = |r|^2
+int launch_cg_step(tnml_ctx* c, size_t n, double lambda);          // pAp, alpha, B += alpha p
+int launch_cg_resid(tnml_ctx* c, size_t n, double lambda, double cconv);   // nr, beta, r, cost, conv, p
+int launch_sqnorm(tnml_ctx* c, const double* x, size_t n, double* out);    // out[0] = |x|^2
+int launch_diffnorm(tnml_ctx* c, const double* x, const double* y, size_t n, double* out2);  // out2[0]=|x|^2, out2[1]=|x-y|^2
+int launch_fill_f32(tnml_ctx* c, float* p, float v, size_t n);
+
+// ---- svd.hip ------------------------------------------------------------------------------
+int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cutoff, int maxm, int minm,
+                     double* truncerr, int* newm, double* sv_host, int* nsv);

@@ -1,0 +1,244 @@
+"""Host-side mirror of the reference's fixedL interface on top of the C-ABI (include/tnml.h).
+
+Names follow /root/reference/fixedL.cc so that parity tests read like the reference:
+  TrainStates.{init,setBond,shiftE}   fixedL.cc:122-233   (device resident environments)
+  quadcost / cgrad                    fixedL.cc:280-445
+  mldmrg                              fixedL.cc:451-570   (sweep loop; one C call per bond update)
+Tensors cross this layer as numpy arrays with ITensor index order as axis order:
+A_j[a,s,r(,L)], B[a,s,t,r(,L)], E[n,m(,L)].  Everything here calls the HIP path; nothing falls
+back to the CPU and nothing imports the oracle.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _lib
+
+NL = _lib.NL
+
+
+class TnmlError(RuntimeError):
+    pass
+
+
+class TrainStates:
+    """Training set + environments + W replica of one rank (TrainStates + MPS W of fixedL.cc)."""
+
+    def __init__(self, labels, N, maxm, pixels=None, phi=None, device=0, rank=0, nranks=1, NT_total=None, dtype="f64"):
+        self._L = _lib.load()
+        self._h = C.c_void_p()
+        labels = np.ascontiguousarray(labels, dtype=np.int32)
+        self.NT = int(labels.shape[0])
+        self.N = int(N)
+        self.c0 = self.N // 2
+        self.maxm = int(maxm)
+        self.rank, self.nranks = rank, nranks
+        self.NT_total = int(NT_total if NT_total is not None else self.NT)
+        self.dtype = dtype
+        cfg = _lib.Config(device, rank, nranks, self.N, self.NT, self.NT_total, self.maxm, _lib.DTYPES[dtype], 0)
+        rc = self._L.tnml_create(C.byref(self._h), C.byref(cfg))
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise TnmlError(self._L.tnml_last_error(None).decode())
+        if pixels is not None:
+            px = np.ascontiguousarray(pixels, dtype=np.uint8)
+            assert px.shape == (self.NT, self.N)
+            self._ck(self._L.tnml_set_data_u8(self._h, px.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                              labels.ctypes.data_as(C.POINTER(C.c_int32))))
+        elif phi is not None:
+            ph = np.ascontiguousarray(phi, dtype=np.float64)
+            assert ph.shape == (self.NT, self.N, 2)
+            self._ck(self._L.tnml_set_data_phi(self._h, _lib.dptr(ph), labels.ctypes.data_as(C.POINTER(C.c_int32))))
+        else:
+            raise ValueError("need pixels or phi")
+
+    # -- plumbing
+    def _ck(self, rc):
+        if rc != 0:
+            raise TnmlError(self._L.tnml_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.tnml_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def comm_init(self, unique_id: bytes):
+        buf = C.create_string_buffer(unique_id, 128)
+        self._ck(self._L.tnml_comm_init(self._h, buf))
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        if _lib.load().tnml_comm_unique_id(buf) != 0:
+            raise TnmlError("tnml_comm_unique_id failed")
+        return buf.raw
+
+    def size(self):
+        return self.NT
+
+    def synchronize(self):
+        self._ck(self._L.tnml_synchronize(self._h))
+
+    def device_bytes(self):
+        return self._L.tnml_device_bytes(self._h)
+
+    # -- W
+    def set_mps(self, W):
+        for j, A in enumerate(W, start=1):
+            A = np.asarray(A, dtype=np.float64)
+            self._ck(self._L.tnml_set_site(self._h, j, A.shape[0], A.shape[2], int(A.ndim == 4), _lib.dptr(_lib.flat(A))))
+
+    def get_site(self, j):
+        ml, mr, hl = C.c_int(), C.c_int(), C.c_int()
+        self._ck(self._L.tnml_site_dims(self._h, j, ml, mr, hl))
+        shape = (ml.value, 2, mr.value) + ((NL,) if hl.value else ())
+        buf = np.empty(int(np.prod(shape)))
+        self._ck(self._L.tnml_get_site(self._h, j, _lib.dptr(buf)))
+        return buf.reshape(shape, order="F")
+
+    def get_mps(self):
+        return [self.get_site(j) for j in range(1, self.N + 1)]
+
+    # -- TrainStates
+    def init(self):
+        self._ck(self._L.tnml_env_init(self._h))
+
+    def setBond(self, b):
+        self._ck(self._L.tnml_set_bond(self._h, b))
+
+    def shiftE(self, b, from_left):
+        self._ck(self._L.tnml_shift_env(self._h, b, int(bool(from_left))))
+
+    def env(self, j):
+        m, hl = C.c_int(), C.c_int()
+        self._ck(self._L.tnml_env_dims(self._h, j, m, hl))
+        L = NL if hl.value else 1
+        buf = np.empty((self.NT, m.value * L))
+        self._ck(self._L.tnml_get_env(self._h, j, _lib.dptr(buf)))
+        if hl.value:
+            return buf.reshape(self.NT, NL, m.value).transpose(0, 2, 1).copy()
+        return buf
+
+    # -- bond tensor and per-image contractions
+    def bond_shape(self, b):
+        mL, mR, lab = C.c_int(), C.c_int(), C.c_int()
+        self._ck(self._L.tnml_bond_dims(self._h, b, mL, mR, lab))
+        return (mL.value, 2, 2, mR.value) + ((NL,) if lab.value else ())
+
+    def bond_tensor(self, b):
+        shape = self.bond_shape(b)
+        buf = np.empty(int(np.prod(shape)))
+        self._ck(self._L.tnml_bond_tensor(self._h, b, _lib.dptr(buf)))
+        return buf.reshape(shape, order="F")
+
+    def forward(self, B):
+        P = np.empty((self.NT, NL))
+        self._ck(self._L.tnml_forward(self._h, _lib.dptr(_lib.flat(B)), _lib.dptr(P)))
+        return P
+
+    def gradient(self, B):
+        G = np.empty(B.size)
+        self._ck(self._L.tnml_gradient(self._h, _lib.dptr(_lib.flat(B)), _lib.dptr(G)))
+        return G.reshape(B.shape, order="F")
+
+    def quadcost(self, B, lam):
+        lc = np.empty(NL)
+        cost, cr, nc = C.c_double(), C.c_double(), C.c_int64()
+        self._ck(self._L.tnml_quadcost(self._h, _lib.dptr(_lib.flat(B)), lam, C.byref(cost), _lib.dptr(lc),
+                                       C.byref(cr), C.byref(nc)))
+        return cost.value, lc, cr.value, nc.value
+
+    def cgrad(self, B, npass, lam, cconv):
+        buf = _lib.flat(B)
+        tr = _lib.CgTrace()
+        self._ck(self._L.tnml_cgrad(self._h, _lib.dptr(buf), npass, lam, cconv, C.byref(tr)))
+        return buf.reshape(B.shape, order="F"), _trace_dict(tr)
+
+    def svd_split(self, B, b, ha, cutoff, maxm, minm):
+        te, m, nsv = C.c_double(), C.c_int(), C.c_int()
+        sv = np.empty(4 * self.maxm + 8)
+        self._ck(self._L.tnml_svd_split(self._h, _lib.dptr(_lib.flat(B)), b, ha, cutoff, maxm, minm, C.byref(te),
+                                        C.byref(m), _lib.dptr(sv), C.byref(nsv)))
+        return m.value, te.value, sv[:nsv.value].copy()
+
+    def bond_update(self, b, ha, maxm, minm, cutoff, npass, lam, cconv, lam_cost=None):
+        sp = _lib.SweepParams(maxm, minm, cutoff, npass, lam, lam if lam_cost is None else lam_cost, cconv)
+        rep = _lib.BondReport()
+        self._ck(self._L.tnml_bond_update(self._h, b, ha, C.byref(sp), C.byref(rep)))
+        return dict(bond=rep.bond, half=rep.half, c=rep.c, origm=rep.origm, newm=rep.newm, truncerr=rep.truncerr,
+                    norm_newB=rep.norm_newB, diff=rep.diff_B_newB, cost=rep.cost_after_svd,
+                    label_cost=np.array(rep.label_cost[:]), reg_cost=rep.reg_cost, ncorrect=rep.ncorrect,
+                    cg=_trace_dict(rep.cg))
+
+    # -- measurement
+    def profile(self, on):
+        self._ck(self._L.tnml_profile_enable(self._h, int(on)))
+
+    def profile_reset(self):
+        self._ck(self._L.tnml_profile_reset(self._h))
+
+    def profile_read(self):
+        out = {}
+        name = C.create_string_buffer(64)
+        for i in range(self._L.tnml_profile_count(self._h)):
+            n, ms = C.c_int64(), C.c_double()
+            self._ck(self._L.tnml_profile_get(self._h, i, name, C.byref(n), C.byref(ms)))
+            out[name.value.decode()] = (n.value, ms.value)
+        return out
+
+
+def _trace_dict(tr):
+    n = tr.npass_done
+    k = n if tr.converged else max(n - 1, 0)
+    return dict(npass_done=n, converged=bool(tr.converged), cost=list(tr.cost[:k]), rnorm=list(tr.rnorm[:k]),
+                pAp=list(tr.pAp[:n]), alpha=list(tr.alpha[:n]))
+
+
+def quadcost(B, ts, lam=0.0):
+    """fixedL.cc:280-344: returns the un-normalised cost C = sum_l C_l + lambda|B|^2"""
+    return ts.quadcost(B, lam)[0]
+
+
+def cgrad(B, ts, npass=4, lam=0.0, cconv=1e-10):
+    """fixedL.cc:349-445"""
+    return ts.cgrad(B, npass, lam, cconv)
+
+
+def mldmrg(ts, nsweep, maxm, minm, cutoff, npass, lam, cconv, max_bonds=0, log=None):
+    """fixedL.cc:451-570: the sweep loop; emits the reference's log lines through `log` if given."""
+    NT = float(ts.NT_total)
+    reports = []
+    for sw in range(1, nsweep + 1):
+        if log:
+            log("\nSweep %d maxm=%d minm=%d" % (sw, maxm, minm))
+        b, ha = 1, 1
+        while ha <= 2:
+            if max_bonds and len(reports) >= max_bonds:
+                return reports
+            r = ts.bond_update(b, ha, maxm, minm, cutoff, npass, lam, cconv)
+            r["sweep"] = sw
+            reports.append(r)
+            if log:
+                log("Sweep %d Half %d Bond %d" % (sw, ha, r["c"]))
+                log("In cgrad, lambda = %.3E" % lam)
+                for p in range(r["cg"]["npass_done"]):
+                    log("  Conj grad pass %d" % (p + 1))
+                    if p < len(r["cg"]["cost"]):
+                        log("  Cost = %.10f" % (r["cg"]["cost"][p] / NT))
+                        log("  |r| = %.1E" % r["cg"]["rnorm"][p])
+                log("SVD trunc err = %.2E" % r["truncerr"])
+                log("Original m=%d, New m=%d" % (r["origm"], r["newm"]))
+                log("|B-newB| = %.3E" % r["diff"])
+                for l in range(NL):
+                    log("  Label l=%d C%d = %.10f" % (l, l, r["label_cost"][l] / NT))
+                log("  Reg. cost CR = %.10f" % (r["reg_cost"] / NT))
+                log("Percent correct = %.4f%%, # incorrect = %d/%d" % (r["ncorrect"] * 100.0 / NT, NT - r["ncorrect"], NT))
+                log("--> After SVD, Cost = %.10f" % (r["cost"] / NT))
+            b, ha = _lib.sweepnext(b, ha, ts.N)
+    return reports

@@ -1,0 +1,133 @@
+"""ctypes binding of libtnml.so (include/tnml.h) -- the only way Python reaches the HIP path.
+
+`import torch` happens first on purpose: the PyTorch wheel bundles its own ROCm runtime
+(libamdhip64.so.7, librccl.so.1, librocblas.so.5, librocsolver.so.0 -- same SONAMEs as
+/opt/rocm/lib), and a process must never hold two HIP runtimes.  Loading torch first makes
+libtnml.so bind to the copies torch already mapped.  The library fails loudly when it is missing
+or when no HIP device is usable: there is no CPU fallback on the product path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
+
+NL = 10
+MAX_PASS = 64
+DTYPES = {"f32": 0, "f64": 1}    # TNML_F32 / TNML_F64 (include/tnml.h)
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtnml.so")
+
+EXPORTS = [
+    "tnml_create", "tnml_destroy", "tnml_last_error", "tnml_comm_unique_id", "tnml_comm_init",
+    "tnml_set_data_u8", "tnml_set_data_phi", "tnml_set_site", "tnml_site_dims", "tnml_get_site",
+    "tnml_env_init", "tnml_set_bond", "tnml_shift_env", "tnml_env_dims", "tnml_get_env",
+    "tnml_bond_dims", "tnml_bond_tensor", "tnml_forward", "tnml_gradient", "tnml_quadcost",
+    "tnml_cgrad", "tnml_svd_split", "tnml_bond_update", "tnml_truncate", "tnml_sweepnext",
+    "tnml_shard_bounds", "tnml_profile_enable", "tnml_profile_count", "tnml_profile_get",
+    "tnml_profile_reset", "tnml_synchronize", "tnml_device_bytes",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int), ("rank", C.c_int), ("nranks", C.c_int), ("N", C.c_int),
+                ("NT_local", C.c_int), ("NT_total", C.c_int64), ("maxm", C.c_int), ("dtype", C.c_int),
+                ("svd_backend", C.c_int)]
+
+
+class CgTrace(C.Structure):
+    _fields_ = [("npass_done", C.c_int), ("converged", C.c_int), ("cost", C.c_double * MAX_PASS),
+                ("rnorm", C.c_double * MAX_PASS), ("pAp", C.c_double * MAX_PASS), ("alpha", C.c_double * MAX_PASS)]
+
+
+class SweepParams(C.Structure):
+    _fields_ = [("maxm", C.c_int), ("minm", C.c_int), ("cutoff", C.c_double), ("npass", C.c_int),
+                ("lambda_", C.c_double), ("lambda_cost", C.c_double), ("cconv", C.c_double)]
+
+
+class BondReport(C.Structure):
+    _fields_ = [("bond", C.c_int), ("half", C.c_int), ("c", C.c_int), ("origm", C.c_int), ("newm", C.c_int),
+                ("truncerr", C.c_double), ("norm_newB", C.c_double), ("diff_B_newB", C.c_double),
+                ("cost_after_svd", C.c_double), ("label_cost", C.c_double * NL), ("reg_cost", C.c_double),
+                ("ncorrect", C.c_int64), ("cg", CgTrace)]
+
+
+_lib = None
+
+
+def load():
+    """Load libtnml.so; raises (never falls back) when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "or `make -C tnml_amd/csrc` (the HIP extension is mandatory, there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
+    L.tnml_create.argtypes = [C.POINTER(vp), C.POINTER(Config)]
+    L.tnml_destroy.argtypes = [vp]
+    L.tnml_last_error.restype = C.c_char_p
+    L.tnml_last_error.argtypes = [vp]
+    L.tnml_comm_unique_id.argtypes = [vp]
+    L.tnml_comm_init.argtypes = [vp, vp]
+    L.tnml_set_data_u8.argtypes = [vp, C.POINTER(C.c_uint8), C.POINTER(C.c_int32)]
+    L.tnml_set_data_phi.argtypes = [vp, dp, C.POINTER(C.c_int32)]
+    L.tnml_set_site.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, dp]
+    L.tnml_site_dims.argtypes = [vp, C.c_int, ip, ip, ip]
+    L.tnml_get_site.argtypes = [vp, C.c_int, dp]
+    L.tnml_env_init.argtypes = [vp]
+    L.tnml_set_bond.argtypes = [vp, C.c_int]
+    L.tnml_shift_env.argtypes = [vp, C.c_int, C.c_int]
+    L.tnml_env_dims.argtypes = [vp, C.c_int, ip, ip]
+    L.tnml_get_env.argtypes = [vp, C.c_int, dp]
+    L.tnml_bond_dims.argtypes = [vp, C.c_int, ip, ip, ip]
+    L.tnml_bond_tensor.argtypes = [vp, C.c_int, dp]
+    L.tnml_forward.argtypes = [vp, dp, dp]
+    L.tnml_gradient.argtypes = [vp, dp, dp]
+    L.tnml_quadcost.argtypes = [vp, dp, C.c_double, dp, dp, dp, C.POINTER(C.c_int64)]
+    L.tnml_cgrad.argtypes = [vp, dp, C.c_int, C.c_double, C.c_double, C.POINTER(CgTrace)]
+    L.tnml_svd_split.argtypes = [vp, dp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, dp, ip, dp, ip]
+    L.tnml_bond_update.argtypes = [vp, C.c_int, C.c_int, C.POINTER(SweepParams), C.POINTER(BondReport)]
+    L.tnml_truncate.argtypes = [dp, C.c_int, C.c_int, C.c_int, C.c_double, dp]
+    L.tnml_sweepnext.argtypes = [ip, ip, C.c_int]
+    L.tnml_sweepnext.restype = None
+    L.tnml_shard_bounds.argtypes = [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.tnml_shard_bounds.restype = None
+    L.tnml_profile_enable.argtypes = [vp, C.c_int]
+    L.tnml_profile_count.argtypes = [vp]
+    L.tnml_profile_get.argtypes = [vp, C.c_int, C.c_char_p, C.POINTER(C.c_int64), dp]
+    L.tnml_profile_reset.argtypes = [vp]
+    L.tnml_synchronize.argtypes = [vp]
+    L.tnml_device_bytes.argtypes = [vp]
+    L.tnml_device_bytes.restype = C.c_int64
+    _lib = L
+    return L
+
+
+def dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def flat(a):
+    """fp64 copy flattened in ITensor (first-index-fastest) order"""
+    return np.array(np.asarray(a, dtype=np.float64).ravel(order="F"), copy=True)
+
+
+def truncate(p, maxm, minm, cutoff):
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    te = C.c_double()
+    m = load().tnml_truncate(dptr(p), len(p), maxm, minm, cutoff, C.byref(te))
+    return m, te.value
+
+
+def sweepnext(b, ha, N):
+    bb, hh = C.c_int(b), C.c_int(ha)
+    load().tnml_sweepnext(C.byref(bb), C.byref(hh), N)
+    return bb.value, hh.value
+
+
+def shard_bounds(NT_total, nranks, rank):
+    b, e = C.c_int64(), C.c_int64()
+    load().tnml_shard_bounds(NT_total, nranks, rank, C.byref(b), C.byref(e))
+    return b.value, e.value
