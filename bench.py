@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""bench.py -- two-site bond updates/sec of the fixedL sweep on MI355X (BASELINE.json metric).
+
+Workload (config.workload): BASELINE config 3 -- N=784 sites, maxm=120, 60 000 synthetic
+MNIST-shaped images (no MNIST files offline), random-init weight MPS at bond dimension 120,
+Npass=4, lambda=1e-3, cutoff=1e-10, minm=60.  One "step" = one iteration of the mldmrg loop body
+(fixedL.cc:478-540): setBond + cgrad(Npass) + svd + quadcost + shiftE, device resident.
+At --gpus N the 60 000 images are sharded over N ranks (strong scaling) and the gradient / cost
+partials are summed by an RCCL all-reduce inside the library; the control plane (unique-id
+broadcast, barriers, max-over-ranks timing) uses torch.distributed.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md section "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+F64_MFMA_PEAK_TF = 78.6      # MI355X FP64 matrix peak (AMD spec); 77.4 TF measured (profiles/r01_probe64.txt)
+F32_MFMA_PEAK_TF = 157.3     # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md "HBM3E peak BW"
+
+
+def cpu_baseline(maxm, npass, lam, cutoff, nthread, NT_total):
+    """The CPU oracle (dense t.v restatement of fixedL.cc) timed on the host cores on a bounded
+    sample: N=20 sites (a bond update costs O(NT m^2), independent of N -- SURVEY.md section 5),
+    interior bonds 8..9 at the full bond dimension, NT_s images; the rate is scaled to NT_total."""
+    from oracle import pyoracle
+    from tnml_amd import synth
+    N = 20
+    NT_s = 240 if maxm >= 100 else 2000
+    NT_s = (NT_s // nthread) * nthread
+    labels = synth.synthetic_labels(NT_s, seed=7)
+    pixels = synth.synthetic_images(N, labels, seed=7)
+    phi = pyoracle.features_series(pixels)
+    W = synth.random_mps(N, maxm, seed=1)
+    o = pyoracle.Oracle(phi, labels, W, nthread=nthread, nbatch=1)
+    o.init()
+    b0 = 8
+    for bb in range(1, b0):
+        o.shiftE(bb, True)
+    nb = 2
+    t0 = time.time()
+    for b in range(b0, b0 + nb):                      # the mldmrg loop body, fixedL.cc:482-540
+        o.set_bond(b)
+        B = o.bond_tensor(b)
+        B, _ = o.cgrad(B, npass, lam, 1e-10)
+        o.svd_split(B, b, 1, cutoff, maxm, maxm // 2)
+        o.quadcost(o.bond_tensor(b), lam)
+        o.shiftE(b, True)
+    dt = time.time() - t0
+    rate_sample = nb / dt
+    return {
+        "value": rate_sample * NT_s / NT_total,
+        "unit": "bond updates/s",
+        "cores": nthread,
+        "kind": "port",
+        "sample": "oracle (dense t.v fp64 restatement of fixedL.cc, %d threads): %d bond updates at m=%d on %d images took "
+                  "%.2f s (%.3f bond updates/s); value = that rate x %d/%d (work per bond update is linear in the "
+                  "image count)" % (nthread, nb, maxm, NT_s, dt, rate_sample, NT_s, NT_total),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--sites", type=int, default=784)
+    ap.add_argument("--images", type=int, default=60000)
+    ap.add_argument("--maxm", type=int, default=120)
+    ap.add_argument("--npass", type=int, default=4)
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    from tnml_amd import lib, synth
+    from tnml_amd.fixedl import TrainStates
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    N, NT, maxm = args.sites, args.images, args.maxm
+    lam, cutoff, cconv, npass, minm = 1e-3, 1e-10, 1e-10, args.npass, max(1, maxm // 2)
+
+    labels = synth.synthetic_labels(NT)
+    pixels = synth.synthetic_images(N, labels)
+    W = synth.random_mps(N, maxm, seed=1)
+    lo, hi = lib.shard_bounds(NT, world, rank)
+    ts = TrainStates(labels[lo:hi], N, maxm, pixels=pixels[lo:hi], device=local_rank, rank=rank, nranks=world,
+                     NT_total=NT, dtype=args.dtype)
+    del pixels
+    if world > 1:
+        uid = [TrainStates.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ts.comm_init(uid[0])
+    ts.set_mps(W)
+    t_init = time.time()
+    ts.init()
+    ts.synchronize()
+    t_init = time.time() - t_init
+
+    def sync():
+        ts.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    b, ha = 1, 1
+    reports = []
+
+    def step():
+        nonlocal b, ha
+        r = ts.bond_update(b, ha, maxm, minm, cutoff, npass, lam, cconv)
+        reports.append(r)
+        b, ha = lib.sweepnext(b, ha, N)
+        if ha > 2:
+            b, ha = 1, 1
+
+    for _ in range(args.warmup):
+        step()
+    ts.profile(True)
+    ts.profile_reset()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    ts.profile(False)
+    prof = ts.profile_read()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+
+    if rank == 0:
+        timed = reports[args.warmup:]
+        NTl = hi - lo
+        # dominant kernel: the feature GEMM (T = X*B_mat).  Algorithmic flops per launch = SURVEY.md 8(d)
+        # GEMM term 2*NT*(2mL)*(2mR) for the images one launch processes (x10 on the two Label-on-B bonds).
+        n_fg, ms_fg = prof.get("fgemm_fwd", (0, 0.0))
+        # every timed bond calls the feature GEMM 2*npass+1 times with its own (mL, mR); average the flops
+        fl = []
+        for r in timed:
+            fl.append(2.0 * NTl * (2 * r["mL"]) * (2 * r["mR"]) * (10 if r["label_on_B"] else 1))
+        flops_per_launch = float(np.mean(fl)) if fl else 0.0
+        avg_ms = ms_fg / max(n_fg, 1)
+        achieved_tf = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        peak = F64_MFMA_PEAK_TF if args.dtype == "f64" else F32_MFMA_PEAK_TF
+        out = {
+            "metric": "two-site bond updates/sec",
+            "value": args.steps / elapsed,
+            "unit": "bond updates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": "fixedL N=%d, maxm=%d, %d images (BASELINE config 3), Npass=%d, lambda=%g, "
+                                   "bonds %d..%d of sweep 1 (m=%d interior)" % (N, maxm, NT, npass, lam,
+                                                                               timed[0]["bond"] if timed else 0,
+                                                                               timed[-1]["bond"] if timed else 0, maxm),
+                       "global_images": NT, "sites": N, "maxm": maxm, "parallelism": "dp%d (image sharding + RCCL all-reduce)" % world},
+            "roofline": {"bound": "mfma", "kernel": "k_fgemm64" if args.dtype == "f64" else "k_fgemm",
+                         "achieved": achieved_tf, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved_tf / peak, "traffic": None,
+                         "avg_launch_ms": avg_ms, "launches": n_fg, "flops_per_launch": flops_per_launch},
+            "kernel_ms_per_step": {k: v[1] / args.steps for k, v in prof.items() if v[0]},
+            "env_init_s": t_init,
+            "device_gb": ts.device_bytes() / 1e9,
+            "last_cost_per_image": timed[-1]["cost"] / NT if timed else None,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            ncore = os.cpu_count() or 1
+            out["cpu_baseline"] = cpu_baseline(maxm, npass, lam, cutoff, min(16, ncore), NT)   # paralleldo.h:55-56 caps at 16
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ts.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -78,6 +78,7 @@ typedef struct {
 /* mirrors the prints of fixedL.cc:490,523-533,341-342 */
 typedef struct {
     int bond, half, c;
+    int mL, mR, label_on_B;                /* outer link dimensions of the bond tensor; Label on B? */
     int origm, newm;
     double truncerr;
     double norm_newB, diff_B_newB;

@@ -592,6 +592,7 @@ int tnml_bond_update(tnml_ctx* c, int b, int ha, const tnml_sweep_params* sp, tn
     const size_t ne = (size_t)p.mL * 4 * p.mR * p.LB;
     rep->bond = b; rep->half = ha; rep->c = (ha == 1) ? b : b + 1;    // :482
     rep->origm = c->W[b].mr;                                          // :493
+    rep->mL = p.mL; rep->mR = p.mR; rep->label_on_B = (p.kind == 2);
     const PackDesc pd = bond_pack_desc(p);
     TCK(launch_bond_form(c, c->W[b], c->W[b + 1], c->tB));            // :494
     TCK(launch_pack(c, pd, c->tB, c->vB, nullptr));

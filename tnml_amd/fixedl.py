@@ -171,7 +171,7 @@ class TrainStates:
         sp = _lib.SweepParams(maxm, minm, cutoff, npass, lam, lam if lam_cost is None else lam_cost, cconv)
         rep = _lib.BondReport()
         self._ck(self._L.tnml_bond_update(self._h, b, ha, C.byref(sp), C.byref(rep)))
-        return dict(bond=rep.bond, half=rep.half, c=rep.c, origm=rep.origm, newm=rep.newm, truncerr=rep.truncerr,
+        return dict(bond=rep.bond, half=rep.half, c=rep.c, mL=rep.mL, mR=rep.mR, label_on_B=bool(rep.label_on_B), origm=rep.origm, newm=rep.newm, truncerr=rep.truncerr,
                     norm_newB=rep.norm_newB, diff=rep.diff_B_newB, cost=rep.cost_after_svd,
                     label_cost=np.array(rep.label_cost[:]), reg_cost=rep.reg_cost, ncorrect=rep.ncorrect,
                     cg=_trace_dict(rep.cg))

@@ -46,7 +46,8 @@ class SweepParams(C.Structure):
 
 
 class BondReport(C.Structure):
-    _fields_ = [("bond", C.c_int), ("half", C.c_int), ("c", C.c_int), ("origm", C.c_int), ("newm", C.c_int),
+    _fields_ = [("bond", C.c_int), ("half", C.c_int), ("c", C.c_int), ("mL", C.c_int), ("mR", C.c_int),
+                ("label_on_B", C.c_int), ("origm", C.c_int), ("newm", C.c_int),
                 ("truncerr", C.c_double), ("norm_newB", C.c_double), ("diff_B_newB", C.c_double),
                 ("cost_after_svd", C.c_double), ("label_cost", C.c_double * NL), ("reg_cost", C.c_double),
                 ("ncorrect", C.c_int64), ("cg", CgTrace)]
