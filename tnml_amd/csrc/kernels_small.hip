@@ -91,10 +91,14 @@ int launch_bond_form(tnml_ctx* c, const SiteT& A1, const SiteT& A2, double* B) {
     return 0;
 }
 
-// ---- block reductions (fp64, fixed order) -----------------------------------------------------
-#define VB 1024
+// ---- CG vector algebra: two-phase multi-workgroup kernels (fp64, fixed summation order) ---------
+// phase 1: every workgroup reduces its contiguous slice to partial sums part[blk][2];
+// phase 2: every workgroup re-reduces the partials in the same order (identical scalars everywhere),
+//          derives the CG scalars and updates its slice; workgroup 0 publishes the scalars.
+// A single workgroup streams at ~25-50 GB/s (one CU), which made the 1-block versions 40-90 us each.
+#define VB 256
+#define VNB_MAX 256
 static __device__ __forceinline__ double block_sum(double v, double* sh) {
-    // deterministic: every thread writes its partial, thread 0.. tree over fixed layout
     const int tid = threadIdx.x;
     sh[tid] = v;
     __syncthreads();
@@ -106,110 +110,153 @@ static __device__ __forceinline__ double block_sum(double v, double* sh) {
     __syncthreads();
     return r;
 }
+static __device__ __forceinline__ void slice(size_t n, size_t* lo, size_t* hi) {
+    const size_t per = (n + gridDim.x - 1) / gridDim.x;
+    *lo = per * blockIdx.x; *hi = *lo + per; if (*hi > n) *hi = n; if (*lo > n) *lo = n;
+}
+static __device__ __forceinline__ void sum_partials(const double* part, int nb, double* s0, double* s1) {
+    double a = 0., b = 0.;
+    for (int k = 0; k < nb; ++k) { a += part[2 * k]; b += part[2 * k + 1]; }   // same order in every workgroup
+    *s0 = a; *s1 = b;
+}
 
-// r = G - lambda*B (fixedL.cc:385-386); p = r (:388); RR = |r|^2
-__global__ __launch_bounds__(VB) void k_cg_init(const double* __restrict__ G, const double* __restrict__ B, double* __restrict__ R,
-                                               double* __restrict__ Pv, size_t n, double lambda, double* __restrict__ scal) {
+// r = G - lambda*B (fixedL.cc:385-386); p = r (:388); partial |r|^2
+__global__ __launch_bounds__(VB) void k_cg_init1(const double* __restrict__ G, const double* __restrict__ B, double* __restrict__ R,
+                                                double* __restrict__ Pv, size_t n, double lambda, double* __restrict__ part) {
     __shared__ double sh[VB];
+    size_t lo, hi; slice(n, &lo, &hi);
     double acc = 0.;
-    for (size_t i = threadIdx.x; i < n; i += VB) {
+    for (size_t i = lo + threadIdx.x; i < hi; i += VB) {
         double r = G[i];
         if (lambda != 0.) r = r - lambda * B[i];
         R[i] = r; Pv[i] = r;
         acc += r * r;
     }
-    const double rr = block_sum(acc, sh);
-    if (threadIdx.x == 0) scal[SC_RR] = rr;
+    const double s = block_sum(acc, sh);
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = s; part[2 * blockIdx.x + 1] = 0.; }
+}
+__global__ void k_cg_init2(const double* __restrict__ part, int nb, double* __restrict__ scal, int rr_out) {
+    if (threadIdx.x == 0) { double a, b; sum_partials(part, nb, &a, &b); scal[rr_out] = a; }
+}
+// partial |x|^2 (and |y|^2)
+__global__ __launch_bounds__(VB) void k_norm1(const double* __restrict__ x, const double* __restrict__ y, size_t n, double* __restrict__ part) {
+    __shared__ double sh[VB];
+    size_t lo, hi; slice(n, &lo, &hi);
+    double a = 0., b = 0.;
+    for (size_t i = lo + threadIdx.x; i < hi; i += VB) { a += x[i] * x[i]; if (y) b += y[i] * y[i]; }
+    const double s0 = block_sum(a, sh);
+    const double s1 = block_sum(b, sh);
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = s0; part[2 * blockIdx.x + 1] = s1; }
 }
 // pAp = sum_n|p v_n|^2 + lambda|p|^2 (:402-403); a = |r|^2/pAp (:405); B = B + a p (:406)
-__global__ __launch_bounds__(VB) void k_cg_step(double* __restrict__ B, const double* __restrict__ Pv, size_t n, double lambda,
-                                               const double* __restrict__ tail, double* __restrict__ scal) {
-    __shared__ double sh[VB];
-    double acc = 0.;
-    for (size_t i = threadIdx.x; i < n; i += VB) acc += Pv[i] * Pv[i];
-    const double pn2 = block_sum(acc, sh);
+__global__ __launch_bounds__(VB) void k_cg_step2(double* __restrict__ B, const double* __restrict__ Pv, size_t n, double lambda,
+                                                const double* __restrict__ tail, const double* __restrict__ part, int nb,
+                                                double* __restrict__ scal, int rr_in) {
+    double pn2, unused; sum_partials(part, nb, &pn2, &unused);
     const double pAp = tail[SC_PP] + lambda * pn2;
-    const double a = scal[SC_RR] / pAp;
-    for (size_t i = threadIdx.x; i < n; i += VB) B[i] = B[i] + a * Pv[i];
-    if (threadIdx.x == 0) { scal[SC_PNORM2] = pn2; scal[SC_PAP] = pAp; scal[SC_ALPHA] = a; }
+    const double a = scal[rr_in] / pAp;
+    size_t lo, hi; slice(n, &lo, &hi);
+    for (size_t i = lo + threadIdx.x; i < hi; i += VB) B[i] = B[i] + a * Pv[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { scal[SC_PNORM2] = pn2; scal[SC_PAP] = pAp; scal[SC_ALPHA] = a; }
 }
-// nr = G - lambda B (:421-422); beta = sqr(norm(nr)/norm(r)) (:423); r = nr (:424);
-// C = sum dP^2 + lambda|B|^2 (:427-428); conv = |r| < cconv (:432); p = r + beta p (:442)
-__global__ __launch_bounds__(VB) void k_cg_resid(const double* __restrict__ G, const double* __restrict__ B, double* __restrict__ R,
-                                                double* __restrict__ Pv, size_t n, double lambda, double cconv,
-                                                const double* __restrict__ tail, double* __restrict__ scal) {
+// partial |nr|^2 with nr = G - lambda B, and |B|^2
+__global__ __launch_bounds__(VB) void k_cg_resid1(const double* __restrict__ G, const double* __restrict__ B, size_t n, double lambda,
+                                                 double* __restrict__ part) {
     __shared__ double sh[VB];
+    size_t lo, hi; slice(n, &lo, &hi);
     double an = 0., ab = 0.;
-    for (size_t i = threadIdx.x; i < n; i += VB) {
+    for (size_t i = lo + threadIdx.x; i < hi; i += VB) {
         double nr = G[i];
         if (lambda != 0.) nr = nr - lambda * B[i];
-        an += nr * nr;
-        ab += B[i] * B[i];
+        an += nr * nr; ab += B[i] * B[i];
     }
-    const double nn = block_sum(an, sh);
-    const double bn2 = block_sum(ab, sh);
-    const double q = sqrt(nn) / sqrt(scal[SC_RR]);
+    const double s0 = block_sum(an, sh);
+    const double s1 = block_sum(ab, sh);
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = s0; part[2 * blockIdx.x + 1] = s1; }
+}
+// beta = sqr(norm(nr)/norm(r)) (:423); r = nr (:424); C = sum dP^2 + lambda|B|^2 (:427-428);
+// conv = |r| < cconv (:432); p = r + beta p (:442)
+__global__ __launch_bounds__(VB) void k_cg_resid2(const double* __restrict__ G, const double* __restrict__ B, double* __restrict__ R,
+                                                 double* __restrict__ Pv, size_t n, double lambda, double cconv,
+                                                 const double* __restrict__ tail, const double* __restrict__ part, int nb,
+                                                 double* __restrict__ scal, int rr_in, int rr_out) {
+    double nn, bn2; sum_partials(part, nb, &nn, &bn2);
+    const double q = sqrt(nn) / sqrt(scal[rr_in]);
     const double beta = q * q;
     const double rn = sqrt(nn);
     const int conv = rn < cconv;
-    for (size_t i = threadIdx.x; i < n; i += VB) {
+    size_t lo, hi; slice(n, &lo, &hi);
+    for (size_t i = lo + threadIdx.x; i < hi; i += VB) {
         double nr = G[i];
         if (lambda != 0.) nr = nr - lambda * B[i];
         R[i] = nr;
         if (!conv) Pv[i] = nr + beta * Pv[i];
     }
-    if (threadIdx.x == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         double cs = 0.;
         for (int l = 0; l < TNML_NL; ++l) cs += tail[SC_COST0 + l];
         scal[SC_COST] = cs + lambda * bn2;
         scal[SC_BNORM2] = bn2; scal[SC_BETA] = beta; scal[SC_RNORM] = rn; scal[SC_CONV] = (double)conv;
+        scal[rr_out] = nn;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) scal[SC_RR] = nn;
 }
-__global__ __launch_bounds__(VB) void k_sqnorm(const double* __restrict__ x, size_t n, double* __restrict__ out) {
-    __shared__ double sh[VB];
-    double acc = 0.;
-    for (size_t i = threadIdx.x; i < n; i += VB) acc += x[i] * x[i];
-    const double s = block_sum(acc, sh);
-    if (threadIdx.x == 0) out[0] = s;
+__global__ void k_norm2(const double* __restrict__ part, int nb, double* __restrict__ out, int nout) {
+    if (threadIdx.x == 0) { double a, b; sum_partials(part, nb, &a, &b); out[0] = a; if (nout > 1) out[1] = b; }
 }
-__global__ __launch_bounds__(VB) void k_diffnorm(const double* __restrict__ x, const double* __restrict__ y, size_t n, double* __restrict__ out) {
+__global__ __launch_bounds__(VB) void k_diffnorm1(const double* __restrict__ x, const double* __restrict__ y, size_t n, double* __restrict__ part) {
     __shared__ double sh[VB];
+    size_t lo, hi; slice(n, &lo, &hi);
     double a = 0., d = 0.;
-    for (size_t i = threadIdx.x; i < n; i += VB) { a += x[i] * x[i]; const double t = x[i] - y[i]; d += t * t; }
-    const double s1 = block_sum(a, sh);
-    const double s2 = block_sum(d, sh);
-    if (threadIdx.x == 0) { out[0] = s1; out[1] = s2; }
+    for (size_t i = lo + threadIdx.x; i < hi; i += VB) { a += x[i] * x[i]; const double t = x[i] - y[i]; d += t * t; }
+    const double s0 = block_sum(a, sh);
+    const double s1 = block_sum(d, sh);
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = s0; part[2 * blockIdx.x + 1] = s1; }
 }
 
+static inline int vec_blocks(size_t n) { size_t b = (n + 1023) / 1024; if (b > VNB_MAX) b = VNB_MAX; if (b < 1) b = 1; return (int)b; }
+
+// the |r|^2 of the previous evaluation lives in scal[SC_RR + (c->rr_slot)], alternating between two
+// slots so that phase-2 workgroups never read a slot another workgroup is writing
 int launch_cg_init(tnml_ctx* c, size_t n, double lambda) {
     ProfScope ps(c, KC_VEC);
-    hipLaunchKernelGGL(k_cg_init, dim3(1), dim3(VB), 0, c->stream, c->vG, c->vB, c->vR, c->vP, n, lambda, c->scal);
+    const int nb = vec_blocks(n);
+    c->rr_slot = 0;
+    hipLaunchKernelGGL(k_cg_init1, dim3(nb), dim3(VB), 0, c->stream, c->vG, c->vB, c->vR, c->vP, n, lambda, c->vpart);
+    hipLaunchKernelGGL(k_cg_init2, dim3(1), dim3(64), 0, c->stream, c->vpart, nb, c->scal, (int)SC_RR);
     HIPCK(c, hipGetLastError());
     return 0;
 }
 int launch_cg_step(tnml_ctx* c, size_t n, double lambda) {
     ProfScope ps(c, KC_VEC);
-    hipLaunchKernelGGL(k_cg_step, dim3(1), dim3(VB), 0, c->stream, c->vB, c->vP, n, lambda, c->vG + n, c->scal);
+    const int nb = vec_blocks(n);
+    hipLaunchKernelGGL(k_norm1, dim3(nb), dim3(VB), 0, c->stream, c->vP, (const double*)nullptr, n, c->vpart);
+    hipLaunchKernelGGL(k_cg_step2, dim3(nb), dim3(VB), 0, c->stream, c->vB, c->vP, n, lambda, c->vG + n, c->vpart, nb, c->scal, SC_RR + c->rr_slot);
     HIPCK(c, hipGetLastError());
     return 0;
 }
 int launch_cg_resid(tnml_ctx* c, size_t n, double lambda, double cconv) {
     ProfScope ps(c, KC_VEC);
-    hipLaunchKernelGGL(k_cg_resid, dim3(1), dim3(VB), 0, c->stream, c->vG, c->vB, c->vR, c->vP, n, lambda, cconv, c->vG + n, c->scal);
+    const int nb = vec_blocks(n);
+    const int in = SC_RR + c->rr_slot, out = SC_RR + (c->rr_slot ^ 1);
+    hipLaunchKernelGGL(k_cg_resid1, dim3(nb), dim3(VB), 0, c->stream, c->vG, c->vB, n, lambda, c->vpart);
+    hipLaunchKernelGGL(k_cg_resid2, dim3(nb), dim3(VB), 0, c->stream, c->vG, c->vB, c->vR, c->vP, n, lambda, cconv, c->vG + n, c->vpart, nb, c->scal, in, out);
+    c->rr_slot ^= 1;
     HIPCK(c, hipGetLastError());
     return 0;
 }
 int launch_sqnorm(tnml_ctx* c, const double* x, size_t n, double* out) {
     ProfScope ps(c, KC_VEC);
-    hipLaunchKernelGGL(k_sqnorm, dim3(1), dim3(VB), 0, c->stream, x, n, out);
+    const int nb = vec_blocks(n);
+    hipLaunchKernelGGL(k_norm1, dim3(nb), dim3(VB), 0, c->stream, x, (const double*)nullptr, n, c->vpart);
+    hipLaunchKernelGGL(k_norm2, dim3(1), dim3(64), 0, c->stream, c->vpart, nb, out, 1);
     HIPCK(c, hipGetLastError());
     return 0;
 }
 int launch_diffnorm(tnml_ctx* c, const double* x, const double* y, size_t n, double* out2) {
     ProfScope ps(c, KC_VEC);
-    hipLaunchKernelGGL(k_diffnorm, dim3(1), dim3(VB), 0, c->stream, x, y, n, out2);
+    const int nb = vec_blocks(n);
+    hipLaunchKernelGGL(k_diffnorm1, dim3(nb), dim3(VB), 0, c->stream, x, y, n, c->vpart);
+    hipLaunchKernelGGL(k_norm2, dim3(1), dim3(64), 0, c->stream, c->vpart, nb, out2, 2);
     HIPCK(c, hipGetLastError());
     return 0;
 }

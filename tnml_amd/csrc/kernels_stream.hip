@@ -98,14 +98,15 @@ __global__ __launch_bounds__(64 * NW) void k_labeldot(LdotArgs A, double* __rest
     }
 }
 
-__global__ void k_reduce_partials(const double* __restrict__ partials, int nblk, double* __restrict__ out) {
-    // one wave; lane t < 12 sums column t over all workgroups in order
-    const int t = threadIdx.x;
-    if (t < 12) {
-        double s = 0.;
-        for (int b = 0; b < nblk; ++b) s += partials[(size_t)b * 12 + t];
-        out[t] = s;
-    }
+__global__ __launch_bounds__(768) void k_reduce_partials(const double* __restrict__ partials, int nblk, double* __restrict__ out) {
+    // 12 waves, wave t sums column t: lane i takes rows i, i+64, ... in order, then a fixed shuffle
+    // tree -> deterministic for a given nblk
+    const int t = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double s = 0.;
+    for (int b = lane; b < nblk; b += 64) s += partials[(size_t)b * 12 + t];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if (lane == 0) out[t] = s;
 }
 
 int launch_labeldot(tnml_ctx* c, const LdotArgs& a, double* scal_out) {
@@ -118,7 +119,7 @@ int launch_labeldot(tnml_ctx* c, const LdotArgs& a, double* scal_out) {
     } else {
         hipLaunchKernelGGL((k_labeldot<8, float, float, float>), dim3(nblk), dim3(512), 0, c->stream, a, c->partials);
     }
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(64), 0, c->stream, c->partials, nblk, scal_out);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(768), 0, c->stream, c->partials, nblk, scal_out);
     HIPCK(c, hipGetLastError());
     return 0;
 }

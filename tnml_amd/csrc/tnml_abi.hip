@@ -145,6 +145,7 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     if ((rc = dmalloc(c, &c->vP, c->mcap))) return bail(rc);
     if ((rc = dmalloc(c, &c->vG, c->mcap + TNML_NSCAL_AR))) return bail(rc);
     if ((rc = dmalloc(c, &c->scal, SC_N))) return bail(rc);
+    if ((rc = dmalloc(c, &c->vpart, 512))) return bail(rc);
     if ((rc = dmalloc(c, &c->tB, c->mcap))) return bail(rc);
     if ((rc = dmalloc(c, &c->tB2, c->mcap))) return bail(rc);
     if ((rc = dmalloc(c, &c->sM, (size_t)40 * c->maxm * c->maxm))) return bail(rc);
@@ -174,7 +175,7 @@ int tnml_destroy(tnml_ctx* c) {
     for (auto& p : c->prof_pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     for (auto e : c->prof_free) (void)hipEventDestroy(e);
     void* ptrs[] = {c->phi, c->label, c->ones, c->U, c->P, c->dP, c->Zp, c->Mf, c->slab, c->partials, c->vB, c->vR, c->vP,
-                    c->vG, c->scal, c->tB, c->tB2, c->sM, c->sG, c->sD, c->sE, c->sF, c->sInfo};
+                    c->vG, c->scal, c->vpart, c->tB, c->tB2, c->sM, c->sG, c->sD, c->sE, c->sF, c->sInfo};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& s : c->W) if (s.a) (void)hipFree(s.a);
     for (auto& e : c->env) if (e.ptr) (void)hipFree(e.ptr);

@@ -50,8 +50,8 @@ struct SiteT {
 };
 
 // scalar slots of the device-side CG state (doubles)
-enum { SC_COST0 = 0, /* ..9 */ SC_NCORR = 10, SC_PP = 11, SC_RR = 12, SC_ALPHA = 13, SC_BETA = 14,
-       SC_PNORM2 = 15, SC_BNORM2 = 16, SC_PAP = 17, SC_RNORM = 18, SC_COST = 19, SC_CONV = 20, SC_N = 32 };
+enum { SC_COST0 = 0, /* ..9 */ SC_NCORR = 10, SC_PP = 11, SC_RR = 12, /* 13: second |r|^2 slot */ SC_ALPHA = 14, SC_BETA = 15,
+       SC_PNORM2 = 16, SC_BNORM2 = 17, SC_PAP = 18, SC_RNORM = 19, SC_COST = 20, SC_CONV = 21, SC_N = 32 };
 #define TNML_NSCAL_AR 16   /* scalars that ride behind G in the all-reduce buffer */
 
 struct BondPlan {
@@ -101,6 +101,8 @@ struct tnml_ctx {
     int partial_cap = 0;
     double *vB = nullptr, *vR = nullptr, *vP = nullptr, *vG = nullptr;   // CG vectors, M-layout fp64 (vG has TNML_NSCAL_AR tail)
     double* scal = nullptr;    // device scalars [SC_N]
+    double* vpart = nullptr;   // per-workgroup partial sums of the CG vector kernels [256][2]
+    int rr_slot = 0;           // which of scal[SC_RR], scal[SC_RR+1] holds the current |r|^2
     double* h_scal = nullptr;  // pinned host mirror
     double *tB = nullptr, *tB2 = nullptr;   // bond tensors in ITensor layout (fp64)
     size_t mcap = 0;           // capacity (elements) of M-layout vectors / bond tensors
