@@ -1,0 +1,75 @@
+"""CPU tests of the drop-in boundary: libtnml.so loads without a GPU, exports every symbol that
+include/tnml.h declares, fails loudly instead of falling back, and its host-side rules agree with
+the oracle.  No compute call is made here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "tnml.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(tnml_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from tnml_amd import lib
+    L = lib.load()
+    names = _declared()
+    assert len(names) >= 30
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    assert sorted(lib.EXPORTS) == names, "tnml_amd.lib.EXPORTS out of sync with include/tnml.h"
+
+
+def test_create_fails_loudly_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from tnml_amd.fixedl import TnmlError, TrainStates
+    with pytest.raises(TnmlError, match="no HIP device|no CPU fallback"):
+        TrainStates(np.zeros(10, dtype=np.int32), 8, 4, pixels=np.zeros((10, 8), dtype=np.uint8))
+
+
+def test_product_package_never_imports_the_oracle():
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "tnml_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".cc")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                if re.search(r"^\s*(from|import)\s+oracle\b|fixedl_oracle|libfixedl_oracle", txt, flags=re.M):
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_truncate_rule_matches_oracle(seed):
+    from oracle import pyoracle
+    from tnml_amd import lib
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(2, 40))
+    p = np.sort(rng.random(n) ** 8)[::-1].copy()
+    p[rng.integers(0, n):] *= 1e-14
+    p = np.sort(p)[::-1].copy()
+    for maxm, minm, cutoff in [(10, 1, 1e-10), (100, 5, 1e-10), (6, 3, 1e-3), (50, 1, 0.0)]:
+        assert lib.truncate(p, maxm, minm, cutoff) == pytest.approx(pyoracle.truncate(p, maxm, minm, cutoff), rel=1e-15, abs=0)
+
+
+def test_sweepnext_and_shards():
+    from oracle import pyoracle
+    from tnml_amd import lib
+    for N in (4, 9, 784):
+        b, ha, seq = 1, 1, []
+        while ha <= 2:
+            seq.append((b, ha))
+            assert lib.sweepnext(b, ha, N) == pyoracle.sweepnext(b, ha, N)
+            b, ha = lib.sweepnext(b, ha, N)
+        assert len(seq) == 2 * (N - 1)                         # bond updates per sweep
+    # ParallelDo chunking (paralleldo.h:32-43): equal chunks, last takes the remainder
+    assert [lib.shard_bounds(60000, 8, r) for r in range(8)] == [(7500 * r, 7500 * (r + 1)) for r in range(8)]
+    assert [lib.shard_bounds(10, 3, r) for r in range(3)] == [(0, 3), (3, 6), (6, 10)]
