@@ -66,7 +66,10 @@ __global__ __launch_bounds__(64 * NW) void k_labeldot(LdotArgs A, double* __rest
         TC* dPout = static_cast<TC*>(A.dP);
         if (A.mode == LD_MODE_PAP) {
 #pragma unroll
-            for (int l = 0; l < TNML_NL; ++l) val = fma(P[l], P[l], val);             // sqr(norm(pv)), :400
+            for (int l = 0; l < TNML_NL; ++l) {
+                val = fma(P[l], P[l], val);                                            // sqr(norm(pv)), :400
+                if (Pout) Pout[(size_t)l * NTp + ni] = P[l];
+            }
             if (lab < 0) val = 0;
         } else {
             TC best = fabs(P[0]); int arg = 0;
@@ -151,6 +154,51 @@ int launch_zprime(tnml_ctx* c, const float* EL, size_t lstride, const void* dP, 
     if (blocks > 8192) blocks = 8192;
     if (c->f64()) hipLaunchKernelGGL(k_zprime_t<double>, dim3(blocks), dim3(256), 0, c->stream, EL, lstride, (const double*)dP, (double*)Z, mq, NTp);
     else          hipLaunchKernelGGL(k_zprime_t<float>, dim3(blocks), dim3(256), 0, c->stream, EL, lstride, (const float*)dP, (float*)Z, mq, NTp);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
+
+// Fast CG (tnml_ctx::fast_cg): B*t.v is linear in B, so after B <- B + a p the model outputs are
+// P <- P + a (p*t.v) with p*t.v already computed by the pAp pass (the idea of the reference's own
+// single.h:290-398 fast_cgrad).  Recomputes dP, the per-label cost partials and the argmax count.
+template <typename T>
+__global__ __launch_bounds__(LD_IMGS) void k_pupdate(T* __restrict__ P, const T* __restrict__ Pp, T* __restrict__ dP,
+                                                    const int* __restrict__ label, int NTp,
+                                                    const double* __restrict__ alpha, double* __restrict__ partials) {
+    __shared__ T s_val[LD_IMGS];
+    __shared__ int s_lab[LD_IMGS];
+    __shared__ int s_cor[LD_IMGS];
+    const int tid = threadIdx.x;
+    const int ni = blockIdx.x * LD_IMGS + tid;
+    const T a = (T)alpha[0];
+    const int lab = label[ni];
+    T val = 0; T best = 0; int arg = 0;
+#pragma unroll
+    for (int l = 0; l < TNML_NL; ++l) {
+        const T p = fma(a, Pp[(size_t)l * NTp + ni], P[(size_t)l * NTp + ni]);
+        P[(size_t)l * NTp + ni] = p;
+        const T d = (lab >= 0) ? ((l == lab ? (T)1 : (T)0) - p) : (T)0;
+        dP[(size_t)l * NTp + ni] = d;
+        val = fma(d, d, val);
+        const T wgt = fabs(p);
+        if (l == 0) best = wgt; else if (wgt > best) { best = wgt; arg = l; }
+    }
+    s_val[tid] = val; s_lab[tid] = lab; s_cor[tid] = (lab >= 0 && arg == lab) ? 1 : 0;
+    __syncthreads();
+    if (tid < 12) {
+        double s = 0.;
+        if (tid < TNML_NL) { for (int i = 0; i < LD_IMGS; ++i) if (s_lab[i] == tid) s += (double)s_val[i]; }
+        else if (tid == 10) { for (int i = 0; i < LD_IMGS; ++i) s += (double)s_cor[i]; }
+        partials[(size_t)blockIdx.x * 12 + tid] = s;
+    }
+}
+
+int launch_pupdate(tnml_ctx* c, const double* alpha_dev, double* scal_out) {
+    ProfScope ps(c, KC_LABELDOT);
+    const int nblk = c->NTp / LD_IMGS;
+    if (c->f64()) hipLaunchKernelGGL(k_pupdate<double>, dim3(nblk), dim3(LD_IMGS), 0, c->stream, (double*)c->P, (const double*)c->Pp, (double*)c->dP, c->label, c->NTp, alpha_dev, c->partials);
+    else          hipLaunchKernelGGL(k_pupdate<float>, dim3(nblk), dim3(LD_IMGS), 0, c->stream, (float*)c->P, (const float*)c->Pp, (float*)c->dP, c->label, c->NTp, alpha_dev, c->partials);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(768), 0, c->stream, c->partials, nblk, scal_out);
     HIPCK(c, hipGetLastError());
     return 0;
 }

@@ -4,6 +4,7 @@
 // No CPU fallback lives here: every contraction is a HIP kernel launch on the context's stream.
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 
 #include "tnml_internal.h"
@@ -136,6 +137,8 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     if ((rc = dmalloc(c, (char**)&c->U, c->big_elems * esz))) return bail(rc);
     if ((rc = dmalloc(c, (char**)&c->P, (size_t)TNML_NL * NTp * esz))) return bail(rc);
     if ((rc = dmalloc(c, (char**)&c->dP, (size_t)TNML_NL * NTp * esz))) return bail(rc);
+    if ((rc = dmalloc(c, (char**)&c->Pp, (size_t)TNML_NL * NTp * esz))) return bail(rc);
+    if (const char* e = getenv("TNML_FAST_CG")) c->fast_cg = atoi(e) != 0;
     if ((rc = dmalloc(c, (char**)&c->Zp, c->small_elems * esz))) return bail(rc);
     if ((rc = dmalloc(c, &c->Mf, c->mcap))) return bail(rc);
     if ((rc = dmalloc(c, (char**)&c->slab, c->slab_bytes))) return bail(rc);
@@ -174,7 +177,7 @@ int tnml_destroy(tnml_ctx* c) {
     if (c->comm) ncclCommDestroy(c->comm);
     for (auto& p : c->prof_pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     for (auto e : c->prof_free) (void)hipEventDestroy(e);
-    void* ptrs[] = {c->phi, c->label, c->ones, c->U, c->P, c->dP, c->Zp, c->Mf, c->slab, c->partials, c->vB, c->vR, c->vP,
+    void* ptrs[] = {c->phi, c->label, c->ones, c->U, c->P, c->dP, c->Pp, c->Zp, c->Mf, c->slab, c->partials, c->vB, c->vR, c->vP,
                     c->vG, c->scal, c->vpart, c->tB, c->tB2, c->sM, c->sG, c->sD, c->sE, c->sF, c->sInfo};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& s : c->W) if (s.a) (void)hipFree(s.a);
@@ -443,14 +446,15 @@ static int forward_pass(tnml_ctx* c, const double* vec, int mode, double* tail, 
     if (p.kind == 2) { a.A = c->U; a.A_lstride = ustride; a.Bv = p.EX; a.a_is_env = 0; }
     else             { a.A = p.EX; a.A_lstride = ustride; a.Bv = c->U; a.a_is_env = 1; }
     a.mq = p.mO; a.NTp = c->NTp; a.label = c->label;
-    a.P = want_P ? c->P : nullptr; a.dP = (mode == LD_MODE_PAP) ? nullptr : c->dP; a.mode = mode;
+    a.P = want_P ? (mode == LD_MODE_PAP ? c->Pp : c->P) : nullptr; a.dP = (mode == LD_MODE_PAP) ? nullptr : c->dP; a.mode = mode;
     return launch_labeldot(c, a, tail);
 }
 // G = sum_n dP_n*dag(t.v) over all ranks for the bond tensor in vB; cost partials ride in the tail
-static int grad_eval(tnml_ctx* c) {
+static int grad_eval(tnml_ctx* c, bool from_P_update = false) {
     const BondPlan& p = c->plan;
     const size_t n = p.msize();
-    TCK(forward_pass(c, c->vB, LD_MODE_COST, c->vG + n, false));
+    if (from_P_update) TCK(launch_pupdate(c, c->scal + SC_ALPHA, c->vG + n));          // P += a (p*t.v): no GEMM
+    else               TCK(forward_pass(c, c->vB, LD_MODE_COST, c->vG + n, c->fast_cg)); // keeps P when fast CG is on
     if (p.kind != 2) TCK(launch_zprime(c, p.EX, (size_t)p.mO * c->NTp, c->dP, c->Zp, p.mO, c->NTp));
     if (c->f64()) {
         Bgemm64Args g;
@@ -486,7 +490,7 @@ static int cgrad_device(tnml_ctx* c, int npass, double lambda, double cconv, tnm
     TCK(grad_eval(c));                                   // :374-385
     TCK(launch_cg_init(c, n, lambda));                   // :386-388
     for (int pass = 1; pass <= npass; ++pass) {          // :389
-        TCK(forward_pass(c, c->vP, LD_MODE_PAP, c->vG + n, false));   // :394-401
+        TCK(forward_pass(c, c->vP, LD_MODE_PAP, c->vG + n, c->fast_cg));   // :394-401 (keeps p*t.v for the fast update)
         TCK(allreduce(c, c->vG + n, TNML_NSCAL_AR));                  // :402
         TCK(launch_cg_step(c, n, lambda));               // :403-407
         if (tr) tr->npass_done = pass;
@@ -494,7 +498,7 @@ static int cgrad_device(tnml_ctx* c, int npass, double lambda, double cconv, tnm
             if (tr) { TCK(read_scal(c, c->scal, SC_N, s)); tr->pAp[pass - 1] = s[SC_PAP]; tr->alpha[pass - 1] = s[SC_ALPHA]; }
             break;
         }
-        TCK(grad_eval(c));                               // :412-421
+        TCK(grad_eval(c, c->fast_cg));                   // :412-421
         TCK(launch_cg_resid(c, n, lambda, cconv));       // :422-428, :442
         TCK(read_scal(c, c->scal, SC_N, s));
         if (tr) {

@@ -91,6 +91,8 @@ struct tnml_ctx {
     void* U = nullptr;         // [10][maxm][NTp]
     void* P = nullptr;         // [10][NTp]
     void* dP = nullptr;        // [10][NTp]
+    void* Pp = nullptr;        // [10][NTp]  p*t.v of the last pAp pass (fast CG)
+    bool fast_cg = true;       // P <- P + a (p*t.v) instead of re-running the forward GEMM (env TNML_FAST_CG=0 disables)
     void* Zp = nullptr;        // [maxm][NTp]
     float* Mf = nullptr;       // fp32 GEMM operand, M-layout, capacity 10*Kmax*Kmax (env shifts, F32 mode)
     void* slab = nullptr;      // split-K partial slabs
@@ -188,6 +190,7 @@ struct LdotArgs {
 };
 // partial sums -> scal_out[0..11] (device); deterministic
 int launch_labeldot(tnml_ctx* c, const LdotArgs& a, double* scal_out);
+int launch_pupdate(tnml_ctx* c, const double* alpha_dev, double* scal_out);
 int launch_zprime(tnml_ctx* c, const float* EL, size_t lstride, const void* dP, void* Z, int mq, int NTp);
 int launch_features_u8(tnml_ctx* c, const uint8_t* d_pix, int N, int NT, int NTp, float* phi);
 
