@@ -42,7 +42,11 @@ typedef struct tnml_ctx tnml_ctx;
              in fp64 and its CG is not reproducible below that (DESIGN.md "why fp64 MFMA")
    TNML_F32  v_mfma_f32_16x16x4_f32, exact-fp32 -- 2x the MFMA rate, for the tolerance study only */
 enum { TNML_F32 = 0, TNML_F64 = 1 };
-enum { TNML_SVD_SYEVD = 0, TNML_SVD_GESVDJ = 1 };   /* rocSOLVER back-end of tnml_svd_split */
+/* eigensolver of the Gram matrix inside tnml_svd_split:
+   TNML_SVD_SYEVD      in-house one-workgroup tridiagonalisation + rocSOLVER dstedc + in-house back transform
+                       (n <= 240; larger matrices use TNML_SVD_ROCSOLVER automatically)
+   TNML_SVD_ROCSOLVER  stock rocSOLVER dsyevd */
+enum { TNML_SVD_SYEVD = 0, TNML_SVD_ROCSOLVER = 1 };
 
 typedef struct {
     int device;          /* HIP device ordinal */

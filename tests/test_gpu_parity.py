@@ -206,3 +206,38 @@ def test_f32_study_mode_forward_gradient():
         assert _relmax(ts.forward(B), o.forward(B)) < 1e-4
         assert _relmax(ts.gradient(B), o.gradient(B)) < 2e-4
         assert ts.quadcost(B, 1e-3)[0] == pytest.approx(o.quadcost(B, 1e-3)[0], rel=1e-5)
+
+
+@pytest.mark.parametrize("ha", [1, 2])
+@pytest.mark.parametrize("backend", ["0", "1"])
+def test_svd_split_240x240_against_lapack(ha, backend, monkeypatch):
+    """the n=240 split (in-house tridiagonalisation + dstedc + back transform, and the stock rocSOLVER
+    path) against numpy/LAPACK: singular values, truncation error, optimal rank-120 reconstruction,
+    isometry of the site the sweep leaves"""
+    from tnml_amd import synth
+    from tnml_amd.fixedl import TrainStates
+    monkeypatch.setenv("TNML_SVD_BACKEND", backend)
+    N, m, NT = 20, 120, 16
+    labels = synth.synthetic_labels(NT, seed=1)
+    ts = TrainStates(labels, N, m, pixels=synth.synthetic_images(N, labels, seed=1))
+    W = synth.random_mps(N, m, seed=2)
+    ts.set_mps(W)
+    b = 8
+    rng = np.random.default_rng(ha)
+    decay = np.exp(-0.12 * np.arange(240))
+    U0, _ = np.linalg.qr(rng.standard_normal((240, 240)))
+    V0, _ = np.linalg.qr(rng.standard_normal((240, 240)))
+    M = (U0 * decay) @ V0.T                                   # rows (a,s), cols (t,beta)
+    B = M.reshape(120, 2, 2, 120, order="F")
+    mg, te, sv = ts.svd_split(B, b, ha, 0.0, 120, 60)       # cutoff 0: maxm decides
+    s_ref = np.linalg.svd(M, compute_uv=False)
+    assert mg == 120
+    np.testing.assert_allclose(sv, s_ref, rtol=1e-7, atol=5e-8 * s_ref[0])   # Gram route: sqrt(eps) floor, as in ITensor
+    assert te == pytest.approx(np.sum(s_ref[120:] ** 2) / np.sum(s_ref ** 2), rel=1e-5)
+    newB = ts.bond_tensor(b).reshape(240, 240, order="F")
+    Ur, sr, Vr = np.linalg.svd(M)
+    best = (Ur[:, :120] * sr[:120]) @ Vr[:120]
+    assert np.abs(newB - best).max() < 1e-9 * sr[0]
+    A = ts.get_site(b if ha == 1 else b + 1)
+    Q = A.reshape(240, 120, order="F") if ha == 1 else A.reshape(120, 240, order="F").T
+    np.testing.assert_allclose(Q.T @ Q, np.eye(120), atol=1e-10)

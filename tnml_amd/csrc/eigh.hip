@@ -1,0 +1,278 @@
+// eigh.hip -- single-kernel Householder tridiagonalisation + back-transformation for the bond-tensor
+// split (n <= 240, fp64).
+//
+// Why: the SVD of fixedL.cc:519-521 sits on the critical path of every bond update and rocSOLVER's
+// dsyevd spends 4.0 of its 5.6 ms at n=240 in ~1700 tiny sytrd kernels (profiles/r01_bench_c3_kernel_stats.csv:
+// hemvn, sytd2, dot, syr2, latrd, larfg, set_tau).  The reduction is inherently sequential in n, so it is
+// done here by ONE workgroup with the matrix resident in registers (lower-triangular 16x16 blocks, 4 lanes
+// per block, 64 doubles per lane): per Householder step one LDS round for the column, a symmetric
+// matrix-vector product reduced through LDS in a fixed order, and the rank-2 update -- five barriers per
+// step, no kernel boundary; the Householder scalars are recomputed by every wave instead of broadcast.  The tridiagonal eigenproblem stays on rocSOLVER (dstedc); the back
+// transformation U = H_0 H_1 ... Z is one wave per kept column.
+#include "tnml_internal.h"
+
+#define TB 16            // block edge
+#define TU 4             // lanes per block (each owns 4 columns of the block)
+#define TRI_MAXN 240
+#define TRI_MAXNB (TRI_MAXN / TB)
+
+#ifdef TNML_EIGH_PROF
+#define TP(i) do { if (tid == 0) { long long t_ = clock64(); prof[i] += t_ - tlast; tlast = t_; } } while (0)
+#else
+#define TP(i) do {} while (0)
+#endif
+
+struct TriArgs {
+    const double* A; int n; int lda;     // symmetric input (both triangles valid)
+    double* D; double* E; double* tau;   // outputs: diagonal n, subdiagonal n-1, tau n-1
+    double* V; int ldv;                  // Householder vectors: column k holds v_k (v_k[k+1] = 1, zeros above)
+    long long* dbg;                      // TNML_EIGH_PROF builds: per-phase cycle counters
+};
+
+// quad-lane exchange of a double through DPP (lanes 4q..4q+3 hold the 4 column strips of one block)
+template <int CTRL>
+static __device__ __forceinline__ double dpp_quad(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROWMASK>
+static __device__ __forceinline__ double dpp_masked(double x) {       // rows outside ROWMASK receive 0
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWMASK, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+// wave64 sum broadcast to every lane, all in DPP (a ds_bpermute shuffle costs an LDS round trip per
+// step, ~12 of them per reduction; this sits on the serial path of every Householder step)
+static __device__ __forceinline__ double wave_sum(double x) {
+    x += dpp_quad<0xB1>(x);                 // quad_perm [1,0,3,2]
+    x += dpp_quad<0x4E>(x);                 // quad_perm [2,3,0,1]
+    x += dpp_quad<0x141>(x);                // row_half_mirror: 8-lane sums
+    x += dpp_quad<0x140>(x);                // row_mirror: 16-lane (row) sums in every lane
+    x += dpp_masked<0x142, 0xA>(x);         // row_bcast:15 -> rows 1,3 += row 0,2
+    x += dpp_masked<0x143, 0xC>(x);         // row_bcast:31 -> rows 2,3 += rows 0..1
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), 63);
+    return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(512) void k_sytrd_onewg(TriArgs T) {
+    __shared__ double s_v[TRI_MAXN + TB], s_w[TRI_MAXN + TB], s_x[TRI_MAXN + TB];
+    __shared__ double s_red[16];
+    __shared__ double S1[TB * (TRI_MAXNB * (TRI_MAXNB + 1) / 2)];            // [R][C][16], quad-reduced
+    __shared__ double S2[TB * (TRI_MAXNB * (TRI_MAXNB - 1) / 2) + TB];      // [C][R-C-1][16]
+    const int n = T.n;
+    const int nb = (n + TB - 1) / TB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int nthr_blocks = nb * (nb + 1) / 2;
+    const int bi = tid >> 2, u = tid & 3;
+    const bool owner = bi < nthr_blocks;
+    // blocks are enumerated column-block major (C = 0 first) so that the blocks left of the active
+    // window -- a prefix of this order -- retire whole waves as the reduction proceeds
+    int R = 0, C = 0;
+    if (owner) { int cc = 0; while ((cc + 1) * nb - (cc + 1) * cc / 2 <= bi) ++cc; C = cc; R = cc + (bi - (cc * nb - cc * (cc - 1) / 2)); }
+    const int off1 = TB * (R * (R + 1) / 2);                      // S1 base of row-block R: [R][C][16]
+    const int off2 = TB * (C * nb - C * (C + 1) / 2);            // S2 base of column-block C: sum_{c<C}(nb-1-c)
+    const int i0 = TB * R, j0 = TB * C + TU * u;
+    const int nwaves = (blockDim.x + 63) / 64;
+
+    double a[TB][TU];
+#pragma unroll
+    for (int r = 0; r < TB; ++r)
+#pragma unroll
+        for (int jj = 0; jj < TU; ++jj) {
+            const int i = i0 + r, j = j0 + jj;
+            a[r][jj] = (owner && i < n && j < n) ? T.A[i + (size_t)T.lda * j] : 0.;
+        }
+    for (int i = tid; i < TRI_MAXN + TB; i += blockDim.x) { s_v[i] = 0.; s_w[i] = 0.; s_x[i] = 0.; }
+    __syncthreads();
+
+#ifdef TNML_EIGH_PROF
+    long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tlast = clock64(); const long long w0 = wall_clock64();
+#endif
+    for (int k = 0; k < n - 1; ++k) {
+        const int kb = (k + 1) / TB;                 // first block (row or column) that still holds rows/cols > k
+        const int kc = k / TB, ku = (k % TB) / TU, kj = k % TU;
+        // 1. column k of the current matrix -> LDS; the diagonal entry is d_k
+        if (owner && C == kc && u == ku) {
+#pragma unroll
+            for (int r = 0; r < TB; ++r) {
+                double x = 0.;
+#pragma unroll
+                for (int jj = 0; jj < TU; ++jj) if (jj == kj) x = a[r][jj];
+                s_x[i0 + r] = x;
+            }
+        }
+        __syncthreads();
+        TP(0);
+        // 2. Householder vector (LAPACK dlarfg), computed redundantly by every wave: no barrier, no
+        //    serial section.  v = [0..0, 1, x[k+2:]*scale]
+        double sig = 0.;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                  // n <= 256: four independent LDS reads
+            const int i = k + 2 + lane + 64 * e;
+            const double x = i < n ? s_x[i] : 0.;
+            sig = fma(x, x, sig);
+        }
+        sig = wave_sum(sig);
+        const double alpha = s_x[k + 1];
+        double tau = 0., beta = alpha, scale = 0.;
+        if (sig > 0.) {
+            const double nrm = sqrt(fma(alpha, alpha, sig));
+            beta = alpha >= 0. ? -nrm : nrm;
+            const double dlt = alpha - beta;           // one reciprocal serves tau and scale
+            const double inv = 1. / (beta * dlt);
+            tau = -dlt * dlt * inv;                    // (beta - alpha)/beta
+            scale = beta * inv;                        // 1/(alpha - beta)
+        }
+        auto vval = [&](int i) -> double { return i == k + 1 ? 1. : ((i > k + 1 && i < n) ? s_x[i] * scale : 0.); };
+        if (tid < nb * TB) {
+            const double v = vval(tid);
+            s_v[tid] = v;                              // read only after the next barrier (step 4)
+            if (tid < n) T.V[tid + (size_t)T.ldv * k] = v;
+        }
+        if (tid == 0) { T.D[k] = s_x[k]; T.E[k] = beta; T.tau[k] = tau; }
+        TP(1);
+        if (tau != 0.) {                               // uniform: every lane computed the same tau
+            // 3. y = A v : every lane multiplies its 16x4 sub-tile both ways
+            const bool active = owner && C >= kb;
+            double vI[TB], vJ[TU];
+            if (active) {
+#pragma unroll
+                for (int r = 0; r < TB; ++r) vI[r] = vval(i0 + r);
+#pragma unroll
+                for (int jj = 0; jj < TU; ++jj) vJ[jj] = vval(j0 + jj);
+#pragma unroll
+                for (int r = 0; r < TB; ++r) {
+                    double c1 = 0.;
+#pragma unroll
+                    for (int jj = 0; jj < TU; ++jj) c1 = fma(a[r][jj], vJ[jj], c1);
+                    c1 += dpp_quad<0xB1>(c1);          // lane ^ 1
+                    c1 += dpp_quad<0x4E>(c1);          // lane ^ 2
+                    if ((r & 3) == u) S1[off1 + C * TB + r] = c1;
+                }
+                if (R != C) {
+#pragma unroll
+                    for (int jj = 0; jj < TU; ++jj) {
+                        double c2 = 0.;
+#pragma unroll
+                        for (int r = 0; r < TB; ++r) c2 = fma(a[r][jj], vI[r], c2);
+                        S2[off2 + (R - C - 1) * TB + TU * u + jj] = c2;
+                    }
+                }
+            }
+            __syncthreads();
+            TP(2);
+            // 4. reduce y (fixed order), p = tau*y, K = -tau/2 p.v, w = p + K v
+            double pi = 0., part = 0.;
+            if (tid > k && tid < n) {
+                const int Ri = tid / TB, r = tid % TB;
+                double y0 = 0., y1 = 0., y2 = 0., y3 = 0.;
+                const int o1 = TB * (Ri * (Ri + 1) / 2) + r;
+                int s = kb;
+                for (; s + 3 <= Ri; s += 4) { y0 += S1[o1 + s * TB]; y1 += S1[o1 + (s + 1) * TB]; y2 += S1[o1 + (s + 2) * TB]; y3 += S1[o1 + (s + 3) * TB]; }
+                for (; s <= Ri; ++s) y0 += S1[o1 + s * TB];
+                const int o2 = TB * (Ri * nb - Ri * (Ri + 1) / 2) + r - (Ri + 1) * TB;
+                int Rp = Ri + 1;
+                for (; Rp + 3 < nb; Rp += 4) { y0 += S2[o2 + Rp * TB]; y1 += S2[o2 + (Rp + 1) * TB]; y2 += S2[o2 + (Rp + 2) * TB]; y3 += S2[o2 + (Rp + 3) * TB]; }
+                for (; Rp < nb; ++Rp) y1 += S2[o2 + Rp * TB];
+                pi = tau * ((y0 + y1) + (y2 + y3));
+                part = pi * s_v[tid];
+            }
+            part = wave_sum(part);
+            if (lane == 0) s_red[tid >> 6] = part;
+            TP(3);
+            __syncthreads();
+            double ksum = 0.;
+            for (int w = 0; w < nwaves; ++w) ksum += s_red[w];      // same order in every lane
+            const double K = -0.5 * tau * ksum;
+            if (tid < nb * TB) s_w[tid] = (tid > k && tid < n) ? fma(K, s_v[tid], pi) : 0.;
+            __syncthreads();
+            TP(4);
+            // 5. A <- A - v w^T - w v^T on the trailing blocks
+            if (active) {
+                double wJ[TU];
+#pragma unroll
+                for (int jj = 0; jj < TU; ++jj) wJ[jj] = s_w[j0 + jj];
+#pragma unroll
+                for (int r = 0; r < TB; ++r) {
+                    const double wr = s_w[i0 + r];
+#pragma unroll
+                    for (int jj = 0; jj < TU; ++jj) a[r][jj] = fma(-vI[r], wJ[jj], fma(-wr, vJ[jj], a[r][jj]));
+                }
+            }
+        }
+        else __syncthreads();     // no reflector (zero column): still fence this iteration's s_x reads
+        TP(5);
+        // every LDS read above is separated from the next write of the same array by one of the three
+        // barriers inside the branch (s_v[tid] is only ever touched by lane tid)
+    }
+#ifdef TNML_EIGH_PROF
+    if (tid == 0 && T.dbg) { for (int i = 0; i < 6; ++i) T.dbg[i] = prof[i]; T.dbg[6] = wall_clock64() - w0; }
+#endif
+    // last diagonal entry
+    const int kl = n - 1;
+    if (owner && C == kl / TB && R == C && u == (kl % TB) / TU) {
+        const int r = kl % TB, kj = kl % TU;
+        double x = 0.;
+#pragma unroll
+        for (int rr = 0; rr < TB; ++rr)
+#pragma unroll
+            for (int jj = 0; jj < TU; ++jj) if (rr == r && jj == kj) x = a[rr][jj];
+        T.D[kl] = x;
+    }
+}
+
+// U[:, c] = H_0 H_1 ... H_{n-2} Z[:, c]; one wave per column, 4 rows per lane (n <= 256).  The
+// reflectors are fetched 8 at a time so that the L2 latency of V is paid once per 8 dependent updates.
+#define BT_PF 8
+__global__ __launch_bounds__(64) void k_backtransform(const double* __restrict__ V, int ldv, const double* __restrict__ tau, int n,
+                                                     const double* __restrict__ Z, int ldz, double* __restrict__ U, int ldu) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    double z[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const int i = lane + 64 * e; z[e] = i < n ? Z[i + (size_t)ldz * c] : 0.; }
+    for (int k0 = n - 2; k0 >= 0; k0 -= BT_PF) {
+        double v[BT_PF][4], t[BT_PF];
+#pragma unroll
+        for (int q = 0; q < BT_PF; ++q) {
+            const int k = k0 - q;
+            t[q] = k >= 0 ? tau[k] : 0.;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const int i = lane + 64 * e; v[q][e] = (k >= 0 && i < n && i > k) ? V[i + (size_t)ldv * k] : 0.; }
+        }
+#pragma unroll
+        for (int q = 0; q < BT_PF; ++q) {
+            double dot = 0.;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dot = fma(v[q][e], z[e], dot);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+            const double f = t[q] * dot;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) z[e] -= f * v[q][e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const int i = lane + 64 * e; if (i < n) U[i + (size_t)ldu * c] = z[e]; }
+}
+
+// A (n x n symmetric, device) -> D, E, tau, V on the context's stream.  n <= TRI_MAXN.
+int eigh_tridiagonalize(tnml_ctx* c, const double* A, int n, double* D, double* E, double* tau, double* V) {
+    if (n > TRI_MAXN) return tnml_fail(c, "eigh_tridiagonalize: n=%d exceeds %d", n, TRI_MAXN);
+    TriArgs t{A, n, n, D, E, tau, V, n, nullptr};
+    const int nb = (n + TB - 1) / TB;
+    int threads = TU * nb * (nb + 1) / 2;
+    if (threads < nb * TB) threads = nb * TB;
+    threads = (threads + 63) / 64 * 64;
+    hipLaunchKernelGGL(k_sytrd_onewg, dim3(1), dim3(threads), 0, c->stream, t);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
+int eigh_backtransform(tnml_ctx* c, const double* V, const double* tau, int n, const double* Z, int ldz, double* U, int ldu, int ncols) {
+    hipLaunchKernelGGL(k_backtransform, dim3(ncols), dim3(64), 0, c->stream, V, n, tau, n, Z, ldz, U, ldu);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}

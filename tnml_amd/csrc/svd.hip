@@ -4,8 +4,9 @@
 // M M^T; this back-end does the same on the device in fp64:
 //   M (nl x nr): rows = (a,s[,l]) indices of site b, columns = (t,beta[,l]) indices of site b+1
 //   rho = M M^T or M^T M on the smaller side  (rocBLAS dgemm)
-//   rho = Q diag(lambda) Q^T                  (rocSOLVER dsyevd, measured 5.9 ms at n=240 vs
-//                                              29 ms dgesvdj / 153 ms dgesvd, profiles/r01_probe_*)
+//   rho = Q diag(lambda) Q^T                  (eigh.hip tridiagonalisation + rocSOLVER dstedc; stock
+//                                              rocSOLVER dsyevd measured 5.9 ms at n=240, dgesvdj 29 ms,
+//                                              dgesvd 153 ms -- profiles/r01_probe_*)
 //   sigma = sqrt(lambda), truncation rule on the host (tnml_truncate), kept factors by dgemm:
 //   the site the sweep leaves gets the orthonormal factor, the site it moves to gets S*V
 //   ("W.Aref(c+dc) *= S", fixedL.cc:521).
@@ -87,7 +88,15 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
     const double one = 1.0, zero = 0.0;
     if (left) RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_transpose, nl, nl, nr, &one, M, nl, M, nl, &zero, c->sG, nl));
     else      RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, nr, nr, nl, &one, M, nl, M, nl, &zero, c->sG, nr));
-    RBCK(c, rocsolver_dsyevd(c->blas, rocblas_evect_original, rocblas_fill_upper, n, c->sG, n, c->sD, c->sE, c->sInfo));
+    // eigen-decomposition of rho: in-house one-workgroup tridiagonalisation + rocSOLVER dstedc + in-house back
+    // transformation (TNML_SVD_SYEVD, n <= 240), or stock rocSOLVER dsyevd (TNML_SVD_ROCSOLVER / larger n)
+    const bool custom = (c->cfg.svd_backend == TNML_SVD_SYEVD) && n <= 240 && n >= 3;
+    if (custom) {
+        TCK(eigh_tridiagonalize(c, c->sG, n, c->sD, c->sE2, c->sTau, c->sV));
+        RBCK(c, rocsolver_dstedc(c->blas, rocblas_evect_tridiagonal, n, c->sD, c->sE2, c->sC, n, c->sInfo));
+    } else {
+        RBCK(c, rocsolver_dsyevd(c->blas, rocblas_evect_original, rocblas_fill_upper, n, c->sG, n, c->sD, c->sE, c->sInfo));
+    }
     // eigenvalues -> host: the truncation decision (ITensor truncate()) fixes the new bond dimension
     double* h = c->h_scal;          // pinned, capacity >= 2*svd_n + 64
     HIPCK(c, hipMemcpyAsync(h, c->sD, sizeof(double) * n, hipMemcpyDeviceToHost, st));
@@ -111,7 +120,13 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
 
     double* Q = c->sF;                                   // kept eigenvectors, n x m
     double* Lf = c->sF + (size_t)c->svd_n * c->maxm;     // left factor when a permutation is still needed
-    hipLaunchKernelGGL(k_take_top, dim3(nblk((size_t)n * m)), dim3(256), 0, st, c->sG, Q, n, m, (const double*)nullptr);
+    if (custom) {
+        // kept eigenvectors of the tridiagonal matrix (largest first), then U = H_0 H_1 ... Z
+        hipLaunchKernelGGL(k_take_top, dim3(nblk((size_t)n * m)), dim3(256), 0, st, c->sC, c->sG, n, m, (const double*)nullptr);
+        TCK(eigh_backtransform(c, c->sV, c->sTau, n, c->sG, n, Q, n, m));
+    } else {
+        hipLaunchKernelGGL(k_take_top, dim3(nblk((size_t)n * m)), dim3(256), 0, st, c->sG, Q, n, m, (const double*)nullptr);
+    }
     double* Aleft = labL ? Lf : Sl.a;      // left factor target, (nl x m), ld = nl
     double* Aright = Sr.a;                 // right factor (m x nr), ld = m  == A_{b+1}[g][t][be](,[l])
     if (left) {

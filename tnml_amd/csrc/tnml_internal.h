@@ -110,6 +110,7 @@ struct tnml_ctx {
     size_t mcap = 0;           // capacity (elements) of M-layout vectors / bond tensors
     // svd workspaces (fp64)
     double *sM = nullptr, *sG = nullptr, *sD = nullptr, *sE = nullptr, *sF = nullptr;
+    double *sE2 = nullptr, *sTau = nullptr, *sV = nullptr, *sC = nullptr;   // eigh.hip: subdiagonal, tau, reflectors, tridiagonal eigenvectors
     int* sInfo = nullptr;
     int svd_n = 0;
 
@@ -211,6 +212,10 @@ int launch_cg_resid(tnml_ctx* c, size_t n, double lambda, double cconv);   // nr
 int launch_sqnorm(tnml_ctx* c, const double* x, size_t n, double* out);    // out[0] = |x|^2
 int launch_diffnorm(tnml_ctx* c, const double* x, const double* y, size_t n, double* out2);  // out2[0]=|x|^2, out2[1]=|x-y|^2
 int launch_fill_f32(tnml_ctx* c, float* p, float v, size_t n);
+
+// ---- eigh.hip -----------------------------------------------------------------------------
+int eigh_tridiagonalize(tnml_ctx* c, const double* A, int n, double* D, double* E, double* tau, double* V);
+int eigh_backtransform(tnml_ctx* c, const double* V, const double* tau, int n, const double* Z, int ldz, double* U, int ldu, int ncols);
 
 // ---- svd.hip ------------------------------------------------------------------------------
 int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cutoff, int maxm, int minm,
