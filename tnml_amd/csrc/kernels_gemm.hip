@@ -20,6 +20,8 @@
 // The f64 forms put the IMAGES on the MFMA column index: the f64 C fragment is
 // col = lane&15, row = (lane>>4) + 4*reg, so 16 consecutive lanes hold 16 consecutive images of one
 // output row -> 128-byte coalesced stores into the image-fastest output.
+#include <cstdlib>
+
 #include "tnml_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -265,15 +267,22 @@ int launch_bgemm(tnml_ctx* c, const BgemmArgs& a, double* G) {
 // ==========================================================================================
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-// RT: image tiles per wave, CT: output-column tiles per wave
-template <int RT, int CT, int WR, int WC>
+// RT: image tiles per wave, CT: output-column tiles per wave, KT: reduction chunk.
+// Software pipelined: the global loads of chunk k+1 are issued before the MFMA phase of chunk k and
+// land in registers; they are widened to fp64 and written to LDS after the MFMAs (two barriers per
+// chunk, one LDS buffer), so the L2/HBM latency of the operands hides behind the matrix pipe.
+// ABL (tools/probe/kbench_fgemm.hip only): 1 = no MFMA, 2 = no operand staging inside the loop
+template <int RT, int CT, int WR, int WC, int KT, int DB, int ABL = 0>
 __global__ __launch_bounds__(64 * WR * WC) void k_fgemm64(Fgemm64Args A) {
-    constexpr int T = 64 * WR * WC, BM = 16 * RT * WR, BN = 16 * CT * WC, KT = 16;
+    constexpr int T = 64 * WR * WC, BM = 16 * RT * WR, BN = 16 * CT * WC;
     constexpr int XS = BM + 16;                          // doubles; (XS*2) % 64 == 32 -> conflict-free ds_read_b64
     constexpr int MS = BN + ((BN % 32 == 16) ? 0 : 16);
-    __shared__ __attribute__((aligned(16))) double lds[KT * XS + KT * MS];
-    double* Xs = lds;
-    double* Ms = lds + KT * XS;
+    constexpr int NXI = (KT / 2) * (BM / 4);             // float4 env loads per chunk
+    constexpr int NMI = KT * (BN / 2);                   // double2 matrix loads per chunk
+    constexpr int NX = (NXI + T - 1) / T, NM = (NMI + T - 1) / T;
+    static_assert(T % (BM / 4) == 0, "feature columns must be fixed per thread");
+    constexpr int LB = KT * XS + KT * MS;                // doubles per LDS buffer
+    __shared__ __attribute__((aligned(16))) double lds[(DB + 1) * LB];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid / WC, wc = wid % WC;
@@ -282,50 +291,137 @@ __global__ __launch_bounds__(64 * WR * WC) void k_fgemm64(Fgemm64Args A) {
     const double* M = A.M + (size_t)l * A.M_lstride;
     const int NTp = A.NTp;
 
+    // this thread's feature columns never change across chunks
+    const int xc4 = tid % (BM / 4);
+    const float4 p0 = *reinterpret_cast<const float4*>(A.phiI + n0 + xc4 * 4);
+    const float4 p1 = *reinterpret_cast<const float4*>(A.phiI + NTp + n0 + xc4 * 4);
+
     f64x4 acc[CT][RT];
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
         for (int r = 0; r < RT; ++r) acc[c][r] = f64x4{0., 0., 0., 0.};
 
-    for (int k0 = 0; k0 < A.Kp; k0 += KT) {
-        for (int idx = tid; idx < (KT / 2) * (BM / 4); idx += T) {
-            const int ar = idx / (BM / 4), c4 = idx % (BM / 4);
-            const int a = k0 / 2 + ar, n = n0 + c4 * 4;
-            float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a < A.mI) e = *reinterpret_cast<const float4*>(E + (size_t)a * NTp + n);
-            const float4 p0 = *reinterpret_cast<const float4*>(A.phiI + n);
-            const float4 p1 = *reinterpret_cast<const float4*>(A.phiI + NTp + n);
-            double* x0 = &Xs[(2 * ar) * XS + c4 * 4];
-            double* x1 = &Xs[(2 * ar + 1) * XS + c4 * 4];
-            *reinterpret_cast<double2*>(x0) = make_double2((double)e.x * p0.x, (double)e.y * p0.y);
-            *reinterpret_cast<double2*>(x0 + 2) = make_double2((double)e.z * p0.z, (double)e.w * p0.w);
-            *reinterpret_cast<double2*>(x1) = make_double2((double)e.x * p1.x, (double)e.y * p1.y);
-            *reinterpret_cast<double2*>(x1 + 2) = make_double2((double)e.z * p1.z, (double)e.w * p1.w);
+    float4 xr[NX];
+    double2 mr[NM];
+    auto load_chunk = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < NX; ++q) {
+            const int idx = tid + q * T;
+            const int ar = idx / (BM / 4);
+            const int a = k0 / 2 + ar;
+            xr[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < NXI && a < A.mI) xr[q] = *reinterpret_cast<const float4*>(E + (size_t)a * NTp + n0 + xc4 * 4);
         }
-        for (int idx = tid; idx < KT * (BN / 2); idx += T) {
+#pragma unroll
+        for (int q = 0; q < NM; ++q) {
+            const int idx = tid + q * T;
             const int r = idx / (BN / 2), c2 = idx % (BN / 2);
             const int j = j0 + c2 * 2;
-            double2 v = make_double2(0., 0.);
-            if (j < A.Np) v = *reinterpret_cast<const double2*>(M + (size_t)(k0 + r) * A.Np + j);
-            *reinterpret_cast<double2*>(&Ms[r * MS + c2 * 2]) = v;
+            mr[q] = make_double2(0., 0.);
+            if (idx < NMI && j < A.Np) mr[q] = *reinterpret_cast<const double2*>(M + (size_t)(k0 + r) * A.Np + j);
         }
-        __syncthreads();
+    };
+    auto store_chunk = [&](double* Xs, double* Ms) {
 #pragma unroll
-        for (int kk = 0; kk < KT; kk += 4) {
-            double x[RT], m[CT];
-            const int krow = kk + (lane >> 4);
-#pragma unroll
-            for (int r = 0; r < RT; ++r) x[r] = Xs[krow * XS + (wr * RT + r) * 16 + (lane & 15)];
-#pragma unroll
-            for (int c = 0; c < CT; ++c) m[c] = Ms[krow * MS + (wc * CT + c) * 16 + (lane & 15)];
-#pragma unroll
-            for (int c = 0; c < CT; ++c)
-#pragma unroll
-                for (int r = 0; r < RT; ++r)      // D[i = column j of M][j = image]
-                    acc[c][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(m[c], x[r], acc[c][r], 0, 0, 0);
+        for (int q = 0; q < NX; ++q) {
+            const int idx = tid + q * T;
+            if (idx < NXI) {
+                const int ar = idx / (BM / 4);
+                const float4 e = xr[q];
+                double* x0 = &Xs[(2 * ar) * XS + xc4 * 4];
+                double* x1 = &Xs[(2 * ar + 1) * XS + xc4 * 4];
+                *reinterpret_cast<double2*>(x0) = make_double2((double)e.x * p0.x, (double)e.y * p0.y);
+                *reinterpret_cast<double2*>(x0 + 2) = make_double2((double)e.z * p0.z, (double)e.w * p0.w);
+                *reinterpret_cast<double2*>(x1) = make_double2((double)e.x * p1.x, (double)e.y * p1.y);
+                *reinterpret_cast<double2*>(x1 + 2) = make_double2((double)e.z * p1.z, (double)e.w * p1.w);
+            }
         }
+#pragma unroll
+        for (int q = 0; q < NM; ++q) {
+            const int idx = tid + q * T;
+            if (idx < NMI) {
+                const int r = idx / (BN / 2), c2 = idx % (BN / 2);
+                *reinterpret_cast<double2*>(&Ms[r * MS + c2 * 2]) = mr[q];
+            }
+        }
+    };
+
+    auto frag_load = [&](const double* Xb, const double* Mb, int ks, double* xf, double* mf) {
+        const int krow = 4 * ks + (lane >> 4);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) xf[r] = Xb[krow * XS + (wr * RT + r) * 16 + (lane & 15)];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) mf[c] = Mb[krow * MS + (wc * CT + c) * 16 + (lane & 15)];
+    };
+    auto mfma_step = [&](const double* xf, const double* mf) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {        // D[i = column j of M][j = image]
+                if (ABL == 1) acc[c][r][0] += mf[c] * xf[r];
+                else acc[c][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(mf[c], xf[r], acc[c][r], 0, 0, 0);
+            }
+    };
+    constexpr int KS = KT / 4;
+    static_assert(KS % 2 == 0, "fragment double buffer assumes an even number of k-steps per chunk");
+    double xf[2][RT], mf[2][CT];
+    const int nc = A.Kp / KT;
+
+    if (DB == 2) {
+        // three LDS buffers: chunk c lives in buffer c%3.  The barrier sits at the START of an iteration
+        // (it publishes the chunk stored one iteration ago and frees the buffer read two iterations
+        // ago); nothing right after it depends on this iteration's LDS writes, so the fragments of the
+        // next chunk are prefetched during the last k-step and the matrix pipe never drains.
+        load_chunk(0); store_chunk(lds, lds + KT * XS);
+        if (nc > 1) { load_chunk(KT); store_chunk(lds + LB, lds + LB + KT * XS); }
+        if (nc > 2) load_chunk(2 * KT);
         __syncthreads();
+        frag_load(lds, lds + KT * XS, 0, xf[0], mf[0]);
+        for (int c = 0; c < nc; ++c) {
+            if (c > 0) __syncthreads();
+            if (ABL != 2) {
+                if (c + 2 < nc) { double* Xn = lds + ((c + 2) % 3) * LB; store_chunk(Xn, Xn + KT * XS); }
+                if (c + 3 < nc) load_chunk((c + 3) * KT);
+            }
+            const double* Xb = lds + (c % 3) * LB;
+            const double* Mb = Xb + KT * XS;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks + 1 < KS) frag_load(Xb, Mb, ks + 1, xf[(ks + 1) & 1], mf[(ks + 1) & 1]);
+                else if (c + 1 < nc) { const double* Xn = lds + ((c + 1) % 3) * LB; frag_load(Xn, Xn + KT * XS, 0, xf[0], mf[0]); }
+                mfma_step(xf[ks & 1], mf[ks & 1]);
+            }
+        }
+    } else {
+        load_chunk(0);
+        store_chunk(lds, lds + KT * XS);
+        __syncthreads();
+        int cur = 0;
+        for (int k0 = 0; k0 < A.Kp; k0 += KT) {
+            const bool more = k0 + KT < A.Kp;
+            if (more && ABL != 2) load_chunk(k0 + KT);       // in flight during the MFMA phase
+            const double* Xb = lds + (DB ? cur * LB : 0);
+            const double* Mb = Xb + KT * XS;
+            frag_load(Xb, Mb, 0, xf[0], mf[0]);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks + 1 < KS) frag_load(Xb, Mb, ks + 1, xf[(ks + 1) & 1], mf[(ks + 1) & 1]);
+                mfma_step(xf[ks & 1], mf[ks & 1]);
+            }
+            if (more && ABL != 2) {
+                if (DB) {                                    // other buffer: no wave can still be reading it
+                    double* Xn = lds + (cur ^ 1) * LB;
+                    store_chunk(Xn, Xn + KT * XS);
+                    __syncthreads();
+                    cur ^= 1;
+                } else {
+                    __syncthreads();                         // every wave is done reading this chunk
+                    store_chunk(lds, lds + KT * XS);
+                    __syncthreads();
+                }
+            }
+        }
     }
 
     // epilogue: lane (g = lane>>4, i = lane&15) holds rows g+4e of column-tile c for image i of tile r;
@@ -350,21 +446,44 @@ __global__ __launch_bounds__(64 * WR * WC) void k_fgemm64(Fgemm64Args A) {
     }
 }
 
-template <int RT, int CT, int WR, int WC>
+template <int RT, int CT, int WR, int WC, int KT, int DB = 0>
 static void fgemm64_go(tnml_ctx* c, const Fgemm64Args& a) {
     constexpr int BM = 16 * RT * WR, BN = 16 * CT * WC;
     dim3 grid(a.NTp / BM, (a.Np + BN - 1) / BN, a.L);
-    hipLaunchKernelGGL((k_fgemm64<RT, CT, WR, WC>), grid, dim3(64 * WR * WC), 0, c->stream, a);
+    hipLaunchKernelGGL((k_fgemm64<RT, CT, WR, WC, KT, DB>), grid, dim3(64 * WR * WC), 0, c->stream, a);
 }
 
 int launch_fgemm64(tnml_ctx* c, const Fgemm64Args& a) {
     ProfScope ps(c, KC_FGEMM_FWD);
     if (a.NTp % TNML_NTPAD) return tnml_fail(c, "fgemm64: NTp not padded");
     if (!a.phiO) return tnml_fail(c, "fgemm64: output-site features required");
-    if (a.Np == 240)      fgemm64_go<2, 5, 2, 3>(c, a);     // m = 120: 64 images x 240 columns, 6 waves
-    else if (a.Np > 64)   fgemm64_go<2, 4, 2, 2>(c, a);     // 64 x 128
-    else if (a.Np > 32)   fgemm64_go<2, 2, 2, 2>(c, a);     // 64 x 64
-    else                  fgemm64_go<2, 1, 2, 2>(c, a);     // 64 x 32
+    static const int cfg = getenv("TNML_FG64_CFG") ? atoi(getenv("TNML_FG64_CFG")) : 0;   // tuning knob (tools/tune_fgemm.sh)
+    if (a.Np == 240) {                                       // m = 120: exactly 15 column tiles, no padding waste
+        switch (cfg) {
+            case 1:  fgemm64_go<1, 5, 4, 3, 16>(c, a); break;   // 64 x 240, 12 waves
+            case 2:  fgemm64_go<2, 5, 4, 3, 16>(c, a); break;   // 128 x 240, 12 waves
+            case 3:  fgemm64_go<4, 5, 2, 3, 16>(c, a); break;   // 128 x 240, 6 waves
+            case 4:  fgemm64_go<2, 5, 2, 3, 8>(c, a); break;    // 64 x 240, 6 waves, KT 8
+            case 5:  fgemm64_go<1, 5, 4, 3, 8>(c, a); break;
+            case 6:  fgemm64_go<2, 3, 2, 5, 16>(c, a); break;   // 64 x 240, 10 waves
+            case 7:  fgemm64_go<4, 3, 2, 5, 16>(c, a); break;   // 128 x 240, 10 waves
+            case 8:  fgemm64_go<2, 5, 4, 3, 32>(c, a); break;   // 128 x 240, 12 waves, KT 32
+            case 9:  fgemm64_go<2, 5, 4, 3, 8>(c, a); break;    // 128 x 240, 12 waves, KT 8
+            case 10: fgemm64_go<1, 5, 4, 3, 32>(c, a); break;   // 64 x 240, 12 waves, KT 32
+            case 11: fgemm64_go<2, 5, 4, 3, 16, 1>(c, a); break; // 128 x 240, 12 waves, double-buffered LDS
+            case 12: fgemm64_go<1, 5, 4, 3, 16, 1>(c, a); break; // 64 x 240, 12 waves, double-buffered
+            case 13: fgemm64_go<2, 5, 4, 3, 8, 1>(c, a); break;  // KT 8, double-buffered
+            case 14: fgemm64_go<2, 5, 2, 3, 16, 1>(c, a); break; // 64 x 240, 6 waves, double-buffered
+            case 15: fgemm64_go<2, 5, 4, 3, 16, 2>(c, a); break; // 128 x 240, 12 waves, 3 LDS buffers
+            case 16: fgemm64_go<1, 5, 4, 3, 16, 2>(c, a); break; // 64 x 240, 12 waves, 3 LDS buffers
+            case 17: fgemm64_go<1, 5, 5, 3, 16, 2>(c, a); break; // 80 x 240, 15 waves, 3 LDS buffers
+            case 18: fgemm64_go<2, 5, 2, 3, 16>(c, a); break;   // 64 x 240, 6 waves
+            default: fgemm64_go<2, 5, 4, 3, 16>(c, a); break;   // 128 x 240, 12 waves: best of tools/tune_fgemm.sh (gpurun_out/tune_fgemm_r01.txt)
+        }
+    }
+    else if (a.Np > 64)   fgemm64_go<2, 4, 2, 2, 16>(c, a);     // 64 x 128
+    else if (a.Np > 32)   fgemm64_go<2, 2, 2, 2, 16>(c, a);     // 64 x 64
+    else                  fgemm64_go<2, 1, 2, 2, 16>(c, a);     // 64 x 32
     HIPCK(c, hipGetLastError());
     return 0;
 }
@@ -375,9 +494,13 @@ struct Bgemm64KArgs {
     int nsplit, imgs_per_split;
 };
 
+// Software pipelined like k_fgemm64: the image chunk n+1 is fetched into registers while chunk n feeds
+// the matrix pipe from LDS.
 template <int RT, int CT, int WR, int WC>
 __global__ __launch_bounds__(64 * WR * WC) void k_bgemm64(Bgemm64KArgs K) {
     constexpr int T = 64 * WR * WC, BMr = 16 * RT * WR, BNc = 16 * CT * WC, KTn = 32, ST = KTn + 2;   // doubles
+    constexpr int NAI = (BMr / 2) * (KTn / 4), NBI = (BNc / 2) * (KTn / 4);
+    constexpr int NA = (NAI + T - 1) / T, NB = (NBI + T - 1) / T;
     __shared__ __attribute__((aligned(16))) double lds[(BMr + BNc) * ST];
     double* As = lds;
     double* Bs = lds + BMr * ST;
@@ -397,50 +520,83 @@ __global__ __launch_bounds__(64 * WR * WC) void k_bgemm64(Bgemm64KArgs K) {
 #pragma unroll
         for (int c = 0; c < CT; ++c) acc[r][c] = f64x4{0., 0., 0., 0.};
 
-    for (int nb = nbeg; nb < nend; nb += KTn) {
-        for (int idx = tid; idx < (BMr / 2) * (KTn / 4); idx += T) {
+    float4 ea[NA], pa0[NA], pa1[NA];
+    double zb[NB][4]; float4 pb0[NB], pb1[NB];
+    auto load_chunk = [&](int nb) {
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            const int idx = tid + q * T;
             const int ar = idx / (KTn / 4), c4 = idx % (KTn / 4);
             const int a = i0 / 2 + ar, n = nb + c4 * 4;
-            float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a < A.mI) e = *reinterpret_cast<const float4*>(A.EI + (size_t)a * NTp + n);
-            const float4 p0 = *reinterpret_cast<const float4*>(A.phiI + n);
-            const float4 p1 = *reinterpret_cast<const float4*>(A.phiI + NTp + n);
-            double* x0 = &As[(2 * ar) * ST + c4 * 4];
-            double* x1 = &As[(2 * ar + 1) * ST + c4 * 4];
-            *reinterpret_cast<double2*>(x0) = make_double2((double)e.x * p0.x, (double)e.y * p0.y);
-            *reinterpret_cast<double2*>(x0 + 2) = make_double2((double)e.z * p0.z, (double)e.w * p0.w);
-            *reinterpret_cast<double2*>(x1) = make_double2((double)e.x * p1.x, (double)e.y * p1.y);
-            *reinterpret_cast<double2*>(x1 + 2) = make_double2((double)e.z * p1.z, (double)e.w * p1.w);
+            ea[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < NAI && a < A.mI) ea[q] = *reinterpret_cast<const float4*>(A.EI + (size_t)a * NTp + n);
+            pa0[q] = *reinterpret_cast<const float4*>(A.phiI + n);
+            pa1[q] = *reinterpret_cast<const float4*>(A.phiI + NTp + n);
         }
-        for (int idx = tid; idx < (BNc / 2) * (KTn / 4); idx += T) {
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int idx = tid + q * T;
             const int qr = idx / (KTn / 4), c4 = idx % (KTn / 4);
-            const int q = j0 / 2 + qr, n = nb + c4 * 4;
-            double z0 = 0., z1 = 0., z2 = 0., z3 = 0.;
-            if (q < A.mO) {
+            const int qq = j0 / 2 + qr, n = nb + c4 * 4;
+            zb[q][0] = zb[q][1] = zb[q][2] = zb[q][3] = 0.;
+            if (idx < NBI && qq < A.mO) {
                 if (A.Zq64) {
-                    const double2 za = *reinterpret_cast<const double2*>(A.Zq64 + (size_t)q * NTp + n);
-                    const double2 zb = *reinterpret_cast<const double2*>(A.Zq64 + (size_t)q * NTp + n + 2);
-                    z0 = za.x; z1 = za.y; z2 = zb.x; z3 = zb.y;
+                    const double2 za = *reinterpret_cast<const double2*>(A.Zq64 + (size_t)qq * NTp + n);
+                    const double2 zc = *reinterpret_cast<const double2*>(A.Zq64 + (size_t)qq * NTp + n + 2);
+                    zb[q][0] = za.x; zb[q][1] = za.y; zb[q][2] = zc.x; zb[q][3] = zc.y;
                 } else {
-                    const float4 zf = *reinterpret_cast<const float4*>(A.Zq32 + (size_t)q * NTp + n);
-                    z0 = zf.x; z1 = zf.y; z2 = zf.z; z3 = zf.w;
+                    const float4 zf = *reinterpret_cast<const float4*>(A.Zq32 + (size_t)qq * NTp + n);
+                    zb[q][0] = zf.x; zb[q][1] = zf.y; zb[q][2] = zf.z; zb[q][3] = zf.w;
                 }
             }
             if (w) {
                 const double2 wa = *reinterpret_cast<const double2*>(w + n);
                 const double2 wb = *reinterpret_cast<const double2*>(w + n + 2);
-                z0 *= wa.x; z1 *= wa.y; z2 *= wb.x; z3 *= wb.y;
+                zb[q][0] *= wa.x; zb[q][1] *= wa.y; zb[q][2] *= wb.x; zb[q][3] *= wb.y;
             }
-            const float4 p0 = *reinterpret_cast<const float4*>(A.phiO + n);
-            const float4 p1 = *reinterpret_cast<const float4*>(A.phiO + NTp + n);
-            double* b0 = &Bs[(2 * qr) * ST + c4 * 4];
-            double* b1 = &Bs[(2 * qr + 1) * ST + c4 * 4];
-            *reinterpret_cast<double2*>(b0) = make_double2(z0 * p0.x, z1 * p0.y);
-            *reinterpret_cast<double2*>(b0 + 2) = make_double2(z2 * p0.z, z3 * p0.w);
-            *reinterpret_cast<double2*>(b1) = make_double2(z0 * p1.x, z1 * p1.y);
-            *reinterpret_cast<double2*>(b1 + 2) = make_double2(z2 * p1.z, z3 * p1.w);
+            pb0[q] = *reinterpret_cast<const float4*>(A.phiO + n);
+            pb1[q] = *reinterpret_cast<const float4*>(A.phiO + NTp + n);
         }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            const int idx = tid + q * T;
+            if (idx < NAI) {
+                const int ar = idx / (KTn / 4), c4 = idx % (KTn / 4);
+                const float4 e = ea[q], p0 = pa0[q], p1 = pa1[q];
+                double* x0 = &As[(2 * ar) * ST + c4 * 4];
+                double* x1 = &As[(2 * ar + 1) * ST + c4 * 4];
+                *reinterpret_cast<double2*>(x0) = make_double2((double)e.x * p0.x, (double)e.y * p0.y);
+                *reinterpret_cast<double2*>(x0 + 2) = make_double2((double)e.z * p0.z, (double)e.w * p0.w);
+                *reinterpret_cast<double2*>(x1) = make_double2((double)e.x * p1.x, (double)e.y * p1.y);
+                *reinterpret_cast<double2*>(x1 + 2) = make_double2((double)e.z * p1.z, (double)e.w * p1.w);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int idx = tid + q * T;
+            if (idx < NBI) {
+                const int qr = idx / (KTn / 4), c4 = idx % (KTn / 4);
+                const float4 p0 = pb0[q], p1 = pb1[q];
+                double* b0 = &Bs[(2 * qr) * ST + c4 * 4];
+                double* b1 = &Bs[(2 * qr + 1) * ST + c4 * 4];
+                *reinterpret_cast<double2*>(b0) = make_double2(zb[q][0] * p0.x, zb[q][1] * p0.y);
+                *reinterpret_cast<double2*>(b0 + 2) = make_double2(zb[q][2] * p0.z, zb[q][3] * p0.w);
+                *reinterpret_cast<double2*>(b1) = make_double2(zb[q][0] * p1.x, zb[q][1] * p1.y);
+                *reinterpret_cast<double2*>(b1 + 2) = make_double2(zb[q][2] * p1.z, zb[q][3] * p1.w);
+            }
+        }
+    };
+
+    if (nbeg < nend) {
+        load_chunk(nbeg);
+        store_chunk();
         __syncthreads();
+    }
+    for (int nb = nbeg; nb < nend; nb += KTn) {
+        const bool more = nb + KTn < nend;
+        if (more) load_chunk(nb + KTn);
 #pragma unroll
         for (int kk = 0; kk < KTn; kk += 8) {
             // lane group g owns images kk+2g, kk+2g+1; MFMA step e uses element e of every group
@@ -458,7 +614,11 @@ __global__ __launch_bounds__(64 * WR * WC) void k_bgemm64(Bgemm64KArgs K) {
                     acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r].y, b[c].y, acc[r][c], 0, 0, 0);
                 }
         }
-        __syncthreads();
+        if (more) {
+            __syncthreads();
+            store_chunk();
+            __syncthreads();
+        }
     }
 
     double* slab = K.slab + ((size_t)split * A.L + l) * A.Kp * A.Np;
@@ -484,10 +644,12 @@ __global__ void k_slab_reduce64(const double* __restrict__ slab, double* __restr
 }
 
 template <int RT, int CT, int WR, int WC>
-static int bgemm64_go(tnml_ctx* c, const Bgemm64Args& a, double* G) {
+static int bgemm64_go(tnml_ctx* c, const Bgemm64Args& a, double* G, int default_wgs = 768) {
     constexpr int BMr = 16 * RT * WR, BNc = 16 * CT * WC;
     const int tiles = ((a.Kp + BMr - 1) / BMr) * ((a.Np + BNc - 1) / BNc) * a.L;
-    int nsplit = (768 + tiles - 1) / tiles;
+    static const int env_wgs = getenv("TNML_BG64_WGS") ? atoi(getenv("TNML_BG64_WGS")) : 0;
+    const int target_wgs = env_wgs > 0 ? env_wgs : default_wgs;
+    int nsplit = (target_wgs + tiles - 1) / tiles;
     const int chunks = a.NTp / 32;
     if (nsplit > chunks) nsplit = chunks;
     if (nsplit < 1) nsplit = 1;
@@ -512,6 +674,18 @@ static int bgemm64_go(tnml_ctx* c, const Bgemm64Args& a, double* G) {
 }
 
 int launch_bgemm64(tnml_ctx* c, const Bgemm64Args& a, double* G) {
+    static const int cfg = getenv("TNML_BG64_CFG") ? atoi(getenv("TNML_BG64_CFG")) : 0;
+    if (a.Kp % 240 == 0 && a.Np % 240 == 0) {
+        // 15-wave workgroups, one per CU (255 = 3 tiles x 85 image splits): tools/tune_bgemm.sh,
+        // gpurun_out/tune_bgemm_r01.txt
+        switch (cfg) {
+            case 1: return bgemm64_go<1, 5, 5, 3>(c, a, G, 255 * a.L);    // 80 x 240 tiles, 15 waves
+            case 3: return bgemm64_go<1, 5, 3, 3>(c, a, G);              // 48 x 240, 9 waves
+            case 4: return bgemm64_go<3, 5, 5, 1>(c, a, G);              // 240 x 80, 5 waves
+            case 5: return bgemm64_go<1, 5, 5, 1>(c, a, G);              // 80 x 80, 5 waves
+            default: return bgemm64_go<5, 1, 3, 5>(c, a, G, 255 * a.L);  // 240 x 80 tiles, 15 waves
+        }
+    }
     if (a.Kp % 80 == 0 && a.Np % 80 == 0) return bgemm64_go<1, 5, 5, 1>(c, a, G);
     if (a.Kp > 32 && a.Np > 32) return bgemm64_go<2, 2, 2, 2>(c, a, G);
     return bgemm64_go<1, 1, 2, 2>(c, a, G);
