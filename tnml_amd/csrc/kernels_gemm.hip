@@ -496,12 +496,17 @@ struct Bgemm64KArgs {
 
 // Software pipelined like k_fgemm64: the image chunk n+1 is fetched into registers while chunk n feeds
 // the matrix pipe from LDS.
-template <int RT, int CT, int WR, int WC>
+// FUSE: the B operand is built from the Label-carrying environment itself,
+//   Z[q][n] = sum_l EL[l][q][n] * dP[l][n]   (the first half of dP*dag(t.v), fixedL.cc:379,418),
+// so the separate k_zprime pass (a second full stream of EL plus a Z' round trip) disappears and the
+// HBM stream of EL overlaps the matrix pipe.
+template <int RT, int CT, int WR, int WC, int FUSE = 0>
 __global__ __launch_bounds__(64 * WR * WC) void k_bgemm64(Bgemm64KArgs K) {
     constexpr int T = 64 * WR * WC, BMr = 16 * RT * WR, BNc = 16 * CT * WC, KTn = 32, ST = KTn + 2;   // doubles
     constexpr int NAI = (BMr / 2) * (KTn / 4), NBI = (BNc / 2) * (KTn / 4);
     constexpr int NA = (NAI + T - 1) / T, NB = (NBI + T - 1) / T;
-    __shared__ __attribute__((aligned(16))) double lds[(BMr + BNc) * ST];
+    static_assert(!FUSE || T >= TNML_NL * KTn, "dP tile needs one lane per entry");
+    __shared__ __attribute__((aligned(16))) double lds[(BMr + BNc) * ST + (FUSE ? TNML_NL * KTn : 0)];
     double* As = lds;
     double* Bs = lds + BMr * ST;
     const Bgemm64Args& A = K.a;
@@ -522,6 +527,10 @@ __global__ __launch_bounds__(64 * WR * WC) void k_bgemm64(Bgemm64KArgs K) {
 
     float4 ea[NA], pa0[NA], pa1[NA];
     double zb[NB][4]; float4 pb0[NB], pb1[NB];
+    constexpr int NFI = (BNc / 2) * (KTn / 2), NF = (NFI + T - 1) / T;   // FUSE: B tasks are (q-row, image pair)
+    float2 el[FUSE ? NF : 1][FUSE ? TNML_NL : 1];   // Label-carrying env rows of the chunk in flight (FUSE)
+    double dpr = 0.;                               // this lane's entry of the dP tile [10][KTn] (FUSE)
+    double* dPs = lds + (BMr + BNc) * ST;          // [10][KTn]
     auto load_chunk = [&](int nb) {
 #pragma unroll
         for (int q = 0; q < NA; ++q) {
@@ -530,41 +539,61 @@ __global__ __launch_bounds__(64 * WR * WC) void k_bgemm64(Bgemm64KArgs K) {
             const int a = i0 / 2 + ar, n = nb + c4 * 4;
             ea[q] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (idx < NAI && a < A.mI) ea[q] = *reinterpret_cast<const float4*>(A.EI + (size_t)a * NTp + n);
-            pa0[q] = *reinterpret_cast<const float4*>(A.phiI + n);
-            pa1[q] = *reinterpret_cast<const float4*>(A.phiI + NTp + n);
+            if (!FUSE) {
+                pa0[q] = *reinterpret_cast<const float4*>(A.phiI + n);
+                pa1[q] = *reinterpret_cast<const float4*>(A.phiI + NTp + n);
+            }
         }
+        if (FUSE) {
 #pragma unroll
-        for (int q = 0; q < NB; ++q) {
-            const int idx = tid + q * T;
-            const int qr = idx / (KTn / 4), c4 = idx % (KTn / 4);
-            const int qq = j0 / 2 + qr, n = nb + c4 * 4;
-            zb[q][0] = zb[q][1] = zb[q][2] = zb[q][3] = 0.;
-            if (idx < NBI && qq < A.mO) {
-                if (A.Zq64) {
-                    const double2 za = *reinterpret_cast<const double2*>(A.Zq64 + (size_t)qq * NTp + n);
-                    const double2 zc = *reinterpret_cast<const double2*>(A.Zq64 + (size_t)qq * NTp + n + 2);
-                    zb[q][0] = za.x; zb[q][1] = za.y; zb[q][2] = zc.x; zb[q][3] = zc.y;
-                } else {
-                    const float4 zf = *reinterpret_cast<const float4*>(A.Zq32 + (size_t)qq * NTp + n);
-                    zb[q][0] = zf.x; zb[q][1] = zf.y; zb[q][2] = zf.z; zb[q][3] = zf.w;
+            for (int q = 0; q < NF; ++q) {
+                const int idx = tid + q * T;
+                const int qr = idx / (KTn / 2), c2 = idx % (KTn / 2);
+                const int qq = j0 / 2 + qr, n = nb + c2 * 2;
+#pragma unroll
+                for (int ll = 0; ll < TNML_NL; ++ll) {
+                    el[q][ll] = make_float2(0.f, 0.f);
+                    if (idx < NFI && qq < A.mO) el[q][ll] = *reinterpret_cast<const float2*>(A.EL + (size_t)ll * A.EL_lstride + (size_t)qq * NTp + n);
                 }
             }
-            if (w) {
-                const double2 wa = *reinterpret_cast<const double2*>(w + n);
-                const double2 wb = *reinterpret_cast<const double2*>(w + n + 2);
-                zb[q][0] *= wa.x; zb[q][1] *= wa.y; zb[q][2] *= wb.x; zb[q][3] *= wb.y;
+        } else {
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                const int idx = tid + q * T;
+                const int qr = idx / (KTn / 4), c4 = idx % (KTn / 4);
+                const int qq = j0 / 2 + qr, n = nb + c4 * 4;
+                zb[q][0] = zb[q][1] = zb[q][2] = zb[q][3] = 0.;
+                if (idx < NBI && qq < A.mO) {
+                    if (A.Zq64) {
+                        const double2 za = *reinterpret_cast<const double2*>(A.Zq64 + (size_t)qq * NTp + n);
+                        const double2 zc = *reinterpret_cast<const double2*>(A.Zq64 + (size_t)qq * NTp + n + 2);
+                        zb[q][0] = za.x; zb[q][1] = za.y; zb[q][2] = zc.x; zb[q][3] = zc.y;
+                    } else {
+                        const float4 zf = *reinterpret_cast<const float4*>(A.Zq32 + (size_t)qq * NTp + n);
+                        zb[q][0] = zf.x; zb[q][1] = zf.y; zb[q][2] = zf.z; zb[q][3] = zf.w;
+                    }
+                }
+                if (w) {
+                    const double2 wa = *reinterpret_cast<const double2*>(w + n);
+                    const double2 wb = *reinterpret_cast<const double2*>(w + n + 2);
+                    zb[q][0] *= wa.x; zb[q][1] *= wa.y; zb[q][2] *= wb.x; zb[q][3] *= wb.y;
+                }
+                pb0[q] = *reinterpret_cast<const float4*>(A.phiO + n);
+                pb1[q] = *reinterpret_cast<const float4*>(A.phiO + NTp + n);
             }
-            pb0[q] = *reinterpret_cast<const float4*>(A.phiO + n);
-            pb1[q] = *reinterpret_cast<const float4*>(A.phiO + NTp + n);
         }
+        if (FUSE && tid < TNML_NL * KTn) dpr = A.dPz[(size_t)(tid / KTn) * NTp + nb + (tid % KTn)];
     };
-    auto store_chunk = [&]() {
+    auto store_dp = [&]() { if (FUSE && tid < TNML_NL * KTn) dPs[tid] = dpr; };
+    auto store_chunk = [&](int nb) {
 #pragma unroll
         for (int q = 0; q < NA; ++q) {
             const int idx = tid + q * T;
             if (idx < NAI) {
                 const int ar = idx / (KTn / 4), c4 = idx % (KTn / 4);
-                const float4 e = ea[q], p0 = pa0[q], p1 = pa1[q];
+                const float4 e = ea[q];
+                const float4 p0 = FUSE ? *reinterpret_cast<const float4*>(A.phiI + nb + c4 * 4) : pa0[q];          // FUSE: register budget,
+                const float4 p1 = FUSE ? *reinterpret_cast<const float4*>(A.phiI + NTp + nb + c4 * 4) : pa1[q];    // the features are cache hot
                 double* x0 = &As[(2 * ar) * ST + c4 * 4];
                 double* x1 = &As[(2 * ar + 1) * ST + c4 * 4];
                 *reinterpret_cast<double2*>(x0) = make_double2((double)e.x * p0.x, (double)e.y * p0.y);
@@ -573,25 +602,47 @@ __global__ __launch_bounds__(64 * WR * WC) void k_bgemm64(Bgemm64KArgs K) {
                 *reinterpret_cast<double2*>(x1 + 2) = make_double2((double)e.z * p1.z, (double)e.w * p1.w);
             }
         }
+        if (FUSE) {
 #pragma unroll
-        for (int q = 0; q < NB; ++q) {
-            const int idx = tid + q * T;
-            if (idx < NBI) {
-                const int qr = idx / (KTn / 4), c4 = idx % (KTn / 4);
-                const float4 p0 = pb0[q], p1 = pb1[q];
-                double* b0 = &Bs[(2 * qr) * ST + c4 * 4];
-                double* b1 = &Bs[(2 * qr + 1) * ST + c4 * 4];
-                *reinterpret_cast<double2*>(b0) = make_double2(zb[q][0] * p0.x, zb[q][1] * p0.y);
-                *reinterpret_cast<double2*>(b0 + 2) = make_double2(zb[q][2] * p0.z, zb[q][3] * p0.w);
-                *reinterpret_cast<double2*>(b1) = make_double2(zb[q][0] * p1.x, zb[q][1] * p1.y);
-                *reinterpret_cast<double2*>(b1 + 2) = make_double2(zb[q][2] * p1.z, zb[q][3] * p1.w);
+            for (int q = 0; q < NF; ++q) {
+                const int idx = tid + q * T;
+                if (idx < NFI) {
+                    const int qr = idx / (KTn / 2), c2 = idx % (KTn / 2);
+                    double z0 = 0., z1 = 0.;
+#pragma unroll
+                    for (int ll = 0; ll < TNML_NL; ++ll) {
+                        const double2 d = *reinterpret_cast<const double2*>(&dPs[ll * KTn + c2 * 2]);
+                        z0 = fma((double)el[q][ll].x, d.x, z0);
+                        z1 = fma((double)el[q][ll].y, d.y, z1);
+                    }
+                    const float2 f0 = *reinterpret_cast<const float2*>(A.phiO + nb + c2 * 2);
+                    const float2 f1 = *reinterpret_cast<const float2*>(A.phiO + NTp + nb + c2 * 2);
+                    *reinterpret_cast<double2*>(&Bs[(2 * qr) * ST + c2 * 2]) = make_double2(z0 * f0.x, z1 * f0.y);
+                    *reinterpret_cast<double2*>(&Bs[(2 * qr + 1) * ST + c2 * 2]) = make_double2(z0 * f1.x, z1 * f1.y);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                const int idx = tid + q * T;
+                if (idx < NBI) {
+                    const int qr = idx / (KTn / 4), c4 = idx % (KTn / 4);
+                    const float4 p0 = pb0[q], p1 = pb1[q];
+                    double* b0 = &Bs[(2 * qr) * ST + c4 * 4];
+                    double* b1 = &Bs[(2 * qr + 1) * ST + c4 * 4];
+                    *reinterpret_cast<double2*>(b0) = make_double2(zb[q][0] * p0.x, zb[q][1] * p0.y);
+                    *reinterpret_cast<double2*>(b0 + 2) = make_double2(zb[q][2] * p0.z, zb[q][3] * p0.w);
+                    *reinterpret_cast<double2*>(b1) = make_double2(zb[q][0] * p1.x, zb[q][1] * p1.y);
+                    *reinterpret_cast<double2*>(b1 + 2) = make_double2(zb[q][2] * p1.z, zb[q][3] * p1.w);
+                }
             }
         }
     };
 
     if (nbeg < nend) {
         load_chunk(nbeg);
-        store_chunk();
+        if (FUSE) { store_dp(); __syncthreads(); }
+        store_chunk(nbeg);
         __syncthreads();
     }
     for (int nb = nbeg; nb < nend; nb += KTn) {
@@ -616,7 +667,8 @@ __global__ __launch_bounds__(64 * WR * WC) void k_bgemm64(Bgemm64KArgs K) {
         }
         if (more) {
             __syncthreads();
-            store_chunk();
+            if (FUSE) { store_dp(); __syncthreads(); }      // the dP tile feeds the Z build below
+            store_chunk(nb + KTn);
             __syncthreads();
         }
     }
@@ -643,7 +695,7 @@ __global__ void k_slab_reduce64(const double* __restrict__ slab, double* __restr
     G[i] = s;
 }
 
-template <int RT, int CT, int WR, int WC>
+template <int RT, int CT, int WR, int WC, int FUSE = 0>
 static int bgemm64_go(tnml_ctx* c, const Bgemm64Args& a, double* G, int default_wgs = 768) {
     constexpr int BMr = 16 * RT * WR, BNc = 16 * CT * WC;
     const int tiles = ((a.Kp + BMr - 1) / BMr) * ((a.Np + BNc - 1) / BNc) * a.L;
@@ -663,7 +715,7 @@ static int bgemm64_go(tnml_ctx* c, const Bgemm64Args& a, double* G, int default_
     {
         ProfScope ps(c, KC_BGEMM);
         dim3 grid((a.Kp + BMr - 1) / BMr, (a.Np + BNc - 1) / BNc, nsplit * a.L);
-        hipLaunchKernelGGL((k_bgemm64<RT, CT, WR, WC>), grid, dim3(64 * WR * WC), 0, c->stream, K);
+        hipLaunchKernelGGL((k_bgemm64<RT, CT, WR, WC, FUSE>), grid, dim3(64 * WR * WC), 0, c->stream, K);
     }
     {
         ProfScope ps(c, KC_SLABRED);
@@ -675,6 +727,16 @@ static int bgemm64_go(tnml_ctx* c, const Bgemm64Args& a, double* G, int default_
 
 int launch_bgemm64(tnml_ctx* c, const Bgemm64Args& a, double* G) {
     static const int cfg = getenv("TNML_BG64_CFG") ? atoi(getenv("TNML_BG64_CFG")) : 0;
+    if (a.EL) {                                             // fused Z build: >= 320 lanes per workgroup
+        static const int fcfg = getenv("TNML_BGF_CFG") ? atoi(getenv("TNML_BGF_CFG")) : 0;
+        if (a.Kp % 240 == 0 && a.Np % 240 == 0) {
+            if (fcfg == 1) return bgemm64_go<5, 1, 3, 5, 1>(c, a, G, 255 * a.L);   // 240 x 80, 15 waves (128-VGPR cap: spills)
+            if (fcfg == 2) return bgemm64_go<5, 1, 3, 3, 1>(c, a, G, 255 * a.L);   // 240 x 48, 9 waves
+            return bgemm64_go<5, 1, 3, 4, 1>(c, a, G, 256 * a.L);                  // 240 x 64, 12 waves: 187 us vs 153+90 unfused
+        }
+        if (a.Kp % 80 == 0 && a.Np % 80 == 0) return bgemm64_go<1, 5, 5, 1, 1>(c, a, G);               // 80 x 80, 5 waves
+        return bgemm64_go<2, 2, 3, 2, 1>(c, a, G);                                                     // 96 x 64, 6 waves
+    }
     if (a.Kp % 240 == 0 && a.Np % 240 == 0) {
         // 15-wave workgroups, one per CU (255 = 3 tiles x 85 image splits): tools/tune_bgemm.sh,
         // gpurun_out/tune_bgemm_r01.txt

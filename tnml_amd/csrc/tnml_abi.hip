@@ -139,6 +139,7 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     if ((rc = dmalloc(c, (char**)&c->dP, (size_t)TNML_NL * NTp * esz))) return bail(rc);
     if ((rc = dmalloc(c, (char**)&c->Pp, (size_t)TNML_NL * NTp * esz))) return bail(rc);
     if (const char* e = getenv("TNML_FAST_CG")) c->fast_cg = atoi(e) != 0;
+    if (const char* e = getenv("TNML_FUSE_Z")) c->fuse_z = atoi(e) != 0;
     if ((rc = dmalloc(c, (char**)&c->Zp, c->small_elems * esz))) return bail(rc);
     if ((rc = dmalloc(c, &c->Mf, c->mcap))) return bail(rc);
     if ((rc = dmalloc(c, (char**)&c->slab, c->slab_bytes))) return bail(rc);
@@ -460,12 +461,15 @@ static int grad_eval(tnml_ctx* c, bool from_P_update = false) {
     const size_t n = p.msize();
     if (from_P_update) TCK(launch_pupdate(c, c->scal + SC_ALPHA, c->vG + n));          // P += a (p*t.v): no GEMM
     else               TCK(forward_pass(c, c->vB, LD_MODE_COST, c->vG + n, c->fast_cg)); // keeps P when fast CG is on
-    if (p.kind != 2) TCK(launch_zprime(c, p.EX, (size_t)p.mO * c->NTp, c->dP, c->Zp, p.mO, c->NTp));
+    const bool fuse = c->f64() && c->fuse_z && p.kind != 2;
+    if (p.kind != 2 && !fuse) TCK(launch_zprime(c, p.EX, (size_t)p.mO * c->NTp, c->dP, c->Zp, p.mO, c->NTp));
     if (c->f64()) {
         Bgemm64Args g;
+        g.EL = nullptr; g.EL_lstride = 0; g.dPz = nullptr;
         g.EI = p.EI; g.mI = p.mI; g.phiI = p.phiI; g.phiO = p.phiO; g.mO = p.mO;
         g.Kp = p.Kp; g.Np = p.Np; g.NTp = c->NTp; g.L = p.LB;
         if (p.kind == 2) { g.Zq64 = nullptr; g.Zq32 = p.EX; g.w = (const double*)c->dP; g.w_lstride = c->NTp; }
+        else if (fuse)   { g.Zq64 = nullptr; g.Zq32 = nullptr; g.w = nullptr; g.w_lstride = 0; g.EL = p.EX; g.EL_lstride = (size_t)p.mO * c->NTp; g.dPz = (const double*)c->dP; }
         else             { g.Zq64 = (const double*)c->Zp; g.Zq32 = nullptr; g.w = nullptr; g.w_lstride = 0; }
         TCK(launch_bgemm64(c, g, c->vG));
     } else {

@@ -92,6 +92,7 @@ struct tnml_ctx {
     void* P = nullptr;         // [10][NTp]
     void* dP = nullptr;        // [10][NTp]
     void* Pp = nullptr;        // [10][NTp]  p*t.v of the last pAp pass (fast CG)
+    bool fuse_z = true;        // gradient GEMM builds Z from EL and dP itself instead of a k_zprime pass (env TNML_FUSE_Z=0 disables)
     bool fast_cg = true;       // P <- P + a (p*t.v) instead of re-running the forward GEMM (env TNML_FAST_CG=0 disables)
     void* Zp = nullptr;        // [maxm][NTp]
     float* Mf = nullptr;       // fp32 GEMM operand, M-layout, capacity 10*Kmax*Kmax (env shifts, F32 mode)
@@ -172,7 +173,8 @@ struct Fgemm64Args {
 int launch_fgemm64(tnml_ctx* c, const Fgemm64Args& a);
 struct Bgemm64Args {
     const float* EI; int mI; const float* phiI;
-    const double* Zq64; const float* Zq32; int mO; const float* phiO;   // exactly one of Zq64 / Zq32
+    const double* Zq64; const float* Zq32; int mO; const float* phiO;   // exactly one of Zq64 / Zq32 / EL
+    const float* EL; size_t EL_lstride; const double* dPz;              // fused: Z = sum_l EL[l] * dPz[l]
     const double* w; size_t w_lstride;
     int Kp, Np, NTp, L;
 };
