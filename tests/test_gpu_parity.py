@@ -241,3 +241,18 @@ def test_svd_split_240x240_against_lapack(ha, backend, monkeypatch):
     A = ts.get_site(b if ha == 1 else b + 1)
     Q = A.reshape(240, 120, order="F") if ha == 1 else A.reshape(120, 240, order="F").T
     np.testing.assert_allclose(Q.T @ Q, np.eye(120), atol=1e-10)
+
+
+def test_cgrad_early_exit_on_cconv():
+    """|r| < cconv (fixedL.cc:432-436) is a device-side flag here: later passes must be no-ops"""
+    ts, o = _pair()
+    B0 = o.bond_tensor(1)
+    _, t_ref = o.cgrad(B0, 4, 1e-3, 1e-10)
+    cconv = 0.5 * (t_ref["rnorm"][0] + t_ref["rnorm"][1])            # trips at the second pass
+    assert t_ref["rnorm"][1] < cconv < t_ref["rnorm"][0]
+    Bg, tg = ts.cgrad(B0, 4, 1e-3, cconv)
+    Bo, to = o.cgrad(B0, 4, 1e-3, cconv)
+    assert to["converged"] and tg["converged"]
+    assert tg["npass_done"] == to["npass_done"] == 2
+    np.testing.assert_allclose(tg["cost"], to["cost"], rtol=1e-5)
+    assert _relmax(Bg, Bo) < 1e-4

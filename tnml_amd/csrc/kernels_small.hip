@@ -136,7 +136,7 @@ __global__ __launch_bounds__(VB) void k_cg_init1(const double* __restrict__ G, c
     if (threadIdx.x == 0) { part[2 * blockIdx.x] = s; part[2 * blockIdx.x + 1] = 0.; }
 }
 __global__ void k_cg_init2(const double* __restrict__ part, int nb, double* __restrict__ scal, int rr_out) {
-    if (threadIdx.x == 0) { double a, b; sum_partials(part, nb, &a, &b); scal[rr_out] = a; }
+    if (threadIdx.x == 0) { double a, b; sum_partials(part, nb, &a, &b); scal[rr_out] = a; scal[SC_CONV] = 0.; scal[SC_NPASS] = 0.; }
 }
 // partial |x|^2 (and |y|^2)
 __global__ __launch_bounds__(VB) void k_norm1(const double* __restrict__ x, const double* __restrict__ y, size_t n, double* __restrict__ part) {
@@ -151,13 +151,17 @@ __global__ __launch_bounds__(VB) void k_norm1(const double* __restrict__ x, cons
 // pAp = sum_n|p v_n|^2 + lambda|p|^2 (:402-403); a = |r|^2/pAp (:405); B = B + a p (:406)
 __global__ __launch_bounds__(VB) void k_cg_step2(double* __restrict__ B, const double* __restrict__ Pv, size_t n, double lambda,
                                                 const double* __restrict__ tail, const double* __restrict__ part, int nb,
-                                                double* __restrict__ scal, int rr_in) {
+                                                double* __restrict__ scal, int rr_in, double* __restrict__ trace, int pass) {
+    if (scal[SC_CONV] != 0.) return;                       // |r| < cconv was hit in an earlier pass (fixedL.cc:432-436)
     double pn2, unused; sum_partials(part, nb, &pn2, &unused);
     const double pAp = tail[SC_PP] + lambda * pn2;
     const double a = scal[rr_in] / pAp;
     size_t lo, hi; slice(n, &lo, &hi);
     for (size_t i = lo + threadIdx.x; i < hi; i += VB) B[i] = B[i] + a * Pv[i];
-    if (blockIdx.x == 0 && threadIdx.x == 0) { scal[SC_PNORM2] = pn2; scal[SC_PAP] = pAp; scal[SC_ALPHA] = a; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        scal[SC_PNORM2] = pn2; scal[SC_PAP] = pAp; scal[SC_ALPHA] = a; scal[SC_NPASS] = (double)pass;
+        trace[4 * (pass - 1) + 0] = pAp; trace[4 * (pass - 1) + 1] = a;
+    }
 }
 // partial |nr|^2 with nr = G - lambda B, and |B|^2
 __global__ __launch_bounds__(VB) void k_cg_resid1(const double* __restrict__ G, const double* __restrict__ B, size_t n, double lambda,
@@ -179,7 +183,9 @@ __global__ __launch_bounds__(VB) void k_cg_resid1(const double* __restrict__ G, 
 __global__ __launch_bounds__(VB) void k_cg_resid2(const double* __restrict__ G, const double* __restrict__ B, double* __restrict__ R,
                                                  double* __restrict__ Pv, size_t n, double lambda, double cconv,
                                                  const double* __restrict__ tail, const double* __restrict__ part, int nb,
-                                                 double* __restrict__ scal, int rr_in, int rr_out) {
+                                                 double* __restrict__ scal, int rr_in, int rr_out,
+                                                 double* __restrict__ trace, int pass) {
+    if (scal[SC_CONV] != 0.) return;
     double nn, bn2; sum_partials(part, nb, &nn, &bn2);
     const double q = sqrt(nn) / sqrt(scal[rr_in]);
     const double beta = q * q;
@@ -196,9 +202,14 @@ __global__ __launch_bounds__(VB) void k_cg_resid2(const double* __restrict__ G, 
         double cs = 0.;
         for (int l = 0; l < TNML_NL; ++l) cs += tail[SC_COST0 + l];
         scal[SC_COST] = cs + lambda * bn2;
-        scal[SC_BNORM2] = bn2; scal[SC_BETA] = beta; scal[SC_RNORM] = rn; scal[SC_CONV] = (double)conv;
+        scal[SC_BNORM2] = bn2; scal[SC_BETA] = beta; scal[SC_RNORM] = rn;
         scal[rr_out] = nn;
+        trace[4 * (pass - 1) + 2] = cs + lambda * bn2; trace[4 * (pass - 1) + 3] = rn;
+        scal[SC_CONV_NEXT] = (double)conv;                 // becomes visible to the next kernels through k_cg_commit
     }
+}
+__global__ void k_cg_commit(double* __restrict__ scal) {
+    if (threadIdx.x == 0 && scal[SC_CONV] == 0.) scal[SC_CONV] = scal[SC_CONV_NEXT];
 }
 __global__ void k_norm2(const double* __restrict__ part, int nb, double* __restrict__ out, int nout) {
     if (threadIdx.x == 0) { double a, b; sum_partials(part, nb, &a, &b); out[0] = a; if (nout > 1) out[1] = b; }
@@ -226,20 +237,21 @@ int launch_cg_init(tnml_ctx* c, size_t n, double lambda) {
     HIPCK(c, hipGetLastError());
     return 0;
 }
-int launch_cg_step(tnml_ctx* c, size_t n, double lambda) {
+int launch_cg_step(tnml_ctx* c, size_t n, double lambda, int pass) {
     ProfScope ps(c, KC_VEC);
     const int nb = vec_blocks(n);
     hipLaunchKernelGGL(k_norm1, dim3(nb), dim3(VB), 0, c->stream, c->vP, (const double*)nullptr, n, c->vpart);
-    hipLaunchKernelGGL(k_cg_step2, dim3(nb), dim3(VB), 0, c->stream, c->vB, c->vP, n, lambda, c->vG + n, c->vpart, nb, c->scal, SC_RR + c->rr_slot);
+    hipLaunchKernelGGL(k_cg_step2, dim3(nb), dim3(VB), 0, c->stream, c->vB, c->vP, n, lambda, c->vG + n, c->vpart, nb, c->scal, SC_RR + c->rr_slot, c->cgtrace, pass);
     HIPCK(c, hipGetLastError());
     return 0;
 }
-int launch_cg_resid(tnml_ctx* c, size_t n, double lambda, double cconv) {
+int launch_cg_resid(tnml_ctx* c, size_t n, double lambda, double cconv, int pass) {
     ProfScope ps(c, KC_VEC);
     const int nb = vec_blocks(n);
     const int in = SC_RR + c->rr_slot, out = SC_RR + (c->rr_slot ^ 1);
     hipLaunchKernelGGL(k_cg_resid1, dim3(nb), dim3(VB), 0, c->stream, c->vG, c->vB, n, lambda, c->vpart);
-    hipLaunchKernelGGL(k_cg_resid2, dim3(nb), dim3(VB), 0, c->stream, c->vG, c->vB, c->vR, c->vP, n, lambda, cconv, c->vG + n, c->vpart, nb, c->scal, in, out);
+    hipLaunchKernelGGL(k_cg_resid2, dim3(nb), dim3(VB), 0, c->stream, c->vG, c->vB, c->vR, c->vP, n, lambda, cconv, c->vG + n, c->vpart, nb, c->scal, in, out, c->cgtrace, pass);
+    hipLaunchKernelGGL(k_cg_commit, dim3(1), dim3(64), 0, c->stream, c->scal);
     c->rr_slot ^= 1;
     HIPCK(c, hipGetLastError());
     return 0;

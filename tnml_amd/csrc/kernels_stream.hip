@@ -164,7 +164,9 @@ int launch_zprime(tnml_ctx* c, const float* EL, size_t lstride, const void* dP, 
 template <typename T>
 __global__ __launch_bounds__(LD_IMGS) void k_pupdate(T* __restrict__ P, const T* __restrict__ Pp, T* __restrict__ dP,
                                                     const int* __restrict__ label, int NTp,
-                                                    const double* __restrict__ alpha, double* __restrict__ partials) {
+                                                    const double* __restrict__ alpha, const double* __restrict__ conv,
+                                                    double* __restrict__ partials) {
+    if (conv[0] != 0.) return;                             // CG already converged: P must stay as it is
     __shared__ T s_val[LD_IMGS];
     __shared__ int s_lab[LD_IMGS];
     __shared__ int s_cor[LD_IMGS];
@@ -196,8 +198,8 @@ __global__ __launch_bounds__(LD_IMGS) void k_pupdate(T* __restrict__ P, const T*
 int launch_pupdate(tnml_ctx* c, const double* alpha_dev, double* scal_out) {
     ProfScope ps(c, KC_LABELDOT);
     const int nblk = c->NTp / LD_IMGS;
-    if (c->f64()) hipLaunchKernelGGL(k_pupdate<double>, dim3(nblk), dim3(LD_IMGS), 0, c->stream, (double*)c->P, (const double*)c->Pp, (double*)c->dP, c->label, c->NTp, alpha_dev, c->partials);
-    else          hipLaunchKernelGGL(k_pupdate<float>, dim3(nblk), dim3(LD_IMGS), 0, c->stream, (float*)c->P, (const float*)c->Pp, (float*)c->dP, c->label, c->NTp, alpha_dev, c->partials);
+    if (c->f64()) hipLaunchKernelGGL(k_pupdate<double>, dim3(nblk), dim3(LD_IMGS), 0, c->stream, (double*)c->P, (const double*)c->Pp, (double*)c->dP, c->label, c->NTp, alpha_dev, c->scal + SC_CONV, c->partials);
+    else          hipLaunchKernelGGL(k_pupdate<float>, dim3(nblk), dim3(LD_IMGS), 0, c->stream, (float*)c->P, (const float*)c->Pp, (float*)c->dP, c->label, c->NTp, alpha_dev, c->scal + SC_CONV, c->partials);
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(768), 0, c->stream, c->partials, nblk, scal_out);
     HIPCK(c, hipGetLastError());
     return 0;

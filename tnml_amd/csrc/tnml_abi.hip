@@ -150,6 +150,7 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     if ((rc = dmalloc(c, &c->vG, c->mcap + TNML_NSCAL_AR))) return bail(rc);
     if ((rc = dmalloc(c, &c->scal, SC_N))) return bail(rc);
     if ((rc = dmalloc(c, &c->vpart, 512))) return bail(rc);
+    if ((rc = dmalloc(c, &c->cgtrace, (size_t)4 * TNML_MAX_PASS))) return bail(rc);
     if ((rc = dmalloc(c, &c->tB, c->mcap))) return bail(rc);
     if ((rc = dmalloc(c, &c->tB2, c->mcap))) return bail(rc);
     if ((rc = dmalloc(c, &c->sM, (size_t)40 * c->maxm * c->maxm))) return bail(rc);
@@ -163,7 +164,7 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     if ((rc = dmalloc(c, &c->sV, (size_t)c->svd_n * c->svd_n))) return bail(rc);
     if ((rc = dmalloc(c, &c->sC, (size_t)c->svd_n * c->svd_n))) return bail(rc);
     if (const char* e = getenv("TNML_SVD_BACKEND")) c->cfg.svd_backend = atoi(e);
-    if (hipHostMalloc((void**)&c->h_scal, sizeof(double) * (2 * c->svd_n + 64 + SC_N)) != hipSuccess) return bail(tnml_fail(c, "hipHostMalloc failed"));
+    if (hipHostMalloc((void**)&c->h_scal, sizeof(double) * (2 * c->svd_n + 64 + SC_N + 4 * TNML_MAX_PASS)) != hipSuccess) return bail(tnml_fail(c, "hipHostMalloc failed"));
     for (int j = 1; j <= c->N; ++j) {
         const size_t cap = (size_t)2 * c->maxm * c->maxm * (j == c->c0 ? TNML_NL : 1);
         if ((rc = dmalloc(c, &c->W[j].a, cap))) return bail(rc);
@@ -184,7 +185,7 @@ int tnml_destroy(tnml_ctx* c) {
     for (auto& p : c->prof_pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     for (auto e : c->prof_free) (void)hipEventDestroy(e);
     void* ptrs[] = {c->phi, c->label, c->ones, c->U, c->P, c->dP, c->Pp, c->Zp, c->Mf, c->slab, c->partials, c->vB, c->vR, c->vP,
-                    c->vG, c->scal, c->vpart, c->tB, c->tB2, c->sM, c->sG, c->sD, c->sE, c->sF, c->sInfo, c->sE2, c->sTau, c->sV, c->sC};
+                    c->vG, c->scal, c->vpart, c->cgtrace, c->tB, c->tB2, c->sM, c->sG, c->sD, c->sE, c->sF, c->sInfo, c->sE2, c->sTau, c->sV, c->sC};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& s : c->W) if (s.a) (void)hipFree(s.a);
     for (auto& e : c->env) if (e.ptr) (void)hipFree(e.ptr);
@@ -484,6 +485,7 @@ static int grad_eval(tnml_ctx* c, bool from_P_update = false) {
 }
 static int read_scal(tnml_ctx* c, const double* dev, int count, double* host_out) {
     double* h = c->h_scal + 2 * c->svd_n + 64;
+    if (count > SC_N + 4 * TNML_MAX_PASS) return tnml_fail(c, "read_scal: count too large");
     HIPCK(c, hipMemcpyAsync(h, dev, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
     memcpy(host_out, h, sizeof(double) * count);
@@ -491,30 +493,40 @@ static int read_scal(tnml_ctx* c, const double* dev, int count, double* host_out
 }
 
 // cgrad, fixedL.cc:349-445, on the bond tensor in vB (M-layout)
-static int cgrad_device(tnml_ctx* c, int npass, double lambda, double cconv, tnml_cg_trace* tr) {
+// issues the whole CG without a host round trip: the |r| < cconv exit (fixedL.cc:432-436) is a device
+// flag that turns the state-changing kernels of later passes into no-ops; the per-pass numbers the
+// reference prints are collected in a device trace and fetched once by cgrad_fetch_trace().
+static int cgrad_device(tnml_ctx* c, int npass, double lambda, double cconv) {
     if (npass < 1 || npass > TNML_MAX_PASS) return tnml_fail(c, "cgrad: Npass must be in 1..%d", TNML_MAX_PASS);
     const size_t n = c->plan.msize();
-    if (tr) memset(tr, 0, sizeof *tr);
-    double s[SC_N];
+    HIPCK(c, hipMemsetAsync(c->cgtrace, 0, sizeof(double) * 4 * TNML_MAX_PASS, c->stream));
     TCK(grad_eval(c));                                   // :374-385
     TCK(launch_cg_init(c, n, lambda));                   // :386-388
     for (int pass = 1; pass <= npass; ++pass) {          // :389
         TCK(forward_pass(c, c->vP, LD_MODE_PAP, c->vG + n, c->fast_cg));   // :394-401 (keeps p*t.v for the fast update)
         TCK(allreduce(c, c->vG + n, TNML_NSCAL_AR));                  // :402
-        TCK(launch_cg_step(c, n, lambda));               // :403-407
-        if (tr) tr->npass_done = pass;
-        if (pass == npass) {                             // :409
-            if (tr) { TCK(read_scal(c, c->scal, SC_N, s)); tr->pAp[pass - 1] = s[SC_PAP]; tr->alpha[pass - 1] = s[SC_ALPHA]; }
-            break;
-        }
+        TCK(launch_cg_step(c, n, lambda, pass));         // :403-407
+        if (pass == npass) break;                        // :409
         TCK(grad_eval(c, c->fast_cg));                   // :412-421
-        TCK(launch_cg_resid(c, n, lambda, cconv));       // :422-428, :442
-        TCK(read_scal(c, c->scal, SC_N, s));
-        if (tr) {
-            tr->pAp[pass - 1] = s[SC_PAP]; tr->alpha[pass - 1] = s[SC_ALPHA];
-            tr->cost[pass - 1] = s[SC_COST]; tr->rnorm[pass - 1] = s[SC_RNORM];
-        }
-        if (s[SC_CONV] != 0.) { if (tr) tr->converged = 1; break; }   // :432-436
+        TCK(launch_cg_resid(c, n, lambda, cconv, pass)); // :422-428, :432-436, :442
+    }
+    return 0;
+}
+static int cgrad_fetch_trace(tnml_ctx* c, int npass, tnml_cg_trace* tr) {
+    if (!tr) return 0;
+    memset(tr, 0, sizeof *tr);
+    std::vector<double> h(SC_N + 4 * TNML_MAX_PASS);
+    // scal and cgtrace are separate allocations: two small copies, one synchronisation
+    double* hp = c->h_scal + 2 * c->svd_n + 64;
+    HIPCK(c, hipMemcpyAsync(hp, c->scal, sizeof(double) * SC_N, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync(hp + SC_N, c->cgtrace, sizeof(double) * 4 * TNML_MAX_PASS, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    const int done = (int)llround(hp[SC_NPASS]);
+    tr->npass_done = done;
+    tr->converged = hp[SC_CONV] != 0.;
+    for (int p = 0; p < done && p < npass; ++p) {
+        const double* t = hp + SC_N + 4 * p;
+        tr->pAp[p] = t[0]; tr->alpha[p] = t[1]; tr->cost[p] = t[2]; tr->rnorm[p] = t[3];
     }
     return 0;
 }
@@ -524,10 +536,10 @@ static int quadcost_device(tnml_ctx* c, double lambda, double* cost, double* lab
     double* tail = c->vG + n;
     TCK(forward_pass(c, c->vB, LD_MODE_COST, tail, want_P));
     TCK(allreduce(c, tail, TNML_NSCAL_AR));
-    TCK(launch_sqnorm(c, c->vB, n, c->scal + SC_BNORM2));
-    double t[12], bn2;
-    TCK(read_scal(c, tail, 12, t));
-    TCK(read_scal(c, c->scal + SC_BNORM2, 1, &bn2));
+    TCK(launch_sqnorm(c, c->vB, n, tail + 12));                 // |B|^2 rides behind the cost partials
+    double t[13];
+    TCK(read_scal(c, tail, 13, t));
+    const double bn2 = t[12];
     const double CR = lambda * bn2;                       // :329
     double C = 0.;
     for (int l = 0; l < TNML_NL; ++l) { if (label_cost) label_cost[l] = t[l]; C += t[l]; }   // :331-336
@@ -581,7 +593,8 @@ int tnml_quadcost(tnml_ctx* c, const double* B, double lambda, double* cost, dou
 int tnml_cgrad(tnml_ctx* c, double* B, int npass, double lambda, double cconv, tnml_cg_trace* trace) {
     HIPCK(c, hipSetDevice(c->cfg.device));
     TCK(upload_bond(c, B));
-    TCK(cgrad_device(c, npass, lambda, cconv, trace));
+    TCK(cgrad_device(c, npass, lambda, cconv));
+    TCK(cgrad_fetch_trace(c, npass, trace));
     return download_bond(c, c->vB, B);
 }
 int tnml_svd_split(tnml_ctx* c, const double* B, int b, int ha, double cutoff, int maxm, int minm,
@@ -610,15 +623,16 @@ int tnml_bond_update(tnml_ctx* c, int b, int ha, const tnml_sweep_params* sp, tn
     const PackDesc pd = bond_pack_desc(p);
     TCK(launch_bond_form(c, c->W[b], c->W[b + 1], c->tB));            // :494
     TCK(launch_pack(c, pd, c->tB, c->vB, nullptr));
-    TCK(cgrad_device(c, sp->npass, sp->lambda, sp->cconv, &rep->cg)); // :504
+    TCK(cgrad_device(c, sp->npass, sp->lambda, sp->cconv));           // :504 (trace fetched with the SVD's own sync)
     TCK(launch_unpack(c, pd, c->vB, c->tB));
+    TCK(cgrad_fetch_trace(c, sp->npass, &rep->cg));
     TCK(svd_split_device(c, c->tB, b, ha, sp->cutoff, sp->maxm, sp->minm, &rep->truncerr, &rep->newm, nullptr, nullptr));   // :519-522
     TCK(launch_bond_form(c, c->W[b], c->W[b + 1], c->tB2));           // :527
-    TCK(launch_diffnorm(c, c->tB2, c->tB, ne, c->scal + SC_N - 2));   // :528,:530
+    TCK(launch_diffnorm(c, c->tB2, c->tB, ne, c->scal + SC_NORMS));   // :528,:530
     TCK(launch_pack(c, pd, c->tB2, c->vB, nullptr));
     TCK(quadcost_device(c, sp->lambda_cost, &rep->cost_after_svd, rep->label_cost, &rep->reg_cost, &rep->ncorrect, false));   // :532
     double d2[2];
-    TCK(read_scal(c, c->scal + SC_N - 2, 2, d2));
+    TCK(read_scal(c, c->scal + SC_NORMS, 2, d2));
     rep->norm_newB = std::sqrt(d2[0]); rep->diff_B_newB = std::sqrt(d2[1]);
     TCK(tnml_shift_env(c, b, ha == 1));                               // :540
     return 0;

@@ -51,7 +51,8 @@ struct SiteT {
 
 // scalar slots of the device-side CG state (doubles)
 enum { SC_COST0 = 0, /* ..9 */ SC_NCORR = 10, SC_PP = 11, SC_RR = 12, /* 13: second |r|^2 slot */ SC_ALPHA = 14, SC_BETA = 15,
-       SC_PNORM2 = 16, SC_BNORM2 = 17, SC_PAP = 18, SC_RNORM = 19, SC_COST = 20, SC_CONV = 21, SC_N = 32 };
+       SC_PNORM2 = 16, SC_BNORM2 = 17, SC_PAP = 18, SC_RNORM = 19, SC_COST = 20, SC_CONV = 21, SC_CONV_NEXT = 22, SC_NPASS = 23,
+       SC_NORMS = 28 /* |newB|^2, |B-newB|^2 */, SC_N = 32 };
 #define TNML_NSCAL_AR 16   /* scalars that ride behind G in the all-reduce buffer */
 
 struct BondPlan {
@@ -104,6 +105,7 @@ struct tnml_ctx {
     int partial_cap = 0;
     double *vB = nullptr, *vR = nullptr, *vP = nullptr, *vG = nullptr;   // CG vectors, M-layout fp64 (vG has TNML_NSCAL_AR tail)
     double* scal = nullptr;    // device scalars [SC_N]
+    double* cgtrace = nullptr; // device CG trace [TNML_MAX_PASS][4] = pAp, alpha, cost, |r|
     double* vpart = nullptr;   // per-workgroup partial sums of the CG vector kernels [256][2]
     int rr_slot = 0;           // which of scal[SC_RR], scal[SC_RR+1] holds the current |r|^2
     double* h_scal = nullptr;  // pinned host mirror
@@ -209,8 +211,8 @@ int launch_cvt(tnml_ctx* c, const double* src, float* dst, size_t n);
 int launch_bond_form(tnml_ctx* c, const SiteT& A1, const SiteT& A2, double* B);            // B = A1*A2, ITensor layout
 // CG vector algebra on device scalars (single-block kernels)
 int launch_cg_init(tnml_ctx* c, size_t n, double lambda);          // r = G - lambda B ; p = r ; RR = |r|^2
-int launch_cg_step(tnml_ctx* c, size_t n, double lambda);          // pAp, alpha, B += alpha p
-int launch_cg_resid(tnml_ctx* c, size_t n, double lambda, double cconv);   // nr, beta, r, cost, conv, p
+int launch_cg_step(tnml_ctx* c, size_t n, double lambda, int pass);          // pAp, alpha, B += alpha p
+int launch_cg_resid(tnml_ctx* c, size_t n, double lambda, double cconv, int pass);   // nr, beta, r, cost, conv, p
 int launch_sqnorm(tnml_ctx* c, const double* x, size_t n, double* out);    // out[0] = |x|^2
 int launch_diffnorm(tnml_ctx* c, const double* x, const double* y, size_t n, double* out2);  // out2[0]=|x|^2, out2[1]=|x-y|^2
 int launch_fill_f32(tnml_ctx* c, float* p, float v, size_t n);
