@@ -140,7 +140,9 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    ts.profile(True)
+    # timed region: HIP events only around the roofline kernel (two event records per launch cost host
+    # time; timing all ~70 launches of a bond update would lower the very throughput being measured)
+    ts.profile(os.environ.get("TNML_BENCH_NOPROF", "0") != "1", only="fgemm_fwd")
     ts.profile_reset()
     sync()
     t0 = time.perf_counter()
@@ -150,13 +152,21 @@ def main():
     elapsed = time.perf_counter() - t0
     ts.profile(False)
     prof = ts.profile_read()
+    # untimed extra steps with every kernel class timed: the per-class breakdown
+    ts.profile(True)
+    ts.profile_reset()
+    nbreak = min(args.steps, 10)
+    for _ in range(nbreak):
+        step()
+    ts.profile(False)
+    prof_all = ts.profile_read()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
 
     if rank == 0:
-        timed = reports[args.warmup:]
+        timed = reports[args.warmup:args.warmup + args.steps]
         NTl = hi - lo
         # dominant kernel: the feature GEMM (T = X*B_mat).  Algorithmic flops per launch = SURVEY.md 8(d)
         # GEMM term 2*NT*(2mL)*(2mR) for the images one launch processes (x10 on the two Label-on-B bonds).
@@ -191,10 +201,11 @@ def main():
                          "achieved": achieved_tf, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved_tf / peak, "traffic": None,
                          "avg_launch_ms": avg_ms, "launches": n_fg, "flops_per_launch": flops_per_launch},
-            "kernel_ms_per_step": {k: v[1] / args.steps for k, v in prof.items() if v[0]},
+            "kernel_ms_per_step": {k: v[1] / nbreak for k, v in prof_all.items() if v[0]},
             "env_init_s": t_init,
             "device_gb": ts.device_bytes() / 1e9,
             "last_cost_per_image": timed[-1]["cost"] / NT if timed else None,
+            "svd_stats": ts.svd_stats(),
         }
         if world == 1 and not args.no_cpu_baseline:
             ncore = os.cpu_count() or 1

@@ -42,11 +42,14 @@ typedef struct tnml_ctx tnml_ctx;
              in fp64 and its CG is not reproducible below that (DESIGN.md "why fp64 MFMA")
    TNML_F32  v_mfma_f32_16x16x4_f32, exact-fp32 -- 2x the MFMA rate, for the tolerance study only */
 enum { TNML_F32 = 0, TNML_F64 = 1 };
-/* eigensolver of the Gram matrix inside tnml_svd_split:
-   TNML_SVD_SYEVD      in-house one-workgroup tridiagonalisation + rocSOLVER dstedc + in-house back transform
-                       (n <= 240; larger matrices use TNML_SVD_ROCSOLVER automatically)
-   TNML_SVD_ROCSOLVER  stock rocSOLVER dsyevd */
-enum { TNML_SVD_SYEVD = 0, TNML_SVD_ROCSOLVER = 1 };
+/* eigensolver of the Gram matrix inside tnml_svd_split (n = smaller side of the matricised bond tensor):
+   TNML_SVD_SYEVD      in-house: one-workgroup tridiagonalisation, bisection + inverse iteration, back
+                       transform, Newton-Schulz polish; verified per call, falls back to rocSOLVER dstedc
+                       for the tridiagonal stage when the check fails (n <= 240; larger matrices use
+                       TNML_SVD_ROCSOLVER automatically)
+   TNML_SVD_ROCSOLVER  stock rocSOLVER dsyevd
+   TNML_SVD_STEDC      in-house tridiagonalisation + rocSOLVER dstedc */
+enum { TNML_SVD_SYEVD = 0, TNML_SVD_ROCSOLVER = 1, TNML_SVD_STEDC = 2 };
 
 typedef struct {
     int device;          /* HIP device ordinal */
@@ -158,10 +161,16 @@ void tnml_shard_bounds(int64_t NT_total, int nranks, int rank, int64_t* begin, i
 /* ---- measurement -------------------------------------------------------------------------- */
 /* per-kernel-class HIP-event timing on the context's stream (bench.py roofline figures) */
 int tnml_profile_enable(tnml_ctx* ctx, int on);
+/* restrict the timing to one kernel class (e.g. "fgemm_fwd"), or NULL / "" for all classes: two event
+   records per timed launch cost host time, so a throughput measurement should time only what it reports */
+int tnml_profile_select(tnml_ctx* ctx, const char* class_name);
 int tnml_profile_count(tnml_ctx* ctx);
 int tnml_profile_get(tnml_ctx* ctx, int idx, char* name64, int64_t* launches, double* total_ms);
 int tnml_profile_reset(tnml_ctx* ctx);
 int tnml_synchronize(tnml_ctx* ctx);
+/* health of the in-house eigensolver: number of fallbacks to rocSOLVER so far, and max|Q^T Q - I| of the
+   kept basis before the first / second Newton-Schulz polish step of the last split */
+int tnml_svd_stats(tnml_ctx* ctx, int64_t* fallbacks, double* dev_before_polish, double* dev_after_first_polish);
 int64_t tnml_device_bytes(tnml_ctx* ctx);              /* device memory currently owned by ctx */
 
 #ifdef __cplusplus

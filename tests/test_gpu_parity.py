@@ -209,7 +209,7 @@ def test_f32_study_mode_forward_gradient():
 
 
 @pytest.mark.parametrize("ha", [1, 2])
-@pytest.mark.parametrize("backend", ["0", "1"])
+@pytest.mark.parametrize("backend", ["0", "1", "2"])
 def test_svd_split_240x240_against_lapack(ha, backend, monkeypatch):
     """the n=240 split (in-house tridiagonalisation + dstedc + back transform, and the stock rocSOLVER
     path) against numpy/LAPACK: singular values, truncation error, optimal rank-120 reconstruction,
@@ -241,6 +241,8 @@ def test_svd_split_240x240_against_lapack(ha, backend, monkeypatch):
     A = ts.get_site(b if ha == 1 else b + 1)
     Q = A.reshape(240, 120, order="F") if ha == 1 else A.reshape(120, 240, order="F").T
     np.testing.assert_allclose(Q.T @ Q, np.eye(120), atol=1e-10)
+    st = ts.svd_stats()
+    assert st["fallbacks"] == 0, st
 
 
 def test_cgrad_early_exit_on_cconv():

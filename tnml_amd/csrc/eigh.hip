@@ -276,3 +276,218 @@ int eigh_backtransform(tnml_ctx* c, const double* V, const double* tau, int n, c
     HIPCK(c, hipGetLastError());
     return 0;
 }
+
+// ==========================================================================================
+// Tridiagonal eigenproblem in one launch: all eigenvalues by Sturm bisection (one lane per eigenvalue),
+// then the eigenvectors of the `mk` largest by inverse iteration (one lane per vector, LAPACK
+// dlagtf/dlagts-style LU with partial pivoting, scratch in global memory laid out [k][lane] so that the
+// lanes' sequential sweeps stay coalesced).  The vectors are NOT re-orthogonalised against each other
+// here (that is what makes LAPACK's dstein sequential); the caller polishes them with Newton-Schulz
+// steps, verifies Z^T Z = I and falls back to rocSOLVER dstedc when the check fails.
+// Replaces rocSOLVER dstedc, whose ~140 tiny launches cost ~1.0 ms per bond split at n=240.
+// ==========================================================================================
+struct TeigArgs {
+    const double* D; const double* E; int n;      // tridiagonal (E has n-1 entries)
+    double* W;                                     // eigenvalues, ascending (out of k_tridiag_eigvals, in of k_tridiag_invit)
+    int mk; double* Z; int ldz;                    // out: eigenvectors of the mk largest (column g = g-th largest)
+};
+
+// Sturm count: number of eigenvalues < x = sign changes of the leading principal minors p_j(x).
+// Three-term recurrence on the matrix scaled to unit norm (s_de[j] = {d_j, e_{j-1}^2} / norm), one FMA on
+// the dependent path per step; magnitudes are renormalised every 4 steps (growth per step <= ~3, decay
+// per step >= ~1e-17, thresholds 1e+-100); a zero minor takes the sign opposite to its predecessor.
+static __device__ __forceinline__ int sturm_count(const double2* s_de, int n, double x) {
+    double pm2 = 1., pm1 = s_de[0].x - x;
+    int cnt = pm1 < 0. ? 1 : 0;
+    int j = 1;
+    for (; j + 3 < n; j += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double2 de = s_de[j + u];
+            double p = fma(de.x - x, pm1, -de.y * pm2);
+            if (p == 0.) p = pm1 < 0. ? 1e-300 : -1e-300;
+            cnt += ((__double2hiint(p) ^ __double2hiint(pm1)) >> 31) & 1;
+            pm2 = pm1; pm1 = p;
+        }
+        const double ap = fabs(pm1);
+        if (ap > 1e100) { pm1 *= 1e-100; pm2 *= 1e-100; }
+        else if (ap < 1e-100) { pm1 *= 1e100; pm2 *= 1e100; }
+    }
+    for (; j < n; ++j) {
+        const double2 de = s_de[j];
+        double p = fma(de.x - x, pm1, -de.y * pm2);
+        if (p == 0.) p = pm1 < 0. ? 1e-300 : -1e-300;
+        cnt += ((__double2hiint(p) ^ __double2hiint(pm1)) >> 31) & 1;
+        pm2 = pm1; pm1 = p;
+    }
+    return cnt;
+}
+
+// all eigenvalues by 65-section: one wave per eigenvalue, every lane probes one interior point of the
+// bracket per round, so the bracket shrinks 65x per round (9-10 rounds to fp64 resolution instead of
+// 53 bisections).  The recurrence is a pure latency chain, so width is free: 240 waves on 240 CUs.
+__global__ __launch_bounds__(64) void k_tridiag_eigvals(TeigArgs T) {
+    __shared__ double2 s_de[256];
+    __shared__ double s_bounds[4];
+    const int n = T.n, lane = threadIdx.x;
+    {   // Gershgorin interval and norm (lanes stride over the rows, then a wave reduction)
+        double gl = 1e300, gu = -1e300, tn = 0.;
+        for (int j = lane; j < n; j += 64) {
+            const double r = (j > 0 ? fabs(T.E[j - 1]) : 0.) + (j < n - 1 ? fabs(T.E[j]) : 0.);
+            gl = fmin(gl, T.D[j] - r); gu = fmax(gu, T.D[j] + r);
+            tn = fmax(tn, fabs(T.D[j]) + r);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            gl = fmin(gl, __shfl_xor(gl, off)); gu = fmax(gu, __shfl_xor(gu, off)); tn = fmax(tn, __shfl_xor(tn, off));
+        }
+        if (!(tn > 0.)) tn = 1.;
+        const double pad = 2.2e-16 * tn * n + 1e-300;
+        if (lane == 0) { s_bounds[0] = (gl - pad) / tn; s_bounds[1] = (gu + pad) / tn; s_bounds[2] = tn; }
+    }
+    __syncthreads();
+    const double tn = s_bounds[2], itn = 1. / tn;
+    for (int k = lane; k < n; k += 64) {
+        const double e = k > 0 ? T.E[k - 1] * itn : 0.;
+        s_de[k] = make_double2(T.D[k] * itn, e * e);
+    }
+    __syncthreads();
+    const int i = blockIdx.x;                                    // eigenvalue index (ascending)
+    double lo = s_bounds[0], hi = s_bounds[1];
+    for (int it = 0; it < 16; ++it) {
+        const double w = hi - lo;
+        if (!(w > 4.4e-16 * (1. + fmax(fabs(lo), fabs(hi))))) break;
+        const double step = w * (1. / 65.);
+        const double x = lo + step * (lane + 1);
+        const bool below = sturm_count(s_de, n, x) > i;                          // eigenvalue i is below x
+        const unsigned long long mask = __ballot(below);
+        const int p = mask ? __ffsll((long long)mask) - 1 : 64;                 // first probe above the eigenvalue
+        const double nlo = p > 0 ? lo + step * p : lo;
+        const double nhi = p < 64 ? lo + step * (p + 1) : hi;
+        if (!(nhi > nlo)) break;
+        lo = nlo; hi = nhi;
+    }
+    if (lane == 0) T.W[i] = 0.5 * (lo + hi) * tn;
+}
+
+// eigenvectors of the mk largest eigenvalues by inverse iteration; 16 vectors per workgroup, their LU
+// factors and iterates live in LDS as [array][k][lane]
+#define IV_L 16
+__global__ __launch_bounds__(64) void k_tridiag_invit(TeigArgs T) {
+    extern __shared__ __attribute__((aligned(16))) double iv_lds[];
+    const int n = T.n, lane = threadIdx.x;
+    double* s_d = iv_lds;                 // [n]
+    double* s_e = s_d + 256;              // [n]
+    double* a = s_e + 256;                // U diagonal            [k][IV_L]
+    double* b = a + (size_t)n * IV_L;     // U first superdiagonal
+    double* c = b + (size_t)n * IV_L;     // L multipliers
+    double* d2 = c + (size_t)n * IV_L;    // U second superdiagonal
+    double* x = d2 + (size_t)n * IV_L;    // iterate
+    for (int k = lane; k < n; k += 64) { s_d[k] = T.D[k]; s_e[k] = k < n - 1 ? T.E[k] : 0.; }
+    __syncthreads();
+    const int g = blockIdx.x * IV_L + lane;           // g-th largest eigenvalue
+    if (lane >= IV_L || g >= T.mk) return;
+    double tnorm = 0.;
+    for (int k = 0; k < n; ++k) tnorm = fmax(tnorm, fabs(s_d[k]) + (k > 0 ? fabs(s_e[k - 1]) : 0.) + fabs(s_e[k]));
+    const double lam = T.W[n - 1 - g];
+    const double tiny = 2.2e-16 * tnorm + 1e-300;
+#define IX(k) ((k) * IV_L + lane)
+    // LAPACK dlagtf: (T - lam I) = P L U with partial pivoting; the rows are generated on the fly
+    unsigned long long pv0 = 0, pv1 = 0, pv2 = 0, pv3 = 0;   // interchange flags, n <= 256 (named: no dynamic register indexing)
+    double ak = s_d[0] - lam, bk = n > 1 ? s_e[0] : 0.;
+    double scale1 = fabs(ak) + fabs(bk);
+    for (int k = 0; k < n - 1; ++k) {
+        const double ck = s_e[k];                       // sub-diagonal entry of row k+1
+        double ak1 = s_d[k + 1] - lam;
+        const double bk1 = k < n - 2 ? s_e[k + 1] : 0.;
+        const double scale2 = fabs(ck) + fabs(ak1) + fabs(bk1);
+        double nak, nbk;                                // row k+1 after elimination
+        if (ck == 0.) {
+            a[IX(k)] = ak; b[IX(k)] = bk; c[IX(k)] = 0.; d2[IX(k)] = 0.;
+            nak = ak1; nbk = bk1;
+        } else {
+            // dlagtf's test |c_k|/scale2 <= |a_k|/scale1, cross-multiplied (no divisions)
+            if (fabs(ck) * scale1 <= fabs(ak) * scale2) {     // no interchange
+                const double mult = ck / ak;
+                a[IX(k)] = ak; b[IX(k)] = bk; c[IX(k)] = mult; d2[IX(k)] = 0.;
+                nak = ak1 - mult * bk; nbk = bk1;
+            } else {                                    // interchange rows k, k+1
+                const double mult = ak / ck;
+                a[IX(k)] = ck; b[IX(k)] = ak1; c[IX(k)] = mult; d2[IX(k)] = bk1;
+                nak = bk - mult * ak1; nbk = -mult * bk1;
+                const unsigned long long bit = 1ull << (k & 63); const int wq = k >> 6;
+                pv0 |= wq == 0 ? bit : 0ull; pv1 |= wq == 1 ? bit : 0ull; pv2 |= wq == 2 ? bit : 0ull; pv3 |= wq == 3 ? bit : 0ull;
+            }
+        }
+        scale1 = scale2;
+        ak = nak; bk = nbk;
+    }
+    a[IX(n - 1)] = ak; b[IX(n - 1)] = 0.; d2[IX(n - 1)] = 0.;
+    if (n >= 2) d2[IX(n - 2)] = 0.;
+    // reciprocal pivots, tiny ones perturbed (dlagts job = -1 in spirit): the solves below only multiply
+    for (int k = 0; k < n; ++k) { double pk = a[IX(k)]; if (fabs(pk) < tiny) pk = pk < 0. ? -tiny : tiny; a[IX(k)] = 1. / pk; }
+    // start vector: deterministic pseudo-random entries in (-1, 1), different for every vector
+    unsigned int seed = 12345u + 7919u * (unsigned)g;
+    for (int k = 0; k < n; ++k) { seed = seed * 1664525u + 1013904223u; x[IX(k)] = ((seed >> 8) * (1.0 / 8388608.0)) - 1.0; }
+    for (int iter = 0; iter < 2; ++iter) {                 // the shift is exact to round-off: two sweeps suffice
+        // forward: apply (P L)^-1
+        double xk = x[IX(0)];
+        for (int k = 0; k < n - 1; ++k) {
+            const int wq = k >> 6;
+            const unsigned long long word = wq == 0 ? pv0 : wq == 1 ? pv1 : wq == 2 ? pv2 : pv3;
+            const bool sw = (word >> (k & 63)) & 1;
+            const double xk1 = x[IX(k + 1)], m = c[IX(k)];
+            if (!sw) { x[IX(k)] = xk; xk = xk1 - m * xk; }
+            else     { x[IX(k)] = xk1; xk = xk - m * xk1; }
+        }
+        x[IX(n - 1)] = xk;
+        // back substitution
+        double xn1 = 0., xn2 = 0., vmax = 0.;
+        for (int k = n - 1; k >= 0; --k) {
+            const double t = (x[IX(k)] - b[IX(k)] * xn1 - d2[IX(k)] * xn2) * a[IX(k)];
+            x[IX(k)] = t;
+            xn2 = xn1; xn1 = t;
+            vmax = fmax(vmax, fabs(t));
+        }
+        const double inv = vmax > 0. ? 1. / vmax : 1.;          // max-norm scaling keeps the iterates in range
+        for (int k = 0; k < n; ++k) x[IX(k)] *= inv;
+    }
+    double nrm2 = 0.;
+    for (int k = 0; k < n; ++k) { const double v = x[IX(k)]; nrm2 = fma(v, v, nrm2); }
+    const double inv = nrm2 > 0. ? 1. / sqrt(nrm2) : 0.;
+    for (int k = 0; k < n; ++k) T.Z[k + (size_t)T.ldz * g] = x[IX(k)] * inv;
+#undef IX
+}
+
+int eigh_tridiag_eig(tnml_ctx* c, const double* D, const double* E, int n, double* W, int mk, double* Z, int ldz, double*) {
+    if (n > 256 || mk > 256) return tnml_fail(c, "eigh_tridiag_eig: n=%d mk=%d exceed 256", n, mk);
+    TeigArgs t{D, E, n, W, mk, Z, ldz};
+    hipLaunchKernelGGL(k_tridiag_eigvals, dim3(n), dim3(64), 0, c->stream, t);
+    const size_t lds = sizeof(double) * (512 + (size_t)5 * n * IV_L);
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_tridiag_invit, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    hipLaunchKernelGGL(k_tridiag_invit, dim3((mk + IV_L - 1) / IV_L), dim3(64), lds, c->stream, t);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
+
+// C = 1.5 I - 0.5 S (Newton-Schulz polish of a nearly orthonormal basis), dev[0] = max |S - I|
+__global__ __launch_bounds__(256) void k_ns_matrix(const double* __restrict__ S, double* __restrict__ Cm, int m, double* __restrict__ dev) {
+    __shared__ double sh[256];
+    double mx = 0.;
+    for (int idx = threadIdx.x; idx < m * m; idx += 256) {
+        const int i = idx % m, j = idx / m;
+        const double s = S[idx], id = (i == j) ? 1. : 0.;
+        mx = fmax(mx, fabs(s - id));
+        Cm[idx] = 1.5 * id - 0.5 * s;
+    }
+    sh[threadIdx.x] = mx;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + s]); __syncthreads(); }
+    if (threadIdx.x == 0) dev[0] = sh[0];
+}
+int eigh_ns_matrix(tnml_ctx* c, const double* S, double* Cm, int m, double* dev) {
+    hipLaunchKernelGGL(k_ns_matrix, dim3(1), dim3(256), 0, c->stream, S, Cm, m, dev);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}

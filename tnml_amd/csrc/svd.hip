@@ -90,16 +90,22 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
     else      RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, nr, nr, nl, &one, M, nl, M, nl, &zero, c->sG, nr));
     // eigen-decomposition of rho: in-house one-workgroup tridiagonalisation + rocSOLVER dstedc + in-house back
     // transformation (TNML_SVD_SYEVD, n <= 240), or stock rocSOLVER dsyevd (TNML_SVD_ROCSOLVER / larger n)
-    const bool custom = (c->cfg.svd_backend == TNML_SVD_SYEVD) && n <= 240 && n >= 3;
-    if (custom) {
+    // backend: 0 = in-house tridiagonalisation + in-house bisection/inverse iteration (verified, with
+    // fallback), 2 = in-house tridiagonalisation + rocSOLVER dstedc, 1 = stock rocSOLVER dsyevd
+    const bool tri = (c->cfg.svd_backend != TNML_SVD_ROCSOLVER) && n <= 240 && n >= 3;
+    bool own_eig = tri && c->cfg.svd_backend == TNML_SVD_SYEVD;
+    const int mk = maxm < n ? maxm : n;                   // the truncation never keeps more than maxm
+    const double* evals = c->sD;                          // ascending eigenvalues of rho
+    if (tri) {
         TCK(eigh_tridiagonalize(c, c->sG, n, c->sD, c->sE2, c->sTau, c->sV));
-        RBCK(c, rocsolver_dstedc(c->blas, rocblas_evect_tridiagonal, n, c->sD, c->sE2, c->sC, n, c->sInfo));
+        if (own_eig) { TCK(eigh_tridiag_eig(c, c->sD, c->sE2, n, c->sW, mk, c->sC, n, c->sScr)); evals = c->sW; }
+        else RBCK(c, rocsolver_dstedc(c->blas, rocblas_evect_tridiagonal, n, c->sD, c->sE2, c->sC, n, c->sInfo));
     } else {
         RBCK(c, rocsolver_dsyevd(c->blas, rocblas_evect_original, rocblas_fill_upper, n, c->sG, n, c->sD, c->sE, c->sInfo));
     }
     // eigenvalues -> host: the truncation decision (ITensor truncate()) fixes the new bond dimension
     double* h = c->h_scal;          // pinned, capacity >= 2*svd_n + 64
-    HIPCK(c, hipMemcpyAsync(h, c->sD, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+    HIPCK(c, hipMemcpyAsync(h, evals, sizeof(double) * n, hipMemcpyDeviceToHost, st));
     HIPCK(c, hipStreamSynchronize(st));
     std::vector<double> p(n), sig(n);
     for (int g = 0; g < n; ++g) { double lam = h[n - 1 - g]; if (!(lam > 0.)) lam = 0.; p[g] = lam; sig[g] = std::sqrt(lam); }
@@ -120,11 +126,32 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
 
     double* Q = c->sF;                                   // kept eigenvectors, n x m
     double* Lf = c->sF + (size_t)c->svd_n * c->maxm;     // left factor when a permutation is still needed
-    if (custom) {
+    if (own_eig) {
+        // Z (already "largest first") -> U = H_0 H_1 ... Z, then one Newton-Schulz step Q <- Q (1.5 I - 0.5 Q^T Q);
+        // d = max|Q^T Q - I| before the step is checked on the host (after it: ~0.75 d^2).
+        double* Q0 = c->sQ1;
+        TCK(eigh_backtransform(c, c->sV, c->sTau, n, c->sC, n, Q0, n, m));
+        RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, m, m, n, &one, Q0, n, Q0, n, &zero, c->sS, m));
+        TCK(eigh_ns_matrix(c, c->sS, c->sCm, m, c->sDev));
+        RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, n, m, m, &one, Q0, n, c->sCm, m, &zero, Q, n));
+        double* hd = c->h_scal + 2 * c->svd_n + 32;
+        HIPCK(c, hipMemcpyAsync(hd, c->sDev, sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCK(c, hipStreamSynchronize(st));
+        c->svd_last_dev0 = hd[0]; c->svd_last_dev1 = 0.75 * hd[0] * hd[0];      // Newton-Schulz: error -> 3/4 error^2
+        hd[1] = hd[0] < 1e-4 ? 0. : 1.;                                          // 1e-4 -> ~1e-8 -> the polish leaves < 1e-8
+        if (!(hd[1] < 1e-6)) {
+            // inverse iteration left (nearly) dependent vectors -- a tight eigenvalue cluster: redo the
+            // tridiagonal stage with rocSOLVER's divide and conquer (D, E, V, tau are still intact)
+            c->svd_fallbacks += 1;
+            own_eig = false;
+            RBCK(c, rocsolver_dstedc(c->blas, rocblas_evect_tridiagonal, n, c->sD, c->sE2, c->sC, n, c->sInfo));
+        }
+    }
+    if (tri && !own_eig) {
         // kept eigenvectors of the tridiagonal matrix (largest first), then U = H_0 H_1 ... Z
         hipLaunchKernelGGL(k_take_top, dim3(nblk((size_t)n * m)), dim3(256), 0, st, c->sC, c->sG, n, m, (const double*)nullptr);
         TCK(eigh_backtransform(c, c->sV, c->sTau, n, c->sG, n, Q, n, m));
-    } else {
+    } else if (!tri) {
         hipLaunchKernelGGL(k_take_top, dim3(nblk((size_t)n * m)), dim3(256), 0, st, c->sG, Q, n, m, (const double*)nullptr);
     }
     double* Aleft = labL ? Lf : Sl.a;      // left factor target, (nl x m), ld = nl

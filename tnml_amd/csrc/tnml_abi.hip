@@ -41,6 +41,12 @@ void prof_resolve(tnml_ctx* c) {
     c->prof_pending.clear();
 }
 int tnml_profile_enable(tnml_ctx* c, int on) { prof_resolve(c); c->prof = on != 0; return 0; }
+int tnml_profile_select(tnml_ctx* c, const char* class_name) {
+    prof_resolve(c);
+    if (!class_name || !*class_name) { c->prof_mask = 0xffffffffu; return 0; }
+    for (int i = 0; i < KC_COUNT; ++i) if (!strcmp(class_name, kclass_names[i])) { c->prof_mask = 1u << i; return 0; }
+    return tnml_fail(c, "tnml_profile_select: unknown kernel class %s", class_name);
+}
 int tnml_profile_count(tnml_ctx*) { return KC_COUNT; }
 int tnml_profile_get(tnml_ctx* c, int idx, char* name64, int64_t* launches, double* total_ms) {
     if (idx < 0 || idx >= KC_COUNT) return tnml_fail(c, "profile index out of range");
@@ -57,6 +63,12 @@ int tnml_profile_reset(tnml_ctx* c) {
 }
 int tnml_synchronize(tnml_ctx* c) { HIPCK(c, hipStreamSynchronize(c->stream)); return 0; }
 int64_t tnml_device_bytes(tnml_ctx* c) { return c->bytes; }
+int tnml_svd_stats(tnml_ctx* c, int64_t* fallbacks, double* d0, double* d1) {
+    if (fallbacks) *fallbacks = c->svd_fallbacks;
+    if (d0) *d0 = c->svd_last_dev0;
+    if (d1) *d1 = c->svd_last_dev1;
+    return 0;
+}
 
 // ---- host-side rules ------------------------------------------------------------------------
 // ITensor v2 truncate() as recalled in SURVEY.md 8(a9): always cut to maxm; then with
@@ -163,6 +175,12 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     if ((rc = dmalloc(c, &c->sTau, (size_t)c->svd_n))) return bail(rc);
     if ((rc = dmalloc(c, &c->sV, (size_t)c->svd_n * c->svd_n))) return bail(rc);
     if ((rc = dmalloc(c, &c->sC, (size_t)c->svd_n * c->svd_n))) return bail(rc);
+    if ((rc = dmalloc(c, &c->sW, (size_t)c->svd_n))) return bail(rc);
+    if ((rc = dmalloc(c, &c->sScr, (size_t)5 * c->svd_n * c->maxm))) return bail(rc);
+    if ((rc = dmalloc(c, &c->sS, (size_t)c->maxm * c->maxm))) return bail(rc);
+    if ((rc = dmalloc(c, &c->sCm, (size_t)c->maxm * c->maxm))) return bail(rc);
+    if ((rc = dmalloc(c, &c->sQ1, (size_t)c->svd_n * c->maxm))) return bail(rc);
+    if ((rc = dmalloc(c, &c->sDev, 4))) return bail(rc);
     if (const char* e = getenv("TNML_SVD_BACKEND")) c->cfg.svd_backend = atoi(e);
     if (hipHostMalloc((void**)&c->h_scal, sizeof(double) * (2 * c->svd_n + 64 + SC_N + 4 * TNML_MAX_PASS)) != hipSuccess) return bail(tnml_fail(c, "hipHostMalloc failed"));
     for (int j = 1; j <= c->N; ++j) {
@@ -185,7 +203,7 @@ int tnml_destroy(tnml_ctx* c) {
     for (auto& p : c->prof_pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     for (auto e : c->prof_free) (void)hipEventDestroy(e);
     void* ptrs[] = {c->phi, c->label, c->ones, c->U, c->P, c->dP, c->Pp, c->Zp, c->Mf, c->slab, c->partials, c->vB, c->vR, c->vP,
-                    c->vG, c->scal, c->vpart, c->cgtrace, c->tB, c->tB2, c->sM, c->sG, c->sD, c->sE, c->sF, c->sInfo, c->sE2, c->sTau, c->sV, c->sC};
+                    c->vG, c->scal, c->vpart, c->cgtrace, c->tB, c->tB2, c->sM, c->sG, c->sD, c->sE, c->sF, c->sInfo, c->sE2, c->sTau, c->sV, c->sC, c->sW, c->sScr, c->sS, c->sCm, c->sQ1, c->sDev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& s : c->W) if (s.a) (void)hipFree(s.a);
     for (auto& e : c->env) if (e.ptr) (void)hipFree(e.ptr);
@@ -297,7 +315,10 @@ static int check_W(tnml_ctx* c) {
 static int env_alloc(tnml_ctx* c, int j, int m, int L) {
     EnvSlot& e = c->env[j];
     if (e.ptr) { (e.big ? c->pool_big : c->pool_small).push_back(e.ptr); e.ptr = nullptr; }
-    const int big = (L == TNML_NL);
+    int big = (L == TNML_NL);
+    // a Label-free env may sit in a recycled Label-carrying slot: during a sweep every shift frees one big
+    // slot (the stale env of the other direction) and needs one small one -- no hipMalloc on the hot path
+    if (!big && c->pool_small.empty() && !c->pool_big.empty()) big = 1;
     auto& pool = big ? c->pool_big : c->pool_small;
     if (!pool.empty()) { e.ptr = pool.back(); pool.pop_back(); }
     else TCK(dmalloc(c, &e.ptr, big ? c->big_elems : c->small_elems));

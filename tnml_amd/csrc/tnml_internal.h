@@ -114,6 +114,9 @@ struct tnml_ctx {
     // svd workspaces (fp64)
     double *sM = nullptr, *sG = nullptr, *sD = nullptr, *sE = nullptr, *sF = nullptr;
     double *sE2 = nullptr, *sTau = nullptr, *sV = nullptr, *sC = nullptr;   // eigh.hip: subdiagonal, tau, reflectors, tridiagonal eigenvectors
+    double *sW = nullptr, *sScr = nullptr, *sS = nullptr, *sCm = nullptr, *sQ1 = nullptr, *sDev = nullptr;   // own tridiagonal eigensolver + Newton-Schulz polish
+    double svd_last_dev0 = 0., svd_last_dev1 = 0.;   // max|Q^T Q - I| before the 1st / 2nd polish step of the last split
+    long svd_fallbacks = 0;
     int* sInfo = nullptr;
     int svd_n = 0;
 
@@ -122,6 +125,7 @@ struct tnml_ctx {
 
     // profiling
     bool prof = false;
+    unsigned prof_mask = 0xffffffffu;   // kernel classes that are timed while prof is on
     int64_t prof_launches[KC_COUNT] = {0};
     double prof_ms[KC_COUNT] = {0};
     std::vector<ProfPending> prof_pending;
@@ -139,8 +143,9 @@ void prof_resolve(tnml_ctx* c);
 // RAII-less profiling bracket around a group of launches of one kernel class
 struct ProfScope {
     tnml_ctx* c; int kc; hipEvent_t e0 = nullptr;
-    ProfScope(tnml_ctx* c_, int kc_) : c(c_), kc(kc_) { if (c->prof) prof_begin(c, kc, &e0); }
-    ~ProfScope() { if (c->prof) prof_end(c, kc, e0); }
+    bool on;
+    ProfScope(tnml_ctx* c_, int kc_) : c(c_), kc(kc_), on(c_->prof && ((c_->prof_mask >> kc_) & 1u)) { if (on) prof_begin(c, kc, &e0); }
+    ~ProfScope() { if (on) prof_end(c, kc, e0); }
 };
 
 // ---- kernels_gemm.hip ---------------------------------------------------------------------
@@ -219,6 +224,8 @@ int launch_fill_f32(tnml_ctx* c, float* p, float v, size_t n);
 
 // ---- eigh.hip -----------------------------------------------------------------------------
 int eigh_tridiagonalize(tnml_ctx* c, const double* A, int n, double* D, double* E, double* tau, double* V);
+int eigh_tridiag_eig(tnml_ctx* c, const double* D, const double* E, int n, double* W, int mk, double* Z, int ldz, double* scratch);
+int eigh_ns_matrix(tnml_ctx* c, const double* S, double* Cm, int m, double* dev);
 int eigh_backtransform(tnml_ctx* c, const double* V, const double* tau, int n, const double* Z, int ldz, double* U, int ldu, int ncols);
 
 // ---- svd.hip ------------------------------------------------------------------------------

@@ -85,6 +85,11 @@ class TrainStates:
     def synchronize(self):
         self._ck(self._L.tnml_synchronize(self._h))
 
+    def svd_stats(self):
+        fb, d0, d1 = C.c_int64(), C.c_double(), C.c_double()
+        self._ck(self._L.tnml_svd_stats(self._h, C.byref(fb), C.byref(d0), C.byref(d1)))
+        return dict(fallbacks=fb.value, dev_before_polish=d0.value, dev_after_first_polish=d1.value)
+
     def device_bytes(self):
         return self._L.tnml_device_bytes(self._h)
 
@@ -177,7 +182,9 @@ class TrainStates:
                     cg=_trace_dict(rep.cg))
 
     # -- measurement
-    def profile(self, on):
+    def profile(self, on, only=None):
+        """HIP-event timing of kernel launches; `only` restricts it to one kernel class"""
+        self._ck(self._L.tnml_profile_select(self._h, (only or "").encode()))
         self._ck(self._L.tnml_profile_enable(self._h, int(on)))
 
     def profile_reset(self):

@@ -24,8 +24,8 @@ EXPORTS = [
     "tnml_env_init", "tnml_set_bond", "tnml_shift_env", "tnml_env_dims", "tnml_get_env",
     "tnml_bond_dims", "tnml_bond_tensor", "tnml_forward", "tnml_gradient", "tnml_quadcost",
     "tnml_cgrad", "tnml_svd_split", "tnml_bond_update", "tnml_truncate", "tnml_sweepnext",
-    "tnml_shard_bounds", "tnml_profile_enable", "tnml_profile_count", "tnml_profile_get",
-    "tnml_profile_reset", "tnml_synchronize", "tnml_device_bytes",
+    "tnml_shard_bounds", "tnml_profile_enable", "tnml_profile_select", "tnml_profile_count", "tnml_profile_get",
+    "tnml_profile_reset", "tnml_synchronize", "tnml_device_bytes", "tnml_svd_stats",
 ]
 
 
@@ -96,10 +96,12 @@ def load():
     L.tnml_shard_bounds.argtypes = [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.tnml_shard_bounds.restype = None
     L.tnml_profile_enable.argtypes = [vp, C.c_int]
+    L.tnml_profile_select.argtypes = [vp, C.c_char_p]
     L.tnml_profile_count.argtypes = [vp]
     L.tnml_profile_get.argtypes = [vp, C.c_int, C.c_char_p, C.POINTER(C.c_int64), dp]
     L.tnml_profile_reset.argtypes = [vp]
     L.tnml_synchronize.argtypes = [vp]
+    L.tnml_svd_stats.argtypes = [vp, C.POINTER(C.c_int64), dp, dp]
     L.tnml_device_bytes.argtypes = [vp]
     L.tnml_device_bytes.restype = C.c_int64
     _lib = L
