@@ -40,8 +40,11 @@ typedef struct tnml_ctx tnml_ctx;
 /* arithmetic type of the per-image bond contractions (environments are stored in fp32 either way):
    TNML_F64  v_mfma_f64_16x16x4_f64, fp64 operands/accumulation -- the default: the reference computes
              in fp64 and its CG is not reproducible below that (DESIGN.md "why fp64 MFMA")
-   TNML_F32  v_mfma_f32_16x16x4_f32, exact-fp32 -- 2x the MFMA rate, for the tolerance study only */
-enum { TNML_F32 = 0, TNML_F64 = 1 };
+   TNML_F32  v_mfma_f32_16x16x4_f32, exact-fp32 -- 2x the MFMA rate, for the tolerance study only
+   TNML_F64_STRICT  as TNML_F64 but environments and features are also stored and shifted in fp64: twice
+             the HBM footprint and traffic; reproduces the reference to ~1e-10 even with its own, very
+             ill-conditioned feature map (DESIGN.md "fp32 environments") */
+enum { TNML_F32 = 0, TNML_F64 = 1, TNML_F64_STRICT = 2 };
 /* eigensolver of the Gram matrix inside tnml_svd_split (n = smaller side of the matricised bond tensor):
    TNML_SVD_SYEVD      in-house: one-workgroup tridiagonalisation, bisection + inverse iteration, back
                        transform, Newton-Schulz polish; verified per call, falls back to rocSOLVER dstedc
@@ -58,7 +61,7 @@ typedef struct {
     int NT_local;        /* training images owned by this rank */
     int64_t NT_total;    /* training images over all ranks (costs are reported un-normalised) */
     int maxm;            /* largest bond dimension that will occur (workspace sizing) */
-    int dtype;           /* TNML_F64 (default choice) or TNML_F32 */
+    int dtype;           /* TNML_F64 (default choice), TNML_F64_STRICT or TNML_F32 */
     int svd_backend;     /* TNML_SVD_* */
 } tnml_config;
 

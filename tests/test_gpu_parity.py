@@ -258,3 +258,78 @@ def test_cgrad_early_exit_on_cconv():
     assert tg["npass_done"] == to["npass_done"] == 2
     np.testing.assert_allclose(tg["cost"], to["cost"], rtol=1e-5)
     assert _relmax(Bg, Bo) < 1e-4
+
+
+def test_fixedl_cli_driver_end_to_end(tmp_path):
+    """the C++ `fixedL <inputfile>` driver (tnml_amd/host) on a tiny idx dataset: its per-bond
+    "--> After SVD, Cost" log lines against the oracle started from the same initial W"""
+    import os
+    import re
+    import subprocess
+    from oracle import pyoracle
+    from tnml_amd import hostlib, synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    N, per_label = 16, 20
+    labels = synth.synthetic_labels(10 * per_label, seed=9, per_label=per_label)
+    pixels = synth.synthetic_images(N, labels, seed=9)
+    pixels = np.clip(pixels.astype(np.int32) * 3, 0, 255).astype(np.uint8)
+    data = str(tmp_path / "data")
+    synth.write_idx(data, pixels, labels)
+    inp = tmp_path / "input"
+    inp.write_text("input\n{\ndatadir = %s\nNtrain = %d\nNbatch = 4\nNsweep = 1\ncutoff = 1E-10\nmaxm = 6\nminm = 3\n"
+                   "ninitial = 3\nlambda = 1E-3\nNpass = 3\nseed = 5\nprecision = strict\n}\n" % (data, per_label))
+    run = subprocess.run([os.path.join(root, "tnml_amd", "fixedL"), str(inp)], capture_output=True, text=True, cwd=tmp_path, timeout=300)
+    assert run.returncode == 0, run.stderr[-2000:]
+    log = run.stdout
+    assert "Total of %d training images" % (10 * per_label) in log and "%d sites of dimension 2" % N in log
+    costs = [float(x) for x in re.findall(r"--> After SVD, Cost = ([0-9.eE+-]+)", log)]
+    newm = [int(x) for x in re.findall(r"New m=(\d+)", log)]
+    assert len(costs) == 2 * (N - 1)
+    assert os.path.exists(tmp_path / "W") and os.path.exists(tmp_path / "sites")
+    # oracle from the identical initial W (same builder, same seed) and the identical selection of images
+    w0 = str(tmp_path / "W0ref")
+    hostlib.build_initial_w(data, per_label, 3, 5, w0)
+    px, lab, _ = hostlib.read_mnist(data, True, per_label)
+    o = pyoracle.Oracle(pyoracle.features_series(px), lab, hostlib.read_mps(w0))
+    o.init()
+    ro = o.mldmrg(1, 6, 3, 1e-10, 3, 1e-3, 1e-10)
+    # strict precision (fp64 environments and features).  With the reference's own feature map every image is
+    # almost the same vector and the CG is so ill conditioned that two fp64 implementations with different
+    # summation orders agree only to ~1e-5 from the first Label-on-B bond on (alpha differs at 4e-5 there,
+    # DESIGN.md section 2); bond dimensions can then differ by one where the tail of the spectrum is noise.
+    ref_m = [r["newm"] for r in ro]
+    assert newm[:6] == ref_m[:6] and all(abs(a - b) <= 1 for a, b in zip(newm, ref_m))
+    ref_c = np.array([r["cost"] / len(lab) for r in ro])
+    np.testing.assert_allclose(costs[:6], ref_c[:6], rtol=1e-9)              # before the first Label-on-B bond
+    np.testing.assert_allclose(costs, ref_c, rtol=2e-5)
+    # the final W on disk carries the Label index on site N/2 only
+    Wf = hostlib.read_mps(str(tmp_path / "W"))
+    assert [A.ndim == 4 for A in Wf] == [j == N // 2 for j in range(1, N + 1)]
+
+
+@pytest.mark.parametrize("b", [1, 3, 6, 9])
+def test_strict_mode_reference_features(b):
+    """TNML_F64_STRICT with the reference's own feature map [1, byte/260100] (raw bytes through
+    tnml_set_data_u8): environments, P, gradient, CG trace to ~1e-9"""
+    ts, o = _pair(use_u8=True, boost=1.0, dtype="f64_strict")
+    for j in range(3, o.N + 1):
+        assert _relmax(ts.env(j), o.env(j)) < 1e-12
+    _walk(ts, o, b)
+    B0 = o.bond_tensor(b)
+    assert _relmax(ts.forward(B0), o.forward(B0)) < 1e-11
+    assert _relmax(ts.gradient(B0), o.gradient(B0)) < 1e-9
+    Bg, tg = ts.cgrad(B0, 4, 1e-3, 1e-10)
+    Bo, to = o.cgrad(B0, 4, 1e-3, 1e-10)
+    np.testing.assert_allclose(tg["cost"], to["cost"], rtol=1e-10)
+    np.testing.assert_allclose(tg["alpha"], to["alpha"], rtol=1e-3)      # alpha ~ 1e3 on the Label-on-B bond: ill conditioned
+    assert _relmax(Bg, Bo) < 1e-3
+
+
+def test_strict_mode_full_sweep():
+    ts, o = _pair(N=10, NT=40, m=4, use_u8=True, boost=1.0, dtype="f64_strict")
+    from tnml_amd.fixedl import mldmrg
+    rg = mldmrg(ts, 1, 4, 2, 1e-10, 3, 1e-3, 1e-10)
+    ro = o.mldmrg(1, 4, 2, 1e-10, 3, 1e-3, 1e-10)
+    assert [r["newm"] for r in rg] == [r["newm"] for r in ro]
+    np.testing.assert_allclose([r["cost"] for r in rg], [r["cost"] for r in ro], rtol=1e-8)
+    assert [r["ncorrect"] for r in rg] == [r["ncorrect"] for r in ro]

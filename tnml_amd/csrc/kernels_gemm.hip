@@ -267,12 +267,50 @@ int launch_bgemm(tnml_ctx* c, const BgemmArgs& a, double* G) {
 // ==========================================================================================
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
+// 4 / 2 consecutive environment (or feature) elements, stored as fp32 (TNML_F64) or fp64 (TNML_F64_STRICT)
+template <typename T> struct V4;
+template <> struct V4<float> {
+    float4 v;
+    static __device__ __forceinline__ V4 load(const float* p) { V4 r; r.v = *reinterpret_cast<const float4*>(p); return r; }
+    static __device__ __forceinline__ V4 zero() { V4 r; r.v = make_float4(0.f, 0.f, 0.f, 0.f); return r; }
+    __device__ __forceinline__ double x() const { return v.x; }
+    __device__ __forceinline__ double y() const { return v.y; }
+    __device__ __forceinline__ double z() const { return v.z; }
+    __device__ __forceinline__ double w() const { return v.w; }
+};
+template <> struct V4<double> {
+    double2 a, b;
+    static __device__ __forceinline__ V4 load(const double* p) { V4 r; r.a = *reinterpret_cast<const double2*>(p); r.b = *reinterpret_cast<const double2*>(p + 2); return r; }
+    static __device__ __forceinline__ V4 zero() { V4 r; r.a = make_double2(0., 0.); r.b = make_double2(0., 0.); return r; }
+    __device__ __forceinline__ double x() const { return a.x; }
+    __device__ __forceinline__ double y() const { return a.y; }
+    __device__ __forceinline__ double z() const { return b.x; }
+    __device__ __forceinline__ double w() const { return b.y; }
+};
+template <typename T> struct V2;
+template <> struct V2<float> {
+    float2 v;
+    static __device__ __forceinline__ V2 load(const float* p) { V2 r; r.v = *reinterpret_cast<const float2*>(p); return r; }
+    static __device__ __forceinline__ V2 zero() { V2 r; r.v = make_float2(0.f, 0.f); return r; }
+    __device__ __forceinline__ double x() const { return v.x; }
+    __device__ __forceinline__ double y() const { return v.y; }
+};
+template <> struct V2<double> {
+    double2 v;
+    static __device__ __forceinline__ V2 load(const double* p) { V2 r; r.v = *reinterpret_cast<const double2*>(p); return r; }
+    static __device__ __forceinline__ V2 zero() { V2 r; r.v = make_double2(0., 0.); return r; }
+    __device__ __forceinline__ double x() const { return v.x; }
+    __device__ __forceinline__ double y() const { return v.y; }
+};
+
 // RT: image tiles per wave, CT: output-column tiles per wave, KT: reduction chunk.
 // Software pipelined: the global loads of chunk k+1 are issued before the MFMA phase of chunk k and
 // land in registers; they are widened to fp64 and written to LDS after the MFMAs (two barriers per
 // chunk, one LDS buffer), so the L2/HBM latency of the operands hides behind the matrix pipe.
 // ABL (tools/probe/kbench_fgemm.hip only): 1 = no MFMA, 2 = no operand staging inside the loop
-template <int RT, int CT, int WR, int WC, int KT, int DB, int ABL = 0>
+// TE: storage type of environments and features; TO = 2: contract with the output-site feature
+// (forward pass), TO = 1: no output site index (environment shift in strict fp64 mode).
+template <int RT, int CT, int WR, int WC, int KT, int DB, int ABL = 0, typename TE = float, int TO = 2>
 __global__ __launch_bounds__(64 * WR * WC) void k_fgemm64(Fgemm64Args A) {
     constexpr int T = 64 * WR * WC, BM = 16 * RT * WR, BN = 16 * CT * WC;
     constexpr int XS = BM + 16;                          // doubles; (XS*2) % 64 == 32 -> conflict-free ds_read_b64
@@ -287,14 +325,16 @@ __global__ __launch_bounds__(64 * WR * WC) void k_fgemm64(Fgemm64Args A) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid / WC, wc = wid % WC;
     const int n0 = blockIdx.x * BM, j0 = blockIdx.y * BN, l = blockIdx.z;
-    const float* E = A.EI + (size_t)l * A.EI_lstride;
+    const TE* E = static_cast<const TE*>(A.EI) + (size_t)l * A.EI_lstride;
+    const TE* phiI = static_cast<const TE*>(A.phiI);
+    const TE* phiO = static_cast<const TE*>(A.phiO);
     const double* M = A.M + (size_t)l * A.M_lstride;
     const int NTp = A.NTp;
 
     // this thread's feature columns never change across chunks
     const int xc4 = tid % (BM / 4);
-    const float4 p0 = *reinterpret_cast<const float4*>(A.phiI + n0 + xc4 * 4);
-    const float4 p1 = *reinterpret_cast<const float4*>(A.phiI + NTp + n0 + xc4 * 4);
+    const V4<TE> p0 = V4<TE>::load(phiI + n0 + xc4 * 4);
+    const V4<TE> p1 = V4<TE>::load(phiI + NTp + n0 + xc4 * 4);
 
     f64x4 acc[CT][RT];
 #pragma unroll
@@ -302,7 +342,7 @@ __global__ __launch_bounds__(64 * WR * WC) void k_fgemm64(Fgemm64Args A) {
 #pragma unroll
         for (int r = 0; r < RT; ++r) acc[c][r] = f64x4{0., 0., 0., 0.};
 
-    float4 xr[NX];
+    V4<TE> xr[NX];
     double2 mr[NM];
     auto load_chunk = [&](int k0) {
 #pragma unroll
@@ -310,8 +350,8 @@ __global__ __launch_bounds__(64 * WR * WC) void k_fgemm64(Fgemm64Args A) {
             const int idx = tid + q * T;
             const int ar = idx / (BM / 4);
             const int a = k0 / 2 + ar;
-            xr[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < NXI && a < A.mI) xr[q] = *reinterpret_cast<const float4*>(E + (size_t)a * NTp + n0 + xc4 * 4);
+            xr[q] = V4<TE>::zero();
+            if (idx < NXI && a < A.mI) xr[q] = V4<TE>::load(E + (size_t)a * NTp + n0 + xc4 * 4);
         }
 #pragma unroll
         for (int q = 0; q < NM; ++q) {
@@ -328,13 +368,13 @@ __global__ __launch_bounds__(64 * WR * WC) void k_fgemm64(Fgemm64Args A) {
             const int idx = tid + q * T;
             if (idx < NXI) {
                 const int ar = idx / (BM / 4);
-                const float4 e = xr[q];
+                const V4<TE> e = xr[q];
                 double* x0 = &Xs[(2 * ar) * XS + xc4 * 4];
                 double* x1 = &Xs[(2 * ar + 1) * XS + xc4 * 4];
-                *reinterpret_cast<double2*>(x0) = make_double2((double)e.x * p0.x, (double)e.y * p0.y);
-                *reinterpret_cast<double2*>(x0 + 2) = make_double2((double)e.z * p0.z, (double)e.w * p0.w);
-                *reinterpret_cast<double2*>(x1) = make_double2((double)e.x * p1.x, (double)e.y * p1.y);
-                *reinterpret_cast<double2*>(x1 + 2) = make_double2((double)e.z * p1.z, (double)e.w * p1.w);
+                *reinterpret_cast<double2*>(x0) = make_double2(e.x() * p0.x(), e.y() * p0.y());
+                *reinterpret_cast<double2*>(x0 + 2) = make_double2(e.z() * p0.z(), e.w() * p0.w());
+                *reinterpret_cast<double2*>(x1) = make_double2(e.x() * p1.x(), e.y() * p1.y());
+                *reinterpret_cast<double2*>(x1 + 2) = make_double2(e.z() * p1.z(), e.w() * p1.w());
             }
         }
 #pragma unroll
@@ -431,16 +471,20 @@ __global__ __launch_bounds__(64 * WR * WC) void k_fgemm64(Fgemm64Args A) {
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
         const int n = n0 + (wr * RT + r) * 16 + (lane & 15);
-        const double ph = (double)A.phiO[(size_t)(g & 1) * NTp + n];
+        const double ph = TO == 2 ? (double)phiO[(size_t)(g & 1) * NTp + n] : 1.;
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int j = j0 + (wc * CT + c) * 16 + g + 4 * e;
-                double v = acc[c][r][e] * ph;
-                v += __shfl_xor(v, 16);
-                const int q = j >> 1;
-                if ((g & 1) == 0 && q < A.mO) out[(size_t)q * NTp + n] = v;
+                if (TO == 2) {
+                    double v = acc[c][r][e] * ph;
+                    v += __shfl_xor(v, 16);
+                    const int q = j >> 1;
+                    if ((g & 1) == 0 && q < A.mO) out[(size_t)q * NTp + n] = v;
+                } else {
+                    if (j < A.mO) out[(size_t)j * NTp + n] = acc[c][r][e];
+                }
             }
         }
     }
@@ -450,15 +494,18 @@ template <int RT, int CT, int WR, int WC, int KT, int DB = 0>
 static void fgemm64_go(tnml_ctx* c, const Fgemm64Args& a) {
     constexpr int BM = 16 * RT * WR, BN = 16 * CT * WC;
     dim3 grid(a.NTp / BM, (a.Np + BN - 1) / BN, a.L);
-    hipLaunchKernelGGL((k_fgemm64<RT, CT, WR, WC, KT, DB>), grid, dim3(64 * WR * WC), 0, c->stream, a);
+    dim3 block(64 * WR * WC);
+    if (!a.env64)     hipLaunchKernelGGL((k_fgemm64<RT, CT, WR, WC, KT, DB, 0, float, 2>), grid, block, 0, c->stream, a);
+    else if (a.phiO)  hipLaunchKernelGGL((k_fgemm64<RT, CT, WR, WC, KT, DB, 0, double, 2>), grid, block, 0, c->stream, a);
+    else              hipLaunchKernelGGL((k_fgemm64<RT, CT, WR, WC, KT, DB, 0, double, 1>), grid, block, 0, c->stream, a);
 }
 
 int launch_fgemm64(tnml_ctx* c, const Fgemm64Args& a) {
-    ProfScope ps(c, KC_FGEMM_FWD);
+    ProfScope ps(c, a.phiO ? KC_FGEMM_FWD : KC_FGEMM_SHIFT);
     if (a.NTp % TNML_NTPAD) return tnml_fail(c, "fgemm64: NTp not padded");
-    if (!a.phiO) return tnml_fail(c, "fgemm64: output-site features required");
+    if (!a.phiO && !a.env64) return tnml_fail(c, "fgemm64: the shift form exists only for fp64 environments");
     static const int cfg = getenv("TNML_FG64_CFG") ? atoi(getenv("TNML_FG64_CFG")) : 0;   // tuning knob (tools/tune_fgemm.sh)
-    if (a.Np == 240) {                                       // m = 120: exactly 15 column tiles, no padding waste
+    if (a.Np == 240 && a.phiO) {                             // m = 120: exactly 15 column tiles, no padding waste
         switch (cfg) {
             case 1:  fgemm64_go<1, 5, 4, 3, 16>(c, a); break;   // 64 x 240, 12 waves
             case 2:  fgemm64_go<2, 5, 4, 3, 16>(c, a); break;   // 128 x 240, 12 waves
@@ -500,7 +547,7 @@ struct Bgemm64KArgs {
 //   Z[q][n] = sum_l EL[l][q][n] * dP[l][n]   (the first half of dP*dag(t.v), fixedL.cc:379,418),
 // so the separate k_zprime pass (a second full stream of EL plus a Z' round trip) disappears and the
 // HBM stream of EL overlaps the matrix pipe.
-template <int RT, int CT, int WR, int WC, int FUSE = 0>
+template <int RT, int CT, int WR, int WC, int FUSE = 0, typename TE = float>
 __global__ __launch_bounds__(64 * WR * WC) void k_bgemm64(Bgemm64KArgs K) {
     constexpr int T = 64 * WR * WC, BMr = 16 * RT * WR, BNc = 16 * CT * WC, KTn = 32, ST = KTn + 2;   // doubles
     constexpr int NAI = (BMr / 2) * (KTn / 4), NBI = (BNc / 2) * (KTn / 4);
@@ -518,6 +565,11 @@ __global__ __launch_bounds__(64 * WR * WC) void k_bgemm64(Bgemm64KArgs K) {
     const int nbeg = split * K.imgs_per_split;
     const int nend = min(nbeg + K.imgs_per_split, NTp);
     const double* w = A.w ? A.w + (size_t)l * A.w_lstride : nullptr;
+    const TE* EIp = static_cast<const TE*>(A.EI);
+    const TE* ELp = static_cast<const TE*>(A.EL);
+    const TE* Zq32 = static_cast<const TE*>(A.Zq32);
+    const TE* phiI = static_cast<const TE*>(A.phiI);
+    const TE* phiO = static_cast<const TE*>(A.phiO);
 
     f64x4 acc[RT][CT];
 #pragma unroll
@@ -525,10 +577,10 @@ __global__ __launch_bounds__(64 * WR * WC) void k_bgemm64(Bgemm64KArgs K) {
 #pragma unroll
         for (int c = 0; c < CT; ++c) acc[r][c] = f64x4{0., 0., 0., 0.};
 
-    float4 ea[NA], pa0[NA], pa1[NA];
-    double zb[NB][4]; float4 pb0[NB], pb1[NB];
+    V4<TE> ea[NA], pa0[NA], pa1[NA];
+    double zb[NB][4]; V4<TE> pb0[NB], pb1[NB];
     constexpr int NFI = (BNc / 2) * (KTn / 2), NF = (NFI + T - 1) / T;   // FUSE: B tasks are (q-row, image pair)
-    float2 el[FUSE ? NF : 1][FUSE ? TNML_NL : 1];   // Label-carrying env rows of the chunk in flight (FUSE)
+    V2<TE> el[FUSE ? NF : 1][FUSE ? TNML_NL : 1];   // Label-carrying env rows of the chunk in flight (FUSE)
     double dpr = 0.;                               // this lane's entry of the dP tile [10][KTn] (FUSE)
     double* dPs = lds + (BMr + BNc) * ST;          // [10][KTn]
     auto load_chunk = [&](int nb) {
@@ -537,11 +589,11 @@ __global__ __launch_bounds__(64 * WR * WC) void k_bgemm64(Bgemm64KArgs K) {
             const int idx = tid + q * T;
             const int ar = idx / (KTn / 4), c4 = idx % (KTn / 4);
             const int a = i0 / 2 + ar, n = nb + c4 * 4;
-            ea[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < NAI && a < A.mI) ea[q] = *reinterpret_cast<const float4*>(A.EI + (size_t)a * NTp + n);
+            ea[q] = V4<TE>::zero();
+            if (idx < NAI && a < A.mI) ea[q] = V4<TE>::load(EIp + (size_t)a * NTp + n);
             if (!FUSE) {
-                pa0[q] = *reinterpret_cast<const float4*>(A.phiI + n);
-                pa1[q] = *reinterpret_cast<const float4*>(A.phiI + NTp + n);
+                pa0[q] = V4<TE>::load(phiI + n);
+                pa1[q] = V4<TE>::load(phiI + NTp + n);
             }
         }
         if (FUSE) {
@@ -552,8 +604,8 @@ __global__ __launch_bounds__(64 * WR * WC) void k_bgemm64(Bgemm64KArgs K) {
                 const int qq = j0 / 2 + qr, n = nb + c2 * 2;
 #pragma unroll
                 for (int ll = 0; ll < TNML_NL; ++ll) {
-                    el[q][ll] = make_float2(0.f, 0.f);
-                    if (idx < NFI && qq < A.mO) el[q][ll] = *reinterpret_cast<const float2*>(A.EL + (size_t)ll * A.EL_lstride + (size_t)qq * NTp + n);
+                    el[q][ll] = V2<TE>::zero();
+                    if (idx < NFI && qq < A.mO) el[q][ll] = V2<TE>::load(ELp + (size_t)ll * A.EL_lstride + (size_t)qq * NTp + n);
                 }
             }
         } else {
@@ -569,8 +621,8 @@ __global__ __launch_bounds__(64 * WR * WC) void k_bgemm64(Bgemm64KArgs K) {
                         const double2 zc = *reinterpret_cast<const double2*>(A.Zq64 + (size_t)qq * NTp + n + 2);
                         zb[q][0] = za.x; zb[q][1] = za.y; zb[q][2] = zc.x; zb[q][3] = zc.y;
                     } else {
-                        const float4 zf = *reinterpret_cast<const float4*>(A.Zq32 + (size_t)qq * NTp + n);
-                        zb[q][0] = zf.x; zb[q][1] = zf.y; zb[q][2] = zf.z; zb[q][3] = zf.w;
+                        const V4<TE> zf = V4<TE>::load(Zq32 + (size_t)qq * NTp + n);
+                        zb[q][0] = zf.x(); zb[q][1] = zf.y(); zb[q][2] = zf.z(); zb[q][3] = zf.w();
                     }
                 }
                 if (w) {
@@ -578,8 +630,8 @@ __global__ __launch_bounds__(64 * WR * WC) void k_bgemm64(Bgemm64KArgs K) {
                     const double2 wb = *reinterpret_cast<const double2*>(w + n + 2);
                     zb[q][0] *= wa.x; zb[q][1] *= wa.y; zb[q][2] *= wb.x; zb[q][3] *= wb.y;
                 }
-                pb0[q] = *reinterpret_cast<const float4*>(A.phiO + n);
-                pb1[q] = *reinterpret_cast<const float4*>(A.phiO + NTp + n);
+                pb0[q] = V4<TE>::load(phiO + n);
+                pb1[q] = V4<TE>::load(phiO + NTp + n);
             }
         }
         if (FUSE && tid < TNML_NL * KTn) dpr = A.dPz[(size_t)(tid / KTn) * NTp + nb + (tid % KTn)];
@@ -591,15 +643,15 @@ __global__ __launch_bounds__(64 * WR * WC) void k_bgemm64(Bgemm64KArgs K) {
             const int idx = tid + q * T;
             if (idx < NAI) {
                 const int ar = idx / (KTn / 4), c4 = idx % (KTn / 4);
-                const float4 e = ea[q];
-                const float4 p0 = FUSE ? *reinterpret_cast<const float4*>(A.phiI + nb + c4 * 4) : pa0[q];          // FUSE: register budget,
-                const float4 p1 = FUSE ? *reinterpret_cast<const float4*>(A.phiI + NTp + nb + c4 * 4) : pa1[q];    // the features are cache hot
+                const V4<TE> e = ea[q];
+                const V4<TE> p0 = FUSE ? V4<TE>::load(phiI + nb + c4 * 4) : pa0[q];          // FUSE: register budget,
+                const V4<TE> p1 = FUSE ? V4<TE>::load(phiI + NTp + nb + c4 * 4) : pa1[q];    // the features are cache hot
                 double* x0 = &As[(2 * ar) * ST + c4 * 4];
                 double* x1 = &As[(2 * ar + 1) * ST + c4 * 4];
-                *reinterpret_cast<double2*>(x0) = make_double2((double)e.x * p0.x, (double)e.y * p0.y);
-                *reinterpret_cast<double2*>(x0 + 2) = make_double2((double)e.z * p0.z, (double)e.w * p0.w);
-                *reinterpret_cast<double2*>(x1) = make_double2((double)e.x * p1.x, (double)e.y * p1.y);
-                *reinterpret_cast<double2*>(x1 + 2) = make_double2((double)e.z * p1.z, (double)e.w * p1.w);
+                *reinterpret_cast<double2*>(x0) = make_double2(e.x() * p0.x(), e.y() * p0.y());
+                *reinterpret_cast<double2*>(x0 + 2) = make_double2(e.z() * p0.z(), e.w() * p0.w());
+                *reinterpret_cast<double2*>(x1) = make_double2(e.x() * p1.x(), e.y() * p1.y());
+                *reinterpret_cast<double2*>(x1 + 2) = make_double2(e.z() * p1.z(), e.w() * p1.w());
             }
         }
         if (FUSE) {
@@ -612,13 +664,13 @@ __global__ __launch_bounds__(64 * WR * WC) void k_bgemm64(Bgemm64KArgs K) {
 #pragma unroll
                     for (int ll = 0; ll < TNML_NL; ++ll) {
                         const double2 d = *reinterpret_cast<const double2*>(&dPs[ll * KTn + c2 * 2]);
-                        z0 = fma((double)el[q][ll].x, d.x, z0);
-                        z1 = fma((double)el[q][ll].y, d.y, z1);
+                        z0 = fma(el[q][ll].x(), d.x, z0);
+                        z1 = fma(el[q][ll].y(), d.y, z1);
                     }
-                    const float2 f0 = *reinterpret_cast<const float2*>(A.phiO + nb + c2 * 2);
-                    const float2 f1 = *reinterpret_cast<const float2*>(A.phiO + NTp + nb + c2 * 2);
-                    *reinterpret_cast<double2*>(&Bs[(2 * qr) * ST + c2 * 2]) = make_double2(z0 * f0.x, z1 * f0.y);
-                    *reinterpret_cast<double2*>(&Bs[(2 * qr + 1) * ST + c2 * 2]) = make_double2(z0 * f1.x, z1 * f1.y);
+                    const V2<TE> f0 = V2<TE>::load(phiO + nb + c2 * 2);
+                    const V2<TE> f1 = V2<TE>::load(phiO + NTp + nb + c2 * 2);
+                    *reinterpret_cast<double2*>(&Bs[(2 * qr) * ST + c2 * 2]) = make_double2(z0 * f0.x(), z1 * f0.y());
+                    *reinterpret_cast<double2*>(&Bs[(2 * qr + 1) * ST + c2 * 2]) = make_double2(z0 * f1.x(), z1 * f1.y());
                 }
             }
         } else {
@@ -627,13 +679,13 @@ __global__ __launch_bounds__(64 * WR * WC) void k_bgemm64(Bgemm64KArgs K) {
                 const int idx = tid + q * T;
                 if (idx < NBI) {
                     const int qr = idx / (KTn / 4), c4 = idx % (KTn / 4);
-                    const float4 p0 = pb0[q], p1 = pb1[q];
+                    const V4<TE> p0 = pb0[q], p1 = pb1[q];
                     double* b0 = &Bs[(2 * qr) * ST + c4 * 4];
                     double* b1 = &Bs[(2 * qr + 1) * ST + c4 * 4];
-                    *reinterpret_cast<double2*>(b0) = make_double2(zb[q][0] * p0.x, zb[q][1] * p0.y);
-                    *reinterpret_cast<double2*>(b0 + 2) = make_double2(zb[q][2] * p0.z, zb[q][3] * p0.w);
-                    *reinterpret_cast<double2*>(b1) = make_double2(zb[q][0] * p1.x, zb[q][1] * p1.y);
-                    *reinterpret_cast<double2*>(b1 + 2) = make_double2(zb[q][2] * p1.z, zb[q][3] * p1.w);
+                    *reinterpret_cast<double2*>(b0) = make_double2(zb[q][0] * p0.x(), zb[q][1] * p0.y());
+                    *reinterpret_cast<double2*>(b0 + 2) = make_double2(zb[q][2] * p0.z(), zb[q][3] * p0.w());
+                    *reinterpret_cast<double2*>(b1) = make_double2(zb[q][0] * p1.x(), zb[q][1] * p1.y());
+                    *reinterpret_cast<double2*>(b1 + 2) = make_double2(zb[q][2] * p1.z(), zb[q][3] * p1.w());
                 }
             }
         }
@@ -715,7 +767,8 @@ static int bgemm64_go(tnml_ctx* c, const Bgemm64Args& a, double* G, int default_
     {
         ProfScope ps(c, KC_BGEMM);
         dim3 grid((a.Kp + BMr - 1) / BMr, (a.Np + BNc - 1) / BNc, nsplit * a.L);
-        hipLaunchKernelGGL((k_bgemm64<RT, CT, WR, WC, FUSE>), grid, dim3(64 * WR * WC), 0, c->stream, K);
+        if (a.env64) hipLaunchKernelGGL((k_bgemm64<RT, CT, WR, WC, FUSE, double>), grid, dim3(64 * WR * WC), 0, c->stream, K);
+        else         hipLaunchKernelGGL((k_bgemm64<RT, CT, WR, WC, FUSE, float>), grid, dim3(64 * WR * WC), 0, c->stream, K);
     }
     {
         ProfScope ps(c, KC_SLABRED);

@@ -56,6 +56,14 @@ int launch_cvt(tnml_ctx* c, const double* src, float* dst, size_t n) {
     HIPCK(c, hipGetLastError());
     return 0;
 }
+__global__ void k_fill_f64(double* p, double v, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+int launch_fill_f64(tnml_ctx* c, double* p, double v, size_t n) {
+    hipLaunchKernelGGL(k_fill_f64, dim3(nblocks(n)), dim3(256), 0, c->stream, p, v, n);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
 int launch_fill_f32(tnml_ctx* c, float* p, float v, size_t n) {
     hipLaunchKernelGGL(k_fill_f32, dim3(nblocks(n)), dim3(256), 0, c->stream, p, v, n);
     HIPCK(c, hipGetLastError());

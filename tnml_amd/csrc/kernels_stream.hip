@@ -116,7 +116,9 @@ int launch_labeldot(tnml_ctx* c, const LdotArgs& a, double* scal_out) {
     ProfScope ps(c, KC_LABELDOT);
     const int nblk = a.NTp / LD_IMGS;
     if (nblk > c->partial_cap) return tnml_fail(c, "labeldot: partial buffer too small");
-    if (c->f64()) {
+    if (c->env64()) {
+        hipLaunchKernelGGL((k_labeldot<4, double, double, double>), dim3(nblk), dim3(256), 0, c->stream, a, c->partials);
+    } else if (c->f64()) {
         if (a.a_is_env) hipLaunchKernelGGL((k_labeldot<4, float, double, double>), dim3(nblk), dim3(256), 0, c->stream, a, c->partials);
         else            hipLaunchKernelGGL((k_labeldot<4, double, float, double>), dim3(nblk), dim3(256), 0, c->stream, a, c->partials);
     } else {
@@ -127,8 +129,8 @@ int launch_labeldot(tnml_ctx* c, const LdotArgs& a, double* scal_out) {
     return 0;
 }
 
-template <typename T>
-__global__ void k_zprime_t(const float* __restrict__ EL, size_t lstride, const T* __restrict__ dP,
+template <typename T, typename TE>
+__global__ void k_zprime_t(const TE* __restrict__ EL, size_t lstride, const T* __restrict__ dP,
                            T* __restrict__ Z, int mq, int NTp) {
     const size_t n2 = (size_t)NTp / 2;
     const size_t total = (size_t)mq * n2;
@@ -138,7 +140,7 @@ __global__ void k_zprime_t(const float* __restrict__ EL, size_t lstride, const T
         T zx = 0, zy = 0;
 #pragma unroll
         for (int l = 0; l < TNML_NL; ++l) {
-            const float2 e = *reinterpret_cast<const float2*>(EL + (size_t)l * lstride + q * NTp + n);
+            const typename vec2<TE>::type e = *reinterpret_cast<const typename vec2<TE>::type*>(EL + (size_t)l * lstride + q * NTp + n);
             const T2 d = *reinterpret_cast<const T2*>(dP + (size_t)l * NTp + n);
             zx = fma((T)e.x, d.x, zx); zy = fma((T)e.y, d.y, zy);
         }
@@ -147,13 +149,14 @@ __global__ void k_zprime_t(const float* __restrict__ EL, size_t lstride, const T
     }
 }
 
-int launch_zprime(tnml_ctx* c, const float* EL, size_t lstride, const void* dP, void* Z, int mq, int NTp) {
+int launch_zprime(tnml_ctx* c, const void* EL, size_t lstride, const void* dP, void* Z, int mq, int NTp) {
     ProfScope ps(c, KC_ZPRIME);
     const size_t total = (size_t)mq * (NTp / 2);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
-    if (c->f64()) hipLaunchKernelGGL(k_zprime_t<double>, dim3(blocks), dim3(256), 0, c->stream, EL, lstride, (const double*)dP, (double*)Z, mq, NTp);
-    else          hipLaunchKernelGGL(k_zprime_t<float>, dim3(blocks), dim3(256), 0, c->stream, EL, lstride, (const float*)dP, (float*)Z, mq, NTp);
+    if (c->env64())    hipLaunchKernelGGL((k_zprime_t<double, double>), dim3(blocks), dim3(256), 0, c->stream, (const double*)EL, lstride, (const double*)dP, (double*)Z, mq, NTp);
+    else if (c->f64()) hipLaunchKernelGGL((k_zprime_t<double, float>), dim3(blocks), dim3(256), 0, c->stream, (const float*)EL, lstride, (const double*)dP, (double*)Z, mq, NTp);
+    else               hipLaunchKernelGGL((k_zprime_t<float, float>), dim3(blocks), dim3(256), 0, c->stream, (const float*)EL, lstride, (const float*)dP, (float*)Z, mq, NTp);
     HIPCK(c, hipGetLastError());
     return 0;
 }
@@ -205,27 +208,29 @@ int launch_pupdate(tnml_ctx* c, const double* alpha_dev, double* scal_out) {
     return 0;
 }
 
-__global__ void k_features_u8(const uint8_t* __restrict__ pix, int N, int NT, int NTp, float* __restrict__ phi) {
+template <typename TE>
+__global__ void k_features_u8(const uint8_t* __restrict__ pix, int N, int NT, int NTp, TE* __restrict__ phi) {
     // pix [NT][N] -> phi [N][2][NTp]; one thread per (site, image)
     const size_t total = (size_t)N * NTp;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int j = (int)(idx / NTp), n = (int)(idx % NTp);
-        float f0 = 0.f, f1 = 0.f;
+        TE f0 = 0, f1 = 0;
         if (n < NT) {
             // g = byte/255. (mllib/mnist.h:495); x = g/255.; phi = pow(x/4., n-1) (fixedL.cc:640-641),
             // evaluated in fp64 then rounded once to fp32
             const double g = (double)pix[(size_t)n * N + j] / 255.;
-            f0 = 1.f;
-            f1 = (float)((g / 255.) / 4.);
+            f0 = 1;
+            f1 = (TE)((g / 255.) / 4.);
         }
         phi[((size_t)j * 2 + 0) * NTp + n] = f0;
         phi[((size_t)j * 2 + 1) * NTp + n] = f1;
     }
 }
 
-int launch_features_u8(tnml_ctx* c, const uint8_t* d_pix, int N, int NT, int NTp, float* phi) {
+int launch_features_u8(tnml_ctx* c, const uint8_t* d_pix, int N, int NT, int NTp, void* phi) {
     ProfScope ps(c, KC_PACK);
-    hipLaunchKernelGGL(k_features_u8, dim3(4096), dim3(256), 0, c->stream, d_pix, N, NT, NTp, phi);
+    if (c->env64()) hipLaunchKernelGGL(k_features_u8<double>, dim3(4096), dim3(256), 0, c->stream, d_pix, N, NT, NTp, (double*)phi);
+    else            hipLaunchKernelGGL(k_features_u8<float>, dim3(4096), dim3(256), 0, c->stream, d_pix, N, NT, NTp, (float*)phi);
     HIPCK(c, hipGetLastError());
     return 0;
 }

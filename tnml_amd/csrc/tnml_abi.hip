@@ -116,7 +116,7 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     *out = nullptr;
     if (cfg->N < 4) return tnml_fail(nullptr, "tnml_create: need N >= 4 sites");
     if (cfg->NT_local < 1 || cfg->maxm < 1) return tnml_fail(nullptr, "tnml_create: NT_local and maxm must be positive");
-    if (cfg->dtype != TNML_F32 && cfg->dtype != TNML_F64) return tnml_fail(nullptr, "tnml_create: dtype must be TNML_F64 or TNML_F32");
+    if (cfg->dtype != TNML_F32 && cfg->dtype != TNML_F64 && cfg->dtype != TNML_F64_STRICT) return tnml_fail(nullptr, "tnml_create: dtype must be TNML_F64, TNML_F64_STRICT or TNML_F32");
     if (cfg->nranks < 1 || cfg->rank < 0 || cfg->rank >= cfg->nranks) return tnml_fail(nullptr, "tnml_create: bad rank/nranks");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -138,13 +138,13 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     c->small_elems = (size_t)c->maxm * NTp;
     c->big_elems = (size_t)TNML_NL * c->maxm * NTp;
     c->svd_n = 2 * c->maxm;
-    c->slab_bytes = (size_t)128 * Kmax * Kmax * 4 * (cfg->dtype == TNML_F64 ? 2 : 1);
+    c->slab_bytes = (size_t)128 * Kmax * Kmax * 4 * (cfg->dtype != TNML_F32 ? 2 : 1);
     c->partial_cap = (int)(NTp / 128);
     c->W.resize(c->N + 2);
     c->env.resize(c->N + 2);
-    if ((rc = dmalloc(c, &c->phi, (size_t)c->N * 2 * NTp))) return bail(rc);
+    if ((rc = dmalloc(c, (char**)&c->phi, (size_t)c->N * 2 * NTp * c->eesz()))) return bail(rc);
     if ((rc = dmalloc(c, &c->label, NTp))) return bail(rc);
-    if ((rc = dmalloc(c, &c->ones, NTp))) return bail(rc);
+    if ((rc = dmalloc(c, (char**)&c->ones, NTp * c->eesz()))) return bail(rc);
     const size_t esz = c->esz();
     if ((rc = dmalloc(c, (char**)&c->U, c->big_elems * esz))) return bail(rc);
     if ((rc = dmalloc(c, (char**)&c->P, (size_t)TNML_NL * NTp * esz))) return bail(rc);
@@ -189,7 +189,7 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     }
     if (hipMemsetAsync(c->vG, 0, sizeof(double) * (c->mcap + TNML_NSCAL_AR), c->stream) != hipSuccess) return bail(tnml_fail(c, "memset failed"));
     if (hipMemsetAsync(c->scal, 0, sizeof(double) * SC_N, c->stream) != hipSuccess) return bail(tnml_fail(c, "memset failed"));
-    if ((rc = launch_fill_f32(c, c->ones, 1.0f, NTp))) return bail(rc);
+    if ((rc = c->env64() ? launch_fill_f64(c, (double*)c->ones, 1.0, NTp) : launch_fill_f32(c, (float*)c->ones, 1.0f, NTp))) return bail(rc);
     if (hipStreamSynchronize(c->stream) != hipSuccess) return bail(tnml_fail(c, "sync failed"));
     *out = c;
     return 0;
@@ -270,11 +270,18 @@ int tnml_set_data_phi(tnml_ctx* c, const double* phi, const int32_t* labels) {
     HIPCK(c, hipSetDevice(c->cfg.device));
     TCK(set_labels(c, labels));
     // TState::data[(j-1)*d + (n-1)] (fixedL.cc:39-46) -> [N][2][NTp], rounded once to fp32
-    std::vector<float> h((size_t)c->N * 2 * c->NTp, 0.f);
-    for (int i = 0; i < c->NT; ++i)
-        for (int j = 0; j < c->N; ++j)
-            for (int s = 0; s < 2; ++s) h[((size_t)j * 2 + s) * c->NTp + i] = (float)phi[((size_t)i * c->N + j) * 2 + s];
-    HIPCK(c, hipMemcpy(c->phi, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice));
+    const size_t ne = (size_t)c->N * 2 * c->NTp;
+    if (c->env64()) {
+        std::vector<double> h(ne, 0.);
+        for (int i = 0; i < c->NT; ++i) for (int j = 0; j < c->N; ++j) for (int s = 0; s < 2; ++s)
+            h[((size_t)j * 2 + s) * c->NTp + i] = phi[((size_t)i * c->N + j) * 2 + s];
+        HIPCK(c, hipMemcpy(c->phi, h.data(), sizeof(double) * ne, hipMemcpyHostToDevice));
+    } else {
+        std::vector<float> h(ne, 0.f);
+        for (int i = 0; i < c->NT; ++i) for (int j = 0; j < c->N; ++j) for (int s = 0; s < 2; ++s)
+            h[((size_t)j * 2 + s) * c->NTp + i] = (float)phi[((size_t)i * c->N + j) * 2 + s];
+        HIPCK(c, hipMemcpy(c->phi, h.data(), sizeof(float) * ne, hipMemcpyHostToDevice));
+    }
     c->data_set = true; c->currb = -1;
     return 0;
 }
@@ -321,11 +328,11 @@ static int env_alloc(tnml_ctx* c, int j, int m, int L) {
     if (!big && c->pool_small.empty() && !c->pool_big.empty()) big = 1;
     auto& pool = big ? c->pool_big : c->pool_small;
     if (!pool.empty()) { e.ptr = pool.back(); pool.pop_back(); }
-    else TCK(dmalloc(c, &e.ptr, big ? c->big_elems : c->small_elems));
+    else TCK(dmalloc(c, (char**)&e.ptr, (big ? c->big_elems : c->small_elems) * c->eesz()));
     e.m = m; e.L = L; e.big = big;
     return 0;
 }
-static const float* phi_site(const tnml_ctx* c, int j) { return c->phi + (size_t)(j - 1) * 2 * c->NTp; }
+static const void* phi_site(const tnml_ctx* c, int j) { return (const char*)c->phi + (size_t)(j - 1) * 2 * c->NTp * c->eesz(); }
 
 // new env at site cs from the env at ps (0: chain end): nextE = prevE*(t.A(c)*W.A(c)), fixedL.cc:142-149,221-228
 static int shift_site(tnml_ctx* c, int cs, int ps, bool from_left) {
@@ -343,15 +350,28 @@ static int shift_site(tnml_ctx* c, int cs, int ps, bool from_left) {
     if (from_left) { d.nx = A.ml; d.sx = 1; d.ny = A.mr; d.sy = 2 * A.ml; }
     else           { d.nx = A.mr; d.sx = 2 * A.ml; d.ny = A.ml; d.sy = 1; }
     d.Kp = ru16(2 * d.nx); d.Np = ru16(d.ny);
-    TCK(launch_pack(c, d, A.a, nullptr, c->Mf));
     TCK(env_alloc(c, cs, m_out, Lout));
+    if (c->env64()) {                                   // fp64 environments: fp64 MFMA shift (M in the free SVD workspace)
+        d.Np = ru16(d.ny);
+        TCK(launch_pack(c, d, A.a, c->sM, nullptr));
+        Fgemm64Args f;
+        f.EI = has_prev ? c->env[ps].ptr : c->ones;
+        f.EI_lstride = (Le == TNML_NL) ? (size_t)m_in * c->NTp : 0;
+        f.mI = m_in; f.phiI = phi_site(c, cs);
+        f.M = c->sM; f.M_lstride = (A.L == TNML_NL) ? (size_t)d.Kp * d.Np : 0; f.Kp = d.Kp; f.Np = d.Np;
+        f.phiO = nullptr;
+        f.out = (double*)c->env[cs].ptr; f.out_lstride = (size_t)m_out * c->NTp; f.mO = m_out;
+        f.NTp = c->NTp; f.L = Lout; f.env64 = 1;
+        return launch_fgemm64(c, f);
+    }
+    TCK(launch_pack(c, d, A.a, nullptr, c->Mf));
     FgemmArgs f;
-    f.EI = has_prev ? c->env[ps].ptr : c->ones;
+    f.EI = has_prev ? (const float*)c->env[ps].ptr : (const float*)c->ones;
     f.EI_lstride = (Le == TNML_NL) ? (size_t)m_in * c->NTp : 0;
-    f.mI = m_in; f.phiI = phi_site(c, cs);
+    f.mI = m_in; f.phiI = (const float*)phi_site(c, cs);
     f.M = c->Mf; f.M_lstride = (A.L == TNML_NL) ? (size_t)d.Kp * d.Np : 0; f.Kp = d.Kp; f.Np = d.Np;
     f.phiO = nullptr;
-    f.out = c->env[cs].ptr; f.out_lstride = (size_t)m_out * c->NTp; f.mO = m_out;
+    f.out = (float*)c->env[cs].ptr; f.out_lstride = (size_t)m_out * c->NTp; f.mO = m_out;
     f.NTp = c->NTp; f.L = Lout;
     return launch_fgemm(c, f);
 }
@@ -380,12 +400,16 @@ int tnml_env_dims(tnml_ctx* c, int j, int* m, int* has_label) {
 int tnml_get_env(tnml_ctx* c, int j, double* E) {
     if (j < 1 || j > c->N || !c->env[j].ptr) return tnml_fail(c, "tnml_get_env: environment of site %d not built", j);
     const EnvSlot& e = c->env[j];
-    std::vector<float> h((size_t)e.L * e.m * c->NTp);
+    const size_t ne = (size_t)e.L * e.m * c->NTp;
+    std::vector<char> h(ne * c->eesz());
     HIPCK(c, hipStreamSynchronize(c->stream));
-    HIPCK(c, hipMemcpy(h.data(), e.ptr, sizeof(float) * h.size(), hipMemcpyDeviceToHost));
+    HIPCK(c, hipMemcpy(h.data(), e.ptr, h.size(), hipMemcpyDeviceToHost));
     for (int i = 0; i < c->NT; ++i)
         for (int l = 0; l < e.L; ++l)
-            for (int q = 0; q < e.m; ++q) E[(size_t)i * e.m * e.L + q + (size_t)e.m * l] = h[((size_t)l * e.m + q) * c->NTp + i];
+            for (int q = 0; q < e.m; ++q) {
+                const size_t k = ((size_t)l * e.m + q) * c->NTp + i;
+                E[(size_t)i * e.m * e.L + q + (size_t)e.m * l] = c->env64() ? ((const double*)h.data())[k] : (double)((const float*)h.data())[k];
+            }
     return 0;
 }
 
@@ -412,8 +436,8 @@ int tnml_set_bond(tnml_ctx* c, int b) {
     if ((useL ? c->env[lc].m : 1) != p.mL || (useR ? c->env[rc].m : 1) != p.mR) return tnml_fail(c, "setBond: env dims do not match W at bond %d", b);
     const int LL = useL ? c->env[lc].L : 1, LR = useR ? c->env[rc].L : 1;
     const bool onB = (c->c0 == b || c->c0 == b + 1);
-    const float* LE = useL ? c->env[lc].ptr : c->ones;
-    const float* RE = useR ? c->env[rc].ptr : c->ones;
+    const void* LE = useL ? c->env[lc].ptr : c->ones;
+    const void* RE = useR ? c->env[rc].ptr : c->ones;
     if (onB) {
         if (LL != 1 || LR != 1) return tnml_fail(c, "setBond: Label index on an environment and on B at bond %d", b);
         p.kind = 2; p.LB = TNML_NL; p.mI = p.mL; p.mO = p.mR; p.EI = LE; p.phiI = phi_site(c, b); p.EX = RE; p.phiO = phi_site(c, b + 1);
@@ -458,14 +482,14 @@ static int forward_pass(tnml_ctx* c, const double* vec, int mode, double* tail, 
         f.M = vec; f.M_lstride = p.kind == 2 ? (size_t)p.Kp * p.Np : 0; f.Kp = p.Kp; f.Np = p.Np;
         f.phiO = p.phiO;
         f.out = (double*)c->U; f.out_lstride = ustride; f.mO = p.mO;
-        f.NTp = c->NTp; f.L = p.LB;
+        f.NTp = c->NTp; f.L = p.LB; f.env64 = c->env64();
         TCK(launch_fgemm64(c, f));
     } else {
         TCK(launch_cvt(c, vec, c->Mf, p.msize()));
         FgemmArgs f;
-        f.EI = p.EI; f.EI_lstride = 0; f.mI = p.mI; f.phiI = p.phiI;
+        f.EI = (const float*)p.EI; f.EI_lstride = 0; f.mI = p.mI; f.phiI = (const float*)p.phiI;
         f.M = c->Mf; f.M_lstride = p.kind == 2 ? (size_t)p.Kp * p.Np : 0; f.Kp = p.Kp; f.Np = p.Np;
-        f.phiO = p.phiO;
+        f.phiO = (const float*)p.phiO;
         f.out = (float*)c->U; f.out_lstride = ustride; f.mO = p.mO;
         f.NTp = c->NTp; f.L = p.LB;
         TCK(launch_fgemm(c, f));
@@ -487,7 +511,7 @@ static int grad_eval(tnml_ctx* c, bool from_P_update = false) {
     if (p.kind != 2 && !fuse) TCK(launch_zprime(c, p.EX, (size_t)p.mO * c->NTp, c->dP, c->Zp, p.mO, c->NTp));
     if (c->f64()) {
         Bgemm64Args g;
-        g.EL = nullptr; g.EL_lstride = 0; g.dPz = nullptr;
+        g.EL = nullptr; g.EL_lstride = 0; g.dPz = nullptr; g.env64 = c->env64();
         g.EI = p.EI; g.mI = p.mI; g.phiI = p.phiI; g.phiO = p.phiO; g.mO = p.mO;
         g.Kp = p.Kp; g.Np = p.Np; g.NTp = c->NTp; g.L = p.LB;
         if (p.kind == 2) { g.Zq64 = nullptr; g.Zq32 = p.EX; g.w = (const double*)c->dP; g.w_lstride = c->NTp; }
@@ -496,9 +520,9 @@ static int grad_eval(tnml_ctx* c, bool from_P_update = false) {
         TCK(launch_bgemm64(c, g, c->vG));
     } else {
         BgemmArgs g;
-        g.EI = p.EI; g.mI = p.mI; g.phiI = p.phiI; g.phiO = p.phiO; g.mO = p.mO;
+        g.EI = (const float*)p.EI; g.mI = p.mI; g.phiI = (const float*)p.phiI; g.phiO = (const float*)p.phiO; g.mO = p.mO;
         g.Kp = p.Kp; g.Np = p.Np; g.NTp = c->NTp; g.L = p.LB;
-        if (p.kind == 2) { g.Zq = p.EX; g.w = (const float*)c->dP; g.w_lstride = c->NTp; }
+        if (p.kind == 2) { g.Zq = (const float*)p.EX; g.w = (const float*)c->dP; g.w_lstride = c->NTp; }
         else             { g.Zq = (const float*)c->Zp; g.w = nullptr; g.w_lstride = 0; }
         TCK(launch_bgemm(c, g, c->vG));
     }

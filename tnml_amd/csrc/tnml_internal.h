@@ -38,7 +38,7 @@ static const char* const kclass_names[KC_COUNT] = {
     "small_gemm", "svd", "allreduce"};
 
 struct EnvSlot {
-    float* ptr = nullptr;   // [L][cap_m][NTp] (rows beyond m unused)
+    void* ptr = nullptr;    // [L][m][NTp], fp32 or fp64 elements (tnml_ctx::env64)
     int m = 0, L = 0;
     int big = 0;            // allocated from the label-carrying pool
 };
@@ -61,8 +61,8 @@ struct BondPlan {
     int mL = 0, mR = 0;
     int mI = 0, mO = 0;        // link dims of input (label-free GEMM side) and output side
     int Kp = 0, Np = 0, LB = 1;
-    const float* EI = nullptr; const float* phiI = nullptr;   // input env [mI][NTp], its features
-    const float* EX = nullptr; const float* phiO = nullptr;   // other env: [10][mO][NTp] (kind 0/1) or [mO][NTp] (kind 2)
+    const void* EI = nullptr; const void* phiI = nullptr;     // input env [mI][NTp], its features (env-typed)
+    const void* EX = nullptr; const void* phiO = nullptr;     // other env: [10][mO][NTp] (kind 0/1) or [mO][NTp] (kind 2)
     size_t msize() const { return (size_t)LB * Kp * Np; }
 };
 
@@ -77,14 +77,14 @@ struct tnml_ctx {
     std::string err;
     int64_t bytes = 0;
 
-    float* phi = nullptr;      // [N][2][NTp]
+    void* phi = nullptr;       // [N][2][NTp], env-typed
     int* label = nullptr;      // [NTp]
-    float* ones = nullptr;     // [NTp] of 1.0f: the "environment" beyond the chain ends
+    void* ones = nullptr;      // [NTp] of 1: the "environment" beyond the chain ends, env-typed
     bool data_set = false;
 
     std::vector<SiteT> W;      // 1..N
     std::vector<EnvSlot> env;  // 1..N
-    std::vector<float*> pool_small, pool_big;
+    std::vector<void*> pool_small, pool_big;
     size_t small_elems = 0, big_elems = 0;
 
     // workspaces
@@ -99,8 +99,10 @@ struct tnml_ctx {
     float* Mf = nullptr;       // fp32 GEMM operand, M-layout, capacity 10*Kmax*Kmax (env shifts, F32 mode)
     void* slab = nullptr;      // split-K partial slabs
     size_t slab_bytes = 0;
-    bool f64() const { return cfg.dtype == TNML_F64; }
-    size_t esz() const { return cfg.dtype == TNML_F64 ? 8 : 4; }
+    bool f64() const { return cfg.dtype != TNML_F32; }                 // fp64 MFMA arithmetic
+    bool env64() const { return cfg.dtype == TNML_F64_STRICT; }        // fp64 environment / feature storage
+    size_t esz() const { return f64() ? 8 : 4; }
+    size_t eesz() const { return env64() ? 8 : 4; }
     double* partials = nullptr;  // [nblk][16]
     int partial_cap = 0;
     double *vB = nullptr, *vR = nullptr, *vP = nullptr, *vG = nullptr;   // CG vectors, M-layout fp64 (vG has TNML_NSCAL_AR tail)
@@ -170,20 +172,22 @@ int launch_bgemm(tnml_ctx* c, const BgemmArgs& a, double* G);
 
 // fp64-MFMA flavour (operands converted/expanded to fp64 while staging into LDS)
 struct Fgemm64Args {
-    const float* EI; size_t EI_lstride; int mI;
-    const float* phiI;
+    const void* EI; size_t EI_lstride; int mI;        // environment: fp32 (env64 == 0) or fp64 elements
+    const void* phiI;
     const double* M; size_t M_lstride; int Kp, Np;    // the fp64 CG vector itself (M-layout)
-    const float* phiO;
+    const void* phiO;                                 // null: no output site index (strict-mode env shift)
     double* out; size_t out_lstride; int mO;
     int NTp; int L;
+    int env64;
 };
 int launch_fgemm64(tnml_ctx* c, const Fgemm64Args& a);
 struct Bgemm64Args {
-    const float* EI; int mI; const float* phiI;
-    const double* Zq64; const float* Zq32; int mO; const float* phiO;   // exactly one of Zq64 / Zq32 / EL
-    const float* EL; size_t EL_lstride; const double* dPz;              // fused: Z = sum_l EL[l] * dPz[l]
+    const void* EI; int mI; const void* phiI;                            // env-typed (fp32 / fp64 by env64)
+    const double* Zq64; const void* Zq32; int mO; const void* phiO;      // exactly one of Zq64 / Zq32 (an env) / EL
+    const void* EL; size_t EL_lstride; const double* dPz;                // fused: Z = sum_l EL[l] * dPz[l]
     const double* w; size_t w_lstride;
     int Kp, Np, NTp, L;
+    int env64;
 };
 int launch_bgemm64(tnml_ctx* c, const Bgemm64Args& a, double* G);
 
@@ -201,8 +205,8 @@ struct LdotArgs {
 // partial sums -> scal_out[0..11] (device); deterministic
 int launch_labeldot(tnml_ctx* c, const LdotArgs& a, double* scal_out);
 int launch_pupdate(tnml_ctx* c, const double* alpha_dev, double* scal_out);
-int launch_zprime(tnml_ctx* c, const float* EL, size_t lstride, const void* dP, void* Z, int mq, int NTp);
-int launch_features_u8(tnml_ctx* c, const uint8_t* d_pix, int N, int NT, int NTp, float* phi);
+int launch_zprime(tnml_ctx* c, const void* EL, size_t lstride, const void* dP, void* Z, int mq, int NTp);
+int launch_features_u8(tnml_ctx* c, const uint8_t* d_pix, int N, int NT, int NTp, void* phi);
 
 // ---- kernels_small.hip --------------------------------------------------------------------
 struct PackDesc {       // M[l][2x+s][TO==2 ? 2y+t : y] <-> T[off + x*sx + s*ss + y*sy + t*st + l*sl]
@@ -221,6 +225,7 @@ int launch_cg_resid(tnml_ctx* c, size_t n, double lambda, double cconv, int pass
 int launch_sqnorm(tnml_ctx* c, const double* x, size_t n, double* out);    // out[0] = |x|^2
 int launch_diffnorm(tnml_ctx* c, const double* x, const double* y, size_t n, double* out2);  // out2[0]=|x|^2, out2[1]=|x-y|^2
 int launch_fill_f32(tnml_ctx* c, float* p, float v, size_t n);
+int launch_fill_f64(tnml_ctx* c, double* p, double v, size_t n);
 
 // ---- eigh.hip -----------------------------------------------------------------------------
 int eigh_tridiagonalize(tnml_ctx* c, const double* A, int n, double* D, double* E, double* tau, double* V);

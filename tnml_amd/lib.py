@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
 NL = 10
 MAX_PASS = 64
-DTYPES = {"f32": 0, "f64": 1}    # TNML_F32 / TNML_F64 (include/tnml.h)
+DTYPES = {"f32": 0, "f64": 1, "f64_strict": 2}    # TNML_F32 / TNML_F64 / TNML_F64_STRICT (include/tnml.h)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtnml.so")
 

@@ -96,3 +96,23 @@ def random_mps(N, m, seed=1, s1_scale=1.0):
             A[:, 1, :] = s1_scale * rng.standard_normal((ml, mr)) / np.sqrt(max(ml, mr))
         W.append(A)
     return W
+
+
+def write_idx(dirname, pixels, labels, train=True, side=None):
+    """Write images/labels as idx-ubyte files with the MNIST names the reference reads
+    (mllib/mnist.h:244,262,279,297): big-endian header, magic 0x803 / 0x801."""
+    import os
+    import struct
+    pixels = np.ascontiguousarray(pixels, dtype=np.uint8)
+    n, npix = pixels.shape
+    side = side or int(round(np.sqrt(npix)))
+    rows, cols = (side, npix // side)
+    assert rows * cols == npix
+    stem = "train" if train else "t10k"
+    os.makedirs(dirname, exist_ok=True)
+    with open(os.path.join(dirname, stem + "-images-idx3-ubyte"), "wb") as f:
+        f.write(struct.pack(">IIII", 0x803, n, rows, cols))
+        f.write(pixels.tobytes())
+    with open(os.path.join(dirname, stem + "-labels-idx1-ubyte"), "wb") as f:
+        f.write(struct.pack(">II", 0x801, n))
+        f.write(np.asarray(labels, dtype=np.uint8).tobytes())
