@@ -154,6 +154,15 @@ int tnml_svd_split(tnml_ctx* ctx, const double* B, int b, int ha, double cutoff,
 int tnml_bond_update(tnml_ctx* ctx, int b, int ha, const tnml_sweep_params* p, tnml_bond_report* rep);
 
 /* ---- host-side rules (no GPU needed) ------------------------------------------------------ */
+/* ---- inference (fulltest.cc:7-100; util.h:19-40 toverlap, util.h:123-200 fullTest) ------------------
+ * Full contraction of every local image with the weight MPS held by the context:
+ *   weights[n][l] = W_l(image n)  ([NT_local][10], may be NULL),
+ *   pred[n]       = argmax_l |W_l|, first maximum on ties (util.h:42-57,160-163; may be NULL),
+ *   count[l] / nincorrect[l] = images of label l / of those, wrongly predicted (local images; a multi-rank
+ *   caller sums them -- no collective is entered).  The images are the ones given to tnml_set_data_*;
+ *   a test set gets its own context.  Training environments held by the context are not modified. */
+int tnml_classify(tnml_ctx* ctx, double* weights, int32_t* pred, int64_t count[TNML_NL], int64_t nincorrect[TNML_NL]);
+
 /* ITensor truncate(): p = sigma^2 descending; returns kept m */
 int tnml_truncate(const double* p, int n, int maxm, int minm, double cutoff, double* truncerr);
 /* ITensor sweepnext (fixedL.cc:478) */

@@ -305,6 +305,26 @@ def test_fixedl_cli_driver_end_to_end(tmp_path):
     # the final W on disk carries the Label index on site N/2 only
     Wf = hostlib.read_mps(str(tmp_path / "W"))
     assert [A.ndim == 4 for A in Wf] == [j == N // 2 for j in range(1, N + 1)]
+    # `fulltest <inputfile>` (fulltest.cc) on a held-out idx test set with the W just written
+    tl = synth.synthetic_labels(130, seed=21)
+    tp = np.clip(synth.synthetic_images(N, tl, seed=21).astype(np.int32) * 3, 0, 255).astype(np.uint8)
+    synth.write_idx(data, tp, tl, train=False)
+    for feat, phi_t in (("series", pyoracle.features_series(tp)),
+                        ("normal", np.stack([np.cos(np.pi / 2 * tp / 65025.), np.sin(np.pi / 2 * tp / 65025.)], axis=-1))):
+        tin = tmp_path / ("input_test_" + feat)
+        tin.write_text("input\n{\ndatadir = %s\nfname = W\nfeature = %s\nprecision = strict\n}\n" % (data, feat))
+        run = subprocess.run([os.path.join(root, "tnml_amd", "fulltest"), str(tin)], capture_output=True, text=True, cwd=tmp_path, timeout=300)
+        assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+        ot = pyoracle.Oracle(phi_t, tl, Wf)
+        Wt = np.stack([ot.toverlap(i) for i in range(len(tl))])
+        pred = np.abs(Wt).argmax(axis=1)
+        ncor = int((pred == tl).sum())
+        m = re.search(r"(\d+)/(\d+) correct \(([0-9.]+)%\), (\d+)/(\d+) incorrect", run.stdout)
+        assert m and int(m.group(2)) == len(tl) and int(m.group(1)) == ncor and int(m.group(4)) == len(tl) - ncor
+        digits = re.findall(r"Digit (\d) (\d+)/(\d+) correct", run.stdout)
+        assert [(int(a), int(b), int(c)) for a, b, c in digits] == \
+            [(l, int(((pred == tl) & (tl == l)).sum()), int((tl == l).sum())) for l in range(10) if (tl == l).any()]
+        assert "Total # test images = %d" % len(tl) in run.stdout
 
 
 @pytest.mark.parametrize("b", [1, 3, 6, 9])
@@ -333,3 +353,39 @@ def test_strict_mode_full_sweep():
     assert [r["newm"] for r in rg] == [r["newm"] for r in ro]
     np.testing.assert_allclose([r["cost"] for r in rg], [r["cost"] for r in ro], rtol=1e-8)
     assert [r["ncorrect"] for r in rg] == [r["ncorrect"] for r in ro]
+
+
+@pytest.mark.parametrize("dtype,tol", [("f64", 2e-6), ("f64_strict", 1e-12), ("f32", 2e-5)])
+@pytest.mark.parametrize("N,m", [(12, 4), (4, 2), (17, 6)])
+def test_classify_matches_toverlap(dtype, tol, N, m):
+    """tnml_classify (fulltest.cc / util.h toverlap + fullTest) against the oracle's per-image full contraction"""
+    ts, o = _pair(N=N, NT=70, m=m, dtype=dtype)
+    W_or = np.stack([o.toverlap(i) for i in range(o.NT)])
+    w, pred, cnt, ninc = ts.classify()
+    assert _relmax(w, W_or) < tol
+    pred_or = np.abs(W_or).argmax(axis=1)                      # numpy argmax = first maximum, util.h:42-57
+    labels = np.asarray(o.labels)
+    if dtype == "f64_strict":
+        np.testing.assert_array_equal(pred, pred_or)
+    else:                                                      # a fp32-rounded near-tie may flip
+        gap = np.sort(np.abs(W_or), axis=1)
+        clear = (gap[:, -1] - gap[:, -2]) > 10 * tol * np.abs(W_or).max()
+        np.testing.assert_array_equal(pred[clear], pred_or[clear])
+    np.testing.assert_array_equal(cnt, np.bincount(labels, minlength=10))
+    np.testing.assert_array_equal(ninc, np.bincount(labels[pred != labels], minlength=10))
+    # the training environments survive a classify call: a bond update afterwards still matches the oracle
+    if dtype == "f64_strict":
+        ts.setBond(1)
+        o.set_bond(1)
+        B0 = o.bond_tensor(1)
+        assert _relmax(ts.forward(B0), o.forward(B0)) < 1e-11
+
+
+def test_classify_after_training_agrees_with_quadcost_count():
+    """after a sweep, the number of correct training images from the full contraction equals quadcost's count
+    at any bond (both are argmax_l |W_l| of the same network)"""
+    ts, o = _pair(N=10, NT=80, m=4, dtype="f64_strict")
+    from tnml_amd.fixedl import mldmrg
+    rg = mldmrg(ts, 1, 4, 2, 1e-10, 3, 1e-3, 1e-10)
+    w, pred, cnt, ninc = ts.classify()
+    assert int(cnt.sum() - ninc.sum()) == rg[-1]["ncorrect"]

@@ -495,15 +495,19 @@ static void fgemm64_go(tnml_ctx* c, const Fgemm64Args& a) {
     constexpr int BM = 16 * RT * WR, BN = 16 * CT * WC;
     dim3 grid(a.NTp / BM, (a.Np + BN - 1) / BN, a.L);
     dim3 block(64 * WR * WC);
-    if (!a.env64)     hipLaunchKernelGGL((k_fgemm64<RT, CT, WR, WC, KT, DB, 0, float, 2>), grid, block, 0, c->stream, a);
-    else if (a.phiO)  hipLaunchKernelGGL((k_fgemm64<RT, CT, WR, WC, KT, DB, 0, double, 2>), grid, block, 0, c->stream, a);
-    else              hipLaunchKernelGGL((k_fgemm64<RT, CT, WR, WC, KT, DB, 0, double, 1>), grid, block, 0, c->stream, a);
+    if (!a.phiO) {                                        // shift form (TO = 1): no second feature on the columns
+        if constexpr (DB == 0 && CT != 5) {
+            if (a.env64) hipLaunchKernelGGL((k_fgemm64<RT, CT, WR, WC, KT, 0, 0, double, 1>), grid, block, 0, c->stream, a);
+            else         hipLaunchKernelGGL((k_fgemm64<RT, CT, WR, WC, KT, 0, 0, float, 1>), grid, block, 0, c->stream, a);
+        }
+    }
+    else if (!a.env64) hipLaunchKernelGGL((k_fgemm64<RT, CT, WR, WC, KT, DB, 0, float, 2>), grid, block, 0, c->stream, a);
+    else               hipLaunchKernelGGL((k_fgemm64<RT, CT, WR, WC, KT, DB, 0, double, 2>), grid, block, 0, c->stream, a);
 }
 
 int launch_fgemm64(tnml_ctx* c, const Fgemm64Args& a) {
     ProfScope ps(c, a.phiO ? KC_FGEMM_FWD : KC_FGEMM_SHIFT);
     if (a.NTp % TNML_NTPAD) return tnml_fail(c, "fgemm64: NTp not padded");
-    if (!a.phiO && !a.env64) return tnml_fail(c, "fgemm64: the shift form exists only for fp64 environments");
     static const int cfg = getenv("TNML_FG64_CFG") ? atoi(getenv("TNML_FG64_CFG")) : 0;   // tuning knob (tools/tune_fgemm.sh)
     if (a.Np == 240 && a.phiO) {                             // m = 120: exactly 15 column tiles, no padding waste
         switch (cfg) {

@@ -334,7 +334,44 @@ static int env_alloc(tnml_ctx* c, int j, int m, int L) {
 }
 static const void* phi_site(const tnml_ctx* c, int j) { return (const char*)c->phi + (size_t)(j - 1) * 2 * c->NTp * c->eesz(); }
 
-// new env at site cs from the env at ps (0: chain end): nextE = prevE*(t.A(c)*W.A(c)), fixedL.cc:142-149,221-228
+// dst = src*(t.A(cs)*W.A(cs)) (fixedL.cc:142-149,221-228); src == nullptr: chain end.  dst is an environment
+// ([Lout][m_out][NTp] in the env type) or, with acc_out, a buffer of the arithmetic type (the last step of toverlap)
+static int shift_core(tnml_ctx* c, int cs, bool from_left, const void* src, int Le, void* dst, bool acc_out, int* Lout_p) {
+    const SiteT& A = c->W[cs];
+    const int m_in = from_left ? A.ml : A.mr, m_out = from_left ? A.mr : A.ml;
+    if (!src && m_in != 1) return tnml_fail(c, "shift: chain-end site %d has outer dimension %d", cs, m_in);
+    if (Le == TNML_NL && A.L == TNML_NL) return tnml_fail(c, "shift: Label index on both env and site");
+    const int Lout = A.L > Le ? A.L : Le;
+    if (Lout_p) *Lout_p = Lout;
+    PackDesc d;
+    d.TO = 1; d.L = A.L; d.st = 0; d.ss = A.ml; d.sl = (long)2 * A.ml * A.mr;
+    if (from_left) { d.nx = A.ml; d.sx = 1; d.ny = A.mr; d.sy = 2 * A.ml; }
+    else           { d.nx = A.mr; d.sx = 2 * A.ml; d.ny = A.ml; d.sy = 1; }
+    d.Kp = ru16(2 * d.nx); d.Np = ru16(d.ny);
+    if (c->env64() || (acc_out && c->f64())) {          // fp64 output: fp64 MFMA shift (M in the free SVD workspace)
+        TCK(launch_pack(c, d, A.a, c->sM, nullptr));
+        Fgemm64Args f;
+        f.EI = src ? src : c->ones;
+        f.EI_lstride = (Le == TNML_NL) ? (size_t)m_in * c->NTp : 0;
+        f.mI = m_in; f.phiI = phi_site(c, cs);
+        f.M = c->sM; f.M_lstride = (A.L == TNML_NL) ? (size_t)d.Kp * d.Np : 0; f.Kp = d.Kp; f.Np = d.Np;
+        f.phiO = nullptr;
+        f.out = (double*)dst; f.out_lstride = (size_t)m_out * c->NTp; f.mO = m_out;
+        f.NTp = c->NTp; f.L = Lout; f.env64 = c->env64();
+        return launch_fgemm64(c, f);
+    }
+    TCK(launch_pack(c, d, A.a, nullptr, c->Mf));
+    FgemmArgs f;
+    f.EI = src ? (const float*)src : (const float*)c->ones;
+    f.EI_lstride = (Le == TNML_NL) ? (size_t)m_in * c->NTp : 0;
+    f.mI = m_in; f.phiI = (const float*)phi_site(c, cs);
+    f.M = c->Mf; f.M_lstride = (A.L == TNML_NL) ? (size_t)d.Kp * d.Np : 0; f.Kp = d.Kp; f.Np = d.Np;
+    f.phiO = nullptr;
+    f.out = (float*)dst; f.out_lstride = (size_t)m_out * c->NTp; f.mO = m_out;
+    f.NTp = c->NTp; f.L = Lout;
+    return launch_fgemm(c, f);
+}
+// new env at site cs from the env at ps (0: chain end)
 static int shift_site(tnml_ctx* c, int cs, int ps, bool from_left) {
     const SiteT& A = c->W[cs];
     const bool has_prev = ps >= 1 && ps <= c->N;
@@ -342,38 +379,9 @@ static int shift_site(tnml_ctx* c, int cs, int ps, bool from_left) {
     const int m_in = from_left ? A.ml : A.mr, m_out = from_left ? A.mr : A.ml;
     const int Le = has_prev ? c->env[ps].L : 1;
     if (has_prev && c->env[ps].m != m_in) return tnml_fail(c, "shift: env dim %d != site dim %d at site %d", c->env[ps].m, m_in, cs);
-    if (!has_prev && m_in != 1) return tnml_fail(c, "shift: chain-end site %d has outer dimension %d", cs, m_in);
     if (Le == TNML_NL && A.L == TNML_NL) return tnml_fail(c, "shift: Label index on both env and site");
-    const int Lout = A.L > Le ? A.L : Le;
-    PackDesc d;
-    d.TO = 1; d.L = A.L; d.st = 0; d.ss = A.ml; d.sl = (long)2 * A.ml * A.mr;
-    if (from_left) { d.nx = A.ml; d.sx = 1; d.ny = A.mr; d.sy = 2 * A.ml; }
-    else           { d.nx = A.mr; d.sx = 2 * A.ml; d.ny = A.ml; d.sy = 1; }
-    d.Kp = ru16(2 * d.nx); d.Np = ru16(d.ny);
-    TCK(env_alloc(c, cs, m_out, Lout));
-    if (c->env64()) {                                   // fp64 environments: fp64 MFMA shift (M in the free SVD workspace)
-        d.Np = ru16(d.ny);
-        TCK(launch_pack(c, d, A.a, c->sM, nullptr));
-        Fgemm64Args f;
-        f.EI = has_prev ? c->env[ps].ptr : c->ones;
-        f.EI_lstride = (Le == TNML_NL) ? (size_t)m_in * c->NTp : 0;
-        f.mI = m_in; f.phiI = phi_site(c, cs);
-        f.M = c->sM; f.M_lstride = (A.L == TNML_NL) ? (size_t)d.Kp * d.Np : 0; f.Kp = d.Kp; f.Np = d.Np;
-        f.phiO = nullptr;
-        f.out = (double*)c->env[cs].ptr; f.out_lstride = (size_t)m_out * c->NTp; f.mO = m_out;
-        f.NTp = c->NTp; f.L = Lout; f.env64 = 1;
-        return launch_fgemm64(c, f);
-    }
-    TCK(launch_pack(c, d, A.a, nullptr, c->Mf));
-    FgemmArgs f;
-    f.EI = has_prev ? (const float*)c->env[ps].ptr : (const float*)c->ones;
-    f.EI_lstride = (Le == TNML_NL) ? (size_t)m_in * c->NTp : 0;
-    f.mI = m_in; f.phiI = (const float*)phi_site(c, cs);
-    f.M = c->Mf; f.M_lstride = (A.L == TNML_NL) ? (size_t)d.Kp * d.Np : 0; f.Kp = d.Kp; f.Np = d.Np;
-    f.phiO = nullptr;
-    f.out = (float*)c->env[cs].ptr; f.out_lstride = (size_t)m_out * c->NTp; f.mO = m_out;
-    f.NTp = c->NTp; f.L = Lout;
-    return launch_fgemm(c, f);
+    TCK(env_alloc(c, cs, m_out, A.L > Le ? A.L : Le));
+    return shift_core(c, cs, from_left, has_prev ? c->env[ps].ptr : nullptr, Le, c->env[cs].ptr, false, nullptr);
 }
 
 int tnml_env_init(tnml_ctx* c) {       // TrainStates::init, fixedL.cc:122-157
@@ -410,6 +418,68 @@ int tnml_get_env(tnml_ctx* c, int j, double* E) {
                 const size_t k = ((size_t)l * e.m + q) * c->NTp + i;
                 E[(size_t)i * e.m * e.L + q + (size_t)e.m * l] = c->env64() ? ((const double*)h.data())[k] : (double)((const float*)h.data())[k];
             }
+    return 0;
+}
+
+// ---- inference: toverlap / fullTest (util.h:19-40,123-200) ------------------------------------------
+// W_n[l] = (prod_{j<c} phi_j*A_j) * (phi_c*A_c) * (prod_{j>c} phi_j*A_j) for every local image, with rolling
+// chain buffers borrowed from the environment pools (the training environments are left untouched).
+int tnml_classify(tnml_ctx* c, double* weights, int32_t* pred, int64_t count[TNML_NL], int64_t nincorrect[TNML_NL]) {
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    if (!c->data_set) return tnml_fail(c, "tnml_classify: image data not set");
+    TCK(check_W(c));
+    struct Borrowed { void* p; int big; };
+    auto borrow = [&](Borrowed* b) -> int {
+        if (!c->pool_small.empty()) { b->p = c->pool_small.back(); c->pool_small.pop_back(); b->big = 0; return 0; }
+        if (!c->pool_big.empty())   { b->p = c->pool_big.back(); c->pool_big.pop_back(); b->big = 1; return 0; }
+        b->big = 0;
+        return dmalloc(c, (char**)&b->p, c->small_elems * c->eesz());
+    };
+    Borrowed buf[3] = {{nullptr, 0}, {nullptr, 0}, {nullptr, 0}};
+    int rc = 0;
+    for (int k = 0; k < 3 && !rc; ++k) rc = borrow(&buf[k]);
+    auto give_back = [&]() { for (auto& b : buf) if (b.p) (b.big ? c->pool_big : c->pool_small).push_back(b.p); };
+    if (rc) { give_back(); return rc; }
+    const int cs = c->c0;
+    // right chain N -> c+1 (util.h:25-29), ping-pong between buf[0] and buf[1]
+    const void* R = nullptr; int cur = 0;
+    for (int j = c->N; j > cs && !rc; --j) { rc = shift_core(c, j, false, R, 1, buf[cur].p, false, nullptr); R = buf[cur].p; cur ^= 1; }
+    // left chain 1 -> c-1 (util.h:32-37), ping-pong between buf[2] and the free one of the pair above
+    const void* Lc = nullptr; void* lbuf[2] = {buf[2].p, buf[cur].p}; int lcur = 0;
+    for (int j = 1; j < cs && !rc; ++j) { rc = shift_core(c, j, true, Lc, 1, lbuf[lcur], false, nullptr); Lc = lbuf[lcur]; lcur ^= 1; }
+    // centre site: T[l][r][n] = sum_{a,s} L[a][n] phi_c[s][n] A_c[a,s,r,l], then W_n[l] = sum_r T[l][r][n] R[r][n]
+    if (!rc) rc = shift_core(c, cs, true, Lc, 1, c->U, true, nullptr);
+    double* tail = c->vG + c->mcap;
+    if (!rc) {
+        LdotArgs a;
+        a.A = c->U; a.A_lstride = (size_t)c->W[cs].mr * c->NTp; a.Bv = R; a.a_is_env = 0;
+        a.mq = c->W[cs].mr; a.NTp = c->NTp; a.label = c->label;
+        a.P = c->P; a.dP = nullptr; a.mode = LD_MODE_COST;
+        rc = launch_labeldot(c, a, tail);
+    }
+    give_back();
+    if (rc) return rc;
+    std::vector<char> h((size_t)TNML_NL * c->NTp * c->esz());
+    std::vector<int> lab(c->NTp);
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    HIPCK(c, hipMemcpy(h.data(), c->P, h.size(), hipMemcpyDeviceToHost));
+    HIPCK(c, hipMemcpy(lab.data(), c->label, sizeof(int) * c->NTp, hipMemcpyDeviceToHost));
+    HIPCK(c, hipMemsetAsync(tail, 0, sizeof(double) * TNML_NSCAL_AR, c->stream));
+    if (count) for (int l = 0; l < TNML_NL; ++l) count[l] = 0;
+    if (nincorrect) for (int l = 0; l < TNML_NL; ++l) nincorrect[l] = 0;
+    for (int i = 0; i < c->NT; ++i) {
+        double w[TNML_NL];
+        for (int l = 0; l < TNML_NL; ++l) {
+            const size_t k = (size_t)l * c->NTp + i;
+            w[l] = c->f64() ? ((const double*)h.data())[k] : (double)((const float*)h.data())[k];
+            if (weights) weights[(size_t)i * TNML_NL + l] = w[l];
+        }
+        int pl = 0; double best = std::fabs(w[0]);                 // argmax of |W_l|, first maximum (util.h:42-57,160-163)
+        for (int l = 1; l < TNML_NL; ++l) if (std::fabs(w[l]) > best) { best = std::fabs(w[l]); pl = l; }
+        if (pred) pred[i] = pl;
+        if (count) count[lab[i]] += 1;
+        if (nincorrect && pl != lab[i]) nincorrect[lab[i]] += 1;
+    }
     return 0;
 }
 

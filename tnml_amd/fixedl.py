@@ -93,6 +93,17 @@ class TrainStates:
     def device_bytes(self):
         return self._L.tnml_device_bytes(self._h)
 
+    def classify(self):
+        """toverlap / fullTest (util.h:19-40,123-200) over the local images: returns (weights[NT,10], pred[NT],
+        count[10], nincorrect[10])."""
+        w = np.zeros((self.NT, 10))
+        pred = np.zeros(self.NT, dtype=np.int32)
+        cnt = np.zeros(10, dtype=np.int64)
+        ninc = np.zeros(10, dtype=np.int64)
+        self._ck(self._L.tnml_classify(self._h, _lib.dptr(w), pred.ctypes.data_as(C.POINTER(C.c_int32)),
+                                       cnt.ctypes.data_as(C.POINTER(C.c_int64)), ninc.ctypes.data_as(C.POINTER(C.c_int64))))
+        return w, pred, cnt, ninc
+
     # -- W
     def set_mps(self, W):
         for j, A in enumerate(W, start=1):

@@ -25,7 +25,7 @@ EXPORTS = [
     "tnml_bond_dims", "tnml_bond_tensor", "tnml_forward", "tnml_gradient", "tnml_quadcost",
     "tnml_cgrad", "tnml_svd_split", "tnml_bond_update", "tnml_truncate", "tnml_sweepnext",
     "tnml_shard_bounds", "tnml_profile_enable", "tnml_profile_select", "tnml_profile_count", "tnml_profile_get",
-    "tnml_profile_reset", "tnml_synchronize", "tnml_device_bytes", "tnml_svd_stats",
+    "tnml_profile_reset", "tnml_synchronize", "tnml_device_bytes", "tnml_svd_stats", "tnml_classify",
 ]
 
 
@@ -103,6 +103,7 @@ def load():
     L.tnml_synchronize.argtypes = [vp]
     L.tnml_svd_stats.argtypes = [vp, C.POINTER(C.c_int64), dp, dp]
     L.tnml_device_bytes.argtypes = [vp]
+    L.tnml_classify.argtypes = [vp, dp, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.tnml_device_bytes.restype = C.c_int64
     _lib = L
     return L
