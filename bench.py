@@ -3,8 +3,16 @@
 
 Workload (config.workload): BASELINE config 3 -- N=784 sites, maxm=120, 60 000 synthetic
 MNIST-shaped images (no MNIST files offline), random-init weight MPS at bond dimension 120,
-Npass=4, lambda=1e-3, cutoff=1e-10, minm=60.  One "step" = one iteration of the mldmrg loop body
-(fixedL.cc:478-540): setBond + cgrad(Npass) + svd + quadcost + shiftE, device resident.
+Npass=4, lambda=1e-3, cutoff=1e-10, minm=maxm (bonds stay at m=120), everything in fp64 like the reference.  One "step" = one
+iteration of the mldmrg loop body (fixedL.cc:478-540): setBond + cgrad(Npass) + svd + quadcost + shiftE,
+device resident.
+
+Which bonds are timed.  A sweep has four kinds of interior bonds of equal GEMM cost: the Label index sits on
+the right (b < N/2) or left (b > N/2) environment, and the environment built by shiftE after the update
+carries the Label index (10x the work of a Label-free shift) on exactly half of them.  With --steps >=
+2(N-1) the timed region is whole sweeps from bond 1 (the exact sweep average, centre bonds included).  With
+fewer steps it is a run of consecutive interior bonds of the MOST expensive kind (first half-sweep, b > N/2:
+every step pays the Label-carrying shift), so a short run never overstates the sweep average.
 At --gpus N the 60 000 images are sharded over N ranks (strong scaling) and the gradient / cost
 partials are summed by an RCCL all-reduce inside the library; the control plane (unique-id
 broadcast, barriers, max-over-ranks timing) uses torch.distributed.
@@ -26,6 +34,21 @@ if ROOT not in sys.path:
 F64_MFMA_PEAK_TF = 78.6      # MI355X FP64 matrix peak (AMD spec); 77.4 TF measured (profiles/r01_probe64.txt)
 F32_MFMA_PEAK_TF = 157.3     # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md "HBM3E peak BW"
+
+
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of a kernel from the committed PMC summary (tools/pmc_bench.sh: rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE in separate passes over this same workload).  FETCH_SIZE is doubled as MI355X_MICROARCH.md "HBM"
+    prescribes for wide streaming reads on gfx950; the label-dot kernel, whose byte count is known exactly
+    (635.5 MB per launch), calibrates it: 310 398 KB reported = half.  Returns None when no summary is present."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.csv")
+    if not os.path.exists(path):
+        return None
+    for r in csv.DictReader(open(path)):
+        if r["kernel"].startswith(kernel_prefix):
+            return (2.0 * float(r["fetch_size_mean"]) + float(r["write_size_mean"])) * 1024.0
+    return None
 
 
 def cpu_baseline(maxm, npass, lam, cutoff, nthread, NT_total):
@@ -68,6 +91,24 @@ def cpu_baseline(maxm, npass, lam, cutoff, nthread, NT_total):
     }
 
 
+def hbm_roofline(prof_all, NTl, timed, args, world):
+    """the HBM-bound kernel of the path: the label dot P_n[l] = sum_q T[q][n] * E[l][q][n] streams the Label-carrying
+    environment (10*m values per image) and the GEMM output (m per image) once; algorithmic bytes per launch from the
+    bond dimensions of the timed bonds, duration from the library's HIP events over the untimed breakdown steps"""
+    n_ld, ms_ld = prof_all.get("labeldot", (0, 0.0))
+    if not n_ld or not timed:
+        return None
+    esz = 4 if args.dtype == "f32" else 8
+    env_sz = 8 if args.dtype == "f64" else 4
+    by = float(np.mean([NTl * (10 * min(r["mL"], r["mR"]) * (esz if r["label_on_B"] else env_sz) +
+                              min(r["mL"], r["mR"]) * (env_sz if r["label_on_B"] else esz) + 4) for r in timed]))
+    avg_ms = ms_ld / n_ld
+    ach = by / (avg_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "k_labeldot", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": pmc_traffic("void k_labeldot<4, double, double, double>") if args.dtype == "f64" and args.maxm == 120 and args.images == 60000 and world == 1 else None,
+            "avg_launch_ms": avg_ms, "launches": n_ld, "bytes_per_launch": by}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,7 +118,9 @@ def main():
     ap.add_argument("--images", type=int, default=60000)
     ap.add_argument("--maxm", type=int, default=120)
     ap.add_argument("--npass", type=int, default=4)
-    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--minm", type=int, default=None, help="default maxm: every interior bond stays at m = maxm whatever the "
+                    "spectrum of the synthetic data (the reference default max(10, maxm/2) lets trained bonds shrink)")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f64_e32", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -102,7 +145,8 @@ def main():
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     N, NT, maxm = args.sites, args.images, args.maxm
-    lam, cutoff, cconv, npass, minm = 1e-3, 1e-10, 1e-10, args.npass, max(1, maxm // 2)
+    lam, cutoff, cconv, npass = 1e-3, 1e-10, 1e-10, args.npass
+    minm = args.minm if args.minm is not None else maxm
 
     labels = synth.synthetic_labels(NT)
     pixels = synth.synthetic_images(N, labels)
@@ -128,6 +172,13 @@ def main():
             dist.barrier()
 
     b, ha = 1, 1
+    full_sweeps = args.steps >= 2 * (N - 1)
+    if not full_sweeps and N >= 64:
+        # left environments up to the window start, as a sweep would have left them (setup, untimed)
+        b0 = max(N // 2 + 8, min(N // 2 + 8 + (N // 2 - 24 - args.warmup - args.steps) // 2, N - 1))
+        for bb in range(1, b0):
+            ts.shiftE(bb, True)
+        b = b0
     reports = []
 
     def step():
@@ -178,7 +229,7 @@ def main():
         flops_per_launch = float(np.mean(fl)) if fl else 0.0
         avg_ms = ms_fg / max(n_fg, 1)
         achieved_tf = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        peak = F64_MFMA_PEAK_TF if args.dtype == "f64" else F32_MFMA_PEAK_TF
+        peak = F64_MFMA_PEAK_TF if args.dtype != "f32" else F32_MFMA_PEAK_TF
         out = {
             "metric": "two-site bond updates/sec",
             "value": args.steps / elapsed,
@@ -192,16 +243,22 @@ def main():
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": "fixedL N=%d, maxm=%d, %d images (BASELINE config 3), Npass=%d, lambda=%g, "
-                                   "bonds %d..%d of sweep 1 (m=%d interior)" % (N, maxm, NT, npass, lam,
+            "config": {"workload": "fixedL N=%d, maxm=%d, %d images (BASELINE config 3), Npass=%d, lambda=%g, minm=%d, "
+                                   "%s; timed bonds %d..%d (%s, m=%d)" % (N, maxm, NT, npass, lam, minm,
+                                                                               {"f64": "fp64 throughout", "f64_e32": "fp64 MFMA over fp32-stored environments", "f32": "fp32 study mode"}[args.dtype],
                                                                                timed[0]["bond"] if timed else 0,
-                                                                               timed[-1]["bond"] if timed else 0, maxm),
+                                                                               timed[-1]["bond"] if timed else 0,
+                                                                               "whole sweeps" if full_sweeps else
+                                                                               "consecutive interior bonds, Label-carrying shiftE on each",
+                                                                               maxm),
                        "global_images": NT, "sites": N, "maxm": maxm, "parallelism": "dp%d (image sharding + RCCL all-reduce)" % world},
-            "roofline": {"bound": "mfma", "kernel": "k_fgemm64" if args.dtype == "f64" else "k_fgemm",
+            "roofline": {"bound": "mfma", "kernel": "k_fgemm64" if args.dtype != "f32" else "k_fgemm",
                          "achieved": achieved_tf, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved_tf / peak, "traffic": None,
+                         "frac": achieved_tf / peak,
+                         "traffic": pmc_traffic("void k_fgemm64<2, 5, 4, 3, 16, 0, 0, double, 2>") if args.dtype == "f64" and maxm == 120 and NT == 60000 and world == 1 else None,
                          "avg_launch_ms": avg_ms, "launches": n_fg, "flops_per_launch": flops_per_launch},
             "kernel_ms_per_step": {k: v[1] / nbreak for k, v in prof_all.items() if v[0]},
+            "roofline_hbm": hbm_roofline(prof_all, NTl, timed, args, world),
             "env_init_s": t_init,
             "device_gb": ts.device_bytes() / 1e9,
             "last_cost_per_image": timed[-1]["cost"] / NT if timed else None,

@@ -1,8 +1,10 @@
 """GPU parity tests: the HIP path (through the C-ABI, tnml_amd.fixedl) against the CPU oracle on
-identical seeded inputs.  Default arithmetic (dtype "f64"): fp64 MFMA contractions over fp32-stored
-environments, fp64 CG/SVD algebra -- the tolerances below are set by the fp32 environment storage
-(~1e-7 per site, accumulated along the chain).  The "f32" study mode gets the looser figures of
-SURVEY.md 8(d)."""
+identical seeded inputs.
+
+dtype "f64" (TNML_F64, the default): everything in fp64 like the reference -- the tolerances are those of two
+fp64 implementations with different summation orders.  dtype "f64_e32" (TNML_F64_E32): fp64 MFMA and fp64
+CG/SVD algebra over fp32-STORED environments -- tolerances set by that storage rounding (~1e-7 per site,
+accumulated along the chain and amplified by the CG).  dtype "f32": the looser study figures of SURVEY.md 8(d)."""
 import numpy as np
 import pytest
 
@@ -10,10 +12,12 @@ from conftest import make_problem
 
 pytestmark = pytest.mark.gpu
 
-P_RTOL = 5e-6        # P_n, ||.||inf relative to max|P|
-G_RTOL = 2e-5        # gradient, relative to max|G| (a cancelled sum over images)
-C_RTOL = 2e-6        # costs
-E_RTOL = 5e-6        # environments (fp32 MFMA chain)
+TOL = {
+    #            environments  P_n (rel max|P|)  gradient (rel max|G|)  costs      CG cost trace  CG alpha/|r|/B
+    "f64":     dict(E=1e-12,   P=1e-11,          G=1e-9,                C=1e-11,   cgc=1e-9,      cga=1e-5),
+    "f64_e32": dict(E=5e-6,    P=5e-6,           G=2e-5,                C=2e-6,    cgc=1e-5,      cga=1e-3),
+}
+BOTH = ["f64", "f64_e32"]
 
 
 def _pair(N=12, NT=60, m=4, seed=3, boost=200.0, use_u8=False, maxm=None, dtype="f64"):
@@ -44,18 +48,21 @@ def _walk(ts, o, b):
     o.set_bond(b)
 
 
+@pytest.mark.parametrize("dtype", BOTH)
 @pytest.mark.parametrize("use_u8", [False, True])
-def test_envs_after_init(use_u8):
-    ts, o = _pair(use_u8=use_u8, boost=1.0 if use_u8 else 200.0)
+def test_envs_after_init(use_u8, dtype):
+    ts, o = _pair(use_u8=use_u8, boost=1.0 if use_u8 else 200.0, dtype=dtype)
     for j in range(3, o.N + 1):
         Eg, Eo = ts.env(j), o.env(j)
         assert Eg.shape == Eo.shape
-        assert _relmax(Eg, Eo) < E_RTOL, f"site {j}"
+        assert _relmax(Eg, Eo) < TOL[dtype]["E"], f"site {j}"
 
 
+@pytest.mark.parametrize("dtype", BOTH)
 @pytest.mark.parametrize("b", [1, 2, 5, 6, 7, 11])
-def test_forward_gradient_quadcost_each_bond_kind(b):
-    ts, o = _pair()
+def test_forward_gradient_quadcost_each_bond_kind(b, dtype):
+    ts, o = _pair(dtype=dtype)
+    P_RTOL, G_RTOL, C_RTOL = TOL[dtype]["P"], TOL[dtype]["G"], TOL[dtype]["C"]
     _walk(ts, o, b)
     B = o.bond_tensor(b)
     assert _relmax(ts.bond_tensor(b), B) < 1e-12
@@ -65,23 +72,24 @@ def test_forward_gradient_quadcost_each_bond_kind(b):
     Cg, lg, crg, ng = ts.quadcost(B, 1e-3)
     Co, lo, cro, no = o.quadcost(B, 1e-3)
     assert Cg == pytest.approx(Co, rel=C_RTOL)
-    np.testing.assert_allclose(lg, lo, rtol=1e-5, atol=1e-7 * Co)
+    np.testing.assert_allclose(lg, lo, rtol=5 * C_RTOL, atol=0.05 * C_RTOL * Co)
     assert crg == pytest.approx(cro, rel=1e-12)
     assert ng == no
 
 
+@pytest.mark.parametrize("dtype", BOTH)
 @pytest.mark.parametrize("b,lam", [(1, 0.0), (3, 1e-3), (6, 1e-3), (9, 1e-3)])
-def test_cgrad_matches_oracle(b, lam):
-    ts, o = _pair()
+def test_cgrad_matches_oracle(b, lam, dtype):
+    ts, o = _pair(dtype=dtype)
     _walk(ts, o, b)
     B0 = o.bond_tensor(b)
     Bg, tg = ts.cgrad(B0, 4, lam, 1e-10)
     Bo, to = o.cgrad(B0, 4, lam, 1e-10)
     assert tg["npass_done"] == to["npass_done"] == 4
-    np.testing.assert_allclose(tg["cost"], to["cost"], rtol=1e-5)
-    np.testing.assert_allclose(tg["alpha"], to["alpha"], rtol=1e-3)
-    np.testing.assert_allclose(tg["rnorm"], to["rnorm"], rtol=1e-3)
-    assert _relmax(Bg, Bo) < 1e-3
+    np.testing.assert_allclose(tg["cost"], to["cost"], rtol=TOL[dtype]["cgc"])
+    np.testing.assert_allclose(tg["alpha"], to["alpha"], rtol=TOL[dtype]["cga"])
+    np.testing.assert_allclose(tg["rnorm"], to["rnorm"], rtol=TOL[dtype]["cga"])
+    assert _relmax(Bg, Bo) < TOL[dtype]["cga"]
     assert all(x >= y * (1 - 1e-6) for x, y in zip(tg["cost"], tg["cost"][1:]))      # CG monotone
 
 
@@ -106,26 +114,30 @@ def test_svd_split_matches_oracle(b, ha):
     np.testing.assert_allclose(M.T @ M, np.eye(M.shape[1]), atol=1e-9)
 
 
-def test_full_sweep_reports_match_oracle():
-    ts, o = _pair(N=10, NT=40, m=4)
+@pytest.mark.parametrize("dtype,sweep_rtol", [("f64", 1e-8), ("f64_e32", 1e-4)])
+def test_full_sweep_reports_match_oracle(dtype, sweep_rtol):
+    ts, o = _pair(N=10, NT=40, m=4, dtype=dtype)
     from tnml_amd.fixedl import mldmrg
     rg = mldmrg(ts, 1, 4, 2, 1e-10, 3, 1e-3, 1e-10)
     ro = o.mldmrg(1, 4, 2, 1e-10, 3, 1e-3, 1e-10)
     assert len(rg) == len(ro) == 2 * (o.N - 1)
     for a, b in zip(rg, ro):
         assert (a["bond"], a["half"], a["origm"], a["newm"]) == (b["bond"], b["half"], b["origm"], b["newm"])
-        assert a["cost"] == pytest.approx(b["cost"], rel=1e-4)
-        assert abs(a["ncorrect"] - b["ncorrect"]) <= 1
+        assert a["cost"] == pytest.approx(b["cost"], rel=sweep_rtol)
+        assert abs(a["ncorrect"] - b["ncorrect"]) <= (0 if dtype == "f64" else 1)
+        np.testing.assert_allclose(a["label_cost"], b["label_cost"], rtol=10 * sweep_rtol, atol=sweep_rtol * b["cost"])
     # first bond: identical (W, data) state -> tight tolerance
-    assert rg[0]["cost"] == pytest.approx(ro[0]["cost"], rel=1e-5)
+    assert rg[0]["cost"] == pytest.approx(ro[0]["cost"], rel=TOL[dtype]["cgc"])
     assert rg[0]["truncerr"] == pytest.approx(ro[0]["truncerr"], rel=1e-3, abs=1e-12)
     for j, A in enumerate(ts.get_mps(), start=1):
         assert (A.ndim == 4) == (j == ts.c0)
 
 
-def test_m120_shapes_forward_gradient():
+@pytest.mark.parametrize("dtype", BOTH)
+def test_m120_shapes_forward_gradient(dtype):
     """the maxm=120 specialisations (240-column feature GEMM, 80x80 gradient tiles) vs the oracle"""
-    ts, o = _pair(N=20, NT=64, m=120, maxm=120)
+    ts, o = _pair(N=20, NT=64, m=120, maxm=120, dtype=dtype)
+    P_RTOL, G_RTOL, E_RTOL = TOL[dtype]["P"], TOL[dtype]["G"], TOL[dtype]["E"]
     _walk(ts, o, 8)          # bond 8: 120 x 120, Label on RE (c0 = 10)
     B = o.bond_tensor(8)
     B = B + 0.05 * np.random.default_rng(1).standard_normal(B.shape)
@@ -147,11 +159,13 @@ def test_m120_shapes_forward_gradient():
     assert _relmax(ts.env(11), o.env(11)) < E_RTOL
 
 
-def test_ragged_image_count_and_padding():
-    """NT not a multiple of any tile size: padding images must not contribute"""
-    ts, o = _pair(N=8, NT=37, m=3)
+@pytest.mark.parametrize("dtype", BOTH)
+@pytest.mark.parametrize("NT", [1, 37, 257])
+def test_ragged_image_count_and_padding(dtype, NT):
+    """NT not a multiple of any tile size (and a single image): padding images must not contribute"""
+    ts, o = _pair(N=8, NT=NT, m=3, dtype=dtype)
     B = o.bond_tensor(1)
-    assert _relmax(ts.gradient(B), o.gradient(B)) < G_RTOL
+    assert _relmax(ts.gradient(B), o.gradient(B)) < TOL[dtype]["G"]
     assert ts.quadcost(B, 0.0)[3] == o.quadcost(B, 0.0)[3]
 
 
@@ -256,8 +270,8 @@ def test_cgrad_early_exit_on_cconv():
     Bo, to = o.cgrad(B0, 4, 1e-3, cconv)
     assert to["converged"] and tg["converged"]
     assert tg["npass_done"] == to["npass_done"] == 2
-    np.testing.assert_allclose(tg["cost"], to["cost"], rtol=1e-5)
-    assert _relmax(Bg, Bo) < 1e-4
+    np.testing.assert_allclose(tg["cost"], to["cost"], rtol=1e-9)
+    assert _relmax(Bg, Bo) < 1e-6
 
 
 def test_fixedl_cli_driver_end_to_end(tmp_path):
@@ -277,7 +291,7 @@ def test_fixedl_cli_driver_end_to_end(tmp_path):
     synth.write_idx(data, pixels, labels)
     inp = tmp_path / "input"
     inp.write_text("input\n{\ndatadir = %s\nNtrain = %d\nNbatch = 4\nNsweep = 1\ncutoff = 1E-10\nmaxm = 6\nminm = 3\n"
-                   "ninitial = 3\nlambda = 1E-3\nNpass = 3\nseed = 5\nprecision = strict\n}\n" % (data, per_label))
+                   "ninitial = 3\nlambda = 1E-3\nNpass = 3\nseed = 5\nprecision = f64\n}\n" % (data, per_label))
     run = subprocess.run([os.path.join(root, "tnml_amd", "fixedL"), str(inp)], capture_output=True, text=True, cwd=tmp_path, timeout=300)
     assert run.returncode == 0, run.stderr[-2000:]
     log = run.stdout
@@ -312,7 +326,7 @@ def test_fixedl_cli_driver_end_to_end(tmp_path):
     for feat, phi_t in (("series", pyoracle.features_series(tp)),
                         ("normal", np.stack([np.cos(np.pi / 2 * tp / 65025.), np.sin(np.pi / 2 * tp / 65025.)], axis=-1))):
         tin = tmp_path / ("input_test_" + feat)
-        tin.write_text("input\n{\ndatadir = %s\nfname = W\nfeature = %s\nprecision = strict\n}\n" % (data, feat))
+        tin.write_text("input\n{\ndatadir = %s\nfname = W\nfeature = %s\nprecision = f64\n}\n" % (data, feat))
         run = subprocess.run([os.path.join(root, "tnml_amd", "fulltest"), str(tin)], capture_output=True, text=True, cwd=tmp_path, timeout=300)
         assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
         ot = pyoracle.Oracle(phi_t, tl, Wf)
@@ -327,11 +341,66 @@ def test_fixedl_cli_driver_end_to_end(tmp_path):
         assert "Total # test images = %d" % len(tl) in run.stdout
 
 
+@pytest.mark.parametrize("precision,rtol", [("f64", 1e-6), ("mixed", 2e-2)])
+def test_fixedl_cli_imglen_and_feature_scale(tmp_path, precision, rtol):
+    """driver extensions: `imglen` (8x8 -> 4x4 block means) and `feature_scale = 255` (the README's [1, x/4] map, well
+    conditioned) -- log costs and the fulltest table against the oracle fed with the same reduced images"""
+    import os
+    import re
+    import subprocess
+    from oracle import pyoracle
+    from tnml_amd import hostlib, synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    per_label = 20
+    labels = synth.synthetic_labels(10 * per_label, seed=4, per_label=per_label)
+    tl = synth.synthetic_labels(90, seed=22)
+    allpx = synth.synthetic_images(64, np.concatenate([labels, tl]), seed=4)     # one seed = one set of class templates
+    pixels, tp = allpx[:len(labels)], allpx[len(labels):]
+    data = str(tmp_path / "data")
+    synth.write_idx(data, pixels, labels)
+    synth.write_idx(data, tp, tl, train=False)
+    inp = tmp_path / "input"
+    keys = "datadir = %s\nimglen = 4\nfeature_scale = 255\nprecision = %s\n" % (data, precision)
+    inp.write_text("input\n{\n%sNtrain = %d\nNbatch = 4\nNsweep = 2\ncutoff = 1E-10\nmaxm = 6\nminm = 3\nninitial = 3\n"
+                   "lambda = 1E-3\nNpass = 3\nseed = 5\n}\n" % (keys, per_label))
+    run = subprocess.run([os.path.join(root, "tnml_amd", "fixedL"), str(inp)], capture_output=True, text=True, cwd=tmp_path, timeout=300)
+    assert run.returncode == 0, run.stdout[-1000:] + run.stderr[-2000:]
+    assert "16 sites of dimension 2" in run.stdout
+    costs = [float(x) for x in re.findall(r"--> After SVD, Cost = ([0-9.eE+-]+)", run.stdout)]
+    newm = [int(x) for x in re.findall(r"New m=(\d+)", run.stdout)]
+
+    def feats(px):
+        g = hostlib.reduce(px, 8, 4) / 255.
+        return np.stack([np.ones_like(g), 255. * ((g / 255.) / 4.)], axis=-1)
+    w0 = str(tmp_path / "W0ref")
+    hostlib.build_initial_w(data, per_label, 3, 5, w0, imglen=4, feature_scale=255.)
+    px, lab, _ = hostlib.read_mnist(data, True, per_label)
+    o = pyoracle.Oracle(feats(px), lab, hostlib.read_mps(w0))
+    o.init()
+    ro = o.mldmrg(2, 6, 3, 1e-10, 3, 1e-3, 1e-10)
+    assert len(costs) == len(ro) == 4 * 15
+    np.testing.assert_allclose(costs, [r["cost"] / len(lab) for r in ro], rtol=rtol, atol=2e-10)   # atol: 10 printed digits
+    if precision == "f64":
+        assert newm == [r["newm"] for r in ro]
+    # evaluator with the same keys
+    tin = tmp_path / "input_test"
+    tin.write_text("input\n{\n%s}\n" % keys)
+    run = subprocess.run([os.path.join(root, "tnml_amd", "fulltest"), str(tin)], capture_output=True, text=True, cwd=tmp_path, timeout=300)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    Wf = hostlib.read_mps(str(tmp_path / "W"))
+    ot = pyoracle.Oracle(feats(tp), tl, Wf)
+    Wt = np.stack([ot.toverlap(i) for i in range(len(tl))])
+    ncor = int((np.abs(Wt).argmax(axis=1) == tl).sum())
+    m = re.search(r"(\d+)/(\d+) correct", run.stdout)
+    assert m and int(m.group(2)) == len(tl) and abs(int(m.group(1)) - ncor) <= (0 if precision == "f64" else 1)
+    assert ncor > 45                                           # the model has learned something on this toy set
+
+
 @pytest.mark.parametrize("b", [1, 3, 6, 9])
-def test_strict_mode_reference_features(b):
-    """TNML_F64_STRICT with the reference's own feature map [1, byte/260100] (raw bytes through
+def test_reference_feature_map_single_bond(b):
+    """TNML_F64 with the reference's own feature map [1, byte/260100] (raw bytes through
     tnml_set_data_u8): environments, P, gradient, CG trace to ~1e-9"""
-    ts, o = _pair(use_u8=True, boost=1.0, dtype="f64_strict")
+    ts, o = _pair(use_u8=True, boost=1.0)
     for j in range(3, o.N + 1):
         assert _relmax(ts.env(j), o.env(j)) < 1e-12
     _walk(ts, o, b)
@@ -345,8 +414,8 @@ def test_strict_mode_reference_features(b):
     assert _relmax(Bg, Bo) < 1e-3
 
 
-def test_strict_mode_full_sweep():
-    ts, o = _pair(N=10, NT=40, m=4, use_u8=True, boost=1.0, dtype="f64_strict")
+def test_reference_feature_map_full_sweep():
+    ts, o = _pair(N=10, NT=40, m=4, use_u8=True, boost=1.0)
     from tnml_amd.fixedl import mldmrg
     rg = mldmrg(ts, 1, 4, 2, 1e-10, 3, 1e-3, 1e-10)
     ro = o.mldmrg(1, 4, 2, 1e-10, 3, 1e-3, 1e-10)
@@ -355,7 +424,7 @@ def test_strict_mode_full_sweep():
     assert [r["ncorrect"] for r in rg] == [r["ncorrect"] for r in ro]
 
 
-@pytest.mark.parametrize("dtype,tol", [("f64", 2e-6), ("f64_strict", 1e-12), ("f32", 2e-5)])
+@pytest.mark.parametrize("dtype,tol", [("f64_e32", 2e-6), ("f64", 1e-12), ("f32", 2e-5)])
 @pytest.mark.parametrize("N,m", [(12, 4), (4, 2), (17, 6)])
 def test_classify_matches_toverlap(dtype, tol, N, m):
     """tnml_classify (fulltest.cc / util.h toverlap + fullTest) against the oracle's per-image full contraction"""
@@ -365,7 +434,7 @@ def test_classify_matches_toverlap(dtype, tol, N, m):
     assert _relmax(w, W_or) < tol
     pred_or = np.abs(W_or).argmax(axis=1)                      # numpy argmax = first maximum, util.h:42-57
     labels = np.asarray(o.labels)
-    if dtype == "f64_strict":
+    if dtype == "f64":
         np.testing.assert_array_equal(pred, pred_or)
     else:                                                      # a fp32-rounded near-tie may flip
         gap = np.sort(np.abs(W_or), axis=1)
@@ -374,7 +443,7 @@ def test_classify_matches_toverlap(dtype, tol, N, m):
     np.testing.assert_array_equal(cnt, np.bincount(labels, minlength=10))
     np.testing.assert_array_equal(ninc, np.bincount(labels[pred != labels], minlength=10))
     # the training environments survive a classify call: a bond update afterwards still matches the oracle
-    if dtype == "f64_strict":
+    if dtype == "f64":
         ts.setBond(1)
         o.set_bond(1)
         B0 = o.bond_tensor(1)
@@ -384,8 +453,72 @@ def test_classify_matches_toverlap(dtype, tol, N, m):
 def test_classify_after_training_agrees_with_quadcost_count():
     """after a sweep, the number of correct training images from the full contraction equals quadcost's count
     at any bond (both are argmax_l |W_l| of the same network)"""
-    ts, o = _pair(N=10, NT=80, m=4, dtype="f64_strict")
+    ts, o = _pair(N=10, NT=80, m=4)
     from tnml_amd.fixedl import mldmrg
     rg = mldmrg(ts, 1, 4, 2, 1e-10, 3, 1e-3, 1e-10)
     w, pred, cnt, ninc = ts.classify()
     assert int(cnt.sum() - ninc.sum()) == rg[-1]["ncorrect"]
+
+
+@pytest.mark.parametrize("rank", [30, 119])
+def test_svd_split_rank_deficient_cluster(rank):
+    """a bond tensor of numerical rank < minm: the kept basis contains a cluster of numerically zero eigenvalues.
+    The in-house eigensolver must still return an isometry (Cholesky-QR repair of the cluster, no rocSOLVER
+    fallback) and the optimal reconstruction."""
+    from tnml_amd import synth
+    from tnml_amd.fixedl import TrainStates
+    N, m, NT = 20, 120, 16
+    labels = synth.synthetic_labels(NT, seed=1)
+    ts = TrainStates(labels, N, m, pixels=synth.synthetic_images(N, labels, seed=1))
+    ts.set_mps(synth.random_mps(N, m, seed=2))
+    rng = np.random.default_rng(rank)
+    U0, _ = np.linalg.qr(rng.standard_normal((240, rank)))
+    V0, _ = np.linalg.qr(rng.standard_normal((240, rank)))
+    sv0 = np.exp(-0.05 * np.arange(rank))
+    M = (U0 * sv0) @ V0.T
+    B = M.reshape(120, 2, 2, 120, order="F")
+    for ha in (1, 2):
+        mg, te, sv = ts.svd_split(B, 8, ha, 1e-10, 120, 120)        # minm = maxm: nothing may be dropped
+        assert mg == 120
+        np.testing.assert_allclose(sv[:rank], sv0, rtol=1e-7, atol=1e-7)
+        assert np.all(sv[rank:] < 1e-6)
+        newB = ts.bond_tensor(8).reshape(240, 240, order="F")
+        assert np.abs(newB - M).max() < 1e-9
+        A = ts.get_site(8 if ha == 1 else 9)
+        Q = A.reshape(240, 120, order="F") if ha == 1 else A.reshape(120, 240, order="F").T
+        np.testing.assert_allclose((Q.T @ Q)[:rank, :rank], np.eye(rank), atol=1e-10)
+        if ha == 1:                                                   # the Gram-side factor is a full isometry
+            np.testing.assert_allclose(Q.T @ Q, np.eye(120), atol=1e-10)
+    st = ts.svd_stats()
+    assert st["fallbacks"] == 0, st
+
+
+def test_svd_split_graded_spectrum_with_close_pairs():
+    """a graded spectrum (13 decades inside the kept 120) with pairs of eigenvalues far closer than eps*lambda_max --
+    what a trained bond looks like.  The eigensolver splits the tridiagonal matrix into unreduced blocks and repairs
+    what inverse iteration leaves non-orthogonal; no rocSOLVER fallback, full isometry."""
+    from tnml_amd import synth
+    from tnml_amd.fixedl import TrainStates
+    N, m, NT = 20, 120, 16
+    labels = synth.synthetic_labels(NT, seed=1)
+    ts = TrainStates(labels, N, m, pixels=synth.synthetic_images(N, labels, seed=1))
+    ts.set_mps(synth.random_mps(N, m, seed=2))
+    rng = np.random.default_rng(11)
+    sv0 = np.concatenate([10.0 ** (-np.arange(16) * 0.45), 1e-7 * (1 + 0.01 * np.arange(104) // 2), 1e-12 * rng.random(120)])
+    sv0 = np.sort(sv0)[::-1]
+    U0, _ = np.linalg.qr(rng.standard_normal((240, 240)))
+    V0, _ = np.linalg.qr(rng.standard_normal((240, 240)))
+    M = (U0 * sv0) @ V0.T
+    B = M.reshape(120, 2, 2, 120, order="F")
+    for ha in (1, 2):
+        mg, te, sv = ts.svd_split(B, 8, ha, 0.0, 120, 120)
+        assert mg == 120
+        np.testing.assert_allclose(sv[:16] ** 2, sv0[:16] ** 2, rtol=1e-7, atol=1e-15)    # Gram route: eps*lambda_max floor
+        newB = ts.bond_tensor(8).reshape(240, 240, order="F")
+        assert np.abs(newB - M).max() < 1e-7
+        A = ts.get_site(8 if ha == 1 else 9)
+        Q = A.reshape(240, 120, order="F") if ha == 1 else A.reshape(120, 240, order="F").T
+        if ha == 1:
+            np.testing.assert_allclose(Q.T @ Q, np.eye(120), atol=1e-9)
+    st = ts.svd_stats()
+    assert st["fallbacks"] == 0, st

@@ -111,3 +111,21 @@ def test_initial_w_builder(tmp_path):
         cands = np.where(labels == l)[0]
         best = min(np.abs(out[:, l] / out[:, l].max() - G[:, m] / G[:, m].max()).max() for m in cands)
         assert best < 1e-5            # the label sum is truncated with Cutoff 1E-8 (fixedL.cc:724)
+
+
+def test_block_mean_reduce():
+    """imglen down-sampling (image.h:316-346 `reduce`): plain mean of side/newlen blocks starting at side % bsize"""
+    from tnml_amd import hostlib
+    rng = np.random.default_rng(5)
+    px = rng.integers(0, 256, size=(7, 28 * 28), dtype=np.uint8)
+    r = hostlib.reduce(px, 28, 14)
+    ref = px.reshape(7, 14, 2, 14, 2).astype(np.float64).mean(axis=(2, 4)).reshape(7, 196)
+    np.testing.assert_array_equal(r, ref)                       # sums of 4 bytes / 4: exact in fp64
+    # side not divisible by newlen: bsize = 28 // 9 = 3, rem = 28 % 3 = 1 -> blocks start at pixel 1
+    r9 = hostlib.reduce(px, 28, 9)
+    img = px.reshape(7, 28, 28).astype(np.float64)
+    ref9 = np.stack([[img[i, 1 + 3 * y:4 + 3 * y, 1 + 3 * x:4 + 3 * x].mean() for y in range(9) for x in range(9)] for i in range(7)])
+    np.testing.assert_allclose(r9, ref9, rtol=1e-15)
+    np.testing.assert_array_equal(hostlib.reduce(px, 28, 28), px.astype(np.float64))
+    with pytest.raises(RuntimeError):
+        hostlib.reduce(px, 28, 29)

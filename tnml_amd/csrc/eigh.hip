@@ -288,19 +288,52 @@ int eigh_backtransform(tnml_ctx* c, const double* V, const double* tau, int n, c
 // ==========================================================================================
 struct TeigArgs {
     const double* D; const double* E; int n;      // tridiagonal (E has n-1 entries)
-    double* W;                                     // eigenvalues, ascending (out of k_tridiag_eigvals, in of k_tridiag_invit)
+    double* W;                                     // eigenvalues, ascending (out of k_tridiag_rank)
     int mk; double* Z; int ldz;                    // out: eigenvectors of the mk largest (column g = g-th largest)
+    // splitting workspace (k_tridiag_split): Es = E with negligible couplings zeroed, mu[i] = eigenvalue owned by
+    // row i (the (i - lo[i])-th smallest of its unreduced block), blo/bhi = block [lo, hi) of row i, src[g] = row
+    // owning the g-th largest eigenvalue
+    double* Es; double* mu; int* blo; int* bhi; int* src;
 };
 
-// Sturm count: number of eigenvalues < x = sign changes of the leading principal minors p_j(x).
-// Three-term recurrence on the matrix scaled to unit norm (s_de[j] = {d_j, e_{j-1}^2} / norm), one FMA on
-// the dependent path per step; magnitudes are renormalised every 4 steps (growth per step <= ~3, decay
-// per step >= ~1e-17, thresholds 1e+-100); a zero minor takes the sign opposite to its predecessor.
-static __device__ __forceinline__ int sturm_count(const double2* s_de, int n, double x) {
-    double pm2 = 1., pm1 = s_de[0].x - x;
+// Split T into unreduced blocks at couplings |e_k| <= eps*||T|| (a normwise backward-stable perturbation, the
+// same size as the error of the Gram matrix itself).  A trained bond tensor is numerically rank deficient: its
+// Gram matrix has a graded spectrum whose tail sits below eps*lambda_max, and the tridiagonal form decouples
+// there.  Eigenvectors of different blocks have disjoint supports -- exactly orthogonal -- and inverse iteration
+// inside a block works at the block's own scale.  (Without the split the tail is one big cluster at the
+// resolution of inverse iteration, and its vectors come out far from orthogonal.)
+__global__ __launch_bounds__(256) void k_tridiag_split(TeigArgs T) {
+    __shared__ double s_red[256];
+    __shared__ int s_cut[257];
+    const int n = T.n, i = threadIdx.x;
+    double rs = 0.;
+    if (i < n) rs = fabs(T.D[i]) + (i > 0 ? fabs(T.E[i - 1]) : 0.) + (i < n - 1 ? fabs(T.E[i]) : 0.);
+    s_red[i] = rs;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (i < s) s_red[i] = fmax(s_red[i], s_red[i + s]); __syncthreads(); }
+    const double thr = 2.220446049250313e-16 * s_red[0];
+    if (i < n) {
+        const bool cut = (i == n - 1) || !(fabs(T.E[i]) > thr);      // block ends after row i
+        s_cut[i] = cut ? 1 : 0;
+        T.Es[i] = cut ? 0. : T.E[i];
+    }
+    __syncthreads();
+    if (i < n) {
+        int lo = i; while (lo > 0 && !s_cut[lo - 1]) --lo;
+        int hi = i; while (!s_cut[hi]) ++hi;
+        T.blo[i] = lo; T.bhi[i] = hi + 1;
+    }
+}
+
+// Sturm count over rows [lo, hi): number of eigenvalues of that block < x = sign changes of the leading
+// principal minors.  Three-term recurrence on the block scaled to unit norm (s_de[j] = {d_j, e_{j-1}^2} / norm),
+// one FMA on the dependent path per step; magnitudes are renormalised every 4 steps (growth per step <= ~3,
+// decay per step >= ~1e-17, thresholds 1e+-100); a zero minor takes the sign opposite to its predecessor.
+static __device__ __forceinline__ int sturm_count(const double2* s_de, int lo, int hi, double x) {
+    double pm2 = 1., pm1 = s_de[lo].x - x;
     int cnt = pm1 < 0. ? 1 : 0;
-    int j = 1;
-    for (; j + 3 < n; j += 4) {
+    int j = lo + 1;
+    for (; j + 3 < hi; j += 4) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const double2 de = s_de[j + u];
@@ -313,7 +346,7 @@ static __device__ __forceinline__ int sturm_count(const double2* s_de, int n, do
         if (ap > 1e100) { pm1 *= 1e-100; pm2 *= 1e-100; }
         else if (ap < 1e-100) { pm1 *= 1e100; pm2 *= 1e100; }
     }
-    for (; j < n; ++j) {
+    for (; j < hi; ++j) {
         const double2 de = s_de[j];
         double p = fma(de.x - x, pm1, -de.y * pm2);
         if (p == 0.) p = pm1 < 0. ? 1e-300 : -1e-300;
@@ -323,17 +356,21 @@ static __device__ __forceinline__ int sturm_count(const double2* s_de, int n, do
     return cnt;
 }
 
-// all eigenvalues by 65-section: one wave per eigenvalue, every lane probes one interior point of the
-// bracket per round, so the bracket shrinks 65x per round (9-10 rounds to fp64 resolution instead of
-// 53 bisections).  The recurrence is a pure latency chain, so width is free: 240 waves on 240 CUs.
+// eigenvalue owned by row i = the (i - lo)-th smallest of its block, by 65-section: one wave per eigenvalue,
+// every lane probes one interior point of the bracket per round, so the bracket shrinks 65x per round (9-10
+// rounds to fp64 resolution instead of 53 bisections).  The recurrence is a pure latency chain, so width is
+// free: one wave per row on as many CUs.
 __global__ __launch_bounds__(64) void k_tridiag_eigvals(TeigArgs T) {
     __shared__ double2 s_de[256];
     __shared__ double s_bounds[4];
-    const int n = T.n, lane = threadIdx.x;
-    {   // Gershgorin interval and norm (lanes stride over the rows, then a wave reduction)
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x;
+    const int lo_r = T.blo[i], hi_r = T.bhi[i];
+    if (hi_r - lo_r == 1) { if (lane == 0) T.mu[i] = T.D[i]; return; }
+    {   // Gershgorin interval and norm of the block (lanes stride over its rows, then a wave reduction)
         double gl = 1e300, gu = -1e300, tn = 0.;
-        for (int j = lane; j < n; j += 64) {
-            const double r = (j > 0 ? fabs(T.E[j - 1]) : 0.) + (j < n - 1 ? fabs(T.E[j]) : 0.);
+        for (int j = lo_r + lane; j < hi_r; j += 64) {
+            const double r = (j > lo_r ? fabs(T.Es[j - 1]) : 0.) + (j < hi_r - 1 ? fabs(T.Es[j]) : 0.);
             gl = fmin(gl, T.D[j] - r); gu = fmax(gu, T.D[j] + r);
             tn = fmax(tn, fabs(T.D[j]) + r);
         }
@@ -342,24 +379,24 @@ __global__ __launch_bounds__(64) void k_tridiag_eigvals(TeigArgs T) {
             gl = fmin(gl, __shfl_xor(gl, off)); gu = fmax(gu, __shfl_xor(gu, off)); tn = fmax(tn, __shfl_xor(tn, off));
         }
         if (!(tn > 0.)) tn = 1.;
-        const double pad = 2.2e-16 * tn * n + 1e-300;
+        const double pad = 2.2e-16 * tn * (hi_r - lo_r) + 1e-300;
         if (lane == 0) { s_bounds[0] = (gl - pad) / tn; s_bounds[1] = (gu + pad) / tn; s_bounds[2] = tn; }
     }
     __syncthreads();
     const double tn = s_bounds[2], itn = 1. / tn;
-    for (int k = lane; k < n; k += 64) {
-        const double e = k > 0 ? T.E[k - 1] * itn : 0.;
+    for (int k = lo_r + lane; k < hi_r; k += 64) {
+        const double e = k > lo_r ? T.Es[k - 1] * itn : 0.;
         s_de[k] = make_double2(T.D[k] * itn, e * e);
     }
     __syncthreads();
-    const int i = blockIdx.x;                                    // eigenvalue index (ascending)
+    const int li = i - lo_r;                                     // local eigenvalue index (ascending)
     double lo = s_bounds[0], hi = s_bounds[1];
     for (int it = 0; it < 16; ++it) {
         const double w = hi - lo;
         if (!(w > 4.4e-16 * (1. + fmax(fabs(lo), fabs(hi))))) break;
         const double step = w * (1. / 65.);
         const double x = lo + step * (lane + 1);
-        const bool below = sturm_count(s_de, n, x) > i;                          // eigenvalue i is below x
+        const bool below = sturm_count(s_de, lo_r, hi_r, x) > li;                // eigenvalue li is below x
         const unsigned long long mask = __ballot(below);
         const int p = mask ? __ffsll((long long)mask) - 1 : 64;                 // first probe above the eigenvalue
         const double nlo = p > 0 ? lo + step * p : lo;
@@ -367,11 +404,25 @@ __global__ __launch_bounds__(64) void k_tridiag_eigvals(TeigArgs T) {
         if (!(nhi > nlo)) break;
         lo = nlo; hi = nhi;
     }
-    if (lane == 0) T.W[i] = 0.5 * (lo + hi) * tn;
+    if (lane == 0) T.mu[i] = 0.5 * (lo + hi) * tn;
 }
 
-// eigenvectors of the mk largest eigenvalues by inverse iteration; 16 vectors per workgroup, their LU
-// factors and iterates live in LDS as [array][k][lane]
+// global order: row i owns the g-th largest eigenvalue, g = #{j : mu_j > mu_i or (mu_j == mu_i and j < i)}
+__global__ __launch_bounds__(256) void k_tridiag_rank(TeigArgs T) {
+    __shared__ double s_mu[256];
+    const int n = T.n, i = threadIdx.x;
+    s_mu[i] = i < n ? T.mu[i] : 0.;
+    __syncthreads();
+    if (i >= n) return;
+    const double mi = s_mu[i];
+    int g = 0;
+    for (int j = 0; j < n; ++j) { const double mj = s_mu[j]; g += (mj > mi || (mj == mi && j < i)) ? 1 : 0; }
+    T.W[n - 1 - g] = mi;
+    T.src[g] = i;
+}
+
+// eigenvectors of the mk largest eigenvalues by inverse iteration inside the owning block; 16 vectors per
+// workgroup, their LU factors and iterates live in LDS as [array][k][lane]
 #define IV_L 16
 __global__ __launch_bounds__(64) void k_tridiag_invit(TeigArgs T) {
     extern __shared__ __attribute__((aligned(16))) double iv_lds[];
@@ -383,23 +434,29 @@ __global__ __launch_bounds__(64) void k_tridiag_invit(TeigArgs T) {
     double* c = b + (size_t)n * IV_L;     // L multipliers
     double* d2 = c + (size_t)n * IV_L;    // U second superdiagonal
     double* x = d2 + (size_t)n * IV_L;    // iterate
-    for (int k = lane; k < n; k += 64) { s_d[k] = T.D[k]; s_e[k] = k < n - 1 ? T.E[k] : 0.; }
+    for (int k = lane; k < n; k += 64) { s_d[k] = T.D[k]; s_e[k] = k < n - 1 ? T.Es[k] : 0.; }
     __syncthreads();
     const int g = blockIdx.x * IV_L + lane;           // g-th largest eigenvalue
     if (lane >= IV_L || g >= T.mk) return;
+    const int row = T.src[g];
+    const int lo = T.blo[row], hi = T.bhi[row];       // the vector is supported on rows [lo, hi)
+    double* zc = T.Z + (size_t)T.ldz * g;
+    for (int k = 0; k < lo; ++k) zc[k] = 0.;
+    for (int k = hi; k < n; ++k) zc[k] = 0.;
+    if (hi - lo == 1) { zc[lo] = 1.; return; }
     double tnorm = 0.;
-    for (int k = 0; k < n; ++k) tnorm = fmax(tnorm, fabs(s_d[k]) + (k > 0 ? fabs(s_e[k - 1]) : 0.) + fabs(s_e[k]));
-    const double lam = T.W[n - 1 - g];
+    for (int k = lo; k < hi; ++k) tnorm = fmax(tnorm, fabs(s_d[k]) + (k > lo ? fabs(s_e[k - 1]) : 0.) + (k < hi - 1 ? fabs(s_e[k]) : 0.));
+    const double lam = T.mu[row];
     const double tiny = 2.2e-16 * tnorm + 1e-300;
 #define IX(k) ((k) * IV_L + lane)
     // LAPACK dlagtf: (T - lam I) = P L U with partial pivoting; the rows are generated on the fly
     unsigned long long pv0 = 0, pv1 = 0, pv2 = 0, pv3 = 0;   // interchange flags, n <= 256 (named: no dynamic register indexing)
-    double ak = s_d[0] - lam, bk = n > 1 ? s_e[0] : 0.;
+    double ak = s_d[lo] - lam, bk = s_e[lo];
     double scale1 = fabs(ak) + fabs(bk);
-    for (int k = 0; k < n - 1; ++k) {
+    for (int k = lo; k < hi - 1; ++k) {
         const double ck = s_e[k];                       // sub-diagonal entry of row k+1
         double ak1 = s_d[k + 1] - lam;
-        const double bk1 = k < n - 2 ? s_e[k + 1] : 0.;
+        const double bk1 = k < hi - 2 ? s_e[k + 1] : 0.;
         const double scale2 = fabs(ck) + fabs(ak1) + fabs(bk1);
         double nak, nbk;                                // row k+1 after elimination
         if (ck == 0.) {
@@ -422,17 +479,17 @@ __global__ __launch_bounds__(64) void k_tridiag_invit(TeigArgs T) {
         scale1 = scale2;
         ak = nak; bk = nbk;
     }
-    a[IX(n - 1)] = ak; b[IX(n - 1)] = 0.; d2[IX(n - 1)] = 0.;
-    if (n >= 2) d2[IX(n - 2)] = 0.;
+    a[IX(hi - 1)] = ak; b[IX(hi - 1)] = 0.; d2[IX(hi - 1)] = 0.;
+    d2[IX(hi - 2)] = 0.;
     // reciprocal pivots, tiny ones perturbed (dlagts job = -1 in spirit): the solves below only multiply
-    for (int k = 0; k < n; ++k) { double pk = a[IX(k)]; if (fabs(pk) < tiny) pk = pk < 0. ? -tiny : tiny; a[IX(k)] = 1. / pk; }
+    for (int k = lo; k < hi; ++k) { double pk = a[IX(k)]; if (fabs(pk) < tiny) pk = pk < 0. ? -tiny : tiny; a[IX(k)] = 1. / pk; }
     // start vector: deterministic pseudo-random entries in (-1, 1), different for every vector
     unsigned int seed = 12345u + 7919u * (unsigned)g;
-    for (int k = 0; k < n; ++k) { seed = seed * 1664525u + 1013904223u; x[IX(k)] = ((seed >> 8) * (1.0 / 8388608.0)) - 1.0; }
+    for (int k = lo; k < hi; ++k) { seed = seed * 1664525u + 1013904223u; x[IX(k)] = ((seed >> 8) * (1.0 / 8388608.0)) - 1.0; }
     for (int iter = 0; iter < 2; ++iter) {                 // the shift is exact to round-off: two sweeps suffice
         // forward: apply (P L)^-1
-        double xk = x[IX(0)];
-        for (int k = 0; k < n - 1; ++k) {
+        double xk = x[IX(lo)];
+        for (int k = lo; k < hi - 1; ++k) {
             const int wq = k >> 6;
             const unsigned long long word = wq == 0 ? pv0 : wq == 1 ? pv1 : wq == 2 ? pv2 : pv3;
             const bool sw = (word >> (k & 63)) & 1;
@@ -440,29 +497,31 @@ __global__ __launch_bounds__(64) void k_tridiag_invit(TeigArgs T) {
             if (!sw) { x[IX(k)] = xk; xk = xk1 - m * xk; }
             else     { x[IX(k)] = xk1; xk = xk - m * xk1; }
         }
-        x[IX(n - 1)] = xk;
+        x[IX(hi - 1)] = xk;
         // back substitution
         double xn1 = 0., xn2 = 0., vmax = 0.;
-        for (int k = n - 1; k >= 0; --k) {
+        for (int k = hi - 1; k >= lo; --k) {
             const double t = (x[IX(k)] - b[IX(k)] * xn1 - d2[IX(k)] * xn2) * a[IX(k)];
             x[IX(k)] = t;
             xn2 = xn1; xn1 = t;
             vmax = fmax(vmax, fabs(t));
         }
         const double inv = vmax > 0. ? 1. / vmax : 1.;          // max-norm scaling keeps the iterates in range
-        for (int k = 0; k < n; ++k) x[IX(k)] *= inv;
+        for (int k = lo; k < hi; ++k) x[IX(k)] *= inv;
     }
     double nrm2 = 0.;
-    for (int k = 0; k < n; ++k) { const double v = x[IX(k)]; nrm2 = fma(v, v, nrm2); }
+    for (int k = lo; k < hi; ++k) { const double v = x[IX(k)]; nrm2 = fma(v, v, nrm2); }
     const double inv = nrm2 > 0. ? 1. / sqrt(nrm2) : 0.;
-    for (int k = 0; k < n; ++k) T.Z[k + (size_t)T.ldz * g] = x[IX(k)] * inv;
+    for (int k = lo; k < hi; ++k) zc[k] = x[IX(k)] * inv;
 #undef IX
 }
 
-int eigh_tridiag_eig(tnml_ctx* c, const double* D, const double* E, int n, double* W, int mk, double* Z, int ldz, double*) {
+int eigh_tridiag_eig(tnml_ctx* c, const double* D, const double* E, int n, double* W, int mk, double* Z, int ldz, double* scratch) {
     if (n > 256 || mk > 256) return tnml_fail(c, "eigh_tridiag_eig: n=%d mk=%d exceed 256", n, mk);
-    TeigArgs t{D, E, n, W, mk, Z, ldz};
+    TeigArgs t{D, E, n, W, mk, Z, ldz, scratch, scratch + 256, (int*)(scratch + 512), (int*)(scratch + 512) + 256, (int*)(scratch + 512) + 512};
+    hipLaunchKernelGGL(k_tridiag_split, dim3(1), dim3(256), 0, c->stream, t);
     hipLaunchKernelGGL(k_tridiag_eigvals, dim3(n), dim3(64), 0, c->stream, t);
+    hipLaunchKernelGGL(k_tridiag_rank, dim3(1), dim3(256), 0, c->stream, t);
     const size_t lds = sizeof(double) * (512 + (size_t)5 * n * IV_L);
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_tridiag_invit, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
@@ -488,6 +547,79 @@ __global__ __launch_bounds__(256) void k_ns_matrix(const double* __restrict__ S,
 }
 int eigh_ns_matrix(tnml_ctx* c, const double* S, double* Cm, int m, double* dev) {
     hipLaunchKernelGGL(k_ns_matrix, dim3(1), dim3(256), 0, c->stream, S, Cm, m, dev);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
+
+// ==========================================================================================
+// Cholesky QR of a basis whose Gram matrix S = Q^T Q is given (m x m, m <= 136): S = L L^T in LDS, then
+// Rinv = L^-T written dense (upper triangular), so that Q Rinv is orthonormal.  Used when inverse iteration
+// returned an eigenvalue CLUSTER: its vectors (random starts) span the right invariant subspace but are
+// not orthogonal to each other; any orthonormal basis of that subspace is an equally valid set of
+// eigenvectors, and well separated vectors are left alone to round-off (their rows of L are ~ e_i).
+// flag[0] = 1 when a pivot is not safely positive (dependent vectors) -- the caller then falls back.
+// ==========================================================================================
+#define CHOL_MAXM 136
+__global__ __launch_bounds__(1024) void k_chol_rinv(const double* __restrict__ S, int m, double* __restrict__ Rinv, double* __restrict__ flag) {
+    extern __shared__ __attribute__((aligned(16))) double ch_lds[];
+    const int ld = m | 1;                                  // odd leading dimension
+    double* A = ch_lds;                                    // [ld * m]: L below/on the diagonal, X = L^-1 (transposed) above
+    double* col = A + (size_t)ld * m;                      // [m] current column
+    double* dinv = col + CHOL_MAXM;                        // [m] 1 / L_jj
+    __shared__ int s_fail;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_fail = 0;
+    for (int idx = tid; idx < m * m; idx += 1024) { const int i = idx % m, j = idx / m; A[i + (size_t)ld * j] = (i >= j) ? S[idx] : 0.; }
+    __syncthreads();
+    for (int k = 0; k < m; ++k) {
+        const double piv = A[k + (size_t)ld * k];
+        if (!(piv > 1e-13)) { if (tid == 0) s_fail = 1; break; }       // S has unit diagonal: this is a relative test
+        const double inv = 1. / sqrt(piv);
+        if (tid < m) {
+            const double v = tid >= k ? A[tid + (size_t)ld * k] * inv : 0.;
+            col[tid] = v;
+            if (tid == k) dinv[k] = inv;
+        }
+        __syncthreads();
+        if (tid < m && tid >= k) A[tid + (size_t)ld * k] = col[tid];
+        const int rem = m - (k + 1);                                    // trailing block (k+1..m-1)^2, lower part
+        for (int idx = tid; idx < rem * rem; idx += 1024) {
+            const int i = k + 1 + idx % rem, j = k + 1 + idx / rem;
+            if (i >= j) A[i + (size_t)ld * j] -= col[i] * col[j];
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (s_fail) { if (tid == 0) flag[0] = 1.; return; }
+    // X = L^-1, column j by lane j: x_j = 1/L_jj, x_i = -(sum_{k<i} L[i][k] x_k) / L_ii ; x_k kept at A[j + ld*k] (k > j)
+    if (tid < m) {
+        const int j = tid;
+        for (int i = j + 1; i < m; ++i) {
+            double acc = A[i + (size_t)ld * j] * dinv[j], acc2 = 0.;   // L[i][j] x_j
+            int k = j + 1;
+#pragma unroll 4
+            for (; k + 1 < i; k += 2) {
+                acc = fma(A[i + (size_t)ld * k], A[j + (size_t)ld * k], acc);
+                acc2 = fma(A[i + (size_t)ld * (k + 1)], A[j + (size_t)ld * (k + 1)], acc2);
+            }
+            if (k < i) acc = fma(A[i + (size_t)ld * k], A[j + (size_t)ld * k], acc);
+            A[j + (size_t)ld * i] = -(acc + acc2) * dinv[i];
+        }
+    }
+    __syncthreads();
+    // Rinv = X^T: Rinv[k][i] = X[i][k] for i > k, 1/L_kk on the diagonal, 0 below
+    for (int idx = tid; idx < m * m; idx += 1024) {
+        const int k = idx % m, i = idx / m;
+        Rinv[idx] = k < i ? A[k + (size_t)ld * i] : (k == i ? dinv[k] : 0.);
+    }
+    if (tid == 0) flag[0] = 0.;
+}
+int eigh_chol_rinv(tnml_ctx* c, const double* S, int m, double* Rinv, double* flag) {
+    if (m > CHOL_MAXM) return tnml_fail(c, "eigh_chol_rinv: m=%d exceeds %d", m, CHOL_MAXM);
+    const size_t lds = sizeof(double) * ((size_t)(m | 1) * m + 2 * CHOL_MAXM);
+    static size_t attr_lds = 0;                          // the kernel also has a few bytes of static LDS: ask for what is needed
+    if (lds > attr_lds) { HIPCK(c, hipFuncSetAttribute((const void*)k_chol_rinv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_lds = lds; }
+    hipLaunchKernelGGL(k_chol_rinv, dim3(1), dim3(1024), lds, c->stream, S, m, Rinv, flag);
     HIPCK(c, hipGetLastError());
     return 0;
 }

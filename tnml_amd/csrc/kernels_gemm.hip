@@ -532,6 +532,20 @@ int launch_fgemm64(tnml_ctx* c, const Fgemm64Args& a) {
             default: fgemm64_go<2, 5, 4, 3, 16>(c, a); break;   // 128 x 240, 12 waves: best of tools/tune_fgemm.sh (gpurun_out/tune_fgemm_r01.txt)
         }
     }
+    else if (a.Np > 64 && !a.phiO) {                          // shift form at m up to 128 (Label-carrying: grid.z = 10)
+        static const int scfg = getenv("TNML_FG64_SHIFT_CFG") ? atoi(getenv("TNML_FG64_SHIFT_CFG")) : 0;
+        switch (scfg) {
+            case 1:  fgemm64_go<2, 4, 4, 2, 16>(c, a); break;   // 128 x 128, 8 waves
+            case 2:  fgemm64_go<4, 4, 2, 2, 16>(c, a); break;   // 128 x 128, 4 waves
+            case 3:  fgemm64_go<2, 2, 4, 4, 16>(c, a); break;   // 128 x 128, 16 waves
+            case 4:  fgemm64_go<4, 2, 2, 4, 16>(c, a); break;   // 128 x 128, 8 waves
+            case 5:  fgemm64_go<2, 4, 2, 2, 16>(c, a); break;   // 64 x 128, 4 waves
+            case 6:  fgemm64_go<1, 4, 4, 2, 16>(c, a); break;   // 64 x 128, 8 waves
+            case 7:  fgemm64_go<2, 4, 6, 2, 16>(c, a); break;   // 192 x 128, 12 waves
+            case 8:  fgemm64_go<4, 4, 4, 2, 16>(c, a); break;   // 256 x 128, 8 waves
+            default: fgemm64_go<2, 4, 4, 2, 8>(c, a); break;    // 128 x 128, 8 waves, KT 8: best of tools/tune_shift.sh (profiles/r01_tune_shift.txt)
+        }
+    }
     else if (a.Np > 64)   fgemm64_go<2, 4, 2, 2, 16>(c, a);     // 64 x 128
     else if (a.Np > 32)   fgemm64_go<2, 2, 2, 2, 16>(c, a);     // 64 x 64
     else                  fgemm64_go<2, 1, 2, 2, 16>(c, a);     // 64 x 32

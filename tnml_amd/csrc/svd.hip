@@ -11,6 +11,10 @@
 //   the site the sweep leaves gets the orthonormal factor, the site it moves to gets S*V
 //   ("W.Aref(c+dc) *= S", fixedL.cc:521).
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <utility>
+#include <vector>
 
 #include "tnml_internal.h"
 
@@ -138,10 +142,52 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
         HIPCK(c, hipMemcpyAsync(hd, c->sDev, sizeof(double), hipMemcpyDeviceToHost, st));
         HIPCK(c, hipStreamSynchronize(st));
         c->svd_last_dev0 = hd[0]; c->svd_last_dev1 = 0.75 * hd[0] * hd[0];      // Newton-Schulz: error -> 3/4 error^2
-        hd[1] = hd[0] < 1e-4 ? 0. : 1.;                                          // 1e-4 -> ~1e-8 -> the polish leaves < 1e-8
-        if (!(hd[1] < 1e-6)) {
-            // inverse iteration left (nearly) dependent vectors -- a tight eigenvalue cluster: redo the
-            // tridiagonal stage with rocSOLVER's divide and conquer (D, E, V, tau are still intact)
+        bool ok = hd[0] < 1e-4;                                                  // 1e-4 -> ~1e-8 -> the polish leaves < 1e-8
+        if (!ok) if (const char* dump = getenv("TNML_SVD_DUMP")) {               // debugging aid: the offending tridiagonal problem
+            static int dumped = 0;
+            if (dumped < 4) {
+                std::vector<double> hb((size_t)3 * n + (size_t)n * m + 2);
+                hb[0] = n; hb[1] = m;
+                (void)hipMemcpy(hb.data() + 2, c->sD, sizeof(double) * n, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(hb.data() + 2 + n, c->sE2, sizeof(double) * n, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(hb.data() + 2 + 2 * n, c->sW, sizeof(double) * n, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(hb.data() + 2 + 3 * n, c->sC, sizeof(double) * (size_t)n * m, hipMemcpyDeviceToHost);
+                char fn[512]; snprintf(fn, sizeof fn, "%s.%d.bin", dump, dumped++);
+                if (FILE* f = fopen(fn, "wb")) { fwrite(hb.data(), sizeof(double), hb.size(), f); fclose(f); }
+            }
+        }
+        if (!ok && hd[0] == hd[0]) {
+            // Close eigenvalues inside one unreduced block: inverse iteration gave independent but not quite
+            // orthogonal vectors of the right invariant subspace.  Mild cases (max|Q^T Q - I| < 0.3) are repaired by
+            // further Newton-Schulz steps (error -> 3/4 error^2); worse ones first go through a Cholesky QR
+            // (Q1 = Q0 R^-1 with Q0^T Q0 = R^T R).  The last step lands in Q and its input deviation is checked.
+            const bool need_chol = !(hd[0] < 0.3);
+            if (!need_chol || m <= TNML_CHOL_MAXM) {
+                c->svd_cholqr += 1;
+                double* cur = Q0; double* other = c->sG;                        // the Gram matrix is consumed by now
+                HIPCK(c, hipMemsetAsync(c->sDev + 1, 0, sizeof(double), st));
+                if (need_chol) {
+                    TCK(eigh_chol_rinv(c, c->sS, m, c->sCm, c->sDev + 1));
+                    RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, n, m, m, &one, cur, n, c->sCm, m, &zero, other, n));
+                    std::swap(cur, other);
+                }
+                const int nit = need_chol ? 1 : (hd[0] < 0.05 ? 2 : 3);
+                for (int it = 0; it <= nit; ++it) {
+                    double* dst = it == nit ? Q : other;
+                    RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, m, m, n, &one, cur, n, cur, n, &zero, c->sS, m));
+                    TCK(eigh_ns_matrix(c, c->sS, c->sCm, m, c->sDev));
+                    RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, n, m, m, &one, cur, n, c->sCm, m, &zero, dst, n));
+                    if (it < nit) std::swap(cur, other);
+                }
+                HIPCK(c, hipMemcpyAsync(hd, c->sDev, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+                HIPCK(c, hipStreamSynchronize(st));
+                ok = hd[1] == 0. && hd[0] < 1e-4;
+                c->svd_last_dev1 = 0.75 * hd[0] * hd[0];
+            }
+        }
+        if (!ok) {
+            // dependent vectors even after re-orthonormalisation: redo the tridiagonal stage with rocSOLVER's
+            // divide and conquer (D, E, V, tau are still intact)
             c->svd_fallbacks += 1;
             own_eig = false;
             RBCK(c, rocsolver_dstedc(c->blas, rocblas_evect_tridiagonal, n, c->sD, c->sE2, c->sC, n, c->sInfo));

@@ -2,6 +2,7 @@
 // one bond update of the reference's mldmrg loop (fixedL.cc:478-540).
 //
 // No CPU fallback lives here: every contraction is a HIP kernel launch on the context's stream.
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdlib>
@@ -63,8 +64,9 @@ int tnml_profile_reset(tnml_ctx* c) {
 }
 int tnml_synchronize(tnml_ctx* c) { HIPCK(c, hipStreamSynchronize(c->stream)); return 0; }
 int64_t tnml_device_bytes(tnml_ctx* c) { return c->bytes; }
-int tnml_svd_stats(tnml_ctx* c, int64_t* fallbacks, double* d0, double* d1) {
+int tnml_svd_stats(tnml_ctx* c, int64_t* fallbacks, int64_t* cluster_repairs, double* d0, double* d1) {
     if (fallbacks) *fallbacks = c->svd_fallbacks;
+    if (cluster_repairs) *cluster_repairs = c->svd_cholqr;
     if (d0) *d0 = c->svd_last_dev0;
     if (d1) *d1 = c->svd_last_dev1;
     return 0;
@@ -116,7 +118,7 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     *out = nullptr;
     if (cfg->N < 4) return tnml_fail(nullptr, "tnml_create: need N >= 4 sites");
     if (cfg->NT_local < 1 || cfg->maxm < 1) return tnml_fail(nullptr, "tnml_create: NT_local and maxm must be positive");
-    if (cfg->dtype != TNML_F32 && cfg->dtype != TNML_F64 && cfg->dtype != TNML_F64_STRICT) return tnml_fail(nullptr, "tnml_create: dtype must be TNML_F64, TNML_F64_STRICT or TNML_F32");
+    if (cfg->dtype != TNML_F32 && cfg->dtype != TNML_F64 && cfg->dtype != TNML_F64_E32) return tnml_fail(nullptr, "tnml_create: dtype must be TNML_F64, TNML_F64_E32 or TNML_F32");
     if (cfg->nranks < 1 || cfg->rank < 0 || cfg->rank >= cfg->nranks) return tnml_fail(nullptr, "tnml_create: bad rank/nranks");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -176,7 +178,7 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     if ((rc = dmalloc(c, &c->sV, (size_t)c->svd_n * c->svd_n))) return bail(rc);
     if ((rc = dmalloc(c, &c->sC, (size_t)c->svd_n * c->svd_n))) return bail(rc);
     if ((rc = dmalloc(c, &c->sW, (size_t)c->svd_n))) return bail(rc);
-    if ((rc = dmalloc(c, &c->sScr, (size_t)5 * c->svd_n * c->maxm))) return bail(rc);
+    if ((rc = dmalloc(c, &c->sScr, std::max<size_t>((size_t)5 * c->svd_n * c->maxm, 1024)))) return bail(rc);
     if ((rc = dmalloc(c, &c->sS, (size_t)c->maxm * c->maxm))) return bail(rc);
     if ((rc = dmalloc(c, &c->sCm, (size_t)c->maxm * c->maxm))) return bail(rc);
     if ((rc = dmalloc(c, &c->sQ1, (size_t)c->svd_n * c->maxm))) return bail(rc);
@@ -206,9 +208,7 @@ int tnml_destroy(tnml_ctx* c) {
                     c->vG, c->scal, c->vpart, c->cgtrace, c->tB, c->tB2, c->sM, c->sG, c->sD, c->sE, c->sF, c->sInfo, c->sE2, c->sTau, c->sV, c->sC, c->sW, c->sScr, c->sS, c->sCm, c->sQ1, c->sDev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& s : c->W) if (s.a) (void)hipFree(s.a);
-    for (auto& e : c->env) if (e.ptr) (void)hipFree(e.ptr);
-    for (auto p : c->pool_small) (void)hipFree(p);
-    for (auto p : c->pool_big) (void)hipFree(p);
+    for (auto& sl : c->slabs) if (sl.base) (void)hipFree(sl.base);
     if (c->h_scal) (void)hipHostFree(c->h_scal);
     if (c->blas) rocblas_destroy_handle(c->blas);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -319,19 +319,32 @@ static int check_W(tnml_ctx* c) {
 }
 
 // ---- environments -------------------------------------------------------------------------------
-static int env_alloc(tnml_ctx* c, int j, int m, int L) {
-    EnvSlot& e = c->env[j];
-    if (e.ptr) { (e.big ? c->pool_big : c->pool_small).push_back(e.ptr); e.ptr = nullptr; }
-    int big = (L == TNML_NL);
-    // a Label-free env may sit in a recycled Label-carrying slot: during a sweep every shift frees one big
-    // slot (the stale env of the other direction) and needs one small one -- no hipMalloc on the hot path
-    if (!big && c->pool_small.empty() && !c->pool_big.empty()) big = 1;
-    auto& pool = big ? c->pool_big : c->pool_small;
-    if (!pool.empty()) { e.ptr = pool.back(); pool.pop_back(); }
-    else TCK(dmalloc(c, (char**)&e.ptr, (big ? c->big_elems : c->small_elems) * c->eesz()));
-    e.m = m; e.L = L; e.big = big;
+static void slot_release(tnml_ctx* c, EnvSlot& e) {
+    if (!e.ptr) return;
+    c->slabs[e.slab].mask &= (e.unit < 0) ? 0u : ~(1u << e.unit);
+    e.ptr = nullptr; e.slab = e.unit = -1;
+}
+static int slot_acquire(tnml_ctx* c, EnvSlot& e, int m, int L) {
+    slot_release(c, e);
+    const unsigned FULL = (1u << TNML_NL) - 1;
+    int pick = -1;
+    if (L != TNML_NL) for (size_t k = 0; k < c->slabs.size(); ++k) if (c->slabs[k].mask && c->slabs[k].mask != FULL) { pick = (int)k; break; }   // fill split slabs first
+    if (pick < 0) for (size_t k = 0; k < c->slabs.size(); ++k) if (!c->slabs[k].mask) { pick = (int)k; break; }
+    if (pick < 0) {
+        EnvSlab sl;
+        TCK(dmalloc(c, &sl.base, c->big_elems * c->eesz()));
+        c->slabs.push_back(sl); pick = (int)c->slabs.size() - 1;
+    }
+    EnvSlab& sl = c->slabs[pick];
+    e.slab = pick; e.m = m; e.L = L;
+    if (L == TNML_NL) { e.unit = -1; sl.mask = FULL; e.ptr = sl.base; }
+    else {
+        int u = 0; while (sl.mask & (1u << u)) ++u;
+        e.unit = u; sl.mask |= 1u << u; e.ptr = sl.base + (size_t)u * c->small_elems * c->eesz();
+    }
     return 0;
 }
+static int env_alloc(tnml_ctx* c, int j, int m, int L) { return slot_acquire(c, c->env[j], m, L); }
 static const void* phi_site(const tnml_ctx* c, int j) { return (const char*)c->phi + (size_t)(j - 1) * 2 * c->NTp * c->eesz(); }
 
 // dst = src*(t.A(cs)*W.A(cs)) (fixedL.cc:142-149,221-228); src == nullptr: chain end.  dst is an environment
@@ -428,24 +441,17 @@ int tnml_classify(tnml_ctx* c, double* weights, int32_t* pred, int64_t count[TNM
     HIPCK(c, hipSetDevice(c->cfg.device));
     if (!c->data_set) return tnml_fail(c, "tnml_classify: image data not set");
     TCK(check_W(c));
-    struct Borrowed { void* p; int big; };
-    auto borrow = [&](Borrowed* b) -> int {
-        if (!c->pool_small.empty()) { b->p = c->pool_small.back(); c->pool_small.pop_back(); b->big = 0; return 0; }
-        if (!c->pool_big.empty())   { b->p = c->pool_big.back(); c->pool_big.pop_back(); b->big = 1; return 0; }
-        b->big = 0;
-        return dmalloc(c, (char**)&b->p, c->small_elems * c->eesz());
-    };
-    Borrowed buf[3] = {{nullptr, 0}, {nullptr, 0}, {nullptr, 0}};
+    EnvSlot buf[3];
     int rc = 0;
-    for (int k = 0; k < 3 && !rc; ++k) rc = borrow(&buf[k]);
-    auto give_back = [&]() { for (auto& b : buf) if (b.p) (b.big ? c->pool_big : c->pool_small).push_back(b.p); };
+    for (int k = 0; k < 3 && !rc; ++k) rc = slot_acquire(c, buf[k], c->maxm, 1);
+    auto give_back = [&]() { for (auto& b : buf) slot_release(c, b); };
     if (rc) { give_back(); return rc; }
     const int cs = c->c0;
     // right chain N -> c+1 (util.h:25-29), ping-pong between buf[0] and buf[1]
     const void* R = nullptr; int cur = 0;
-    for (int j = c->N; j > cs && !rc; --j) { rc = shift_core(c, j, false, R, 1, buf[cur].p, false, nullptr); R = buf[cur].p; cur ^= 1; }
+    for (int j = c->N; j > cs && !rc; --j) { rc = shift_core(c, j, false, R, 1, buf[cur].ptr, false, nullptr); R = buf[cur].ptr; cur ^= 1; }
     // left chain 1 -> c-1 (util.h:32-37), ping-pong between buf[2] and the free one of the pair above
-    const void* Lc = nullptr; void* lbuf[2] = {buf[2].p, buf[cur].p}; int lcur = 0;
+    const void* Lc = nullptr; void* lbuf[2] = {buf[2].ptr, buf[cur].ptr}; int lcur = 0;
     for (int j = 1; j < cs && !rc; ++j) { rc = shift_core(c, j, true, Lc, 1, lbuf[lcur], false, nullptr); Lc = lbuf[lcur]; lcur ^= 1; }
     // centre site: T[l][r][n] = sum_{a,s} L[a][n] phi_c[s][n] A_c[a,s,r,l], then W_n[l] = sum_r T[l][r][n] R[r][n]
     if (!rc) rc = shift_core(c, cs, true, Lc, 1, c->U, true, nullptr);

@@ -40,7 +40,15 @@ static const char* const kclass_names[KC_COUNT] = {
 struct EnvSlot {
     void* ptr = nullptr;    // [L][m][NTp], fp32 or fp64 elements (tnml_ctx::env64)
     int m = 0, L = 0;
-    int big = 0;            // allocated from the label-carrying pool
+    int slab = -1, unit = -1;   // where it lives (unit -1: the whole slab, a Label-carrying environment)
+};
+// Environment memory: slabs of one Label-carrying environment ([10][maxm][NTp]); a Label-free environment takes
+// one tenth of a slab.  During a sweep the mix of the two kinds changes from ~half/half at the chain ends to
+// all Label-free at the centre, at constant total need, so units are recycled inside slabs and hipMalloc is
+// off the hot path (DESIGN.md "HBM layout").
+struct EnvSlab {
+    char* base = nullptr;
+    unsigned mask = 0;      // bit k: unit k in use
 };
 
 struct SiteT {
@@ -84,7 +92,7 @@ struct tnml_ctx {
 
     std::vector<SiteT> W;      // 1..N
     std::vector<EnvSlot> env;  // 1..N
-    std::vector<void*> pool_small, pool_big;
+    std::vector<EnvSlab> slabs;
     size_t small_elems = 0, big_elems = 0;
 
     // workspaces
@@ -100,7 +108,7 @@ struct tnml_ctx {
     void* slab = nullptr;      // split-K partial slabs
     size_t slab_bytes = 0;
     bool f64() const { return cfg.dtype != TNML_F32; }                 // fp64 MFMA arithmetic
-    bool env64() const { return cfg.dtype == TNML_F64_STRICT; }        // fp64 environment / feature storage
+    bool env64() const { return cfg.dtype == TNML_F64; }        // fp64 environment / feature storage
     size_t esz() const { return f64() ? 8 : 4; }
     size_t eesz() const { return env64() ? 8 : 4; }
     double* partials = nullptr;  // [nblk][16]
@@ -118,7 +126,7 @@ struct tnml_ctx {
     double *sE2 = nullptr, *sTau = nullptr, *sV = nullptr, *sC = nullptr;   // eigh.hip: subdiagonal, tau, reflectors, tridiagonal eigenvectors
     double *sW = nullptr, *sScr = nullptr, *sS = nullptr, *sCm = nullptr, *sQ1 = nullptr, *sDev = nullptr;   // own tridiagonal eigensolver + Newton-Schulz polish
     double svd_last_dev0 = 0., svd_last_dev1 = 0.;   // max|Q^T Q - I| before the 1st / 2nd polish step of the last split
-    long svd_fallbacks = 0;
+    long svd_fallbacks = 0, svd_cholqr = 0;
     int* sInfo = nullptr;
     int svd_n = 0;
 
@@ -231,6 +239,8 @@ int launch_fill_f64(tnml_ctx* c, double* p, double v, size_t n);
 int eigh_tridiagonalize(tnml_ctx* c, const double* A, int n, double* D, double* E, double* tau, double* V);
 int eigh_tridiag_eig(tnml_ctx* c, const double* D, const double* E, int n, double* W, int mk, double* Z, int ldz, double* scratch);
 int eigh_ns_matrix(tnml_ctx* c, const double* S, double* Cm, int m, double* dev);
+int eigh_chol_rinv(tnml_ctx* c, const double* S, int m, double* Rinv, double* flag);   // m <= 136
+#define TNML_CHOL_MAXM 136
 int eigh_backtransform(tnml_ctx* c, const double* V, const double* tau, int n, const double* Z, int ldz, double* U, int ldu, int ncols);
 
 // ---- svd.hip ------------------------------------------------------------------------------

@@ -86,9 +86,9 @@ class TrainStates:
         self._ck(self._L.tnml_synchronize(self._h))
 
     def svd_stats(self):
-        fb, d0, d1 = C.c_int64(), C.c_double(), C.c_double()
-        self._ck(self._L.tnml_svd_stats(self._h, C.byref(fb), C.byref(d0), C.byref(d1)))
-        return dict(fallbacks=fb.value, dev_before_polish=d0.value, dev_after_first_polish=d1.value)
+        fb, cr, d0, d1 = C.c_int64(), C.c_int64(), C.c_double(), C.c_double()
+        self._ck(self._L.tnml_svd_stats(self._h, C.byref(fb), C.byref(cr), C.byref(d0), C.byref(d1)))
+        return dict(fallbacks=fb.value, cluster_repairs=cr.value, dev_before_polish=d0.value, dev_after_first_polish=d1.value)
 
     def device_bytes(self):
         return self._L.tnml_device_bytes(self._h)

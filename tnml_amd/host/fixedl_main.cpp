@@ -4,8 +4,10 @@
 // working directory (sites, W, WRITE_WF, LAMBDA), the idx-ubyte dataset under `datadir`, and the log
 // lines, while the sweep itself (mldmrg, fixedL.cc:451-570) is one
 // tnml_bond_update call per bond.  Extensions (never read by the reference, all optional): `seed`
-// (initial-W RNG), `device` (HIP ordinal), `precision` (mixed = fp64 MFMA over fp32 environments [default],
-// strict = fp64 everywhere, f32 = fp32 MFMA study mode).
+// (initial-W RNG), `device` (HIP ordinal), `precision` (f64 = fp64 everywhere [default], mixed = fp64 MFMA over
+// fp32-stored environments, f32 = fp32 MFMA study mode), `imglen` (block-mean down-sampling of the images to
+// imglen x imglen; present in the reference's sample input but never read by fixedL.cc), `feature_scale`
+// (multiplies the second feature component; 1 = the reference's double normalisation).
 #include <array>
 #include <cstdio>
 #include <cstdlib>
@@ -62,13 +64,16 @@ int main(int argc, const char* argv[]) {
         const double cconv = input.getReal("cconv", 1E-10);
         const uint64_t seed = (uint64_t)input.getInt("seed", 1);                         // extension
         const int device = (int)input.getInt("device", 0);                              // extension
-        const std::string precision = input.getString("precision", "mixed");              // extension: mixed | strict | f32
+        const std::string precision = input.getString("precision", "f64");              // extension: f64 | mixed | f32
+        const long imglen = input.getInt("imglen", 0);                                   // extension: 0 = keep the file's size
+        const double feature_scale = input.getReal("feature_scale", 1.);                 // extension
         int dtype = TNML_F64;
-        if (precision == "strict") dtype = TNML_F64_STRICT; else if (precision == "f32") dtype = TNML_F32;
-        else if (precision != "mixed") { std::printf("precision must be mixed, strict or f32\n"); return 1; }
+        if (precision == "mixed") dtype = TNML_F64_E32; else if (precision == "f32") dtype = TNML_F32;
+        else if (precision != "f64" && precision != "strict") { std::printf("precision must be f64, mixed or f32\n"); return 1; }
         if (method != "conj") { std::printf("method type \"%s\" not recognized\n", method.c_str()); return 1; }   // :505
 
         Dataset train = read_mnist(datadir, true, Ntrain);                              // :613
+        if (imglen > 0) reduce(train, (int)imglen);
         std::printf("Training set consists of %d images:\n", train.size());
         for (int l = 0; l < 10; ++l) std::printf("  %d of label %d\n", train.counts[l], l);
         const int N = train.npix();                                                     // :615
@@ -96,7 +101,7 @@ int main(int argc, const char* argv[]) {
             W = read_mps("W");
             if (W.N != N || W.A[c].L != NL) { std::printf("Expected W to have Label type Index at site %d\n", c); return 1; }
         } else {
-            W = build_initial_w(train, (int)ninitial, seed, true);                      // :702-726
+            W = build_initial_w(train, (int)ninitial, seed, true, feature_scale);                      // :702-726
             std::printf("Done making initial W\n");
             write_mps("W", W);                                                          // :727
         }
@@ -109,7 +114,12 @@ int main(int argc, const char* argv[]) {
         cfg.maxm = (int)std::max<long>(std::min<long>(maxm, 4096), wm); cfg.dtype = dtype; cfg.svd_backend = TNML_SVD_SYEVD;
         tnml_ctx* ctx = nullptr;
         if (tnml_create(&ctx, &cfg) != 0) die(nullptr, "tnml_create");
-        CK(ctx, tnml_set_data_u8(ctx, train.pixels.data(), train.labels.data()));       // TState ctor, :644-653
+        if (!train.reduced() && feature_scale == 1.) {
+            CK(ctx, tnml_set_data_u8(ctx, train.pixels.data(), train.labels.data()));   // TState ctor, :644-653
+        } else {
+            std::vector<double> phi = all_features(train, false, feature_scale);
+            CK(ctx, tnml_set_data_phi(ctx, phi.data(), train.labels.data()));
+        }
         upload(ctx, W);
         std::printf("Projecting training states..."); std::fflush(stdout);              // :740
         CK(ctx, tnml_env_init(ctx));                                                    // :741

@@ -4,7 +4,8 @@
 // (series | normal), the files `sites` and <fname> in the working directory, the t10k idx files under
 // `datadir`, and the result table of fullTest (util.h:186-199).  The per-image contraction toverlap
 // (util.h:19-40) is one tnml_classify call on the device.  Extensions: `device`, `precision`
-// (mixed | strict | f32), `Ntest` (per-label cap; the reference takes the whole test set).
+// (f64 | mixed | f32), `Ntest` (per-label cap; the reference takes the whole test set), `imglen` and
+// `feature_scale` as in the fixedL driver (they must match the values W was trained with).
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -13,6 +14,7 @@
 
 #include "../../include/tnml.h"
 #include "host_mps.h"
+#include "init_w.h"
 #include "input_group.h"
 #include "mnist_idx.h"
 
@@ -33,14 +35,17 @@ int main(int argc, const char* argv[]) {
         const std::string fname = input.getString("fname", "W");
         const std::string feature = input.getString("feature", "series");
         const int device = (int)input.getInt("device", 0);
-        const std::string precision = input.getString("precision", "mixed");
+        const std::string precision = input.getString("precision", "f64");
         const long Ntest = input.getInt("Ntest", 50000);                               // mllib/mnist.h:452 default NT
+        const long imglen = input.getInt("imglen", 0);
+        const double feature_scale = input.getReal("feature_scale", 1.);
         int dtype = TNML_F64;
-        if (precision == "strict") dtype = TNML_F64_STRICT; else if (precision == "f32") dtype = TNML_F32;
-        else if (precision != "mixed") { std::printf("precision must be mixed, strict or f32\n"); return 1; }
+        if (precision == "mixed") dtype = TNML_F64_E32; else if (precision == "f32") dtype = TNML_F32;
+        else if (precision != "f64" && precision != "strict") { std::printf("precision must be f64, mixed or f32\n"); return 1; }
 
         std::printf("Labels:"); for (int l = 0; l < 10; ++l) std::printf(" %d", l); std::printf("\n");   // :28
         Dataset test = read_mnist(datadir, false, Ntest);                              // :30
+        if (imglen > 0) reduce(test, (int)imglen);
         const int N = test.npix();
         if (!file_exists("sites")) { std::printf("Couldn't find file 'sites'\n"); return 1; }             // :34-41
         int Ns, ds; read_sites("sites", &Ns, &ds);
@@ -67,15 +72,10 @@ int main(int argc, const char* argv[]) {
         cfg.maxm = wm; cfg.dtype = dtype; cfg.svd_backend = TNML_SVD_SYEVD;
         tnml_ctx* ctx = nullptr;
         if (tnml_create(&ctx, &cfg)) die(nullptr, "tnml_create");
-        if (!normal) {
+        if (!normal && !test.reduced() && feature_scale == 1.) {
             CK(ctx, tnml_set_data_u8(ctx, test.pixels.data(), test.labels.data()));    // phi = [1, x/4], x = (byte/255)/255
         } else {
-            // fulltest.cc:57-66 with g = byte/255 from readMNIST (mllib/mnist.h:495): x = g/255, [cos(pi x/2), sin(pi x/2)]
-            std::vector<double> phi((size_t)totNtest * N * 2);
-            for (size_t k = 0; k < (size_t)totNtest * N; ++k) {
-                const double x = (test.pixels[k] / 255.) / 255.;
-                phi[2 * k] = std::cos(M_PI / 2. * x); phi[2 * k + 1] = std::sin(M_PI / 2. * x);
-            }
+            std::vector<double> phi = all_features(test, normal, feature_scale);       // fulltest.cc:57-70
             CK(ctx, tnml_set_data_phi(ctx, phi.data(), test.labels.data()));
         }
         for (int j = 1; j <= N; ++j) CK(ctx, tnml_set_site(ctx, j, psi.A[j].ml, psi.A[j].mr, psi.A[j].L == NL, psi.A[j].a.data()));

@@ -33,11 +33,22 @@ int tnmlh_read_mnist(const char* datadir, int train, long nt_per_label, int* n, 
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
+// block-mean down-sampling (mnist_idx.h reduce) of n square images of side `side` to newlen x newlen; out[n][newlen^2]
+int tnmlh_reduce(const unsigned char* pixels, int n, int side, int newlen, double* out) {
+    try {
+        Dataset d; d.rows = d.cols = side; d.pixels.assign(pixels, pixels + (size_t)n * side * side); d.labels.assign(n, 0);
+        reduce(d, newlen);
+        for (size_t k = 0; k < (size_t)n * newlen * newlen; ++k) out[k] = d.value(0, k);
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
 // initial W from a dataset directory -> file `out` (TNMLW1); returns overlap(W,W) through *ovl
-int tnmlh_build_initial_w(const char* datadir, long nt_per_label, int ninitial, unsigned long long seed, const char* out, double* ovl, int* maxdim) {
+int tnmlh_build_initial_w(const char* datadir, long nt_per_label, int ninitial, unsigned long long seed, const char* out, double* ovl, int* maxdim,
+                          int imglen, double feature_scale) {
     try {
         Dataset d = read_mnist(datadir, true, nt_per_label);
-        HostMPS W = build_initial_w(d, ninitial, seed, false);
+        if (imglen > 0) reduce(d, imglen);
+        HostMPS W = build_initial_w(d, ninitial, seed, false, feature_scale);
         write_mps(out, W);
         if (ovl) *ovl = overlap(W, W);
         int md = 1; for (int j = 1; j <= W.N; ++j) md = std::max(md, std::max(W.A[j].ml, W.A[j].mr));

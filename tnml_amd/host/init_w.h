@@ -4,6 +4,7 @@
 // normalised.  The reference draws images with ITensor's time-seeded Global::random() (util.h:104-121);
 // here the seed is explicit (input key `seed`, an extension) so runs are reproducible.
 #pragma once
+#include <cmath>
 #include <random>
 
 #include "host_mps.h"
@@ -11,10 +12,28 @@
 
 namespace tnmlh {
 
-// phi(g,n) = pow((g/255.)/4., n-1) with g = byte/255. (mllib/mnist.h:495, fixedL.cc:637-642)
-inline void features_series(const uint8_t* pix, int N, std::vector<double>& phi) {
+// phi(g,n) = pow((g/255.)/4., n-1) with g = byte/255. (mllib/mnist.h:495, fixedL.cc:637-642); `scale` multiplies the
+// second component (1 = the reference's double normalisation, 255 = the README's [1, x/4] -- SURVEY.md 9-Q1)
+inline void features_series(const Dataset& d, int img, std::vector<double>& phi, double scale = 1.) {
+    const int N = d.npix();
     phi.resize((size_t)N * 2);
-    for (int j = 0; j < N; ++j) { const double g = pix[j] / 255.; phi[2 * j] = 1.; phi[2 * j + 1] = (g / 255.) / 4.; }
+    for (int j = 0; j < N; ++j) { const double g = d.value(img, j) / 255.; phi[2 * j] = 1.; phi[2 * j + 1] = scale * ((g / 255.) / 4.); }
+}
+// fulltest.cc:57-66 "normal" map with the same double normalisation: x = g/255
+inline void features_normal(const Dataset& d, int img, std::vector<double>& phi) {
+    const int N = d.npix();
+    phi.resize((size_t)N * 2);
+    for (int j = 0; j < N; ++j) { const double x = (d.value(img, j) / 255.) / 255.; phi[2 * j] = std::cos(M_PI / 2. * x); phi[2 * j + 1] = std::sin(M_PI / 2. * x); }
+}
+// all images: [n][N][2], the layout of tnml_set_data_phi
+inline std::vector<double> all_features(const Dataset& d, bool normal, double scale) {
+    const int N = d.npix();
+    std::vector<double> out((size_t)d.size() * N * 2), phi;
+    for (int i = 0; i < d.size(); ++i) {
+        if (normal) features_normal(d, i, phi); else features_series(d, i, phi, scale);
+        std::copy(phi.begin(), phi.end(), out.begin() + (size_t)i * N * 2);
+    }
+    return out;
 }
 
 // util.h:104-121 randImg: uniform index, retry (<= 1000 times) until the label matches
@@ -36,7 +55,7 @@ inline HostMPS sum_truncated(const std::vector<HostMPS>& v, double cutoff, int m
     return acc;
 }
 
-inline HostMPS build_initial_w(const Dataset& train, int ninitial, uint64_t seed, bool verbose) {
+inline HostMPS build_initial_w(const Dataset& train, int ninitial, uint64_t seed, bool verbose, double feature_scale = 1.) {
     const int N = train.npix();
     std::mt19937_64 rng(seed);
     std::vector<HostMPS> ipsis;
@@ -45,7 +64,7 @@ inline HostMPS build_initial_w(const Dataset& train, int ninitial, uint64_t seed
         std::vector<HostMPS> psis;
         for (int m = 0; m < ninitial; ++m) {
             const int w = rand_img(train, n, rng);
-            features_series(&train.pixels[(size_t)w * N], N, phi);
+            features_series(train, w, phi, feature_scale);
             psis.push_back(product_state(N, phi.data()));                 // :717
         }
         if (verbose) printf("Summing %d random label %d states\n", ninitial, n);   // :719

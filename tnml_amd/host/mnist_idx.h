@@ -17,11 +17,14 @@ namespace tnmlh {
 struct Dataset {
     int rows = 0, cols = 0;
     std::vector<uint8_t> pixels;      // [n][rows*cols]
+    std::vector<double> gray;         // [n][rows*cols] in byte units, only after reduce() (block means are fractional)
     std::vector<int32_t> labels;      // [n]
     std::vector<long> file_index;     // position in the file (Data::n of mllib/data.h)
     std::array<int, 10> counts{};
     int size() const { return (int)labels.size(); }
     int npix() const { return rows * cols; }
+    bool reduced() const { return !gray.empty(); }
+    double value(size_t img, size_t j) const { return reduced() ? gray[img * npix() + j] : (double)pixels[img * npix() + j]; }
 };
 
 inline uint32_t read_be32(std::ifstream& f) {
@@ -58,6 +61,26 @@ inline Dataset read_idx(const std::string& image_file, const std::string& label_
         d.file_index.push_back((long)i);
     }
     return d;
+}
+
+// imglen < side: block-mean down-sampling in the manner of image.h:316-346 `reduce` (dead code in the reference, which
+// never reads its `imglen` key -- SURVEY.md 8(f)-4): bsize = side/newlen, blocks start at rem = side % bsize, the new
+// pixel is the plain mean of the bsize x bsize block, kept as a real number; sites run over the reduced image in the
+// file's row-major order.
+inline void reduce(Dataset& d, int newlen) {
+    if (d.rows != d.cols) throw std::runtime_error("reduce: image is not square");
+    if (newlen == d.rows) return;
+    if (newlen < 1 || newlen > d.rows) throw std::runtime_error("reduce: imglen must be between 1 and the image side");
+    const int side = d.rows, bsize = side / newlen, rem = side % bsize, n = d.size();
+    std::vector<double> g((size_t)n * newlen * newlen);
+    for (int i = 0; i < n; ++i)
+        for (int ny = 0; ny < newlen; ++ny) for (int nx = 0; nx < newlen; ++nx) {
+            double avg = 0.; long cnt = 0;
+            for (int oy = rem + bsize * ny; oy < rem + bsize * ny + bsize; ++oy)
+                for (int ox = rem + bsize * nx; ox < rem + bsize * nx + bsize; ++ox) { avg += d.pixels[((size_t)i * side + oy) * side + ox]; ++cnt; }
+            g[((size_t)i * newlen + ny) * newlen + nx] = avg / cnt;
+        }
+    d.gray = std::move(g); d.pixels.clear(); d.rows = d.cols = newlen;
 }
 
 // datadir layout of the reference (mnist.h:244,262,279,297)

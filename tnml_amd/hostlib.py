@@ -23,7 +23,8 @@ def load():
         L.tnmlh_read_mnist.argtypes = [C.c_char_p, C.c_int, C.c_long, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                        C.POINTER(C.c_ubyte), C.POINTER(C.c_int), C.POINTER(C.c_long)]
         L.tnmlh_build_initial_w.argtypes = [C.c_char_p, C.c_long, C.c_int, C.c_ulonglong, C.c_char_p,
-                                            C.POINTER(C.c_double), C.POINTER(C.c_int)]
+                                            C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int, C.c_double]
+        L.tnmlh_reduce.argtypes = [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.tnmlh_mps_info.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.tnmlh_mps_site.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                      C.POINTER(C.c_double)]
@@ -91,8 +92,18 @@ def write_mps(path, W):
         raise _err()
 
 
-def build_initial_w(datadir, nt_per_label, ninitial, seed, out):
+def build_initial_w(datadir, nt_per_label, ninitial, seed, out, imglen=0, feature_scale=1.0):
     ovl, md = C.c_double(), C.c_int()
-    if load().tnmlh_build_initial_w(datadir.encode(), nt_per_label, ninitial, seed, out.encode(), ovl, md) != 0:
+    if load().tnmlh_build_initial_w(datadir.encode(), nt_per_label, ninitial, seed, out.encode(), ovl, md, imglen, feature_scale) != 0:
         raise _err()
     return ovl.value, md.value
+
+
+def reduce(pixels, side, newlen):
+    """block-mean down-sampling of [n, side*side] uint8 images to [n, newlen*newlen] real values (byte units)"""
+    pixels = np.ascontiguousarray(pixels, dtype=np.uint8)
+    n = pixels.shape[0]
+    out = np.zeros((n, newlen * newlen))
+    if load().tnmlh_reduce(pixels.ctypes.data_as(C.POINTER(C.c_ubyte)), n, side, newlen, out.ctypes.data_as(C.POINTER(C.c_double))) != 0:
+        raise _err()
+    return out

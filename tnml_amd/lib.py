@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
 NL = 10
 MAX_PASS = 64
-DTYPES = {"f32": 0, "f64": 1, "f64_strict": 2}    # TNML_F32 / TNML_F64 / TNML_F64_STRICT (include/tnml.h)
+DTYPES = {"f32": 0, "f64_e32": 1, "f64": 2}    # TNML_F32 / TNML_F64_E32 / TNML_F64 (include/tnml.h)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtnml.so")
 
@@ -101,7 +101,7 @@ def load():
     L.tnml_profile_get.argtypes = [vp, C.c_int, C.c_char_p, C.POINTER(C.c_int64), dp]
     L.tnml_profile_reset.argtypes = [vp]
     L.tnml_synchronize.argtypes = [vp]
-    L.tnml_svd_stats.argtypes = [vp, C.POINTER(C.c_int64), dp, dp]
+    L.tnml_svd_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), dp, dp]
     L.tnml_device_bytes.argtypes = [vp]
     L.tnml_classify.argtypes = [vp, dp, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.tnml_device_bytes.restype = C.c_int64
