@@ -559,7 +559,7 @@ static void jacobi_svd_tall(int R, int C, double* M, double* s, double* V) {
 }
 
 /* thin SVD of R x C column-major A (any shape): U R x k, s[k] descending, Vt k x C, k=min(R,C) */
-static void thin_svd(int R, int C, const double* A, double* U, double* s, double* Vt) {
+void orc_thin_svd(int R, int C, const double* A, double* U, double* s, double* Vt) {
     int k = R < C ? R : C;
     int tall = R >= C;
     int r = tall ? R : C, c = tall ? C : R;       /* work on the tall orientation */
@@ -631,7 +631,7 @@ int orc_svd_split(orc* o, const double* B, int b, int ha, double cutoff, int max
     double* U = (double*)malloc(sizeof(double) * (size_t)R * k);
     double* s = (double*)malloc(sizeof(double) * (size_t)k);
     double* Vt = (double*)malloc(sizeof(double) * (size_t)k * C);
-    thin_svd(R, C, M, U, s, Vt);
+    orc_thin_svd(R, C, M, U, s, Vt);
     double* P = (double*)malloc(sizeof(double) * (size_t)k);
     for (int g = 0; g < k; ++g) P[g] = s[g] * s[g];
     double te = 0.;

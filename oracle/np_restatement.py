@@ -240,3 +240,123 @@ class NpFixedL:
         for j in range(2, c):
             left = left @ np.einsum('s,asr->ar', ph[j - 1], self.W[j])
         return left @ cur
+
+
+# ---------------------------------------------------------------------------------------------------
+# per-label variant: /root/reference/single.cc, single.h (plain MPS, scalar output regressed on [l == L])
+def features_single(pixels, normal=True):
+    """single.cc:71-84 with g = byte/255 (mllib/mnist.h:495): x = g/255"""
+    x = pixels.astype(np.float64) / 255.0 / 255.0
+    if normal:
+        return np.stack([np.cos(np.pi / 2 * x), np.sin(np.pi / 2 * x)], axis=-1)
+    return np.stack([np.ones_like(x), x / 4.0], axis=-1)
+
+
+class NpSingle:
+    def __init__(self, phi, labels, target, W):
+        self.phi = np.asarray(phi, dtype=np.float64)
+        self.NT, self.N, _ = self.phi.shape
+        self.y = (np.asarray(labels) == target).astype(np.float64)          # single.h:103,193
+        self.W = [None] + [np.array(a, dtype=np.float64) for a in W]
+        self.E = [None] * (self.N + 2)
+        self.v = None
+
+    def init(self):                                                          # single.cc:181-199
+        N = self.N
+        for n in range(N, 2, -1):
+            M = np.einsum('ns,asr->nar', self.phi[:, n - 1], self.W[n])
+            self.E[n] = M[:, :, 0] if n == N else np.einsum('nar,nr->na', M, self.E[n + 1])
+        self.set_bond(1)
+
+    def set_bond(self, b):                                                   # single.h:581-596
+        p1, p2 = self.phi[:, b - 1], self.phi[:, b]
+        LE = self.E[b - 1] if b - 1 > 0 else np.ones((self.NT, 1))
+        RE = self.E[b + 2] if b + 2 < self.N + 1 else np.ones((self.NT, 1))
+        self.v = np.einsum('na,ns,nt,nr->nastr', LE, p1, p2, RE)
+
+    def shiftE(self, b, from_left):                                          # single.h:688-710
+        c, dc = (b, 1) if from_left else (b + 1, -1)
+        M = np.einsum('ns,asr->nar', self.phi[:, c - 1], self.W[c])
+        if c == 1 or c == self.N:
+            self.E[c] = M[:, 0, :] if from_left else M[:, :, 0]
+        elif from_left:
+            self.E[c] = np.einsum('na,nar->nr', self.E[c - dc], M)
+        else:
+            self.E[c] = np.einsum('nar,nr->na', M, self.E[c - dc])
+
+    def bond_tensor(self, b):
+        return np.einsum('asg,gtr->astr', self.W[b], self.W[b + 1])
+
+    def forward(self, B):
+        return np.einsum('astr,nastr->n', B, self.v)
+
+    def gradient(self, B):
+        return np.einsum('n,nastr->astr', self.y - self.forward(B), self.v)
+
+    def quadcost(self, B, lam):
+        return float(np.sum((self.y - self.forward(B)) ** 2) + lam * np.sum(B * B))
+
+    def cgrad(self, B, npass, lam, cconv):                                   # single.h:162-288
+        B = B.copy()
+        r = self.gradient(B) - lam * B
+        trace = dict(skipped=False, cost=[], rnorm=[], alpha=[])
+        if np.linalg.norm(r) < cconv:
+            trace["skipped"] = True
+            return B, trace
+        p = r.copy()
+        for ps in range(1, npass + 1):
+            pAp = float(np.sum(self.forward(p) ** 2) + lam * np.sum(p * p))
+            a = float(np.sum(r * r)) / pAp
+            trace["alpha"].append(a)
+            B = B + a * p
+            if ps == npass:
+                break
+            nr = self.gradient(B) - lam * B
+            beta = (np.linalg.norm(nr) / np.linalg.norm(r)) ** 2
+            r = nr
+            trace["cost"].append(self.quadcost(B, lam))
+            trace["rnorm"].append(float(np.linalg.norm(r)))
+            if np.linalg.norm(r) < cconv:
+                break
+            p = r + beta * p
+        return B, trace
+
+    def svd_split(self, B, b, ha, cutoff, maxm, minm):                       # single.h:636-646
+        mL, _, _, mR = B.shape
+        M = B.reshape(2 * mL, 2 * mR, order="F") if False else np.einsum('astr->astr', B).reshape(mL * 2, 2 * mR)
+        # rows (a,s), cols (t,r) in C order of the reshaped einsum view
+        U, s, Vt = np.linalg.svd(M, full_matrices=False)
+        m, te = truncate(s ** 2, maxm, minm, cutoff)
+        U, s, Vt = U[:, :m], s[:m], Vt[:m]
+        if ha == 1:
+            self.W[b] = U.reshape(mL, 2, m)
+            self.W[b + 1] = (s[:, None] * Vt).reshape(m, 2, mR)
+        else:
+            self.W[b] = (U * s).reshape(mL, 2, m)
+            self.W[b + 1] = Vt.reshape(m, 2, mR)
+        return m, te
+
+    def mldmrg(self, nsweep, maxm, minm, cutoff, npass, lam, cconv, max_bonds=0):
+        out = []
+        for sw in range(1, nsweep + 1):
+            b, ha = 1, 1
+            while ha <= 2:
+                if max_bonds and len(out) >= max_bonds:
+                    return out
+                oB = self.bond_tensor(b)
+                self.set_bond(b)
+                B, tr = self.cgrad(oB, npass, lam, cconv)
+                rep = dict(c=b if ha == 1 else b + 1, half=ha, origm=self.W[b].shape[2], cost_old=self.quadcost(oB, lam),
+                           cost_cg=self.quadcost(B, lam), cg_skipped=tr["skipped"])
+                rep["newm"], rep["truncerr"] = self.svd_split(B, b, ha, cutoff, maxm, minm)
+                rep["cost"] = self.quadcost(self.bond_tensor(b), lam)
+                self.shiftE(b, ha == 1)
+                out.append(rep)
+                b, ha = sweepnext(b, ha, self.N)
+        return out
+
+    def output(self, i):
+        cur = np.ones(1)
+        for j in range(self.N, 0, -1):
+            cur = np.einsum('s,asr,r->a', self.phi[i, j - 1], self.W[j], cur)
+        return float(cur[0])

@@ -228,3 +228,175 @@ def features_series(pixels):
     phi = np.empty((NT, N, 2))
     lib().orc_features_series(N, NT, pixels.ctypes.data_as(C.POINTER(C.c_ubyte)), _dp(phi))
     return phi
+
+
+# ---------------------------------------------------------------------------------------------------
+# per-label variant (reference single.cc / single.h) -- oracle/single_oracle.c
+class SingleBondReport(C.Structure):
+    _fields_ = [("sweep", C.c_int), ("half", C.c_int), ("c", C.c_int), ("origm", C.c_int), ("newm", C.c_int),
+                ("truncerr", C.c_double), ("cost_old", C.c_double), ("cost_cg", C.c_double), ("reg_cost", C.c_double),
+                ("cost_after_svd", C.c_double), ("norm_oB", C.c_double), ("norm_newB", C.c_double),
+                ("cg_skipped", C.c_int), ("cg", CgTrace)]
+
+
+_S_BOUND = False
+
+
+def _slib():
+    global _S_BOUND
+    L = lib()
+    if not _S_BOUND:
+        dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
+        L.sorc_create.restype = vp
+        L.sorc_create.argtypes = [C.c_int, C.c_int, dp, ip, C.c_int, C.c_int]
+        L.sorc_destroy.argtypes = [vp]
+        L.sorc_features.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.c_int, dp]
+        L.sorc_set_site.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp]
+        L.sorc_site_dims.argtypes = [vp, C.c_int, ip, ip]
+        L.sorc_get_site.argtypes = [vp, C.c_int, dp]
+        L.sorc_init.argtypes = [vp]
+        L.sorc_set_bond.argtypes = [vp, C.c_int]
+        L.sorc_shiftE.argtypes = [vp, C.c_int, C.c_int]
+        L.sorc_get_env.argtypes = [vp, C.c_int, C.c_int, dp, ip]
+        L.sorc_bond_dims.argtypes = [vp, C.c_int, ip, ip]
+        L.sorc_bond_tensor.argtypes = [vp, C.c_int, dp]
+        L.sorc_forward.argtypes = [vp, dp, dp]
+        L.sorc_gradient.argtypes = [vp, dp, dp]
+        L.sorc_quadcost.restype = C.c_double
+        L.sorc_quadcost.argtypes = [vp, dp, C.c_double, dp]
+        L.sorc_cgrad.argtypes = [vp, dp, C.c_int, C.c_double, C.c_double, C.POINTER(CgTrace)]
+        L.sorc_svd_split.argtypes = [vp, dp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, dp, ip, dp, ip]
+        L.sorc_mldmrg.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int,
+                                  C.POINTER(SingleBondReport)]
+        L.sorc_output.argtypes = [vp, C.c_int, dp]
+        _S_BOUND = True
+    return L
+
+
+def features_single(pixels, normal=True):
+    """single.cc:71-84: [cos(pi x/2), sin(pi x/2)] (normal) or [1, x/4] (series), x = (byte/255)/255"""
+    pixels = np.ascontiguousarray(pixels, dtype=np.uint8)
+    NT, N = pixels.shape
+    phi = np.empty((NT, N, 2))
+    _slib().sorc_features(N, NT, pixels.ctypes.data_as(C.POINTER(C.c_ubyte)), int(normal), _dp(phi))
+    return phi
+
+
+class SingleOracle:
+    """training states + plain weight MPS of the per-label variant (single.cc:153-218, single.h)"""
+
+    def __init__(self, phi, labels, target, W=None, nthread=1):
+        phi = np.ascontiguousarray(phi, dtype=np.float64)
+        self.NT, self.N, d = phi.shape
+        assert d == 2
+        self.labels = np.ascontiguousarray(labels, dtype=np.int32)
+        self.target = int(target)
+        self._L = _slib()
+        self._h = self._L.sorc_create(self.N, self.NT, _dp(phi), self.labels.ctypes.data_as(C.POINTER(C.c_int)), self.target, nthread)
+        if not self._h:
+            raise ValueError("sorc_create failed")
+        if W is not None:
+            self.set_mps(W)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.sorc_destroy(self._h)
+            self._h = None
+
+    def _ck(self, rc):
+        if rc < 0:
+            raise RuntimeError("single oracle call failed")
+        return rc
+
+    def set_mps(self, W):
+        for j, A in enumerate(W, start=1):
+            A = np.asarray(A, dtype=np.float64)
+            assert A.ndim == 3
+            self._ck(self._L.sorc_set_site(self._h, j, A.shape[0], A.shape[2], _dp(_f(A))))
+
+    def get_site(self, j):
+        ml, mr = C.c_int(), C.c_int()
+        self._ck(self._L.sorc_site_dims(self._h, j, ml, mr))
+        buf = np.empty(ml.value * 2 * mr.value)
+        self._ck(self._L.sorc_get_site(self._h, j, _dp(buf)))
+        return buf.reshape((ml.value, 2, mr.value), order="F")
+
+    def get_mps(self):
+        return [self.get_site(j) for j in range(1, self.N + 1)]
+
+    def init(self):
+        self._ck(self._L.sorc_init(self._h))
+
+    def set_bond(self, b):
+        self._ck(self._L.sorc_set_bond(self._h, b))
+
+    def shiftE(self, b, from_left):
+        self._ck(self._L.sorc_shiftE(self._h, b, int(bool(from_left))))
+
+    def env(self, j):
+        m = C.c_int()
+        self._ck(self._L.sorc_get_env(self._h, j, 0, None, m))
+        out = np.empty((self.NT, m.value))
+        for i in range(self.NT):
+            self._ck(self._L.sorc_get_env(self._h, j, i, _dp(out[i]), None))
+        return out
+
+    def bond_shape(self, b):
+        mL, mR = C.c_int(), C.c_int()
+        self._ck(self._L.sorc_bond_dims(self._h, b, mL, mR))
+        return (mL.value, 2, 2, mR.value)
+
+    def bond_tensor(self, b):
+        shape = self.bond_shape(b)
+        buf = np.empty(int(np.prod(shape)))
+        self._ck(self._L.sorc_bond_tensor(self._h, b, _dp(buf)))
+        return buf.reshape(shape, order="F")
+
+    def forward(self, B):
+        P = np.empty(self.NT)
+        self._ck(self._L.sorc_forward(self._h, _dp(_f(B)), _dp(P)))
+        return P
+
+    def gradient(self, B):
+        B = np.asarray(B)
+        G = np.empty(B.size)
+        self._ck(self._L.sorc_gradient(self._h, _dp(_f(B)), _dp(G)))
+        return G.reshape(B.shape, order="F")
+
+    def quadcost(self, B, lam):
+        cr = C.c_double()
+        c = self._L.sorc_quadcost(self._h, _dp(_f(B)), lam, C.byref(cr))
+        return c, cr.value
+
+    def cgrad(self, B, npass, lam, cconv):
+        B = np.asarray(B)
+        buf = _f(B).copy()
+        tr = CgTrace()
+        skipped = self._ck(self._L.sorc_cgrad(self._h, _dp(buf), npass, lam, cconv, C.byref(tr)))
+        n = tr.npass_done
+        return buf.reshape(B.shape, order="F"), dict(skipped=bool(skipped), npass_done=n, converged=bool(tr.converged), cost=list(tr.cost[:max(n - 1, 0)] if not tr.converged else tr.cost[:n]),
+                                                     rnorm=list(tr.rnorm[:max(n - 1, 0)] if not tr.converged else tr.rnorm[:n]), pAp=list(tr.pAp[:n]), alpha=list(tr.alpha[:n]))
+
+    def svd_split(self, B, b, ha, cutoff, maxm, minm):
+        te, m, nsv = C.c_double(), C.c_int(), C.c_int()
+        sv = np.zeros(4 * max(self.bond_shape(b)[0], self.bond_shape(b)[3]))
+        self._ck(self._L.sorc_svd_split(self._h, _dp(_f(B)), b, ha, cutoff, maxm, minm, C.byref(te), C.byref(m), _dp(sv), C.byref(nsv)))
+        return m.value, te.value, sv[:nsv.value].copy()
+
+    def mldmrg(self, nsweep, maxm, minm, cutoff, npass, lam, cconv, max_bonds=0):
+        cap = max_bonds if max_bonds > 0 else nsweep * 2 * (self.N - 1)
+        reps = (SingleBondReport * cap)()
+        n = self._ck(self._L.sorc_mldmrg(self._h, nsweep, maxm, minm, cutoff, npass, lam, cconv, max_bonds, reps))
+        out = []
+        for r in reps[:n]:
+            k = r.cg.npass_done
+            out.append(dict(sweep=r.sweep, half=r.half, c=r.c, origm=r.origm, newm=r.newm, truncerr=r.truncerr,
+                            cost_old=r.cost_old, cost_cg=r.cost_cg, reg_cost=r.reg_cost, cost=r.cost_after_svd,
+                            norm_oB=r.norm_oB, norm_newB=r.norm_newB, cg_skipped=bool(r.cg_skipped),
+                            cg_cost=list(r.cg.cost[:max(k - 1, 0)]), cg_alpha=list(r.cg.alpha[:k])))
+        return out
+
+    def output(self, i):
+        f = C.c_double()
+        self._ck(self._L.sorc_output(self._h, i, C.byref(f)))
+        return f.value

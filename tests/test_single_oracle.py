@@ -1,0 +1,95 @@
+"""CPU tests of the per-label variant's oracle (oracle/single_oracle.c, restating single.cc / single.h) against the
+independently written numpy restatement (oracle/np_restatement.py NpSingle) and its own invariants.
+PARITY UNPINNED as for fixedL: the reference ships no tests and cannot be built here."""
+import numpy as np
+import pytest
+
+from oracle import np_restatement as npr
+from oracle import pyoracle
+from tnml_amd import synth
+
+
+def plain_mps(N, m, seed):
+    W = synth.random_mps(N, m, seed=seed)
+    c0 = N // 2
+    W[c0 - 1] = W[c0 - 1][..., 0] * 3.0                   # drop the Label index of the fixedL generator
+    return W
+
+
+def problem(N=10, NT=50, m=4, seed=2, normal=True, boost=1.0):
+    labels = synth.synthetic_labels(NT, seed=seed, per_label=NT // 10)
+    pixels = synth.synthetic_images(N, labels, seed=seed)
+    if boost != 1.0:
+        pixels = np.clip(pixels.astype(np.int32) * boost, 0, 255).astype(np.uint8)
+    phi = pyoracle.features_single(pixels, normal)
+    return pixels, labels, phi, plain_mps(N, m, seed + 3)
+
+
+def test_features_match_numpy():
+    pixels, _, phi, _ = problem()
+    np.testing.assert_allclose(phi, npr.features_single(pixels, True), rtol=1e-15)
+    np.testing.assert_allclose(pyoracle.features_single(pixels, False), npr.features_single(pixels, False), rtol=1e-15)
+
+
+@pytest.mark.parametrize("nthread", [1, 3])
+def test_single_oracle_matches_numpy_restatement(nthread):
+    pixels, labels, phi, W = problem()
+    phi = phi.copy(); phi[..., 1] *= 300.0               # well-conditioned second component for a meaningful CG comparison
+    o = pyoracle.SingleOracle(phi, labels, 3, W, nthread=nthread)
+    n = npr.NpSingle(phi, labels, 3, W)
+    o.init(); n.init()
+    for j in range(3, 11):
+        np.testing.assert_allclose(o.env(j), n.E[j], rtol=1e-12, atol=1e-14)
+    for b in (1, 2, 5, 9):
+        if b > 1:
+            for bb in range(1, b):
+                o.shiftE(bb, True); n.shiftE(bb, True)
+        o.set_bond(b); n.set_bond(b)
+        B = o.bond_tensor(b)
+        np.testing.assert_allclose(B, n.bond_tensor(b), rtol=1e-12, atol=1e-14)
+        B = B + 0.1 * np.random.default_rng(b).standard_normal(B.shape)
+        np.testing.assert_allclose(o.forward(B), n.forward(B), rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(o.gradient(B), n.gradient(B), rtol=1e-10, atol=1e-12)
+        assert o.quadcost(B, 1e-3)[0] == pytest.approx(n.quadcost(B, 1e-3), rel=1e-12)
+        Bo, to = o.cgrad(B, 4, 1e-3, 1e-10)
+        Bn, tn = n.cgrad(B, 4, 1e-3, 1e-10)
+        np.testing.assert_allclose(to["cost"], tn["cost"], rtol=1e-10)
+        np.testing.assert_allclose(to["alpha"], tn["alpha"], rtol=1e-8)
+        np.testing.assert_allclose(Bo, Bn, rtol=1e-7, atol=1e-9)
+        # rebuild the envs for the next bond from scratch
+        o.init(); n.init()
+
+
+def test_single_sweep_matches_numpy_and_decreases_cost():
+    pixels, labels, phi, W = problem(N=8, NT=60, m=3)
+    phi = phi.copy(); phi[..., 1] *= 300.0
+    o = pyoracle.SingleOracle(phi, labels, 1, W, nthread=2)
+    n = npr.NpSingle(phi, labels, 1, W)
+    o.init(); n.init()
+    ro = o.mldmrg(2, 4, 2, 1e-10, 3, 1e-3, 1e-10)
+    rn = n.mldmrg(2, 4, 2, 1e-10, 3, 1e-3, 1e-10)
+    assert len(ro) == len(rn) == 2 * 2 * 7
+    for a, b in zip(ro, rn):
+        assert (a["c"], a["half"], a["origm"], a["newm"]) == (b["c"], b["half"], b["origm"], b["newm"])
+        assert a["cost_old"] == pytest.approx(b["cost_old"], rel=1e-8)
+        assert a["cost_cg"] == pytest.approx(b["cost_cg"], rel=1e-8)
+        assert a["cost"] == pytest.approx(b["cost"], rel=1e-8)
+        assert a["cost_cg"] <= a["cost_old"] * (1 + 1e-12)              # the CG never increases the cost
+    assert ro[-1]["cost"] < 0.8 * ro[0]["cost_old"]
+    # decision function = full contraction, and consistent with the cost at any bond
+    f = np.array([o.output(i) for i in range(o.NT)])
+    np.testing.assert_allclose(f, [n.output(i) for i in range(n.NT)], rtol=1e-6, atol=1e-8)
+    y = (labels == 1).astype(float)
+    o.set_bond(1)
+    B = o.bond_tensor(1)
+    assert np.sum((y - f) ** 2) + 1e-3 * np.sum(B * B) == pytest.approx(o.quadcost(B, 1e-3)[0], rel=1e-10)
+
+
+def test_cgrad_not_optimizing_branch():
+    """single.h:202-206: |r| < cconv at entry returns without touching B"""
+    pixels, labels, phi, W = problem()
+    o = pyoracle.SingleOracle(phi, labels, 0, W)
+    o.init()
+    B = o.bond_tensor(1)
+    B2, tr = o.cgrad(B, 4, 1e-3, 1e30)
+    assert tr["skipped"] and np.array_equal(B2, B)
