@@ -55,6 +55,14 @@ enum { TNML_F32 = 0, TNML_F64_E32 = 1, TNML_F64 = 2 };
    TNML_SVD_ROCSOLVER  stock rocSOLVER dsyevd
    TNML_SVD_STEDC      in-house tridiagonalisation + rocSOLVER dstedc */
 enum { TNML_SVD_SYEVD = 0, TNML_SVD_ROCSOLVER = 1, TNML_SVD_STEDC = 2 };
+/* which sweep of the reference the context serves:
+   TNML_MODE_FIXEDL  fixedL.cc: one weight MPS with a 10-valued Label index on site N/2, targets delta_{l,l_n}
+   TNML_MODE_SINGLE  single.cc / single.h: a plain weight MPS (no Label index, tnml_set_site has_label = 0 on every
+                     site), scalar output f(x_n) regressed on y_n = [l_n == target_label] (single.h:103,193).  The
+                     same kernels run with a label extent of 1; tnml_forward / tnml_classify return one value per
+                     image, label_cost[] buckets the cost by the true label of the image, ncorrect counts
+                     (f > 1/2) == y (the reference prints no accuracy in this variant). */
+enum { TNML_MODE_FIXEDL = 0, TNML_MODE_SINGLE = 1 };
 
 typedef struct {
     int device;          /* HIP device ordinal */
@@ -65,12 +73,15 @@ typedef struct {
     int maxm;            /* largest bond dimension that will occur (workspace sizing) */
     int dtype;           /* TNML_F64 (default choice), TNML_F64_E32 or TNML_F32 */
     int svd_backend;     /* TNML_SVD_* */
+    int mode;            /* TNML_MODE_FIXEDL (0, default) or TNML_MODE_SINGLE */
+    int target_label;    /* TNML_MODE_SINGLE: the selected label L (single.cc:19); the target is y_n = [l_n == L] */
 } tnml_config;
 
 /* mirrors the prints of fixedL.cc:391,429-439 */
 typedef struct {
     int npass_done;
-    int converged;                         /* |r| < cconv hit (fixedL.cc:432) */
+    int converged;                         /* 1: |r| < cconv hit after a pass (fixedL.cc:432, single.h:273); 2: TNML_MODE_SINGLE only,
+                                              |r| < cconv at entry, "not optimizing", B untouched (single.h:202-206) */
     double cost[TNML_MAX_PASS];            /* un-normalised C printed at :429 (index pass-1) */
     double rnorm[TNML_MAX_PASS];           /* |r| printed at :434/:439 */
     double pAp[TNML_MAX_PASS];
@@ -85,6 +96,8 @@ typedef struct {
     double lambda;       /* used by cgrad (fixedL.cc:356) */
     double lambda_cost;  /* used by the "After SVD" quadcost (cargs copy, fixedL.cc:467) */
     double cconv;
+    int report_costs;    /* also evaluate the cost of the old bond tensor and of the optimised one before the split
+                            (single.h:621-622 "Cost = %.10f --> %.10f"): two more forward passes */
 } tnml_sweep_params;
 
 /* mirrors the prints of fixedL.cc:490,523-533,341-342 */
@@ -99,6 +112,8 @@ typedef struct {
     double reg_cost;
     int64_t ncorrect;
     tnml_cg_trace cg;
+    double cost_old, cost_cg, reg_cost_cg; /* report_costs: quadcost(oB), quadcost(B) and lambda|B|^2 before the split */
+    double norm_oB;                        /* norm of the old bond tensor (single.h:572) */
 } tnml_bond_report;
 
 /* ---- lifetime ------------------------------------------------------------------------- */

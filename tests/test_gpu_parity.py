@@ -522,3 +522,77 @@ def test_svd_split_graded_spectrum_with_close_pairs():
             np.testing.assert_allclose(Q.T @ Q, np.eye(120), atol=1e-9)
     st = ts.svd_stats()
     assert st["fallbacks"] == 0, st
+
+
+# ---------------------------------------------------------------------------------------------------
+# per-label variant (single.cc / single.h): TNML_MODE_SINGLE against oracle/single_oracle.c
+def _single_pair(N=12, NT=60, m=4, target=3, seed=3, boost=300.0, normal=True, dtype="f64", maxm=None):
+    from oracle import pyoracle
+    from tnml_amd import synth
+    from tnml_amd.fixedl import TrainStates
+    labels = synth.synthetic_labels(NT, seed=seed, per_label=NT // 10)
+    pixels = synth.synthetic_images(N, labels, seed=seed)
+    phi = pyoracle.features_single(pixels, normal).copy()
+    phi[..., 1] *= boost
+    W = synth.random_mps(N, m, seed=seed + 7)
+    W[N // 2 - 1] = W[N // 2 - 1][..., 0] * 3.0            # plain MPS: no Label index
+    ts = TrainStates(labels, N, maxm or m, phi=phi, dtype=dtype, single_label=target)
+    o = pyoracle.SingleOracle(phi, labels, target, W)
+    ts.set_mps(W)
+    o.init()
+    ts.init()
+    return ts, o
+
+
+@pytest.mark.parametrize("dtype", BOTH)
+@pytest.mark.parametrize("b", [1, 2, 6, 11])
+def test_single_forward_gradient_cost_cgrad(b, dtype):
+    ts, o = _single_pair(dtype=dtype)
+    T = TOL[dtype]
+    for j in range(3, o.N + 1):
+        assert _relmax(ts.env(j), o.env(j)) < T["E"]
+    for bb in range(1, b):
+        ts.shiftE(bb, True); o.shiftE(bb, True)
+    ts.setBond(b); o.set_bond(b)
+    B0 = o.bond_tensor(b)
+    assert _relmax(ts.bond_tensor(b), B0) < 1e-12
+    B = B0 + 0.1 * np.random.default_rng(b).standard_normal(B0.shape)
+    assert _relmax(ts.forward(B), o.forward(B)) < T["P"]
+    assert _relmax(ts.gradient(B), o.gradient(B)) < T["G"]
+    Cg, lg, crg, ng = ts.quadcost(B, 1e-3)
+    Co, cro = o.quadcost(B, 1e-3)
+    assert Cg == pytest.approx(Co, rel=T["C"]) and lg.sum() + crg == pytest.approx(Cg, rel=1e-12) and crg == pytest.approx(cro, rel=1e-12)
+    y = (np.asarray(o.labels) == o.target)
+    assert ng == int(((o.forward(B) > 0.5) == y).sum())
+    Bg, tg = ts.cgrad(B0, 4, 1e-3, 1e-10)
+    Bo, to = o.cgrad(B0, 4, 1e-3, 1e-10)
+    assert not tg["skipped"] and not to["skipped"]
+    np.testing.assert_allclose(tg["cost"], to["cost"], rtol=T["cgc"])
+    np.testing.assert_allclose(tg["alpha"], to["alpha"], rtol=T["cga"])
+    assert _relmax(Bg, Bo) < T["cga"]
+    # single.h:202-206: |r| < cconv at entry -> B untouched
+    Bs, tsk = ts.cgrad(B0, 4, 1e-3, 1e30)
+    assert tsk["skipped"] and tsk["npass_done"] == 0 and np.array_equal(Bs, B0)
+
+
+@pytest.mark.parametrize("normal", [True, False])
+def test_single_full_sweeps_and_decision_function(normal):
+    ts, o = _single_pair(N=10, NT=80, m=3, target=7, normal=normal, maxm=5)
+    from tnml_amd.fixedl import mldmrg
+    rg = mldmrg(ts, 2, 5, 2, 1e-10, 3, 1e-3, 1e-10)
+    ro = o.mldmrg(2, 5, 2, 1e-10, 3, 1e-3, 1e-10)
+    assert len(rg) == len(ro) == 2 * 2 * 9
+    for a, b in zip(rg, ro):
+        assert (a["c"], a["half"], a["origm"], a["newm"]) == (b["c"], b["half"], b["origm"], b["newm"])
+        assert a["cost_old"] == pytest.approx(b["cost_old"], rel=1e-7)
+        assert a["cost_cg"] == pytest.approx(b["cost_cg"], rel=1e-7)
+        assert a["cost"] == pytest.approx(b["cost"], rel=1e-7)
+        assert a["norm_oB"] == pytest.approx(b["norm_oB"], rel=1e-7)
+        assert a["truncerr"] == pytest.approx(b["truncerr"], rel=1e-3, abs=1e-12)
+    assert ro[-1]["cost"] < 0.9 * ro[0]["cost_old"]
+    w, pred, cnt, ninc = ts.classify()                      # decision function f(x) of separate_fulltest.cc
+    f_or = np.array([o.output(i) for i in range(o.NT)])
+    assert w.shape == (o.NT, 1) and _relmax(w[:, 0], f_or) < 1e-6
+    y = (np.asarray(o.labels) == 7)
+    np.testing.assert_array_equal(pred, (f_or > 0.5).astype(np.int32))
+    assert int(ninc.sum()) == int(((f_or > 0.5) != y).sum())

@@ -143,8 +143,12 @@ __global__ __launch_bounds__(VB) void k_cg_init1(const double* __restrict__ G, c
     const double s = block_sum(acc, sh);
     if (threadIdx.x == 0) { part[2 * blockIdx.x] = s; part[2 * blockIdx.x + 1] = 0.; }
 }
-__global__ void k_cg_init2(const double* __restrict__ part, int nb, double* __restrict__ scal, int rr_out) {
-    if (threadIdx.x == 0) { double a, b; sum_partials(part, nb, &a, &b); scal[rr_out] = a; scal[SC_CONV] = 0.; scal[SC_NPASS] = 0.; }
+// cconv0 >= 0 (TNML_MODE_SINGLE): |r| < cconv at entry -> "not optimizing" (single.h:202-206): flag 2 freezes every later kernel
+__global__ void k_cg_init2(const double* __restrict__ part, int nb, double* __restrict__ scal, int rr_out, double cconv0) {
+    if (threadIdx.x == 0) {
+        double a, b; sum_partials(part, nb, &a, &b);
+        scal[rr_out] = a; scal[SC_CONV] = (cconv0 >= 0. && sqrt(a) < cconv0) ? 2. : 0.; scal[SC_NPASS] = 0.;
+    }
 }
 // partial |x|^2 (and |y|^2)
 __global__ __launch_bounds__(VB) void k_norm1(const double* __restrict__ x, const double* __restrict__ y, size_t n, double* __restrict__ part) {
@@ -236,12 +240,12 @@ static inline int vec_blocks(size_t n) { size_t b = (n + 1023) / 1024; if (b > V
 
 // the |r|^2 of the previous evaluation lives in scal[SC_RR + (c->rr_slot)], alternating between two
 // slots so that phase-2 workgroups never read a slot another workgroup is writing
-int launch_cg_init(tnml_ctx* c, size_t n, double lambda) {
+int launch_cg_init(tnml_ctx* c, size_t n, double lambda, double cconv0) {
     ProfScope ps(c, KC_VEC);
     const int nb = vec_blocks(n);
     c->rr_slot = 0;
     hipLaunchKernelGGL(k_cg_init1, dim3(nb), dim3(VB), 0, c->stream, c->vG, c->vB, c->vR, c->vP, n, lambda, c->vpart);
-    hipLaunchKernelGGL(k_cg_init2, dim3(1), dim3(64), 0, c->stream, c->vpart, nb, c->scal, (int)SC_RR);
+    hipLaunchKernelGGL(k_cg_init2, dim3(1), dim3(64), 0, c->stream, c->vpart, nb, c->scal, (int)SC_RR, cconv0);
     HIPCK(c, hipGetLastError());
     return 0;
 }

@@ -39,9 +39,11 @@ __global__ __launch_bounds__(64 * NW) void k_labeldot(LdotArgs A, double* __rest
         const TA* ap = Ap + (size_t)q * NTp + n;
 #pragma unroll
         for (int l = 0; l < TNML_NL; ++l) {
-            const TA2 e = *reinterpret_cast<const TA2*>(ap + (size_t)l * A.A_lstride);
-            px[l] = fma((TC)e.x, (TC)u.x, px[l]);
-            py[l] = fma((TC)e.y, (TC)u.y, py[l]);
+            if (l < A.nl) {
+                const TA2 e = *reinterpret_cast<const TA2*>(ap + (size_t)l * A.A_lstride);
+                px[l] = fma((TC)e.x, (TC)u.x, px[l]);
+                py[l] = fma((TC)e.y, (TC)u.y, py[l]);
+            }
         }
     }
 #pragma unroll
@@ -67,22 +69,28 @@ __global__ __launch_bounds__(64 * NW) void k_labeldot(LdotArgs A, double* __rest
         if (A.mode == LD_MODE_PAP) {
 #pragma unroll
             for (int l = 0; l < TNML_NL; ++l) {
-                val = fma(P[l], P[l], val);                                            // sqr(norm(pv)), :400
-                if (Pout) Pout[(size_t)l * NTp + ni] = P[l];
+                if (l < A.nl) {
+                    val = fma(P[l], P[l], val);                                        // sqr(norm(pv)), :400
+                    if (Pout) Pout[(size_t)l * NTp + ni] = P[l];
+                }
             }
             if (lab < 0) val = 0;
         } else {
             TC best = fabs(P[0]); int arg = 0;
 #pragma unroll
             for (int l = 0; l < TNML_NL; ++l) {
-                const TC d = (lab >= 0) ? ((l == lab ? (TC)1 : (TC)0) - P[l]) : (TC)0;   // deltas[t.l] - P
-                val = fma(d, d, val);
-                if (dPout) dPout[(size_t)l * NTp + ni] = d;
-                if (Pout) Pout[(size_t)l * NTp + ni] = P[l];
-                const TC wgt = fabs(P[l]);
-                if (wgt > best) { best = wgt; arg = l; }                               // first maximum
+                if (l < A.nl) {
+                    const TC tgt = A.target < 0 ? (l == lab ? (TC)1 : (TC)0) : (lab == A.target ? (TC)1 : (TC)0);   // single.h:103,193
+                    const TC d = (lab >= 0) ? (tgt - P[l]) : (TC)0;                    // deltas[t.l] - P
+                    val = fma(d, d, val);
+                    if (dPout) dPout[(size_t)l * NTp + ni] = d;
+                    if (Pout) Pout[(size_t)l * NTp + ni] = P[l];
+                    const TC wgt = fabs(P[l]);
+                    if (wgt > best) { best = wgt; arg = l; }                           // first maximum
+                }
             }
-            cor = (lab >= 0 && arg == lab) ? 1 : 0;
+            if (A.target < 0) cor = (lab >= 0 && arg == lab) ? 1 : 0;
+            else              cor = (lab >= 0 && ((P[0] > (TC)0.5) == (lab == A.target))) ? 1 : 0;
         }
         s_val[tid] = val; s_lab[tid] = lab; s_cor[tid] = cor;
     }
@@ -168,7 +176,7 @@ template <typename T>
 __global__ __launch_bounds__(LD_IMGS) void k_pupdate(T* __restrict__ P, const T* __restrict__ Pp, T* __restrict__ dP,
                                                     const int* __restrict__ label, int NTp,
                                                     const double* __restrict__ alpha, const double* __restrict__ conv,
-                                                    double* __restrict__ partials) {
+                                                    double* __restrict__ partials, int nl, int target) {
     if (conv[0] != 0.) return;                             // CG already converged: P must stay as it is
     __shared__ T s_val[LD_IMGS];
     __shared__ int s_lab[LD_IMGS];
@@ -177,18 +185,22 @@ __global__ __launch_bounds__(LD_IMGS) void k_pupdate(T* __restrict__ P, const T*
     const int ni = blockIdx.x * LD_IMGS + tid;
     const T a = (T)alpha[0];
     const int lab = label[ni];
-    T val = 0; T best = 0; int arg = 0;
+    T val = 0; T best = 0; int arg = 0; T p0 = 0;
 #pragma unroll
     for (int l = 0; l < TNML_NL; ++l) {
-        const T p = fma(a, Pp[(size_t)l * NTp + ni], P[(size_t)l * NTp + ni]);
-        P[(size_t)l * NTp + ni] = p;
-        const T d = (lab >= 0) ? ((l == lab ? (T)1 : (T)0) - p) : (T)0;
-        dP[(size_t)l * NTp + ni] = d;
-        val = fma(d, d, val);
-        const T wgt = fabs(p);
-        if (l == 0) best = wgt; else if (wgt > best) { best = wgt; arg = l; }
+        if (l < nl) {
+            const T p = fma(a, Pp[(size_t)l * NTp + ni], P[(size_t)l * NTp + ni]);
+            P[(size_t)l * NTp + ni] = p;
+            const T tgt = target < 0 ? (l == lab ? (T)1 : (T)0) : (lab == target ? (T)1 : (T)0);
+            const T d = (lab >= 0) ? (tgt - p) : (T)0;
+            dP[(size_t)l * NTp + ni] = d;
+            val = fma(d, d, val);
+            const T wgt = fabs(p);
+            if (l == 0) { best = wgt; p0 = p; } else if (wgt > best) { best = wgt; arg = l; }
+        }
     }
-    s_val[tid] = val; s_lab[tid] = lab; s_cor[tid] = (lab >= 0 && arg == lab) ? 1 : 0;
+    s_val[tid] = val; s_lab[tid] = lab;
+    s_cor[tid] = target < 0 ? ((lab >= 0 && arg == lab) ? 1 : 0) : ((lab >= 0 && ((p0 > (T)0.5) == (lab == target))) ? 1 : 0);
     __syncthreads();
     if (tid < 12) {
         double s = 0.;
@@ -201,8 +213,8 @@ __global__ __launch_bounds__(LD_IMGS) void k_pupdate(T* __restrict__ P, const T*
 int launch_pupdate(tnml_ctx* c, const double* alpha_dev, double* scal_out) {
     ProfScope ps(c, KC_LABELDOT);
     const int nblk = c->NTp / LD_IMGS;
-    if (c->f64()) hipLaunchKernelGGL(k_pupdate<double>, dim3(nblk), dim3(LD_IMGS), 0, c->stream, (double*)c->P, (const double*)c->Pp, (double*)c->dP, c->label, c->NTp, alpha_dev, c->scal + SC_CONV, c->partials);
-    else          hipLaunchKernelGGL(k_pupdate<float>, dim3(nblk), dim3(LD_IMGS), 0, c->stream, (float*)c->P, (const float*)c->Pp, (float*)c->dP, c->label, c->NTp, alpha_dev, c->scal + SC_CONV, c->partials);
+    if (c->f64()) hipLaunchKernelGGL(k_pupdate<double>, dim3(nblk), dim3(LD_IMGS), 0, c->stream, (double*)c->P, (const double*)c->Pp, (double*)c->dP, c->label, c->NTp, alpha_dev, c->scal + SC_CONV, c->partials, c->nl(), c->target());
+    else          hipLaunchKernelGGL(k_pupdate<float>, dim3(nblk), dim3(LD_IMGS), 0, c->stream, (float*)c->P, (const float*)c->Pp, (float*)c->dP, c->label, c->NTp, alpha_dev, c->scal + SC_CONV, c->partials, c->nl(), c->target());
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(768), 0, c->stream, c->partials, nblk, scal_out);
     HIPCK(c, hipGetLastError());
     return 0;

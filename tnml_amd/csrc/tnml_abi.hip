@@ -120,6 +120,8 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     if (cfg->NT_local < 1 || cfg->maxm < 1) return tnml_fail(nullptr, "tnml_create: NT_local and maxm must be positive");
     if (cfg->dtype != TNML_F32 && cfg->dtype != TNML_F64 && cfg->dtype != TNML_F64_E32) return tnml_fail(nullptr, "tnml_create: dtype must be TNML_F64, TNML_F64_E32 or TNML_F32");
     if (cfg->nranks < 1 || cfg->rank < 0 || cfg->rank >= cfg->nranks) return tnml_fail(nullptr, "tnml_create: bad rank/nranks");
+    if (cfg->mode != TNML_MODE_FIXEDL && cfg->mode != TNML_MODE_SINGLE) return tnml_fail(nullptr, "tnml_create: mode must be TNML_MODE_FIXEDL or TNML_MODE_SINGLE");
+    if (cfg->mode == TNML_MODE_SINGLE && (cfg->target_label < 0 || cfg->target_label >= TNML_NL)) return tnml_fail(nullptr, "tnml_create: target_label must be in 0..9");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return tnml_fail(nullptr, "tnml_create: no HIP device available (the HIP path is the only path; there is no CPU fallback)");
@@ -127,7 +129,8 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     if (hipSetDevice(cfg->device) != hipSuccess) return tnml_fail(nullptr, "tnml_create: hipSetDevice failed");
     tnml_ctx* c = new tnml_ctx();
     c->cfg = *cfg;
-    c->N = cfg->N; c->NT = cfg->NT_local; c->maxm = cfg->maxm; c->c0 = cfg->N / 2;      // fixedL.cc:616
+    c->N = cfg->N; c->NT = cfg->NT_local; c->maxm = cfg->maxm;
+    c->c0 = cfg->mode == TNML_MODE_SINGLE ? -1 : cfg->N / 2;      // fixedL.cc:616; no Label site in the per-label variant
     c->NTp = (cfg->NT_local + TNML_NTPAD - 1) / TNML_NTPAD * TNML_NTPAD;
     int rc = 0;
     auto bail = [&](int r) { g_create_err = c->err; tnml_destroy(c); return r; };
@@ -289,6 +292,7 @@ int tnml_set_data_phi(tnml_ctx* c, const double* phi, const int32_t* labels) {
 // ---- weight MPS replica -------------------------------------------------------------------------
 int tnml_set_site(tnml_ctx* c, int j, int ml, int mr, int has_label, const double* A) {
     if (j < 1 || j > c->N) return tnml_fail(c, "tnml_set_site: site %d out of range", j);
+    if (c->single() && has_label) return tnml_fail(c, "tnml_set_site: the per-label variant has no Label index");
     if ((j == c->c0) != (has_label != 0)) return tnml_fail(c, "Label Index not on site %d", c->c0);     // fixedL.cc:734
     if (ml < 1 || mr < 1 || ml > c->maxm || mr > c->maxm) return tnml_fail(c, "tnml_set_site: bond dimension outside 1..maxm");
     if ((j == 1 && ml != 1) || (j == c->N && mr != 1)) return tnml_fail(c, "tnml_set_site: edge sites must have outer dimension 1");
@@ -446,7 +450,7 @@ int tnml_classify(tnml_ctx* c, double* weights, int32_t* pred, int64_t count[TNM
     for (int k = 0; k < 3 && !rc; ++k) rc = slot_acquire(c, buf[k], c->maxm, 1);
     auto give_back = [&]() { for (auto& b : buf) slot_release(c, b); };
     if (rc) { give_back(); return rc; }
-    const int cs = c->c0;
+    const int cs = c->single() ? 1 : c->c0;                // per-label variant: site 1 plays the centre, no left chain
     // right chain N -> c+1 (util.h:25-29), ping-pong between buf[0] and buf[1]
     const void* R = nullptr; int cur = 0;
     for (int j = c->N; j > cs && !rc; --j) { rc = shift_core(c, j, false, R, 1, buf[cur].ptr, false, nullptr); R = buf[cur].ptr; cur ^= 1; }
@@ -459,7 +463,7 @@ int tnml_classify(tnml_ctx* c, double* weights, int32_t* pred, int64_t count[TNM
     if (!rc) {
         LdotArgs a;
         a.A = c->U; a.A_lstride = (size_t)c->W[cs].mr * c->NTp; a.Bv = R; a.a_is_env = 0;
-        a.mq = c->W[cs].mr; a.NTp = c->NTp; a.label = c->label;
+        a.mq = c->W[cs].mr; a.NTp = c->NTp; a.label = c->label; a.nl = c->nl(); a.target = c->target();
         a.P = c->P; a.dP = nullptr; a.mode = LD_MODE_COST;
         rc = launch_labeldot(c, a, tail);
     }
@@ -473,18 +477,27 @@ int tnml_classify(tnml_ctx* c, double* weights, int32_t* pred, int64_t count[TNM
     HIPCK(c, hipMemsetAsync(tail, 0, sizeof(double) * TNML_NSCAL_AR, c->stream));
     if (count) for (int l = 0; l < TNML_NL; ++l) count[l] = 0;
     if (nincorrect) for (int l = 0; l < TNML_NL; ++l) nincorrect[l] = 0;
+    const int nl = c->nl();
     for (int i = 0; i < c->NT; ++i) {
         double w[TNML_NL];
-        for (int l = 0; l < TNML_NL; ++l) {
+        for (int l = 0; l < nl; ++l) {
             const size_t k = (size_t)l * c->NTp + i;
             w[l] = c->f64() ? ((const double*)h.data())[k] : (double)((const float*)h.data())[k];
-            if (weights) weights[(size_t)i * TNML_NL + l] = w[l];
+            if (weights) weights[(size_t)i * nl + l] = w[l];
         }
-        int pl = 0; double best = std::fabs(w[0]);                 // argmax of |W_l|, first maximum (util.h:42-57,160-163)
-        for (int l = 1; l < TNML_NL; ++l) if (std::fabs(w[l]) > best) { best = std::fabs(w[l]); pl = l; }
-        if (pred) pred[i] = pl;
+        bool wrong;
+        if (c->single()) {                                         // decision function f(x): pred = [f > 1/2]
+            const int pl = w[0] > 0.5 ? 1 : 0;
+            if (pred) pred[i] = pl;
+            wrong = pl != (lab[i] == c->target() ? 1 : 0);
+        } else {
+            int pl = 0; double best = std::fabs(w[0]);             // argmax of |W_l|, first maximum (util.h:42-57,160-163)
+            for (int l = 1; l < TNML_NL; ++l) if (std::fabs(w[l]) > best) { best = std::fabs(w[l]); pl = l; }
+            if (pred) pred[i] = pl;
+            wrong = pl != lab[i];
+        }
         if (count) count[lab[i]] += 1;
-        if (nincorrect && pl != lab[i]) nincorrect[lab[i]] += 1;
+        if (nincorrect && wrong) nincorrect[lab[i]] += 1;
     }
     return 0;
 }
@@ -514,7 +527,9 @@ int tnml_set_bond(tnml_ctx* c, int b) {
     const bool onB = (c->c0 == b || c->c0 == b + 1);
     const void* LE = useL ? c->env[lc].ptr : c->ones;
     const void* RE = useR ? c->env[rc].ptr : c->ones;
-    if (onB) {
+    if (c->single()) {          // single.h:581-596: no Label anywhere; runs the "Label on B" kernels with a label extent of 1
+        p.kind = 2; p.LB = 1; p.mI = p.mL; p.mO = p.mR; p.EI = LE; p.phiI = phi_site(c, b); p.EX = RE; p.phiO = phi_site(c, b + 1);
+    } else if (onB) {
         if (LL != 1 || LR != 1) return tnml_fail(c, "setBond: Label index on an environment and on B at bond %d", b);
         p.kind = 2; p.LB = TNML_NL; p.mI = p.mL; p.mO = p.mR; p.EI = LE; p.phiI = phi_site(c, b); p.EX = RE; p.phiO = phi_site(c, b + 1);
     } else if (LR == TNML_NL && LL == 1) {
@@ -573,7 +588,7 @@ static int forward_pass(tnml_ctx* c, const double* vec, int mode, double* tail, 
     LdotArgs a;
     if (p.kind == 2) { a.A = c->U; a.A_lstride = ustride; a.Bv = p.EX; a.a_is_env = 0; }
     else             { a.A = p.EX; a.A_lstride = ustride; a.Bv = c->U; a.a_is_env = 1; }
-    a.mq = p.mO; a.NTp = c->NTp; a.label = c->label;
+    a.mq = p.mO; a.NTp = c->NTp; a.label = c->label; a.nl = c->nl(); a.target = c->target();
     a.P = want_P ? (mode == LD_MODE_PAP ? c->Pp : c->P) : nullptr; a.dP = (mode == LD_MODE_PAP) ? nullptr : c->dP; a.mode = mode;
     return launch_labeldot(c, a, tail);
 }
@@ -622,7 +637,7 @@ static int cgrad_device(tnml_ctx* c, int npass, double lambda, double cconv) {
     const size_t n = c->plan.msize();
     HIPCK(c, hipMemsetAsync(c->cgtrace, 0, sizeof(double) * 4 * TNML_MAX_PASS, c->stream));
     TCK(grad_eval(c));                                   // :374-385
-    TCK(launch_cg_init(c, n, lambda));                   // :386-388
+    TCK(launch_cg_init(c, n, lambda, c->single() ? cconv : -1.));   // :386-388 (single.h:200-208 with the entry check)
     for (int pass = 1; pass <= npass; ++pass) {          // :389
         TCK(forward_pass(c, c->vP, LD_MODE_PAP, c->vG + n, c->fast_cg));   // :394-401 (keeps p*t.v for the fast update)
         TCK(allreduce(c, c->vG + n, TNML_NSCAL_AR));                  // :402
@@ -644,7 +659,7 @@ static int cgrad_fetch_trace(tnml_ctx* c, int npass, tnml_cg_trace* tr) {
     HIPCK(c, hipStreamSynchronize(c->stream));
     const int done = (int)llround(hp[SC_NPASS]);
     tr->npass_done = done;
-    tr->converged = hp[SC_CONV] != 0.;
+    tr->converged = (int)llround(hp[SC_CONV]);
     for (int p = 0; p < done && p < npass; ++p) {
         const double* t = hp + SC_N + 4 * p;
         tr->pAp[p] = t[0]; tr->alpha[p] = t[1]; tr->cost[p] = t[2]; tr->rnorm[p] = t[3];
@@ -661,6 +676,7 @@ static int quadcost_device(tnml_ctx* c, double lambda, double* cost, double* lab
     double t[13];
     TCK(read_scal(c, tail, 13, t));
     const double bn2 = t[12];
+    c->last_bnorm = std::sqrt(bn2);
     const double CR = lambda * bn2;                       // :329
     double C = 0.;
     for (int l = 0; l < TNML_NL; ++l) { if (label_cost) label_cost[l] = t[l]; C += t[l]; }   // :331-336
@@ -695,9 +711,10 @@ int tnml_forward(tnml_ctx* c, const double* B, double* P) {
     std::vector<char> h(ne * c->esz());
     HIPCK(c, hipStreamSynchronize(c->stream));
     HIPCK(c, hipMemcpy(h.data(), c->P, h.size(), hipMemcpyDeviceToHost));
+    const int nl = c->nl();                                // [NT][10], or [NT] in the per-label variant
     for (int i = 0; i < c->NT; ++i)
-        for (int l = 0; l < TNML_NL; ++l)
-            P[(size_t)i * TNML_NL + l] = c->f64() ? ((const double*)h.data())[(size_t)l * c->NTp + i] : (double)((const float*)h.data())[(size_t)l * c->NTp + i];
+        for (int l = 0; l < nl; ++l)
+            P[(size_t)i * nl + l] = c->f64() ? ((const double*)h.data())[(size_t)l * c->NTp + i] : (double)((const float*)h.data())[(size_t)l * c->NTp + i];
     return 0;
 }
 int tnml_gradient(tnml_ctx* c, const double* B, double* G) {
@@ -744,7 +761,12 @@ int tnml_bond_update(tnml_ctx* c, int b, int ha, const tnml_sweep_params* sp, tn
     const PackDesc pd = bond_pack_desc(p);
     TCK(launch_bond_form(c, c->W[b], c->W[b + 1], c->tB));            // :494
     TCK(launch_pack(c, pd, c->tB, c->vB, nullptr));
+    if (sp->report_costs) {                                           // single.h:572,621: norm(oB), quadcost(oB)
+        TCK(quadcost_device(c, sp->lambda_cost, &rep->cost_old, nullptr, nullptr, nullptr, false));
+        rep->norm_oB = c->last_bnorm;
+    }
     TCK(cgrad_device(c, sp->npass, sp->lambda, sp->cconv));           // :504 (trace fetched with the SVD's own sync)
+    if (sp->report_costs) TCK(quadcost_device(c, sp->lambda_cost, &rep->cost_cg, nullptr, &rep->reg_cost_cg, nullptr, false));   // single.h:622,626
     TCK(launch_unpack(c, pd, c->vB, c->tB));
     TCK(cgrad_fetch_trace(c, sp->npass, &rep->cg));
     TCK(svd_split_device(c, c->tB, b, ha, sp->cutoff, sp->maxm, sp->minm, &rep->truncerr, &rep->newm, nullptr, nullptr));   // :519-522

@@ -108,7 +108,10 @@ struct tnml_ctx {
     void* slab = nullptr;      // split-K partial slabs
     size_t slab_bytes = 0;
     bool f64() const { return cfg.dtype != TNML_F32; }                 // fp64 MFMA arithmetic
-    bool env64() const { return cfg.dtype == TNML_F64; }        // fp64 environment / feature storage
+    bool env64() const { return cfg.dtype == TNML_F64; }
+    bool single() const { return cfg.mode == TNML_MODE_SINGLE; }
+    int nl() const { return single() ? 1 : TNML_NL; }
+    int target() const { return single() ? cfg.target_label : -1; }        // fp64 environment / feature storage
     size_t esz() const { return f64() ? 8 : 4; }
     size_t eesz() const { return env64() ? 8 : 4; }
     double* partials = nullptr;  // [nblk][16]
@@ -127,6 +130,7 @@ struct tnml_ctx {
     double *sW = nullptr, *sScr = nullptr, *sS = nullptr, *sCm = nullptr, *sQ1 = nullptr, *sDev = nullptr;   // own tridiagonal eigensolver + Newton-Schulz polish
     double svd_last_dev0 = 0., svd_last_dev1 = 0.;   // max|Q^T Q - I| before the 1st / 2nd polish step of the last split
     long svd_fallbacks = 0, svd_cholqr = 0;
+    double last_bnorm = 0.;         // |B| of the last quadcost
     int* sInfo = nullptr;
     int svd_n = 0;
 
@@ -205,6 +209,8 @@ struct LdotArgs {
     const void* A; size_t A_lstride;    // label-carrying operand [10][mq][NTp] (elements)
     const void* Bv;                     // label-free operand [mq][NTp]
     int a_is_env;                       // 1: A is an fp32 environment and Bv the GEMM output; 0: the reverse
+    int nl = TNML_NL;                   // label extent actually present (1 in TNML_MODE_SINGLE)
+    int target = -1;                    // TNML_MODE_SINGLE: y_n = [label_n == target]; -1: targets delta_{l,label_n}
     int mq, NTp;
     const int* label;
     void* P; void* dP;                  // [10][NTp] in the context's arithmetic type
@@ -212,7 +218,7 @@ struct LdotArgs {
 };
 // partial sums -> scal_out[0..11] (device); deterministic
 int launch_labeldot(tnml_ctx* c, const LdotArgs& a, double* scal_out);
-int launch_pupdate(tnml_ctx* c, const double* alpha_dev, double* scal_out);
+int launch_pupdate(tnml_ctx* c, const double* alpha_dev, double* scal_out);     // uses c->nl(), c->target()
 int launch_zprime(tnml_ctx* c, const void* EL, size_t lstride, const void* dP, void* Z, int mq, int NTp);
 int launch_features_u8(tnml_ctx* c, const uint8_t* d_pix, int N, int NT, int NTp, void* phi);
 
@@ -227,7 +233,7 @@ int launch_unpack(tnml_ctx* c, const PackDesc& d, const double* Md, double* T);
 int launch_cvt(tnml_ctx* c, const double* src, float* dst, size_t n);
 int launch_bond_form(tnml_ctx* c, const SiteT& A1, const SiteT& A2, double* B);            // B = A1*A2, ITensor layout
 // CG vector algebra on device scalars (single-block kernels)
-int launch_cg_init(tnml_ctx* c, size_t n, double lambda);          // r = G - lambda B ; p = r ; RR = |r|^2
+int launch_cg_init(tnml_ctx* c, size_t n, double lambda, double cconv0);   // cconv0 < 0: no entry check          // r = G - lambda B ; p = r ; RR = |r|^2
 int launch_cg_step(tnml_ctx* c, size_t n, double lambda, int pass);          // pAp, alpha, B += alpha p
 int launch_cg_resid(tnml_ctx* c, size_t n, double lambda, double cconv, int pass);   // nr, beta, r, cost, conv, p
 int launch_sqnorm(tnml_ctx* c, const double* x, size_t n, double* out);    // out[0] = |x|^2

@@ -24,18 +24,23 @@ class TnmlError(RuntimeError):
 class TrainStates:
     """Training set + environments + W replica of one rank (TrainStates + MPS W of fixedL.cc)."""
 
-    def __init__(self, labels, N, maxm, pixels=None, phi=None, device=0, rank=0, nranks=1, NT_total=None, dtype="f64"):
+    def __init__(self, labels, N, maxm, pixels=None, phi=None, device=0, rank=0, nranks=1, NT_total=None, dtype="f64",
+                 single_label=None):
+        """single_label = L selects the per-label variant (single.cc): plain weight MPS, target y_n = [l_n == L]"""
         self._L = _lib.load()
         self._h = C.c_void_p()
         labels = np.ascontiguousarray(labels, dtype=np.int32)
         self.NT = int(labels.shape[0])
         self.N = int(N)
-        self.c0 = self.N // 2
+        self.single = single_label is not None
+        self.c0 = -1 if self.single else self.N // 2
+        self.nl = 1 if self.single else NL
         self.maxm = int(maxm)
         self.rank, self.nranks = rank, nranks
         self.NT_total = int(NT_total if NT_total is not None else self.NT)
         self.dtype = dtype
-        cfg = _lib.Config(device, rank, nranks, self.N, self.NT, self.NT_total, self.maxm, _lib.DTYPES[dtype], 0)
+        cfg = _lib.Config(device, rank, nranks, self.N, self.NT, self.NT_total, self.maxm, _lib.DTYPES[dtype], 0,
+                          1 if self.single else 0, int(single_label) if self.single else 0)
         rc = self._L.tnml_create(C.byref(self._h), C.byref(cfg))
         if rc != 0:
             self._h = C.c_void_p()
@@ -96,7 +101,7 @@ class TrainStates:
     def classify(self):
         """toverlap / fullTest (util.h:19-40,123-200) over the local images: returns (weights[NT,10], pred[NT],
         count[10], nincorrect[10])."""
-        w = np.zeros((self.NT, 10))
+        w = np.zeros((self.NT, self.nl))
         pred = np.zeros(self.NT, dtype=np.int32)
         cnt = np.zeros(10, dtype=np.int64)
         ninc = np.zeros(10, dtype=np.int64)
@@ -154,9 +159,9 @@ class TrainStates:
         return buf.reshape(shape, order="F")
 
     def forward(self, B):
-        P = np.empty((self.NT, NL))
+        P = np.empty((self.NT, self.nl))
         self._ck(self._L.tnml_forward(self._h, _lib.dptr(_lib.flat(B)), _lib.dptr(P)))
-        return P
+        return P[:, 0] if self.single else P
 
     def gradient(self, B):
         G = np.empty(B.size)
@@ -183,14 +188,14 @@ class TrainStates:
                                         C.byref(m), _lib.dptr(sv), C.byref(nsv)))
         return m.value, te.value, sv[:nsv.value].copy()
 
-    def bond_update(self, b, ha, maxm, minm, cutoff, npass, lam, cconv, lam_cost=None):
-        sp = _lib.SweepParams(maxm, minm, cutoff, npass, lam, lam if lam_cost is None else lam_cost, cconv)
+    def bond_update(self, b, ha, maxm, minm, cutoff, npass, lam, cconv, lam_cost=None, report_costs=False):
+        sp = _lib.SweepParams(maxm, minm, cutoff, npass, lam, lam if lam_cost is None else lam_cost, cconv, int(report_costs))
         rep = _lib.BondReport()
         self._ck(self._L.tnml_bond_update(self._h, b, ha, C.byref(sp), C.byref(rep)))
         return dict(bond=rep.bond, half=rep.half, c=rep.c, mL=rep.mL, mR=rep.mR, label_on_B=bool(rep.label_on_B), origm=rep.origm, newm=rep.newm, truncerr=rep.truncerr,
                     norm_newB=rep.norm_newB, diff=rep.diff_B_newB, cost=rep.cost_after_svd,
                     label_cost=np.array(rep.label_cost[:]), reg_cost=rep.reg_cost, ncorrect=rep.ncorrect,
-                    cg=_trace_dict(rep.cg))
+                    cg=_trace_dict(rep.cg), cost_old=rep.cost_old, cost_cg=rep.cost_cg, reg_cost_cg=rep.reg_cost_cg, norm_oB=rep.norm_oB)
 
     # -- measurement
     def profile(self, on, only=None):
@@ -214,7 +219,7 @@ class TrainStates:
 def _trace_dict(tr):
     n = tr.npass_done
     k = n if tr.converged else max(n - 1, 0)
-    return dict(npass_done=n, converged=bool(tr.converged), cost=list(tr.cost[:k]), rnorm=list(tr.rnorm[:k]),
+    return dict(npass_done=n, converged=bool(tr.converged), skipped=tr.converged == 2, cost=list(tr.cost[:k]), rnorm=list(tr.rnorm[:k]),
                 pAp=list(tr.pAp[:n]), alpha=list(tr.alpha[:n]))
 
 
@@ -228,8 +233,9 @@ def cgrad(B, ts, npass=4, lam=0.0, cconv=1e-10):
     return ts.cgrad(B, npass, lam, cconv)
 
 
-def mldmrg(ts, nsweep, maxm, minm, cutoff, npass, lam, cconv, max_bonds=0, log=None):
-    """fixedL.cc:451-570: the sweep loop; emits the reference's log lines through `log` if given."""
+def mldmrg(ts, nsweep, maxm, minm, cutoff, npass, lam, cconv, max_bonds=0, log=None, report_costs=False):
+    """fixedL.cc:451-570 (single.h:523-728 for a per-label TrainStates): the sweep loop; emits the reference's log lines
+    through `log` if given."""
     NT = float(ts.NT_total)
     reports = []
     for sw in range(1, nsweep + 1):
@@ -239,7 +245,7 @@ def mldmrg(ts, nsweep, maxm, minm, cutoff, npass, lam, cconv, max_bonds=0, log=N
         while ha <= 2:
             if max_bonds and len(reports) >= max_bonds:
                 return reports
-            r = ts.bond_update(b, ha, maxm, minm, cutoff, npass, lam, cconv)
+            r = ts.bond_update(b, ha, maxm, minm, cutoff, npass, lam, cconv, report_costs=report_costs or ts.single)
             r["sweep"] = sw
             reports.append(r)
             if log:

@@ -140,7 +140,7 @@ int main(int argc, const char* argv[]) {
         for (long sw = 1; sw <= Nsweep; ++sw) {                                         // mldmrg, :470
             std::printf("\nSweep %ld maxm=%ld minm=%ld\n", sw, maxm, minm);            // :472
             for (int b = 1, ha = 1; ha <= 2; tnml_sweepnext(&b, &ha, N)) {              // :478
-                tnml_sweep_params sp{(int)std::min<long>(maxm, cfg.maxm), (int)minm, cutoff, (int)Npass, lambda, lambda_cost, cconv};
+                tnml_sweep_params sp{(int)std::min<long>(maxm, cfg.maxm), (int)minm, cutoff, (int)Npass, lambda, lambda_cost, cconv, 0};
                 tnml_bond_report r;
                 CK(ctx, tnml_bond_update(ctx, b, ha, &sp, &r));
                 std::printf("Sweep %ld Half %d Bond %d\n", sw, ha, r.c);                // :490

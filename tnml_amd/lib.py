@@ -32,7 +32,7 @@ EXPORTS = [
 class Config(C.Structure):
     _fields_ = [("device", C.c_int), ("rank", C.c_int), ("nranks", C.c_int), ("N", C.c_int),
                 ("NT_local", C.c_int), ("NT_total", C.c_int64), ("maxm", C.c_int), ("dtype", C.c_int),
-                ("svd_backend", C.c_int)]
+                ("svd_backend", C.c_int), ("mode", C.c_int), ("target_label", C.c_int)]
 
 
 class CgTrace(C.Structure):
@@ -42,7 +42,7 @@ class CgTrace(C.Structure):
 
 class SweepParams(C.Structure):
     _fields_ = [("maxm", C.c_int), ("minm", C.c_int), ("cutoff", C.c_double), ("npass", C.c_int),
-                ("lambda_", C.c_double), ("lambda_cost", C.c_double), ("cconv", C.c_double)]
+                ("lambda_", C.c_double), ("lambda_cost", C.c_double), ("cconv", C.c_double), ("report_costs", C.c_int)]
 
 
 class BondReport(C.Structure):
@@ -50,7 +50,8 @@ class BondReport(C.Structure):
                 ("label_on_B", C.c_int), ("origm", C.c_int), ("newm", C.c_int),
                 ("truncerr", C.c_double), ("norm_newB", C.c_double), ("diff_B_newB", C.c_double),
                 ("cost_after_svd", C.c_double), ("label_cost", C.c_double * NL), ("reg_cost", C.c_double),
-                ("ncorrect", C.c_int64), ("cg", CgTrace)]
+                ("ncorrect", C.c_int64), ("cg", CgTrace), ("cost_old", C.c_double), ("cost_cg", C.c_double),
+                ("reg_cost_cg", C.c_double), ("norm_oB", C.c_double)]
 
 
 _lib = None
