@@ -596,3 +596,73 @@ def test_single_full_sweeps_and_decision_function(normal):
     y = (np.asarray(o.labels) == 7)
     np.testing.assert_array_equal(pred, (f_or > 0.5).astype(np.int32))
     assert int(ninc.sum()) == int(((f_or > 0.5) != y).sum())
+
+
+def test_single_and_separate_fulltest_cli(tmp_path):
+    """the C++ `single <inputfile>` driver for all ten labels and `separate_fulltest` on the resulting L<n>/W<n> files,
+    against the oracle started from the same initial W and image order (labels round-robin, single.cc:156-181)"""
+    import os
+    import re
+    import subprocess
+    from oracle import pyoracle
+    from tnml_amd import hostlib, synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    N, per_label = 16, 16
+    labels = synth.synthetic_labels(10 * per_label, seed=6, per_label=per_label)
+    tl = synth.synthetic_labels(120, seed=23)
+    allpx = np.clip(synth.synthetic_images(N, np.concatenate([labels, tl]), seed=6).astype(np.int32) * 3, 0, 255).astype(np.uint8)
+    pixels, tp = allpx[:len(labels)], allpx[len(labels):]
+    data = str(tmp_path / "data")
+    synth.write_idx(data, pixels, labels)
+    synth.write_idx(data, tp, tl, train=False)
+    keys = "datadir = %s\nfeature_scale = 1\n" % data
+    # the image order of the driver: label 0's first image, label 1's first image, ...
+    px, lab, _ = hostlib.read_mnist(data, True, per_label)
+    by = [list(np.flatnonzero(lab == l)) for l in range(10)]
+    order = [by[l][k] for k in range(per_label) for l in range(10)]
+    phi = pyoracle.features_single(px[order], True)
+    for L in range(10):
+        wd = tmp_path / ("L%d" % L)
+        wd.mkdir()
+        inp = wd / "input"
+        inp.write_text("input\n{\n%slabel = %d\nNtrain = %d\nNsweep = 1\ncutoff = 1E-10\nmaxm = 5\nminm = 2\nninitial = 3\n"
+                       "lambda = 1E-3\nNpass = 3\nseed = 4\nnthread = 2\n}\n" % (keys, L, per_label))
+        run = subprocess.run([os.path.join(root, "tnml_amd", "single"), str(inp)], capture_output=True, text=True, cwd=wd, timeout=300)
+        assert run.returncode == 0, run.stdout[-1500:] + run.stderr[-1500:]
+        assert os.path.exists(wd / ("W%d" % L)) and "%d training images with selected label L=%d" % (per_label, L) in run.stdout
+        if L in (3, 8):                                     # full trajectory check on two of the ten
+            w0 = str(tmp_path / ("W0ref%d" % L))
+            hostlib.build_initial_single(data, per_label, L, 3, 4, True, w0)
+            o = pyoracle.SingleOracle(phi, lab[order], L, hostlib.read_mps(w0))
+            o.init()
+            ro = o.mldmrg(1, 5, 2, 1e-10, 3, 1e-3, 1e-10)
+            c_old = [float(a) for a, _ in re.findall(r"Cost = ([0-9.eE+-]+) --> ([0-9.eE+-]+)", run.stdout)]
+            c_cg = [float(b) for _, b in re.findall(r"Cost = ([0-9.eE+-]+) --> ([0-9.eE+-]+)", run.stdout)]
+            c_svd = [float(x) for x in re.findall(r"--> After SVD, Cost = ([0-9.eE+-]+) \(", run.stdout)]
+            newm = [int(x) for x in re.findall(r"New m=(\d+)", run.stdout)]
+            assert len(c_svd) == len(ro) == 2 * (N - 1)
+            nt = float(len(lab))
+            np.testing.assert_allclose(c_old, [r["cost_old"] / nt for r in ro], rtol=2e-5, atol=2e-10)
+            np.testing.assert_allclose(c_cg, [r["cost_cg"] / nt for r in ro], rtol=2e-5, atol=2e-10)
+            np.testing.assert_allclose(c_svd, [r["cost"] / nt for r in ro], rtol=2e-5, atol=2e-10)
+            assert all(abs(a - r["newm"]) <= 1 for a, r in zip(newm, ro))
+            m0 = re.search(r"Before DMRG, Cost = ([0-9.eE+-]+)", run.stdout)
+            assert m0 and float(m0.group(1)) == pytest.approx(ro[0]["cost_old"] / per_label, rel=1e-6)   # divides by the Ntrain key (single.cc:218)
+    # evaluator on the ten weight files
+    (tmp_path / "sites").write_bytes((tmp_path / "L0" / "sites").read_bytes())
+    tin = tmp_path / "input_test"
+    tin.write_text("input\n{\n%simglen = 4\n}\n" % keys)
+    run = subprocess.run([os.path.join(root, "tnml_amd", "separate_fulltest"), str(tin)], capture_output=True, text=True, cwd=tmp_path, timeout=300)
+    assert run.returncode == 0, run.stdout[-1500:] + run.stderr[-1500:]
+    phit = pyoracle.features_single(tp, True)
+    O = np.zeros((10, len(tl)))
+    for L in range(10):
+        oo = pyoracle.SingleOracle(phit, tl, L, hostlib.read_mps(str(tmp_path / ("L%d" % L) / ("W%d" % L))))
+        O[L] = [oo.output(i) for i in range(len(tl))]
+    pred = np.abs(O).argmax(axis=0)
+    m = re.search(r"(\d+)/(\d+) correct", run.stdout)
+    assert m and int(m.group(2)) == len(tl) and int(m.group(1)) == int((pred == tl).sum())
+    costs = [float(x) for x in re.findall(r"Digit \d C = ([0-9.eE+-]+)", run.stdout)]
+    ref = [float(np.sum((O[n] - (tl == n)) ** 2)) for n in range(10)]
+    np.testing.assert_allclose(costs, ref, rtol=1e-8)
+    assert float(re.search(r"Total C = ([0-9.eE+-]+)", run.stdout).group(1)) == pytest.approx(sum(ref), rel=1e-8)

@@ -129,3 +129,35 @@ def test_block_mean_reduce():
     np.testing.assert_array_equal(hostlib.reduce(px, 28, 28), px.astype(np.float64))
     with pytest.raises(RuntimeError):
         hostlib.reduce(px, 28, 29)
+
+
+def test_initial_w_of_the_per_label_variant(tmp_path):
+    """single.cc:112-128: normalised sum of product states of the selected label, orthogonality centre on site 1"""
+    from tnml_amd import hostlib, synth
+    N, per_label = 16, 12
+    labels = synth.synthetic_labels(10 * per_label, seed=3, per_label=per_label)
+    pixels = np.clip(synth.synthetic_images(N, labels, seed=3).astype(np.int32) * 3, 0, 255).astype(np.uint8)
+    data = str(tmp_path / "data")
+    synth.write_idx(data, pixels, labels)
+    out = str(tmp_path / "W4")
+    hostlib.build_initial_single(data, per_label, 4, 5, 7, True, out)
+    W = hostlib.read_mps(out)
+    assert len(W) == N and all(A.ndim == 3 for A in W) and max(max(A.shape[0], A.shape[2]) for A in W) <= 10
+    # norm 1, and sites 2..N right-orthonormal (centre on site 1)
+    E = np.ones((1, 1))
+    for A in W:
+        E = np.einsum('ab,asr,bsq->rq', E, A, A)
+    assert E[0, 0] == pytest.approx(1.0, rel=1e-10)
+    for A in W[1:]:
+        M = A.reshape(A.shape[0], -1)
+        np.testing.assert_allclose(M @ M.T, np.eye(A.shape[0]), atol=1e-10)
+    # it is a combination of label-4 product states: its overlap with a label-4 image exceeds that with the others on average
+    from oracle import pyoracle
+    phi = pyoracle.features_single(pixels, True)
+    o = pyoracle.SingleOracle(phi, labels, 4, W)
+    f = np.array([o.output(i) for i in range(len(labels))])
+    assert np.abs(f[labels == 4]).mean() >= np.abs(f[labels != 4]).mean()
+    # deterministic in the seed
+    out2 = str(tmp_path / "W4b")
+    hostlib.build_initial_single(data, per_label, 4, 5, 7, True, out2)
+    assert all(np.array_equal(a, b) for a, b in zip(W, hostlib.read_mps(out2)))

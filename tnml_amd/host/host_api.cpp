@@ -56,6 +56,16 @@ int tnmlh_build_initial_w(const char* datadir, long nt_per_label, int ninitial, 
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
+// initial W of the per-label variant (single.cc:112-128) -> file `out`
+int tnmlh_build_initial_single(const char* datadir, long nt_per_label, int label, int ninitial, unsigned long long seed, int normal,
+                               const char* out, int imglen, double feature_scale) {
+    try {
+        Dataset d = read_mnist(datadir, true, nt_per_label);
+        if (imglen > 0) reduce(d, imglen);
+        write_mps(out, build_initial_single(d, label, ninitial, seed, normal != 0, feature_scale));
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
 // weight file access: dims of site j, then its data (column-major [ml][2][mr][L])
 int tnmlh_mps_info(const char* file, int* N, int* c0) {
     try { HostMPS W = read_mps(file); *N = W.N; *c0 = W.c0; return 0; } catch (const std::exception& e) { g_err = e.what(); return -1; }

@@ -149,7 +149,7 @@ inline double overlap(const HostMPS& x, const HostMPS& y) {
 }
 // orthogonalise from the right (QR by SVD without truncation), then truncate left to right with
 // (cutoff, maxm): the "orthogonalize(args)" step behind ITensor's sum(psis,args)
-inline void compress(HostMPS& psi, double cutoff, int maxm) {
+inline void compress(HostMPS& psi, double cutoff, int maxm, bool center_first = false) {
     const int N = psi.N;
     auto split = [&](int j, bool to_left, bool trunc) {
         // to_left: A_j = (U S)(V^T): A_j <- V^T (right-orthonormal), A_{j-1} <- A_{j-1} U S
@@ -194,6 +194,7 @@ inline void compress(HostMPS& psi, double cutoff, int maxm) {
     };
     for (int j = N; j >= 2; --j) split(j, true, false);
     for (int j = 1; j <= N - 1; ++j) split(j, false, true);
+    if (center_first) for (int j = N; j >= 2; --j) split(j, true, false);      // W.position(1): orthogonality centre back to site 1
 }
 inline double norm_site(const Site& s) { double n2 = 0.; for (double v : s.a) n2 += v * v; return std::sqrt(n2); }
 

@@ -55,6 +55,26 @@ inline HostMPS sum_truncated(const std::vector<HostMPS>& v, double cutoff, int m
     return acc;
 }
 
+// single.cc:112-128: W = sum of `ninitial` random product states of label `label` (Cutoff 1E-10, Maxm 10), orthogonalised,
+// normalised, orthogonality centre on site 1 (W.position(1,...) is then a no-op)
+inline HostMPS build_initial_single(const Dataset& train, int label, int ninitial, uint64_t seed, bool normal, double feature_scale = 1.) {
+    const int N = train.npix();
+    std::mt19937_64 rng(seed);
+    std::vector<HostMPS> psis;
+    std::vector<double> phi;
+    for (int m = 0; m < ninitial; ++m) {
+        const int w = rand_img(train, label, rng);
+        if (normal) features_normal(train, w, phi); else features_series(train, w, phi, feature_scale);
+        psis.push_back(product_state(N, phi.data()));                     // :119
+    }
+    HostMPS W = psis.at(0);
+    for (size_t k = 1; k < psis.size(); ++k) { W = add(W, psis[k]); compress(W, 1E-10, 10, true); }   // :122 sum(psis,{"Cutoff",1E-10,"Maxm",10})
+    if (psis.size() == 1) compress(W, 1E-10, 10, true);                   // :123 orthogonalize
+    const double nrm = norm_site(W.A[1]);                                 // :124 (centre on site 1: norm(A_1) = norm(W))
+    for (double& x : W.A[1].a) x /= nrm;
+    return W;
+}
+
 inline HostMPS build_initial_w(const Dataset& train, int ninitial, uint64_t seed, bool verbose, double feature_scale = 1.) {
     const int N = train.npix();
     std::mt19937_64 rng(seed);

@@ -1,0 +1,199 @@
+// single_main.cpp -- the `single <inputfile>` command line driver of the per-label variant on top of the C-ABI
+// (include/tnml.h, TNML_MODE_SINGLE).
+//
+// Keeps the reference's surface (single.cc:6-244 and the mldmrg of single.h:523-728): input keys, the files `sites`
+// and `W<label>` in the working directory, the `WRITE_WF` hook, the idx-ubyte training set under `datadir`, the
+// image order (labels taken round-robin, single.cc:156-181) and the log lines.  One tnml_bond_update per bond.
+// Not built: method = fast_conj | exact | pinv and the `noise` density-matrix term (single.h:290-517,648-672); they
+// stop with a message.  Extensions (never read by the reference): `seed`, `device`, `precision`, `imglen`,
+// `feature_scale` as in the fixedL driver.
+#include <array>
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "../../include/tnml.h"
+#include "host_mps.h"
+#include "init_w.h"
+#include "input_group.h"
+#include "mnist_idx.h"
+
+using namespace tnmlh;
+
+static void die(tnml_ctx* c, const char* what) { std::fprintf(stderr, "%s: %s\n", what, tnml_last_error(c)); std::exit(1); }
+#define CK(c, call) do { if ((call) != 0) die((c), #call); } while (0)
+
+static HostMPS download(tnml_ctx* ctx, int N) {
+    HostMPS W(N);
+    for (int j = 1; j <= N; ++j) {
+        int ml, mr, hl; CK(ctx, tnml_site_dims(ctx, j, &ml, &mr, &hl));
+        W.A[j] = Site(ml, mr, 1);
+        CK(ctx, tnml_get_site(ctx, j, W.A[j].a.data()));
+    }
+    return W;
+}
+
+int main(int argc, const char* argv[]) {
+    if (argc != 2) { std::printf("Usage: %s inputfile\n", argv[0]); return 0; }       // single.cc:11-15
+    try {
+        InputGroup input(argv[1], "input");
+        const std::string datadir = input.getString("datadir", "/Users/mstoudenmire/software/tnml/mllib/MNIST");
+        const int L = (int)input.getInt("label", 0);
+        const long Ntrain = input.getInt("Ntrain", 60000);
+        const long Nsweep = input.getInt("Nsweep", 50);
+        const double cutoff = input.getReal("cutoff", 1E-8);
+        const long maxm = input.getInt("maxm", 5000);
+        const long minm = input.getInt("minm", std::max(10L, maxm / 2));
+        const double noise = input.getReal("noise", 0.);
+        const long ninitial = input.getInt("ninitial", 100);
+        const long Nthread = input.getInt("nthread", 4);
+        const bool pause_steps = input.getYesNo("pause_steps", false);
+        const std::string feature = input.getString("feature", "normal");
+        bool normal;
+        if (feature == "normal") normal = true; else if (feature == "series") normal = false;
+        else { std::printf("feature=%s not recognized\n", feature.c_str()); return 1; }   // :33-38
+        const double lambda = input.getReal("lambda", 0.);
+        const std::string method = input.getString("method", "conj");
+        (void)input.getReal("alpha", 1.0); (void)input.getReal("clip", 1.0);
+        const long Npass = input.getInt("Npass", 4);
+        const double cconv = input.getReal("cconv", 1E-10);
+        (void)input.getInt("Ntarget", 10); (void)input.getReal("pcut", 1E-8); (void)input.getYesNo("precalc", true);
+        const uint64_t seed = (uint64_t)input.getInt("seed", 1);
+        const int device = (int)input.getInt("device", 0);
+        const std::string precision = input.getString("precision", "f64");
+        const long imglen = input.getInt("imglen", 0);
+        const double feature_scale = input.getReal("feature_scale", 1.);
+        int dtype = TNML_F64;
+        if (precision == "mixed") dtype = TNML_F64_E32; else if (precision == "f32") dtype = TNML_F32;
+        else if (precision != "f64" && precision != "strict") { std::printf("precision must be f64, mixed or f32\n"); return 1; }
+        if (L < 0 || L > 9) { std::printf("label must be in 0..9\n"); return 1; }
+        if (method == "fast_conj" || method == "exact" || method == "pinv") { std::printf("method \"%s\" is not built here (only conj)\n", method.c_str()); return 1; }
+        if (method != "conj") { std::printf("method type \"%s\" not recognized\n", method.c_str()); return 1; }   // single.h:611
+        if (noise >= 1E-14) { std::printf("noise > 0 (density-matrix split, single.h:648-672) is not built here\n"); return 1; }
+
+        char wname[32]; std::snprintf(wname, sizeof wname, "W%d", L);                  // :53
+        Dataset train = read_mnist(datadir, true, Ntrain);                              // :56
+        if (imglen > 0) reduce(train, (int)imglen);
+        const int N = train.npix();
+        std::printf("%d sites\n", N);                                                  // :59
+        if (file_exists("sites")) { int Ns, ds; read_sites("sites", &Ns, &ds); if (Ns != N || ds != 2) { std::printf("Mismatched sizes\n"); return 1; } }
+        else write_sites("sites", N, 2);                                                // :61-69
+        std::printf("Converting training set to MPS\n");                                // :87
+        const int totNtrain = train.size();
+        const int totL = train.counts[L];
+        std::printf("Total of %d training images\n", totNtrain);                        // :101
+        std::printf("%d training images with selected label L=%d\n", totL, L);          // :102
+
+        HostMPS W;
+        if (file_exists(wname)) {                                                       // :106-110
+            std::printf("Reading %s from file\n", wname);
+            W = read_mps(wname);
+            if (W.N != N) { std::printf("Mismatched sizes\n"); return 1; }
+            for (int j = 1; j <= N; ++j) if (W.A[j].L != 1) { std::printf("%s carries a Label index\n", wname); return 1; }
+        } else {
+            std::printf("Summing %ld random label %d states\n", ninitial, L);           // :121
+            W = build_initial_single(train, L, (int)ninitial, seed, normal, feature_scale);
+        }
+        std::printf("Done making initial W\n");                                         // :127
+        std::printf("Thread %d %d -> %d (%d)\n", 0, 0, totNtrain, totNtrain);           // :147-150 (one GPU in place of Nthread threads)
+        (void)Nthread;
+
+        // ts order: labels round-robin, each label's images in file order (single.cc:156-181)
+        std::vector<std::vector<int>> by_label(10);
+        for (int i = 0; i < totNtrain; ++i) by_label[train.labels[i]].push_back(i);
+        std::vector<int> order; order.reserve(totNtrain);
+        {
+            std::array<size_t, 10> ncount{};
+            int nl = 0;
+            for (int k = 0; k < totNtrain; ++k) {
+                int count = 0, pick = -1;
+                while (pick < 0) {
+                    const int l = nl; nl = (nl + 1 == 10) ? 0 : nl + 1;
+                    if (ncount[l] < by_label[l].size()) pick = by_label[l][ncount[l]++];
+                    if (++count > 20 && pick < 0) { std::printf("Infinite loop while setting up ts\n"); return 1; }
+                }
+                order.push_back(pick);
+            }
+        }
+        std::vector<int32_t> labels(totNtrain);
+        std::vector<double> phi((size_t)totNtrain * N * 2), ph;
+        for (int k = 0; k < totNtrain; ++k) {
+            labels[k] = train.labels[order[k]];
+            if (normal) features_normal(train, order[k], ph); else features_series(train, order[k], ph, feature_scale);
+            std::copy(ph.begin(), ph.end(), phi.begin() + (size_t)k * N * 2);
+        }
+        int wm = 1; for (int j = 1; j <= N; ++j) wm = std::max(wm, std::max(W.A[j].ml, W.A[j].mr));
+
+        tnml_config cfg{};
+        cfg.device = device; cfg.rank = 0; cfg.nranks = 1; cfg.N = N; cfg.NT_local = totNtrain; cfg.NT_total = totNtrain;
+        cfg.maxm = (int)std::max<long>(std::min<long>(maxm, 4096), wm); cfg.dtype = dtype; cfg.svd_backend = TNML_SVD_SYEVD;
+        cfg.mode = TNML_MODE_SINGLE; cfg.target_label = L;
+        tnml_ctx* ctx = nullptr;
+        if (tnml_create(&ctx, &cfg) != 0) die(nullptr, "tnml_create");
+        CK(ctx, tnml_set_data_phi(ctx, phi.data(), labels.data()));
+        phi.clear(); phi.shrink_to_fit();
+        for (int j = 1; j <= N; ++j) CK(ctx, tnml_set_site(ctx, j, W.A[j].ml, W.A[j].mr, 0, W.A[j].a.data()));
+        std::printf("Projecting training states..."); std::fflush(stdout);              // :183
+        CK(ctx, tnml_env_init(ctx));                                                    // :184-199
+        std::printf("done\n");
+        {
+            int mL, mR, lab; CK(ctx, tnml_bond_dims(ctx, 1, &mL, &mR, &lab));
+            std::vector<double> B((size_t)mL * 4 * mR);
+            CK(ctx, tnml_bond_tensor(ctx, 1, B.data()));
+            double C;
+            CK(ctx, tnml_quadcost(ctx, B.data(), lambda, &C, nullptr, nullptr, nullptr));   // :217
+            std::printf("Before DMRG, Cost = %.10f\n", C / Ntrain);                     // :218 (divides by the per-label cap, as the reference)
+        }
+        const double NT = (double)totNtrain;                                            // single.h:535 Ntrain = ts.size()
+        for (long sw = 1; sw <= Nsweep; ++sw) {                                         // single.h:546
+            std::printf("Sweep %ld maxm=%ld\n", sw, maxm);                              // :548
+            for (int b = 1, ha = 1; ha <= 2; tnml_sweepnext(&b, &ha, N)) {              // :554
+                tnml_sweep_params sp{(int)std::min<long>(maxm, cfg.maxm), (int)minm, cutoff, (int)Npass, lambda, lambda, cconv, 1};
+                tnml_bond_report r;
+                CK(ctx, tnml_bond_update(ctx, b, ha, &sp, &r));
+                std::printf("Sweep %ld Half %d Bond %d\n", sw, ha, r.c);                // :566
+                std::printf("norm(oB) = %.12g\n", r.norm_oB);                           // :572
+                if (r.cg.converged == 2) std::printf("  |r| < %.1E, not optimizing\n", cconv);   // :204 (|r| itself stays on the device)
+                for (int p = 0; p < r.cg.npass_done; ++p) {
+                    std::printf("  Conj grad pass %d\n", p + 1);                        // :211
+                    const bool has_cost = r.cg.converged ? true : p + 1 < r.cg.npass_done || r.cg.npass_done < Npass;
+                    if (has_cost && (p + 1 < Npass)) {
+                        std::printf("  %d C = %.10f\n", p + 1, r.cg.cost[p] / NT);      // :271
+                        if (r.cg.converged == 1 && p + 1 == r.cg.npass_done) std::printf("  |r| = %.1E < %.1E, breaking\n", r.cg.rnorm[p], cconv);   // :275
+                        else std::printf("  |r| = %.1E\n", r.cg.rnorm[p]);              // :280
+                    }
+                }
+                std::printf("Sweep %ld Half %d Bond %d\n", sw, ha, r.c);                // :618
+                std::printf("Cost = %.10f --> %.10f\n", r.cost_old / NT, r.cost_cg / NT);   // :623
+                if (lambda > 0.) {
+                    std::printf("Reg. cost RC = %.10f (%.10f)\n", r.reg_cost_cg / NT, r.reg_cost_cg);                       // :627
+                    std::printf("Cost - RC = %.10f (%.10f)\n", (r.cost_cg - r.reg_cost_cg) / NT, r.cost_cg - r.reg_cost_cg);   // :628
+                }
+                std::printf("SVD trunc err = %.2E\n", r.truncerr);                      // :646
+                std::printf("Original m=%d, New m=%d\n", r.origm, r.newm);              // :678
+                std::printf("norm(newB) = %.12g\n", r.norm_newB);                       // :681
+                std::printf("--> After SVD, Cost = %.10f (%.10f)\n", r.cost_after_svd / NT, r.cost_after_svd);   // :684
+                if (r.cost_after_svd > 1.1 * r.cost_cg) std::printf("> 10%% larger C after SVD\n");   // :686
+                if (pause_steps) { std::printf("PAUSE"); std::fflush(stdout); std::getchar(); }
+                if (file_exists("WRITE_WF")) {                                          // :712-718
+                    std::printf("File WRITE_WF found\n");
+                    std::remove("WRITE_WF");
+                    std::printf("Writing %s to disk\n", wname);
+                    write_mps(wname, download(ctx, N));
+                }
+                std::fflush(stdout);
+            }
+            std::printf("Writing %s to disk\n", wname);                                 // :722
+            write_mps(wname, download(ctx, N));
+        }
+        std::printf("Writing %s to disk\n", wname);                                     // single.cc:240
+        write_mps(wname, download(ctx, N));
+        tnml_destroy(ctx);
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "Error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

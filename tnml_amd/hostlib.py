@@ -25,6 +25,7 @@ def load():
         L.tnmlh_build_initial_w.argtypes = [C.c_char_p, C.c_long, C.c_int, C.c_ulonglong, C.c_char_p,
                                             C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int, C.c_double]
         L.tnmlh_reduce.argtypes = [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        L.tnmlh_build_initial_single.argtypes = [C.c_char_p, C.c_long, C.c_int, C.c_int, C.c_ulonglong, C.c_int, C.c_char_p, C.c_int, C.c_double]
         L.tnmlh_mps_info.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.tnmlh_mps_site.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                      C.POINTER(C.c_double)]
@@ -107,3 +108,9 @@ def reduce(pixels, side, newlen):
     if load().tnmlh_reduce(pixels.ctypes.data_as(C.POINTER(C.c_ubyte)), n, side, newlen, out.ctypes.data_as(C.POINTER(C.c_double))) != 0:
         raise _err()
     return out
+
+
+def build_initial_single(datadir, nt_per_label, label, ninitial, seed, normal, out, imglen=0, feature_scale=1.0):
+    """initial W of the per-label variant (single.cc:112-128) written to `out`"""
+    if load().tnmlh_build_initial_single(datadir.encode(), nt_per_label, label, ninitial, seed, int(normal), out.encode(), imglen, feature_scale) != 0:
+        raise _err()
