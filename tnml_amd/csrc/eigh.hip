@@ -225,6 +225,189 @@ __global__ __launch_bounds__(512) void k_sytrd_onewg(TriArgs T) {
     }
 }
 
+// ==========================================================================================
+// k_sytrd_v2 -- the same reduction with 8x8 blocks, ONE lane per block (64 doubles in registers), two barriers
+// per Householder step instead of four, and no cross-lane traffic in the matrix-vector product:
+//   A  (every wave, redundantly) Householder scalars and v from the current column in LDS;
+//   B  per block: row sums a*vJ and (off-diagonal blocks) column sums a^T*vI to LDS, the block's share of
+//      v^T A v through a wave reduction; the owners of column k+1 stage it (pre-update) for the look-ahead;
+//   -- barrier --
+//   C  thread i sums the partials of row i in a fixed order, w_i = tau*y_i - tau^2/2 (v^T A v) v_i;
+//   -- barrier --
+//   D  rank-2 update of the registers; every wave then forms the NEXT column x' = x_old - v w_{k+1} - w
+//      itself (v_{k+1} = 1), so step k+1 starts without another barrier.
+// Blocks are enumerated column-block major so that waves retire as the active window shrinks.  Parity
+// double-buffering of x, x_old and v keeps a fast wave's look-ahead writes away from a slow wave's reads.
+// ==========================================================================================
+#define T8 8
+#define T8_MAXNB (TRI_MAXN / T8)
+static __device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__global__ __launch_bounds__(512) void k_sytrd_v2(TriArgs T) {
+    __shared__ double s_x[2][256], s_xo[2][256], s_v[2][256], s_w[256];
+    __shared__ double s_red[8];
+    __shared__ double S1[T8 * (T8_MAXNB * (T8_MAXNB + 1) / 2)];          // [R][C][8] row partials
+    __shared__ double S2[T8 * (T8_MAXNB * (T8_MAXNB - 1) / 2) + T8];     // [C][R-C-1][8] column partials
+    const int n = T.n, nb = (n + T8 - 1) / T8;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int nblocks = nb * (nb + 1) / 2;
+    const bool owner = tid < nblocks;
+    int R = 0, C = 0;
+    if (owner) { int cc = 0; while ((cc + 1) * nb - (cc + 1) * cc / 2 <= tid) ++cc; C = cc; R = cc + (tid - (cc * nb - cc * (cc - 1) / 2)); }
+    const int i0 = T8 * R, j0 = T8 * C;
+    const int off1 = T8 * (R * (R + 1) / 2 + C);
+    const int off2 = T8 * (C * nb - C * (C + 1) / 2 + (R - C - 1));
+    double a[T8][T8];
+#pragma unroll
+    for (int r = 0; r < T8; ++r)
+#pragma unroll
+        for (int cc = 0; cc < T8; ++cc) {
+            const int i = i0 + r, j = j0 + cc;
+            a[r][cc] = (owner && i < n && j < n) ? T.A[i + (size_t)T.lda * j] : 0.;
+        }
+    if (tid < 256) {
+        s_x[0][tid] = tid < n ? T.A[tid] : 0.; s_x[1][tid] = 0.;
+        s_xo[0][tid] = 0.; s_xo[1][tid] = 0.; s_v[0][tid] = 0.; s_v[1][tid] = 0.; s_w[tid] = 0.;
+    }
+    __syncthreads();
+#ifdef TNML_EIGH_PROF
+    long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tlast = clock64();
+#endif
+    for (int k = 0; k < n - 1; ++k) {
+        const int par = k & 1;
+        const int kb = (k + 1) / T8;                  // first block row/column holding an index > k
+        // ---- A: Householder scalars (LAPACK dlarfg) and v, redundantly per wave
+        double sig = 0.;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int i = k + 2 + lane + 64 * e; const double x = i < n ? s_x[par][i] : 0.; sig = fma(x, x, sig); }
+        sig = wave_sum(sig);
+        const double alpha = s_x[par][k + 1];
+        double tau = 0., beta = alpha, scale = 0.;
+        if (sig > 0.) {
+            const double nrm = sqrt(fma(alpha, alpha, sig));
+            beta = alpha >= 0. ? -nrm : nrm;
+            const double dlt = alpha - beta;
+            const double inv = 1. / (beta * dlt);
+            tau = -dlt * dlt * inv;
+            scale = beta * inv;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = lane + 64 * e;
+            const double v = i == k + 1 ? 1. : ((i > k + 1 && i < n) ? s_x[par][i] * scale : 0.);
+            s_v[par][i] = v;                          // identical values from every wave
+            if (wid == 0 && i < n) T.V[i + (size_t)T.ldv * k] = v;
+        }
+        if (tid == 0) { T.D[k] = s_x[par][k]; T.E[k] = beta; T.tau[k] = tau; }
+        wave_lds_fence();
+        TP(0);
+        const bool active = owner && C >= kb;
+        // the owners of column k+1 stage it as it is before this step's update
+        if (owner && C == (k + 1) / T8) {
+            const int jj = (k + 1) % T8;
+#pragma unroll
+            for (int r = 0; r < T8; ++r) {
+                double x = 0.;
+#pragma unroll
+                for (int cc = 0; cc < T8; ++cc) if (cc == jj) x = a[r][cc];
+                s_xo[par][i0 + r] = x;
+            }
+        }
+        if (tau != 0.) {                              // uniform: every wave computed the same tau
+            double vI[T8], vJ[T8];
+            double q = 0.;
+            if (active) {
+#pragma unroll
+                for (int r = 0; r < T8; ++r) vI[r] = s_v[par][i0 + r];
+#pragma unroll
+                for (int cc = 0; cc < T8; ++cc) vJ[cc] = s_v[par][j0 + cc];
+#pragma unroll
+                for (int r = 0; r < T8; ++r) {
+                    double c1 = 0.;
+#pragma unroll
+                    for (int cc = 0; cc < T8; ++cc) c1 = fma(a[r][cc], vJ[cc], c1);
+                    S1[off1 + r] = c1;
+                    q = fma(vI[r], c1, q);
+                }
+                if (R != C) {
+#pragma unroll
+                    for (int cc = 0; cc < T8; ++cc) {
+                        double c2 = 0.;
+#pragma unroll
+                        for (int r = 0; r < T8; ++r) c2 = fma(a[r][cc], vI[r], c2);
+                        S2[off2 + cc] = c2;
+                    }
+                    q *= 2.;
+                }
+            }
+            q = wave_sum(q);
+            if (lane == 0) s_red[wid] = q;
+            TP(1);
+            __syncthreads();
+            TP(2);
+            // ---- C: y_i in a fixed order, w_i
+            double vAv = 0.;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) vAv += s_red[w];
+            const double K = -0.5 * tau * tau * vAv;
+            if (tid < 256) {
+                double wi = 0.;
+                if (tid > k && tid < n) {
+                    const int Ri = tid / T8, r = tid % T8;
+                    double y0 = 0., y1 = 0., y2 = 0., y3 = 0.;
+                    const int o1 = T8 * (Ri * (Ri + 1) / 2) + r;
+                    int cb = kb;
+                    for (; cb + 3 <= Ri; cb += 4) { y0 += S1[o1 + cb * T8]; y1 += S1[o1 + (cb + 1) * T8]; y2 += S1[o1 + (cb + 2) * T8]; y3 += S1[o1 + (cb + 3) * T8]; }
+                    for (; cb <= Ri; ++cb) y0 += S1[o1 + cb * T8];
+                    const int o2 = T8 * (Ri * nb - Ri * (Ri + 1) / 2) + r;
+                    int q2 = 0; const int nq = nb - 1 - Ri;
+                    for (; q2 + 3 < nq; q2 += 4) { y0 += S2[o2 + q2 * T8]; y1 += S2[o2 + (q2 + 1) * T8]; y2 += S2[o2 + (q2 + 2) * T8]; y3 += S2[o2 + (q2 + 3) * T8]; }
+                    for (; q2 < nq; ++q2) y1 += S2[o2 + q2 * T8];
+                    wi = fma(K, s_v[par][tid], tau * ((y0 + y1) + (y2 + y3)));
+                }
+                s_w[tid] = wi;
+            }
+            TP(3);
+            __syncthreads();
+            TP(4);
+            // ---- D: A <- A - v w^T - w v^T
+            if (active) {
+                double wJ[T8];
+#pragma unroll
+                for (int cc = 0; cc < T8; ++cc) wJ[cc] = s_w[j0 + cc];
+#pragma unroll
+                for (int r = 0; r < T8; ++r) {
+                    const double wr = s_w[i0 + r];
+#pragma unroll
+                    for (int cc = 0; cc < T8; ++cc) a[r][cc] = fma(-vI[r], wJ[cc], fma(-wr, vJ[cc], a[r][cc]));
+                }
+            }
+            // look-ahead: column k+1 of the updated matrix
+            const double wk1 = s_w[k + 1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = lane + 64 * e;
+                const double xn = (i >= k + 1 && i < n) ? (s_xo[par][i] - s_v[par][i] * wk1) - s_w[i] : 0.;
+                s_x[par ^ 1][i] = xn;
+            }
+            TP(5);
+        } else {                                      // no reflector: the matrix is unchanged
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const int i = lane + 64 * e; s_x[par ^ 1][i] = (i >= k + 1 && i < n) ? s_xo[par][i] : 0.; }
+            __syncthreads();
+        }
+        wave_lds_fence();
+    }
+#ifdef TNML_EIGH_PROF
+    if (tid == 0 && T.dbg) for (int i = 0; i < 6; ++i) T.dbg[i] = prof[i];
+#endif
+    if (tid == 0) T.D[n - 1] = s_x[(n - 1) & 1][n - 1];
+}
+
 // U[:, c] = H_0 H_1 ... H_{n-2} Z[:, c]; one wave per column, 4 rows per lane (n <= 256).  The
 // reflectors are fetched 8 at a time so that the L2 latency of V is paid once per 8 dependent updates.
 #define BT_PF 8
@@ -263,6 +446,12 @@ __global__ __launch_bounds__(64) void k_backtransform(const double* __restrict__
 int eigh_tridiagonalize(tnml_ctx* c, const double* A, int n, double* D, double* E, double* tau, double* V) {
     if (n > TRI_MAXN) return tnml_fail(c, "eigh_tridiagonalize: n=%d exceeds %d", n, TRI_MAXN);
     TriArgs t{A, n, n, D, E, tau, V, n, nullptr};
+    static const int ver = getenv("TNML_SYTRD") ? atoi(getenv("TNML_SYTRD")) : 2;
+    if (ver == 2) {
+        hipLaunchKernelGGL(k_sytrd_v2, dim3(1), dim3(512), 0, c->stream, t);
+        HIPCK(c, hipGetLastError());
+        return 0;
+    }
     const int nb = (n + TB - 1) / TB;
     int threads = TU * nb * (nb + 1) / 2;
     if (threads < nb * TB) threads = nb * TB;
