@@ -529,7 +529,13 @@ int launch_fgemm64(tnml_ctx* c, const Fgemm64Args& a) {
             case 16: fgemm64_go<1, 5, 4, 3, 16, 2>(c, a); break; // 64 x 240, 12 waves, 3 LDS buffers
             case 17: fgemm64_go<1, 5, 5, 3, 16, 2>(c, a); break; // 80 x 240, 15 waves, 3 LDS buffers
             case 18: fgemm64_go<2, 5, 2, 3, 16>(c, a); break;   // 64 x 240, 6 waves
-            default: fgemm64_go<2, 5, 4, 3, 16>(c, a); break;   // 128 x 240, 12 waves: best of tools/tune_fgemm.sh (gpurun_out/tune_fgemm_r01.txt)
+            default:
+                // 128 x 240, 12 waves is the best tile when the images fill the chip (profiles/r01_tune_fgemm64.txt); a rank
+                // with few images (multi-GPU shards, small sets) gets smaller row tiles so that every CU has a workgroup
+                if (a.NTp / 128 >= 192)     fgemm64_go<2, 5, 4, 3, 16>(c, a);
+                else if (a.NTp / 64 >= 192) fgemm64_go<1, 5, 4, 3, 16>(c, a);   // 64 x 240, 12 waves
+                else                        fgemm64_go<1, 5, 2, 3, 16>(c, a);   // 32 x 240, 6 waves
+                break;
         }
     }
     else if (a.Np > 64 && !a.phiO) {                          // shift form at m up to 128 (Label-carrying: grid.z = 10)

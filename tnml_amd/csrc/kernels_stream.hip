@@ -17,49 +17,58 @@ template <> struct vec2<float> { typedef float2 type; };
 template <> struct vec2<double> { typedef double2 type; };
 
 // TA: element type of the label-carrying operand, TB: of the label-free one, TC: arithmetic type
-template <int NW, typename TA, typename TB, typename TC>
+// IPL: images per lane.  2 (128 images per workgroup, 16-byte loads) is the streaming configuration; 1 with more
+// waves per workgroup keeps enough loads in flight when a rank holds few images (multi-GPU shards, small sets).
+// NLT: label extent (10, or 1 in TNML_MODE_SINGLE) -- a template parameter so that the label loops stay straight-line code
+// (a run-time bound costs ~35 % of this kernel's bandwidth: the loads can no longer be hoisted ahead of the FMAs).
+template <int NW, int IPL, int NLT, typename TA, typename TB, typename TC>
 __global__ __launch_bounds__(64 * NW) void k_labeldot(LdotArgs A, double* __restrict__ partials) {
-    __shared__ __attribute__((aligned(16))) TC red[NW * TNML_NL * LD_IMGS];
-    __shared__ TC s_val[LD_IMGS];
-    __shared__ int s_lab[LD_IMGS];
-    __shared__ int s_cor[LD_IMGS];
+    constexpr int LDI = 64 * IPL;
+    __shared__ __attribute__((aligned(16))) TC red[NW * NLT * LDI];
+    __shared__ TC s_val[LDI];
+    __shared__ int s_lab[LDI];
+    __shared__ int s_cor[LDI];
     typedef typename vec2<TA>::type TA2;
     typedef typename vec2<TB>::type TB2;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int NTp = A.NTp;
-    const int n = blockIdx.x * LD_IMGS + lane * 2;
+    const int n = blockIdx.x * LDI + lane * IPL;
     const TA* Ap = static_cast<const TA*>(A.A);
     const TB* Bp = static_cast<const TB*>(A.Bv);
 
-    TC px[TNML_NL], py[TNML_NL];
+    TC px[NLT], py[NLT];
 #pragma unroll
-    for (int l = 0; l < TNML_NL; ++l) { px[l] = 0; py[l] = 0; }
+    for (int l = 0; l < NLT; ++l) { px[l] = 0; py[l] = 0; }
     for (int q = w; q < A.mq; q += NW) {
-        const TB2 u = *reinterpret_cast<const TB2*>(Bp + (size_t)q * NTp + n);
         const TA* ap = Ap + (size_t)q * NTp + n;
+        if constexpr (IPL == 2) {
+            const TB2 u = *reinterpret_cast<const TB2*>(Bp + (size_t)q * NTp + n);
 #pragma unroll
-        for (int l = 0; l < TNML_NL; ++l) {
-            if (l < A.nl) {
+            for (int l = 0; l < NLT; ++l) {
                 const TA2 e = *reinterpret_cast<const TA2*>(ap + (size_t)l * A.A_lstride);
                 px[l] = fma((TC)e.x, (TC)u.x, px[l]);
                 py[l] = fma((TC)e.y, (TC)u.y, py[l]);
             }
+        } else {
+            const TC u = (TC)Bp[(size_t)q * NTp + n];
+#pragma unroll
+            for (int l = 0; l < NLT; ++l) px[l] = fma((TC)ap[(size_t)l * A.A_lstride], u, px[l]);
         }
     }
 #pragma unroll
-    for (int l = 0; l < TNML_NL; ++l) {
-        red[(w * TNML_NL + l) * LD_IMGS + lane * 2] = px[l];
-        red[(w * TNML_NL + l) * LD_IMGS + lane * 2 + 1] = py[l];
+    for (int l = 0; l < NLT; ++l) {
+        red[(w * NLT + l) * LDI + lane * IPL] = px[l];
+        if constexpr (IPL == 2) red[(w * NLT + l) * LDI + lane * 2 + 1] = py[l];
     }
     __syncthreads();
 
-    if (tid < LD_IMGS) {
-        const int ni = blockIdx.x * LD_IMGS + tid;
-        TC P[TNML_NL];
+    if (tid < LDI) {
+        const int ni = blockIdx.x * LDI + tid;
+        TC P[NLT];
 #pragma unroll
-        for (int l = 0; l < TNML_NL; ++l) {
+        for (int l = 0; l < NLT; ++l) {
             TC s = 0;
-            for (int ww = 0; ww < NW; ++ww) s += red[(ww * TNML_NL + l) * LD_IMGS + tid];   // fixed order
+            for (int ww = 0; ww < NW; ++ww) s += red[(ww * NLT + l) * LDI + tid];   // fixed order
             P[l] = s;
         }
         const int lab = A.label[ni];
@@ -68,26 +77,22 @@ __global__ __launch_bounds__(64 * NW) void k_labeldot(LdotArgs A, double* __rest
         TC* dPout = static_cast<TC*>(A.dP);
         if (A.mode == LD_MODE_PAP) {
 #pragma unroll
-            for (int l = 0; l < TNML_NL; ++l) {
-                if (l < A.nl) {
-                    val = fma(P[l], P[l], val);                                        // sqr(norm(pv)), :400
-                    if (Pout) Pout[(size_t)l * NTp + ni] = P[l];
-                }
+            for (int l = 0; l < NLT; ++l) {
+                val = fma(P[l], P[l], val);                                            // sqr(norm(pv)), :400
+                if (Pout) Pout[(size_t)l * NTp + ni] = P[l];
             }
             if (lab < 0) val = 0;
         } else {
             TC best = fabs(P[0]); int arg = 0;
 #pragma unroll
-            for (int l = 0; l < TNML_NL; ++l) {
-                if (l < A.nl) {
-                    const TC tgt = A.target < 0 ? (l == lab ? (TC)1 : (TC)0) : (lab == A.target ? (TC)1 : (TC)0);   // single.h:103,193
-                    const TC d = (lab >= 0) ? (tgt - P[l]) : (TC)0;                    // deltas[t.l] - P
-                    val = fma(d, d, val);
-                    if (dPout) dPout[(size_t)l * NTp + ni] = d;
-                    if (Pout) Pout[(size_t)l * NTp + ni] = P[l];
-                    const TC wgt = fabs(P[l]);
-                    if (wgt > best) { best = wgt; arg = l; }                           // first maximum
-                }
+            for (int l = 0; l < NLT; ++l) {
+                const TC tgt = A.target < 0 ? (l == lab ? (TC)1 : (TC)0) : (lab == A.target ? (TC)1 : (TC)0);   // single.h:103,193
+                const TC d = (lab >= 0) ? (tgt - P[l]) : (TC)0;                        // deltas[t.l] - P
+                val = fma(d, d, val);
+                if (dPout) dPout[(size_t)l * NTp + ni] = d;
+                if (Pout) Pout[(size_t)l * NTp + ni] = P[l];
+                const TC wgt = fabs(P[l]);
+                if (wgt > best) { best = wgt; arg = l; }                               // first maximum
             }
             if (A.target < 0) cor = (lab >= 0 && arg == lab) ? 1 : 0;
             else              cor = (lab >= 0 && ((P[0] > (TC)0.5) == (lab == A.target))) ? 1 : 0;
@@ -99,11 +104,11 @@ __global__ __launch_bounds__(64 * NW) void k_labeldot(LdotArgs A, double* __rest
     if (tid < 12) {
         double s = 0.;
         if (A.mode == LD_MODE_PAP) {
-            if (tid == 11) for (int i = 0; i < LD_IMGS; ++i) s += (double)s_val[i];
+            if (tid == 11) for (int i = 0; i < LDI; ++i) s += (double)s_val[i];
         } else if (tid < TNML_NL) {
-            for (int i = 0; i < LD_IMGS; ++i) if (s_lab[i] == tid) s += (double)s_val[i];
+            for (int i = 0; i < LDI; ++i) if (s_lab[i] == tid) s += (double)s_val[i];
         } else if (tid == 10) {
-            for (int i = 0; i < LD_IMGS; ++i) s += (double)s_cor[i];
+            for (int i = 0; i < LDI; ++i) s += (double)s_cor[i];
         }
         partials[(size_t)blockIdx.x * 12 + tid] = s;
     }
@@ -122,16 +127,22 @@ __global__ __launch_bounds__(768) void k_reduce_partials(const double* __restric
 
 int launch_labeldot(tnml_ctx* c, const LdotArgs& a, double* scal_out) {
     ProfScope ps(c, KC_LABELDOT);
-    const int nblk = a.NTp / LD_IMGS;
+    // few images on this rank: 64-image workgroups with 16 (fp64) waves each, so that the chip still has enough loads in flight
+    static const int force = getenv("TNML_LDOT_CFG") ? atoi(getenv("TNML_LDOT_CFG")) : 0;     // 1: streaming form, 2: small-shard form
+    const bool small = force ? force == 2 : a.NTp / 128 < 192;
+    const int nblk = a.NTp / (small ? 64 : 128);
     if (nblk > c->partial_cap) return tnml_fail(c, "labeldot: partial buffer too small");
+#define LDOT(NW, IPL, TA, TB, TC) do { if (a.nl == 1) hipLaunchKernelGGL((k_labeldot<NW, IPL, 1, TA, TB, TC>), dim3(nblk), dim3(64 * NW), 0, c->stream, a, c->partials); \
+                                        else hipLaunchKernelGGL((k_labeldot<NW, IPL, TNML_NL, TA, TB, TC>), dim3(nblk), dim3(64 * NW), 0, c->stream, a, c->partials); } while (0)
     if (c->env64()) {
-        hipLaunchKernelGGL((k_labeldot<4, double, double, double>), dim3(nblk), dim3(256), 0, c->stream, a, c->partials);
+        if (small) LDOT(16, 1, double, double, double); else LDOT(4, 2, double, double, double);
     } else if (c->f64()) {
-        if (a.a_is_env) hipLaunchKernelGGL((k_labeldot<4, float, double, double>), dim3(nblk), dim3(256), 0, c->stream, a, c->partials);
-        else            hipLaunchKernelGGL((k_labeldot<4, double, float, double>), dim3(nblk), dim3(256), 0, c->stream, a, c->partials);
+        if (a.a_is_env) { if (small) LDOT(16, 1, float, double, double); else LDOT(4, 2, float, double, double); }
+        else            { if (small) LDOT(16, 1, double, float, double); else LDOT(4, 2, double, float, double); }
     } else {
-        hipLaunchKernelGGL((k_labeldot<8, float, float, float>), dim3(nblk), dim3(512), 0, c->stream, a, c->partials);
+        if (small) LDOT(16, 1, float, float, float); else LDOT(8, 2, float, float, float);
     }
+#undef LDOT
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(768), 0, c->stream, c->partials, nblk, scal_out);
     HIPCK(c, hipGetLastError());
     return 0;

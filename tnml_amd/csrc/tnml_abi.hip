@@ -144,7 +144,7 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     c->big_elems = (size_t)TNML_NL * c->maxm * NTp;
     c->svd_n = 2 * c->maxm;
     c->slab_bytes = (size_t)128 * Kmax * Kmax * 4 * (cfg->dtype != TNML_F32 ? 2 : 1);
-    c->partial_cap = (int)(NTp / 128);
+    c->partial_cap = (int)(NTp / 64);
     c->W.resize(c->N + 2);
     c->env.resize(c->N + 2);
     if ((rc = dmalloc(c, (char**)&c->phi, (size_t)c->N * 2 * NTp * c->eesz()))) return bail(rc);
