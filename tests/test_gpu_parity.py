@@ -666,3 +666,19 @@ def test_single_and_separate_fulltest_cli(tmp_path):
     ref = [float(np.sum((O[n] - (tl == n)) ** 2)) for n in range(10)]
     np.testing.assert_allclose(costs, ref, rtol=1e-8)
     assert float(re.search(r"Total C = ([0-9.eE+-]+)", run.stdout).group(1)) == pytest.approx(sum(ref), rel=1e-8)
+
+
+def test_rccl_path_with_a_one_rank_communicator(monkeypatch):
+    """TNML_FORCE_COMM=1: a 1-rank RCCL communicator is built and every gradient / cost all-reduce goes through
+    ncclAllReduce on the compute stream -- the results must be unchanged (exercises the multi-GPU code path on one GPU)"""
+    from tnml_amd.fixedl import TrainStates, mldmrg
+    monkeypatch.setenv("TNML_FORCE_COMM", "1")
+    ts, o = _pair(N=10, NT=40, m=4)
+    ts.comm_init(TrainStates.comm_unique_id())
+    ts.setBond(1)
+    B = o.bond_tensor(1)
+    assert _relmax(ts.gradient(B), o.gradient(B)) < 1e-9
+    assert ts.quadcost(B, 1e-3)[0] == pytest.approx(o.quadcost(B, 1e-3)[0], rel=1e-11)
+    rg = mldmrg(ts, 1, 4, 2, 1e-10, 3, 1e-3, 1e-10)
+    ro = o.mldmrg(1, 4, 2, 1e-10, 3, 1e-3, 1e-10)
+    np.testing.assert_allclose([r["cost"] for r in rg], [r["cost"] for r in ro], rtol=1e-8)

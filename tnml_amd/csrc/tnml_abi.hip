@@ -228,7 +228,9 @@ int tnml_comm_unique_id(void* id128) {
     return 0;
 }
 int tnml_comm_init(tnml_ctx* c, const void* id128) {
-    if (c->cfg.nranks == 1) return 0;
+    // a single rank needs no communicator; TNML_FORCE_COMM=1 builds a 1-rank one anyway so that the RCCL path
+    // (communicator setup, stream-ordered all-reduce) can be exercised on a one-GPU box
+    if (c->cfg.nranks == 1 && !(getenv("TNML_FORCE_COMM") && atoi(getenv("TNML_FORCE_COMM")))) return 0;
     ncclUniqueId id; memcpy(&id, id128, sizeof id);
     HIPCK(c, hipSetDevice(c->cfg.device));
     ncclResult_t r = ncclCommInitRank(&c->comm, c->cfg.nranks, id, c->cfg.rank);
@@ -237,8 +239,10 @@ int tnml_comm_init(tnml_ctx* c, const void* id128) {
 }
 // sum over ranks of a fp64 device buffer, in stream order (replaces stdx::accumulate, fixedL.cc:385,402,421,427)
 static int allreduce(tnml_ctx* c, double* buf, size_t count) {
-    if (c->cfg.nranks == 1) return 0;
-    if (!c->comm) return tnml_fail(c, "nranks > 1 but tnml_comm_init was not called");
+    if (!c->comm) {
+        if (c->cfg.nranks == 1) return 0;
+        return tnml_fail(c, "nranks > 1 but tnml_comm_init was not called");
+    }
     ProfScope ps(c, KC_ALLREDUCE);
     ncclResult_t r = ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, c->comm, c->stream);
     if (r != ncclSuccess) return tnml_fail(c, "ncclAllReduce failed: %s", ncclGetErrorString(r));
