@@ -1,0 +1,33 @@
+"""per-kernel summary of the PMC passes of tools/pmc_bench.sh (FETCH_SIZE, WRITE_SIZE, MFMA counters): python tools/pmc_summary.py <dir>"""
+import csv, glob, sys, collections
+out = sys.argv[1]
+res = collections.defaultdict(dict)
+for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob(out + "/**/" + ctr + "_counter_collection.csv", recursive=True)
+    if not f:
+        print("no counter file for", ctr); continue
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f[0])):
+        if r["Counter_Name"] == ctr:
+            acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        res[k][ctr] = (sum(v) / len(v), len(v), max(v))
+f = glob.glob(out + "/**/MFMA_counter_collection.csv", recursive=True)
+if f:
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f[0])):
+        acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, d in acc.items():
+        for c, v in d.items():
+            res[k][c] = (sum(v) / len(v), len(v), max(v))
+print("%-72s %7s %14s %14s %14s" % ("kernel", "calls", "FETCH_mean", "FETCH_max", "WRITE_mean"))
+rows = sorted(res.items(), key=lambda kv: -kv[1].get("FETCH_SIZE", (0, 0, 0))[0] * kv[1].get("FETCH_SIZE", (0, 0, 0))[1])
+with open(out + "/pmc_summary.csv", "w") as g:
+    g.write("kernel,calls,fetch_size_mean,fetch_size_max,write_size_mean,mfma_busy_cycles_mean,mfma_mops_f64_mean,sq_busy_cycles_mean,grbm_gui_active_mean\n")
+    for k, v in rows[:30]:
+        fs = v.get("FETCH_SIZE", (0, 0, 0)); ws = v.get("WRITE_SIZE", (0, 0, 0))
+        print("%-72s %7d %14.1f %14.1f %14.1f" % (k[:72], fs[1], fs[0], fs[2], ws[0]))
+        mf = [v.get(c, (0, 0, 0))[0] for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F64", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE")]
+        g.write('"%s",%d,%.3f,%.3f,%.3f,%.1f,%.1f,%.1f,%.1f\n' % (k, fs[1], fs[0], fs[2], ws[0], mf[0], mf[1], mf[2], mf[3]))
+        if mf[3] > 0 and mf[0] > 0:
+            print("      MFMA busy %.3e cyc (64.0 per v_mfma_f64_16x16x4: %.3e instructions = %.3f GFLOP), GUI active %.3e summed over the 8 XCDs = %.0f cycles of kernel time\n      -> matrix pipe busy %.1f %% of the time (busy / (gui_active / 8 * 1024 SIMDs))" % (mf[0], mf[1] * 512 / 2048, mf[1] * 512 / 1e9, mf[3], mf[3] / 8, 100 * mf[0] / (mf[3] / 8 * 1024)))
