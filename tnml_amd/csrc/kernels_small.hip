@@ -93,6 +93,18 @@ __global__ void k_bond_form(const double* __restrict__ A1, const double* __restr
 int launch_bond_form(tnml_ctx* c, const SiteT& A1, const SiteT& A2, double* B) {
     ProfScope ps(c, KC_SMALLGEMM);
     const int LB = A1.L > A2.L ? A1.L : A2.L;
+    const int nl = 2 * A1.ml, k = A1.mr, nr = 2 * A2.mr;
+    // B[(a,s)][(t,be)](,l) = A1[(a,s)][g] * A2[g][(t,be)]: a plain column-major GEMM in ITensor index order.  The Label
+    // index rides as extra columns when it sits on the right site and as a strided batch when it sits on the left one.
+    if (k >= 16 && (A1.L == 1 || A2.L == 1)) {
+        const double one = 1.0, zero = 0.0;
+        rocblas_status st;
+        if (A1.L == 1) st = rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, nl, nr * A2.L, k, &one, A1.a, nl, A2.a, k, &zero, B, nl);
+        else           st = rocblas_dgemm_strided_batched(c->blas, rocblas_operation_none, rocblas_operation_none, nl, nr, k, &one, A1.a, nl, (rocblas_stride)nl * k,
+                                                         A2.a, k, 0, &zero, B, nl, (rocblas_stride)nl * nr, A1.L);
+        if (st != rocblas_status_success) return tnml_fail(c, "bond_form: rocblas dgemm failed (%d)", (int)st);
+        return 0;
+    }
     const size_t total = (size_t)A1.ml * 4 * A2.mr * LB;
     hipLaunchKernelGGL(k_bond_form, dim3(nblocks(total)), dim3(256), 0, c->stream, A1.a, A2.a, B, A1.ml, A1.mr, A2.mr, A1.L, A2.L);
     HIPCK(c, hipGetLastError());
