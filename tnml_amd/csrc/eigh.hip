@@ -752,47 +752,71 @@ int eigh_ns_matrix(tnml_ctx* c, const double* S, double* Cm, int m, double* dev)
 __global__ __launch_bounds__(1024) void k_chol_rinv(const double* __restrict__ S, int m, double* __restrict__ Rinv, double* __restrict__ flag) {
     extern __shared__ __attribute__((aligned(16))) double ch_lds[];
     const int ld = m | 1;                                  // odd leading dimension
-    double* A = ch_lds;                                    // [ld * m]: L below/on the diagonal, X = L^-1 (transposed) above
-    double* col = A + (size_t)ld * m;                      // [m] current column
-    double* dinv = col + CHOL_MAXM;                        // [m] 1 / L_jj
+    double* A = ch_lds;                                    // [ld * m]: X = L^-1 (transposed) above the diagonal after the factorisation
+    double* col = A + (size_t)ld * m;                      // [2][CHOL_MAXM] scaled pivot column, double buffered
+    double* dinv = col + 2 * CHOL_MAXM;                    // [m] 1 / L_jj
     __shared__ int s_fail;
     const int tid = threadIdx.x;
     if (tid == 0) s_fail = 0;
-    for (int idx = tid; idx < m * m; idx += 1024) { const int i = idx % m, j = idx / m; A[i + (size_t)ld * j] = (i >= j) ? S[idx] : 0.; }
+    // lower-triangular elements e = tid, tid + 1024, ... (column major packed) live in registers: at most 10 per lane
+    constexpr int EPT = (CHOL_MAXM * (CHOL_MAXM + 1) / 2 + 1023) / 1024;
+    const int ntri = m * (m + 1) / 2;
+    double a[EPT]; int ei[EPT], ej[EPT];
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) {
+        const int e = tid + 1024 * q;
+        int j = 0, i = 0;
+        if (e < ntri) {                                    // column j holds m - j elements: offset(j) = j*m - j(j-1)/2
+            j = (int)((2. * m + 1. - sqrt((2. * m + 1.) * (2. * m + 1.) - 8. * e)) * 0.5);
+            while (j > 0 && j * m - j * (j - 1) / 2 > e) --j;
+            while ((j + 1) * m - (j + 1) * j / 2 <= e) ++j;
+            i = j + (e - (j * m - j * (j - 1) / 2));
+        }
+        ei[q] = e < ntri ? i : -1; ej[q] = j;
+        a[q] = e < ntri ? S[i + (size_t)m * j] : 0.;
+    }
+    for (int idx = tid; idx < ld * m; idx += 1024) A[idx] = 0.;
     __syncthreads();
+    // right-looking Cholesky: the owner of (k,k) publishes the pivot, the owners of column k publish L[:,k], everyone updates
     for (int k = 0; k < m; ++k) {
-        const double piv = A[k + (size_t)ld * k];
-        if (!(piv > 1e-13)) { if (tid == 0) s_fail = 1; break; }       // S has unit diagonal: this is a relative test
-        const double inv = 1. / sqrt(piv);
-        if (tid < m) {
-            const double v = tid >= k ? A[tid + (size_t)ld * k] * inv : 0.;
-            col[tid] = v;
-            if (tid == k) dinv[k] = inv;
-        }
+        double* ck = col + (k & 1) * CHOL_MAXM;
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) if (ei[q] == k && ej[q] == k) { if (!(a[q] > 1e-13)) s_fail = 1; dinv[k] = rsqrt(a[q] > 1e-13 ? a[q] : 1.); }
         __syncthreads();
-        if (tid < m && tid >= k) A[tid + (size_t)ld * k] = col[tid];
-        const int rem = m - (k + 1);                                    // trailing block (k+1..m-1)^2, lower part
-        for (int idx = tid; idx < rem * rem; idx += 1024) {
-            const int i = k + 1 + idx % rem, j = k + 1 + idx / rem;
-            if (i >= j) A[i + (size_t)ld * j] -= col[i] * col[j];
-        }
+        const double inv = dinv[k];
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) if (ej[q] == k && ei[q] >= k) { a[q] *= inv; ck[ei[q]] = a[q]; }
         __syncthreads();
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) if (ej[q] > k && ei[q] >= 0) a[q] = fma(-ck[ei[q]], ck[ej[q]], a[q]);
     }
     __syncthreads();
     if (s_fail) { if (tid == 0) flag[0] = 1.; return; }
-    // X = L^-1, column j by lane j: x_j = 1/L_jj, x_i = -(sum_{k<i} L[i][k] x_k) / L_ii ; x_k kept at A[j + ld*k] (k > j)
-    if (tid < m) {
-        const int j = tid;
-        for (int i = j + 1; i < m; ++i) {
-            double acc = A[i + (size_t)ld * j] * dinv[j], acc2 = 0.;   // L[i][j] x_j
-            int k = j + 1;
-#pragma unroll 4
-            for (; k + 1 < i; k += 2) {
-                acc = fma(A[i + (size_t)ld * k], A[j + (size_t)ld * k], acc);
-                acc2 = fma(A[i + (size_t)ld * (k + 1)], A[j + (size_t)ld * (k + 1)], acc2);
+    // L -> LDS (below and on the diagonal); dinv holds 1/L_jj
+#pragma unroll
+    for (int q = 0; q < EPT; ++q) if (ei[q] >= 0) A[ei[q] + (size_t)ld * ej[q]] = a[q];
+    __syncthreads();
+    // X = L^-1, column j by a group of 8 (4 when m > 128) lanes of one wave: x_j = 1/L_jj,
+    // x_i = -(sum_{j<=k<i} L[i][k] x_k) / L_ii with the sum split over the group and combined by DPP; x_k is kept
+    // at A[j + ld*k] (k > j, the unused upper triangle) and read back by the same wave (in-order LDS).
+    {
+        const int lpc = m <= 128 ? 8 : 4;
+        const int j = tid / lpc, sub = tid % lpc;
+        const int jw = (tid & ~63) / lpc;                              // first column of this wave: common loop start
+        const bool col_ok = j < m;
+        for (int i = jw + 1; i < m; ++i) {
+            double acc = 0.;
+            if (col_ok && i > j) {
+                for (int k = j + sub; k < i; k += lpc) {
+                    const double xk = k == j ? dinv[j] : A[j + (size_t)ld * k];
+                    acc = fma(A[i + (size_t)ld * k], xk, acc);
+                }
             }
-            if (k < i) acc = fma(A[i + (size_t)ld * k], A[j + (size_t)ld * k], acc);
-            A[j + (size_t)ld * i] = -(acc + acc2) * dinv[i];
+            acc += dpp_quad<0xB1>(acc);                                   // lane ^ 1
+            acc += dpp_quad<0x4E>(acc);                                   // lane ^ 2
+            if (lpc == 8) acc += dpp_quad<0x141>(acc);                    // row_half_mirror: the other quad of the 8
+            if (col_ok && i > j && sub == 0) A[j + (size_t)ld * i] = -acc * dinv[i];
+            wave_lds_fence();
         }
     }
     __syncthreads();
@@ -805,7 +829,7 @@ __global__ __launch_bounds__(1024) void k_chol_rinv(const double* __restrict__ S
 }
 int eigh_chol_rinv(tnml_ctx* c, const double* S, int m, double* Rinv, double* flag) {
     if (m > CHOL_MAXM) return tnml_fail(c, "eigh_chol_rinv: m=%d exceeds %d", m, CHOL_MAXM);
-    const size_t lds = sizeof(double) * ((size_t)(m | 1) * m + 2 * CHOL_MAXM);
+    const size_t lds = sizeof(double) * ((size_t)(m | 1) * m + 3 * CHOL_MAXM);
     static size_t attr_lds = 0;                          // the kernel also has a few bytes of static LDS: ask for what is needed
     if (lds > attr_lds) { HIPCK(c, hipFuncSetAttribute((const void*)k_chol_rinv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_lds = lds; }
     hipLaunchKernelGGL(k_chol_rinv, dim3(1), dim3(1024), lds, c->stream, S, m, Rinv, flag);
