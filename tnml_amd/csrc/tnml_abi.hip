@@ -187,7 +187,7 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     if ((rc = dmalloc(c, &c->sQ1, (size_t)c->svd_n * c->maxm))) return bail(rc);
     if ((rc = dmalloc(c, &c->sDev, 4))) return bail(rc);
     if (const char* e = getenv("TNML_SVD_BACKEND")) c->cfg.svd_backend = atoi(e);
-    if (hipHostMalloc((void**)&c->h_scal, sizeof(double) * (2 * c->svd_n + 64 + SC_N + 4 * TNML_MAX_PASS)) != hipSuccess) return bail(tnml_fail(c, "hipHostMalloc failed"));
+    if (hipHostMalloc((void**)&c->h_scal, sizeof(double) * (2 * c->svd_n + 64 + SC_N + 4 * TNML_MAX_PASS + 64)) != hipSuccess) return bail(tnml_fail(c, "hipHostMalloc failed"));
     for (int j = 1; j <= c->N; ++j) {
         const size_t cap = (size_t)2 * c->maxm * c->maxm * (j == c->c0 ? TNML_NL : 1);
         if ((rc = dmalloc(c, &c->W[j].a, cap))) return bail(rc);
@@ -652,15 +652,17 @@ static int cgrad_device(tnml_ctx* c, int npass, double lambda, double cconv) {
     }
     return 0;
 }
-static int cgrad_fetch_trace(tnml_ctx* c, int npass, tnml_cg_trace* tr) {
-    if (!tr) return 0;
-    memset(tr, 0, sizeof *tr);
-    std::vector<double> h(SC_N + 4 * TNML_MAX_PASS);
-    // scal and cgtrace are separate allocations: two small copies, one synchronisation
+// the CG's device scalars and per-pass trace: enqueue the copies, parse after any later synchronisation of the stream
+static int cgrad_trace_enqueue(tnml_ctx* c) {
     double* hp = c->h_scal + 2 * c->svd_n + 64;
+    // scal and cgtrace are separate allocations: two small copies
     HIPCK(c, hipMemcpyAsync(hp, c->scal, sizeof(double) * SC_N, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipMemcpyAsync(hp + SC_N, c->cgtrace, sizeof(double) * 4 * TNML_MAX_PASS, hipMemcpyDeviceToHost, c->stream));
-    HIPCK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+static void cgrad_trace_parse(tnml_ctx* c, int npass, tnml_cg_trace* tr) {
+    memset(tr, 0, sizeof *tr);
+    const double* hp = c->h_scal + 2 * c->svd_n + 64;
     const int done = (int)llround(hp[SC_NPASS]);
     tr->npass_done = done;
     tr->converged = (int)llround(hp[SC_CONV]);
@@ -668,17 +670,25 @@ static int cgrad_fetch_trace(tnml_ctx* c, int npass, tnml_cg_trace* tr) {
         const double* t = hp + SC_N + 4 * p;
         tr->pAp[p] = t[0]; tr->alpha[p] = t[1]; tr->cost[p] = t[2]; tr->rnorm[p] = t[3];
     }
+}
+static int cgrad_fetch_trace(tnml_ctx* c, int npass, tnml_cg_trace* tr) {
+    if (!tr) return 0;
+    TCK(cgrad_trace_enqueue(c));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    cgrad_trace_parse(c, npass, tr);
     return 0;
 }
 // quadcost, fixedL.cc:280-344, on the bond tensor in vB
-static int quadcost_device(tnml_ctx* c, double lambda, double* cost, double* label_cost, double* reg_cost, int64_t* ncorrect, bool want_P) {
+// launches only: cost partials, #correct and |B|^2 end up in the 13 doubles behind G (t[0..9] per-label costs, t[10] ncorrect, t[12] |B|^2)
+static int quadcost_launch(tnml_ctx* c, bool want_P) {
     const size_t n = c->plan.msize();
     double* tail = c->vG + n;
     TCK(forward_pass(c, c->vB, LD_MODE_COST, tail, want_P));
     TCK(allreduce(c, tail, TNML_NSCAL_AR));
     TCK(launch_sqnorm(c, c->vB, n, tail + 12));                 // |B|^2 rides behind the cost partials
-    double t[13];
-    TCK(read_scal(c, tail, 13, t));
+    return 0;
+}
+static void quadcost_parse(tnml_ctx* c, const double* t, double lambda, double* cost, double* label_cost, double* reg_cost, int64_t* ncorrect) {
     const double bn2 = t[12];
     c->last_bnorm = std::sqrt(bn2);
     const double CR = lambda * bn2;                       // :329
@@ -688,6 +698,12 @@ static int quadcost_device(tnml_ctx* c, double lambda, double* cost, double* lab
     if (cost) *cost = C;
     if (reg_cost) *reg_cost = CR;
     if (ncorrect) *ncorrect = (int64_t)llround(t[SC_NCORR]);
+}
+static int quadcost_device(tnml_ctx* c, double lambda, double* cost, double* label_cost, double* reg_cost, int64_t* ncorrect, bool want_P) {
+    TCK(quadcost_launch(c, want_P));
+    double t[13];
+    TCK(read_scal(c, c->vG + c->plan.msize(), 13, t));
+    quadcost_parse(c, t, lambda, cost, label_cost, reg_cost, ncorrect);
     return 0;
 }
 
@@ -769,18 +785,23 @@ int tnml_bond_update(tnml_ctx* c, int b, int ha, const tnml_sweep_params* sp, tn
         TCK(quadcost_device(c, sp->lambda_cost, &rep->cost_old, nullptr, nullptr, nullptr, false));
         rep->norm_oB = c->last_bnorm;
     }
-    TCK(cgrad_device(c, sp->npass, sp->lambda, sp->cconv));           // :504 (trace fetched with the SVD's own sync)
+    TCK(cgrad_device(c, sp->npass, sp->lambda, sp->cconv));           // :504
     if (sp->report_costs) TCK(quadcost_device(c, sp->lambda_cost, &rep->cost_cg, nullptr, &rep->reg_cost_cg, nullptr, false));   // single.h:622,626
     TCK(launch_unpack(c, pd, c->vB, c->tB));
-    TCK(cgrad_fetch_trace(c, sp->npass, &rep->cg));
+    TCK(cgrad_trace_enqueue(c));                                      // lands with the split's own synchronisation (eigenvalues)
     TCK(svd_split_device(c, c->tB, b, ha, sp->cutoff, sp->maxm, sp->minm, &rep->truncerr, &rep->newm, nullptr, nullptr));   // :519-522
+    cgrad_trace_parse(c, sp->npass, &rep->cg);
     TCK(launch_bond_form(c, c->W[b], c->W[b + 1], c->tB2));           // :527
     TCK(launch_diffnorm(c, c->tB2, c->tB, ne, c->scal + SC_NORMS));   // :528,:530
     TCK(launch_pack(c, pd, c->tB2, c->vB, nullptr));
-    TCK(quadcost_device(c, sp->lambda_cost, &rep->cost_after_svd, rep->label_cost, &rep->reg_cost, &rep->ncorrect, false));   // :532
-    double d2[2];
-    TCK(read_scal(c, c->scal + SC_NORMS, 2, d2));
-    rep->norm_newB = std::sqrt(d2[0]); rep->diff_B_newB = std::sqrt(d2[1]);
+    TCK(quadcost_launch(c, false));                                   // :532
+    // the end-of-bond scalars come back in one copy after the environment shift has been queued: no idle gap for them
+    double* hq = c->h_scal + 2 * c->svd_n + 64 + SC_N + 4 * TNML_MAX_PASS;
+    HIPCK(c, hipMemcpyAsync(hq, c->vG + c->plan.msize(), sizeof(double) * 13, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync(hq + 16, c->scal + SC_NORMS, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
     TCK(tnml_shift_env(c, b, ha == 1));                               // :540
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    quadcost_parse(c, hq, sp->lambda_cost, &rep->cost_after_svd, rep->label_cost, &rep->reg_cost, &rep->ncorrect);
+    rep->norm_newB = std::sqrt(hq[16]); rep->diff_B_newB = std::sqrt(hq[17]);
     return 0;
 }
