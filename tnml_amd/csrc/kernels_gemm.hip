@@ -307,7 +307,7 @@ template <> struct V2<double> {
 // Software pipelined: the global loads of chunk k+1 are issued before the MFMA phase of chunk k and
 // land in registers; they are widened to fp64 and written to LDS after the MFMAs (two barriers per
 // chunk, one LDS buffer), so the L2/HBM latency of the operands hides behind the matrix pipe.
-// ABL (tools/probe/kbench_fgemm.hip only): 1 = no MFMA, 2 = no operand staging inside the loop
+// ABL (tools/probe/kbench_fgemm.hip only): 1 = no MFMA, 2 = no operand staging inside the loop, 3 = also no LDS fragment loads
 // TE: storage type of environments and features; TO = 2: contract with the output-site feature
 // (forward pass), TO = 1: no output site index (environment shift in strict fp64 mode).
 template <int RT, int CT, int WR, int WC, int KT, int DB, int ABL = 0, typename TE = float, int TO = 2>
@@ -440,16 +440,16 @@ __global__ __launch_bounds__(64 * WR * WC) void k_fgemm64(Fgemm64Args A) {
         int cur = 0;
         for (int k0 = 0; k0 < A.Kp; k0 += KT) {
             const bool more = k0 + KT < A.Kp;
-            if (more && ABL != 2) load_chunk(k0 + KT);       // in flight during the MFMA phase
+            if (more && ABL != 2 && ABL != 3) load_chunk(k0 + KT);       // in flight during the MFMA phase
             const double* Xb = lds + (DB ? cur * LB : 0);
             const double* Mb = Xb + KT * XS;
-            frag_load(Xb, Mb, 0, xf[0], mf[0]);
+            if (ABL != 3 || k0 == 0) frag_load(Xb, Mb, 0, xf[0], mf[0]);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                if (ks + 1 < KS) frag_load(Xb, Mb, ks + 1, xf[(ks + 1) & 1], mf[(ks + 1) & 1]);
+                if (ks + 1 < KS && (ABL != 3 || k0 == 0)) frag_load(Xb, Mb, ks + 1, xf[(ks + 1) & 1], mf[(ks + 1) & 1]);
                 mfma_step(xf[ks & 1], mf[ks & 1]);
             }
-            if (more && ABL != 2) {
+            if (more && ABL != 2 && ABL != 3) {
                 if (DB) {                                    // other buffer: no wave can still be reading it
                     double* Xn = lds + (cur ^ 1) * LB;
                     store_chunk(Xn, Xn + KT * XS);
@@ -529,6 +529,8 @@ int launch_fgemm64(tnml_ctx* c, const Fgemm64Args& a) {
             case 16: fgemm64_go<1, 5, 4, 3, 16, 2>(c, a); break; // 64 x 240, 12 waves, 3 LDS buffers
             case 17: fgemm64_go<1, 5, 5, 3, 16, 2>(c, a); break; // 80 x 240, 15 waves, 3 LDS buffers
             case 18: fgemm64_go<2, 5, 2, 3, 16>(c, a); break;   // 64 x 240, 6 waves
+            case 19: fgemm64_go<1, 5, 2, 3, 16>(c, a); break;   // 32 x 240, 6 waves (several workgroups per CU)
+            case 20: fgemm64_go<1, 5, 4, 3, 8>(c, a); break;    // 64 x 240, 12 waves, KT 8
             default:
                 // 128 x 240, 12 waves is the best tile when the images fill the chip (profiles/r01_tune_fgemm64.txt); a rank
                 // with few images (multi-GPU shards, small sets) gets smaller row tiles so that every CU has a workgroup

@@ -33,6 +33,8 @@ int main(int argc, char** argv) {
     Fgemm64Args a{E, 0, m, phi, M, 0, Kp, Np, phi + 2 * NTp, out, 0, m, NTp, 1};
     run<2, 5, 4, 3, 16, 0, 0>("128x240 12w KT16 full", a);
     run<2, 5, 4, 3, 16, 0, 2>("128x240 12w KT16 MFMA-only (no staging)", a);
+    run<2, 5, 4, 3, 16, 0, 3>("128x240 12w KT16 MFMA only, no LDS fragment loads", a);
+    { Fgemm64Args b = a; b.NTp = 32768; run<2, 5, 4, 3, 16, 0, 0>("   same, 256 tiles (one round): full", b); run<2, 5, 4, 3, 16, 0, 2>("   same, 256 tiles: MFMA-only (no staging)", b); run<2, 5, 4, 3, 16, 0, 3>("   same, 256 tiles: MFMA only, no LDS loads", b); }
     run<2, 5, 4, 3, 16, 1, 0>("128x240 12w KT16 dbuf full", a);
     run<2, 5, 4, 3, 16, 2, 0>("128x240 12w KT16 3buf full", a);
     run<2, 5, 4, 3, 16, 2, 2>("128x240 12w KT16 3buf MFMA-only", a);
