@@ -682,3 +682,49 @@ def test_rccl_path_with_a_one_rank_communicator(monkeypatch):
     rg = mldmrg(ts, 1, 4, 2, 1e-10, 3, 1e-3, 1e-10)
     ro = o.mldmrg(1, 4, 2, 1e-10, 3, 1e-3, 1e-10)
     np.testing.assert_allclose([r["cost"] for r in rg], [r["cost"] for r in ro], rtol=1e-8)
+
+
+def _spectra():
+    rng = np.random.default_rng(77)
+    yield "identity (240-fold degenerate)", np.ones(240)
+    yield "two plateaus", np.concatenate([np.full(60, 3.0), np.full(180, 0.5)])
+    yield "rank one", np.concatenate([[2.0], np.zeros(239)])
+    yield "rank 119 then exact zeros", np.concatenate([np.linspace(2.0, 1.0, 119), np.zeros(121)])
+    yield "pairs of equal values", np.repeat(np.exp(-0.08 * np.arange(120)), 2)
+    yield "geometric 1e0..1e-14", np.logspace(0, -14, 240)
+    yield "cluster of 40 within 1e-13", np.concatenate([np.linspace(2, 1, 100), 0.5 + 1e-13 * rng.random(40), np.logspace(-1, -6, 100)])
+    yield "random uniform", np.sort(rng.random(240))[::-1]
+
+
+@pytest.mark.parametrize("name,sv0", list(_spectra()), ids=[n for n, _ in _spectra()])
+def test_svd_split_hard_spectra(name, sv0):
+    """degenerate, clustered, rank-deficient and widely graded singular value spectra through the in-house eigensolver
+    (split, inverse iteration, Newton-Schulz / Cholesky-QR repair, rocSOLVER fallback): the singular values, the optimal
+    rank-120 reconstruction and the isometry of the site the sweep leaves must come out right in every case"""
+    from tnml_amd import synth
+    from tnml_amd.fixedl import TrainStates
+    N, m, NT = 20, 120, 16
+    labels = synth.synthetic_labels(NT, seed=1)
+    ts = TrainStates(labels, N, m, pixels=synth.synthetic_images(N, labels, seed=1))
+    ts.set_mps(synth.random_mps(N, m, seed=2))
+    rng = np.random.default_rng(len(name))
+    sv0 = np.sort(np.asarray(sv0, dtype=float))[::-1]
+    U0, _ = np.linalg.qr(rng.standard_normal((240, 240)))
+    V0, _ = np.linalg.qr(rng.standard_normal((240, 240)))
+    M = (U0 * sv0) @ V0.T
+    B = M.reshape(120, 2, 2, 120, order="F")
+    best_err = np.sqrt(np.sum(sv0[120:] ** 2))                      # Eckart-Young: Frobenius error of the best rank-120 approximation
+    for ha in (1, 2):
+        mg, te, sv = ts.svd_split(B, 8, ha, 0.0, 120, 120)
+        assert mg == 120
+        np.testing.assert_allclose(sv ** 2, sv0 ** 2, rtol=1e-7, atol=3e-14 * sv0[0] ** 2)   # Gram route: eps*lambda_max floor
+        assert te == pytest.approx(np.sum(sv0[120:] ** 2) / np.sum(sv0 ** 2), rel=1e-6, abs=1e-13)
+        newB = ts.bond_tensor(8).reshape(240, 240, order="F")
+        err = np.linalg.norm(newB - M)
+        assert err <= best_err * (1 + 1e-6) + 2e-7 * sv0[0], (err, best_err)
+        A = ts.get_site(8 if ha == 1 else 9)
+        Q = A.reshape(240, 120, order="F") if ha == 1 else A.reshape(120, 240, order="F").T
+        if ha == 1:                                                   # the Gram-side factor is an isometry whatever the spectrum
+            np.testing.assert_allclose(Q.T @ Q, np.eye(120), atol=1e-9)
+    st = ts.svd_stats()
+    assert st["fallbacks"] <= 2, st
