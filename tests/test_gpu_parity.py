@@ -728,3 +728,30 @@ def test_svd_split_hard_spectra(name, sv0):
             np.testing.assert_allclose(Q.T @ Q, np.eye(120), atol=1e-9)
     st = ts.svd_stats()
     assert st["fallbacks"] <= 2, st
+
+
+def test_invariants_of_the_split_and_of_the_gauge():
+    """SURVEY.md section 4, invariants 2 and 4 on the HIP path itself (no oracle involved):
+    |B - newB|^2 = sum of the discarded sigma^2 = truncerr * sum sigma^2; the data cost evaluated with the
+    un-optimised bond tensor of the NEXT bond equals the "After SVD" data cost of this bond (gauge invariance)."""
+    ts, o = _pair(N=12, NT=80, m=6, maxm=6)
+    lam = 1e-3
+    for b in range(1, 7):
+        r = ts.bond_update(b, 1, 4, 2, 1e-10, 3, lam, 1e-10)           # maxm 4 < 6: real truncation on the interior bonds
+        data_cost = r["cost"] - r["reg_cost"]
+        ts.setBond(b + 1)
+        Bn = ts.bond_tensor(b + 1)
+        C, lc, cr, nc = ts.quadcost(Bn, lam)
+        assert C - cr == pytest.approx(data_cost, rel=1e-10)            # same network, different bond: same outputs
+        assert nc == r["ncorrect"]
+    # the split alone on a fresh random bond tensor
+    ts2, o2 = _pair(N=12, NT=40, m=6, maxm=6)
+    for bb in range(1, 4):
+        ts2.shiftE(bb, True)
+    ts2.setBond(4)
+    B = ts2.bond_tensor(4) + 0.2 * np.random.default_rng(4).standard_normal((6, 2, 2, 6))
+    mnew, te, sv = ts2.svd_split(B, 4, 1, 0.0, 5, 1)
+    newB = ts2.bond_tensor(4)
+    assert mnew == 5
+    assert np.sum((B - newB) ** 2) == pytest.approx(np.sum(sv[5:] ** 2), rel=1e-8)
+    assert te == pytest.approx(np.sum(sv[5:] ** 2) / np.sum(sv ** 2), rel=1e-8)
