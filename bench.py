@@ -259,6 +259,11 @@ def main():
                          "avg_launch_ms": avg_ms, "launches": n_fg, "flops_per_launch": flops_per_launch},
             "kernel_ms_per_step": {k: v[1] / nbreak for k, v in prof_all.items() if v[0]},
             "roofline_hbm": hbm_roofline(prof_all, NTl, timed, args, world),
+            "algebraic_shortcuts": [
+                "fast CG: B*t.v is linear in B, so P <- P + a (p*t.v) replaces Npass-1 forward GEMMs per bond (TNML_FAST_CG=0 disables)",
+                "the network outputs P_n do not depend on the bond they are evaluated at: the after-SVD quadcost of one bond update "
+                "provides the residuals of the next one's first gradient, replacing 1 forward GEMM + label dot per bond (TNML_REUSE_P=0 disables)",
+            ] if os.environ.get("TNML_FAST_CG", "1") != "0" or os.environ.get("TNML_REUSE_P", "1") != "0" else [],
             "env_init_s": t_init,
             "device_gb": ts.device_bytes() / 1e9,
             "last_cost_per_image": timed[-1]["cost"] / NT if timed else None,

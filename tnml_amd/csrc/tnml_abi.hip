@@ -157,6 +157,7 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     if ((rc = dmalloc(c, (char**)&c->Pp, (size_t)TNML_NL * NTp * esz))) return bail(rc);
     if (const char* e = getenv("TNML_FAST_CG")) c->fast_cg = atoi(e) != 0;
     if (const char* e = getenv("TNML_FUSE_Z")) c->fuse_z = atoi(e) != 0;
+    if (const char* e = getenv("TNML_REUSE_P")) c->reuse_p = atoi(e) != 0;
     if ((rc = dmalloc(c, (char**)&c->Zp, c->small_elems * esz))) return bail(rc);
     if ((rc = dmalloc(c, &c->Mf, c->mcap))) return bail(rc);
     if ((rc = dmalloc(c, (char**)&c->slab, c->slab_bytes))) return bail(rc);
@@ -270,7 +271,7 @@ int tnml_set_data_u8(tnml_ctx* c, const uint8_t* pixels, const int32_t* labels) 
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(d_pix);
     if (rc) return rc;
-    c->data_set = true; c->currb = -1;
+    c->data_set = true; c->currb = -1; c->p_valid = false;
     return 0;
 }
 int tnml_set_data_phi(tnml_ctx* c, const double* phi, const int32_t* labels) {
@@ -289,7 +290,7 @@ int tnml_set_data_phi(tnml_ctx* c, const double* phi, const int32_t* labels) {
             h[((size_t)j * 2 + s) * c->NTp + i] = (float)phi[((size_t)i * c->N + j) * 2 + s];
         HIPCK(c, hipMemcpy(c->phi, h.data(), sizeof(float) * ne, hipMemcpyHostToDevice));
     }
-    c->data_set = true; c->currb = -1;
+    c->data_set = true; c->currb = -1; c->p_valid = false;
     return 0;
 }
 
@@ -303,7 +304,7 @@ int tnml_set_site(tnml_ctx* c, int j, int ml, int mr, int has_label, const doubl
     SiteT& s = c->W[j];
     s.ml = ml; s.mr = mr; s.L = has_label ? TNML_NL : 1; s.set = true;
     HIPCK(c, hipMemcpy(s.a, A, sizeof(double) * (size_t)ml * 2 * mr * s.L, hipMemcpyHostToDevice));
-    c->currb = -1;
+    c->currb = -1; c->p_valid = false;
     return 0;
 }
 int tnml_site_dims(tnml_ctx* c, int j, int* ml, int* mr, int* has_label) {
@@ -448,6 +449,7 @@ int tnml_get_env(tnml_ctx* c, int j, double* E) {
 int tnml_classify(tnml_ctx* c, double* weights, int32_t* pred, int64_t count[TNML_NL], int64_t nincorrect[TNML_NL]) {
     HIPCK(c, hipSetDevice(c->cfg.device));
     if (!c->data_set) return tnml_fail(c, "tnml_classify: image data not set");
+    c->p_valid = false;
     TCK(check_W(c));
     EnvSlot buf[3];
     int rc = 0;
@@ -597,11 +599,12 @@ static int forward_pass(tnml_ctx* c, const double* vec, int mode, double* tail, 
     return launch_labeldot(c, a, tail);
 }
 // G = sum_n dP_n*dag(t.v) over all ranks for the bond tensor in vB; cost partials ride in the tail
-static int grad_eval(tnml_ctx* c, bool from_P_update = false) {
+static int grad_eval(tnml_ctx* c, bool from_P_update = false, bool outputs_current = false) {
     const BondPlan& p = c->plan;
     const size_t n = p.msize();
-    if (from_P_update) TCK(launch_pupdate(c, c->scal + SC_ALPHA, c->vG + n));          // P += a (p*t.v): no GEMM
-    else               TCK(forward_pass(c, c->vB, LD_MODE_COST, c->vG + n, c->fast_cg)); // keeps P when fast CG is on
+    if (outputs_current)    HIPCK(c, hipMemsetAsync(c->vG + n, 0, sizeof(double) * TNML_NSCAL_AR, c->stream));   // P/dP already hold B*t.v and the residuals
+    else if (from_P_update) TCK(launch_pupdate(c, c->scal + SC_ALPHA, c->vG + n));          // P += a (p*t.v): no GEMM
+    else                    TCK(forward_pass(c, c->vB, LD_MODE_COST, c->vG + n, c->fast_cg)); // keeps P when fast CG is on
     const bool fuse = c->f64() && c->fuse_z && p.kind != 2;
     if (p.kind != 2 && !fuse) TCK(launch_zprime(c, p.EX, (size_t)p.mO * c->NTp, c->dP, c->Zp, p.mO, c->NTp));
     if (c->f64()) {
@@ -636,11 +639,11 @@ static int read_scal(tnml_ctx* c, const double* dev, int count, double* host_out
 // issues the whole CG without a host round trip: the |r| < cconv exit (fixedL.cc:432-436) is a device
 // flag that turns the state-changing kernels of later passes into no-ops; the per-pass numbers the
 // reference prints are collected in a device trace and fetched once by cgrad_fetch_trace().
-static int cgrad_device(tnml_ctx* c, int npass, double lambda, double cconv) {
+static int cgrad_device(tnml_ctx* c, int npass, double lambda, double cconv, bool outputs_current = false) {
     if (npass < 1 || npass > TNML_MAX_PASS) return tnml_fail(c, "cgrad: Npass must be in 1..%d", TNML_MAX_PASS);
     const size_t n = c->plan.msize();
     HIPCK(c, hipMemsetAsync(c->cgtrace, 0, sizeof(double) * 4 * TNML_MAX_PASS, c->stream));
-    TCK(grad_eval(c));                                   // :374-385
+    TCK(grad_eval(c, false, outputs_current));           // :374-385
     TCK(launch_cg_init(c, n, lambda, c->single() ? cconv : -1.));   // :386-388 (single.h:200-208 with the entry check)
     for (int pass = 1; pass <= npass; ++pass) {          // :389
         TCK(forward_pass(c, c->vP, LD_MODE_PAP, c->vG + n, c->fast_cg));   // :394-401 (keeps p*t.v for the fast update)
@@ -725,6 +728,7 @@ static int download_bond(tnml_ctx* c, const double* Mvec, double* B) {   // M-la
 
 int tnml_forward(tnml_ctx* c, const double* B, double* P) {
     HIPCK(c, hipSetDevice(c->cfg.device));
+    c->p_valid = false;
     TCK(upload_bond(c, B));
     TCK(forward_pass(c, c->vB, LD_MODE_COST, c->vG + c->plan.msize(), true));
     const size_t ne = (size_t)TNML_NL * c->NTp;
@@ -739,17 +743,20 @@ int tnml_forward(tnml_ctx* c, const double* B, double* P) {
 }
 int tnml_gradient(tnml_ctx* c, const double* B, double* G) {
     HIPCK(c, hipSetDevice(c->cfg.device));
+    c->p_valid = false;
     TCK(upload_bond(c, B));
     TCK(grad_eval(c));
     return download_bond(c, c->vG, G);
 }
 int tnml_quadcost(tnml_ctx* c, const double* B, double lambda, double* cost, double label_cost[TNML_NL], double* reg_cost, int64_t* ncorrect) {
     HIPCK(c, hipSetDevice(c->cfg.device));
+    c->p_valid = false;
     TCK(upload_bond(c, B));
     return quadcost_device(c, lambda, cost, label_cost, reg_cost, ncorrect, false);
 }
 int tnml_cgrad(tnml_ctx* c, double* B, int npass, double lambda, double cconv, tnml_cg_trace* trace) {
     HIPCK(c, hipSetDevice(c->cfg.device));
+    c->p_valid = false;
     TCK(upload_bond(c, B));
     TCK(cgrad_device(c, npass, lambda, cconv));
     TCK(cgrad_fetch_trace(c, npass, trace));
@@ -759,6 +766,7 @@ int tnml_svd_split(tnml_ctx* c, const double* B, int b, int ha, double cutoff, i
                    double* truncerr, int* newm, double* sv, int* nsv) {
     HIPCK(c, hipSetDevice(c->cfg.device));
     if (b < 1 || b > c->N - 1 || (ha != 1 && ha != 2)) return tnml_fail(c, "tnml_svd_split: bad bond/half");
+    c->p_valid = false;
     HIPCK(c, hipMemcpyAsync(c->tB, B, sizeof(double) * bond_elems(c, b), hipMemcpyHostToDevice, c->stream));
     TCK(svd_split_device(c, c->tB, b, ha, cutoff, maxm, minm, truncerr, newm, sv, nsv));
     c->currb = -1;
@@ -781,11 +789,14 @@ int tnml_bond_update(tnml_ctx* c, int b, int ha, const tnml_sweep_params* sp, tn
     const PackDesc pd = bond_pack_desc(p);
     TCK(launch_bond_form(c, c->W[b], c->W[b + 1], c->tB));            // :494
     TCK(launch_pack(c, pd, c->tB, c->vB, nullptr));
+    bool outputs_current = c->reuse_p && c->p_valid;                  // left by the previous bond update's quadcost
+    c->p_valid = false;
     if (sp->report_costs) {                                           // single.h:572,621: norm(oB), quadcost(oB)
-        TCK(quadcost_device(c, sp->lambda_cost, &rep->cost_old, nullptr, nullptr, nullptr, false));
+        TCK(quadcost_device(c, sp->lambda_cost, &rep->cost_old, nullptr, nullptr, nullptr, true));
         rep->norm_oB = c->last_bnorm;
+        outputs_current = c->reuse_p;                                 // that was the forward pass of the first gradient
     }
-    TCK(cgrad_device(c, sp->npass, sp->lambda, sp->cconv));           // :504
+    TCK(cgrad_device(c, sp->npass, sp->lambda, sp->cconv, outputs_current));   // :504
     if (sp->report_costs) TCK(quadcost_device(c, sp->lambda_cost, &rep->cost_cg, nullptr, &rep->reg_cost_cg, nullptr, false));   // single.h:622,626
     TCK(launch_unpack(c, pd, c->vB, c->tB));
     TCK(cgrad_trace_enqueue(c));                                      // lands with the split's own synchronisation (eigenvalues)
@@ -794,7 +805,7 @@ int tnml_bond_update(tnml_ctx* c, int b, int ha, const tnml_sweep_params* sp, tn
     TCK(launch_bond_form(c, c->W[b], c->W[b + 1], c->tB2));           // :527
     TCK(launch_diffnorm(c, c->tB2, c->tB, ne, c->scal + SC_NORMS));   // :528,:530
     TCK(launch_pack(c, pd, c->tB2, c->vB, nullptr));
-    TCK(quadcost_launch(c, false));                                   // :532
+    TCK(quadcost_launch(c, true));                                    // :532; P and dP stay for the next bond update
     // the end-of-bond scalars come back in one copy after the environment shift has been queued: no idle gap for them
     double* hq = c->h_scal + 2 * c->svd_n + 64 + SC_N + 4 * TNML_MAX_PASS;
     HIPCK(c, hipMemcpyAsync(hq, c->vG + c->plan.msize(), sizeof(double) * 13, hipMemcpyDeviceToHost, c->stream));
@@ -803,5 +814,6 @@ int tnml_bond_update(tnml_ctx* c, int b, int ha, const tnml_sweep_params* sp, tn
     HIPCK(c, hipStreamSynchronize(c->stream));
     quadcost_parse(c, hq, sp->lambda_cost, &rep->cost_after_svd, rep->label_cost, &rep->reg_cost, &rep->ncorrect);
     rep->norm_newB = std::sqrt(hq[16]); rep->diff_B_newB = std::sqrt(hq[17]);
+    c->p_valid = true;
     return 0;
 }

@@ -103,6 +103,11 @@ struct tnml_ctx {
     void* Pp = nullptr;        // [10][NTp]  p*t.v of the last pAp pass (fast CG)
     bool fuse_z = true;        // gradient GEMM builds Z from EL and dP itself instead of a k_zprime pass (env TNML_FUSE_Z=0 disables)
     bool fast_cg = true;       // P <- P + a (p*t.v) instead of re-running the forward GEMM (env TNML_FAST_CG=0 disables)
+    // The per-image outputs P_n = W.Phi(x_n) belong to the network, not to the bond they are evaluated at: the "after SVD"
+    // quadcost of one bond update leaves in P/dP exactly what the first gradient evaluation of the next bond update would
+    // recompute with its own forward GEMM + label dot.  p_valid marks P/dP as current; anything that changes W, the data or
+    // P itself clears it (env TNML_REUSE_P=0 disables the shortcut).
+    bool reuse_p = true, p_valid = false;
     void* Zp = nullptr;        // [maxm][NTp]
     float* Mf = nullptr;       // fp32 GEMM operand, M-layout, capacity 10*Kmax*Kmax (env shifts, F32 mode)
     void* slab = nullptr;      // split-K partial slabs
