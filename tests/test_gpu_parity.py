@@ -755,3 +755,52 @@ def test_invariants_of_the_split_and_of_the_gauge():
     assert mnew == 5
     assert np.sum((B - newB) ** 2) == pytest.approx(np.sum(sv[5:] ** 2), rel=1e-8)
     assert te == pytest.approx(np.sum(sv[5:] ** 2) / np.sum(sv ** 2), rel=1e-8)
+
+
+def test_fixedl_initial_w_from_ten_per_label_files(tmp_path):
+    """fixedL.cc:682-701: with files W0..W9 present (and no W) the initial weight MPS is the sum of the ten per-label MPS,
+    each with the Label index attached on site N/2.  The ten files come from the `single` driver (feature = series, the
+    map fixedL uses); the summed network must output f_l(x) on label component l for every image."""
+    import os
+    import re
+    import shutil
+    import subprocess
+    from oracle import pyoracle
+    from tnml_amd import hostlib, synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    N, per_label = 16, 8
+    labels = synth.synthetic_labels(10 * per_label, seed=12, per_label=per_label)
+    pixels = np.clip(synth.synthetic_images(N, labels, seed=12).astype(np.int32) * 3, 0, 255).astype(np.uint8)
+    data = str(tmp_path / "data")
+    synth.write_idx(data, pixels, labels)
+    comb = tmp_path / "comb"
+    comb.mkdir()
+    for L in range(10):
+        wd = tmp_path / ("L%d" % L)
+        wd.mkdir()
+        (wd / "input").write_text("input\n{\ndatadir = %s\nlabel = %d\nNtrain = %d\nNsweep = 1\ncutoff = 1E-10\nmaxm = 4\nminm = 2\nninitial = 2\n"
+                                  "lambda = 1E-3\nNpass = 2\nseed = 2\nfeature = series\nfeature_scale = 255\n}\n" % (data, L, per_label))
+        run = subprocess.run([os.path.join(root, "tnml_amd", "single"), "input"], capture_output=True, text=True, cwd=wd, timeout=300)
+        assert run.returncode == 0, run.stdout[-1000:] + run.stderr[-1000:]
+        shutil.copy(wd / ("W%d" % L), comb / ("W%d" % L))
+    (comb / "input").write_text("input\n{\ndatadir = %s\nNtrain = %d\nNbatch = 4\nNsweep = 0\nmaxm = 10\nlambda = 1E-3\nfeature_scale = 255\n}\n" % (data, per_label))
+    run = subprocess.run([os.path.join(root, "tnml_amd", "fixedL"), "input"], capture_output=True, text=True, cwd=comb, timeout=300)
+    assert run.returncode == 0, run.stdout[-1500:] + run.stderr[-1500:]
+    assert "Found separate W0,W1,...,W9 MPS: summing" in run.stdout and "Summing all 10 label states together" in run.stdout
+    W = hostlib.read_mps(str(comb / "W"))
+    assert [A.ndim == 4 for A in W] == [j == N // 2 for j in range(1, N + 1)]
+    px, lab, _ = hostlib.read_mnist(data, True, per_label)
+    g = px.astype(np.float64) / 255.0
+    phi = np.stack([np.ones_like(g), 255.0 * ((g / 255.0) / 4.0)], axis=-1)
+    o = pyoracle.Oracle(phi, lab, W)
+    out = np.stack([o.toverlap(i) for i in range(len(lab))])                     # [n, 10]
+    for L in range(10):
+        so = pyoracle.SingleOracle(phi, lab, L, hostlib.read_mps(str(comb / ("W%d" % L))))
+        fL = np.array([so.output(i) for i in range(len(lab))])
+        np.testing.assert_allclose(out[:, L], fL, rtol=1e-5, atol=1e-6 * np.abs(fL).max())     # the sum is truncated at Cutoff 1E-10
+    o.init()
+    C0 = o.quadcost(o.bond_tensor(1), 1e-3)[0] / len(lab)
+    m0 = re.search(r"Before starting DMRG Cost = ([0-9.eE+-]+)", run.stdout)
+    assert m0 and float(m0.group(1)) == pytest.approx(C0, rel=1e-8)
+    y = np.eye(10)[lab]
+    assert C0 == pytest.approx((np.sum((y - out) ** 2) + 1e-3 * np.sum(o.bond_tensor(1) ** 2)) / len(lab), rel=1e-9)

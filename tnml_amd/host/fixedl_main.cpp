@@ -100,6 +100,22 @@ int main(int argc, const char* argv[]) {
             std::printf("Reading W from disk\n");
             W = read_mps("W");
             if (W.N != N || W.A[c].L != NL) { std::printf("Expected W to have Label type Index at site %d\n", c); return 1; }
+        } else if (file_exists("W0")) {                                                  // :682-701
+            std::printf("Found separate W0,W1,...,W9 MPS: summing\n");
+            std::vector<HostMPS> ipsis;
+            for (int n = 0; n < 10; ++n) {
+                char fn[16]; std::snprintf(fn, sizeof fn, "W%d", n);
+                HostMPS in = read_mps(fn);                                              // :691 per-label weight MPS (single / linear)
+                if (in.N != N) { std::printf("%s has %d sites, data has %d\n", fn, in.N, N); return 1; }
+                for (int j = 1; j <= N; ++j) if (in.A[j].L != 1) { std::printf("%s already carries a Label index\n", fn); return 1; }
+                in.c0 = c;
+                attach_label(in, n, 1.0);                                               // :693 in.Aref(c) *= setElt(Lval(n))
+                ipsis.push_back(std::move(in));
+            }
+            std::printf("Summing all %d label states together\n", (int)ipsis.size());  // :696
+            W = sum_truncated(ipsis, 1E-10, 1 << 30);                                   // :697 sum(ipsis,{"Cutoff",1E-10})
+            std::printf("Done making initial W\n");
+            write_mps("W", W);                                                          // :700
         } else {
             W = build_initial_w(train, (int)ninitial, seed, true, feature_scale);                      // :702-726
             std::printf("Done making initial W\n");
