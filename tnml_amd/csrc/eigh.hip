@@ -306,15 +306,13 @@ __global__ __launch_bounds__(512) void k_sytrd_v2(TriArgs T) {
         TP(0);
         const bool active = owner && C >= kb;
         // the owners of column k+1 stage it as it is before this step's update
-        if (owner && C == (k + 1) / T8) {
-            const int jj = (k + 1) % T8;
-#pragma unroll
-            for (int r = 0; r < T8; ++r) {
-                double x = 0.;
-#pragma unroll
-                for (int cc = 0; cc < T8; ++cc) if (cc == jj) x = a[r][cc];
-                s_xo[par][i0 + r] = x;
+        if (owner && C == kb) {                       // (k + 1) / 8 == kb; the column index is uniform: a scalar switch, no selects
+#define T8_STAGE(J) { _Pragma("unroll") for (int r = 0; r < T8; ++r) s_xo[par][i0 + r] = a[r][J]; } break
+            switch ((k + 1) & 7) {
+                case 0: T8_STAGE(0); case 1: T8_STAGE(1); case 2: T8_STAGE(2); case 3: T8_STAGE(3);
+                case 4: T8_STAGE(4); case 5: T8_STAGE(5); case 6: T8_STAGE(6); default: T8_STAGE(7);
             }
+#undef T8_STAGE
         }
         if (tau != 0.) {                              // uniform: every wave computed the same tau
             double vI[T8], vJ[T8];
