@@ -142,7 +142,7 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
         HIPCK(c, hipMemcpyAsync(hd, c->sDev, sizeof(double), hipMemcpyDeviceToHost, st));
         HIPCK(c, hipStreamSynchronize(st));
         c->svd_last_dev0 = hd[0]; c->svd_last_dev1 = 0.75 * hd[0] * hd[0];      // Newton-Schulz: error -> 3/4 error^2
-        bool ok = hd[0] < 1e-4;                                                  // 1e-4 -> ~1e-8 -> the polish leaves < 1e-8
+        bool ok = hd[0] < 1e-6;                                                  // the polish step leaves 3/4 d^2 < 1e-12
         if (!ok) if (const char* dump = getenv("TNML_SVD_DUMP")) {               // debugging aid: the offending tridiagonal problem
             static int dumped = 0;
             if (dumped < 4) {
@@ -159,7 +159,7 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
         if (!ok && hd[0] == hd[0]) {
             // Close eigenvalues inside one unreduced block: inverse iteration gave independent but not quite
             // orthogonal vectors of the right invariant subspace.  Mild cases (max|Q^T Q - I| < 0.3) are repaired by
-            // further Newton-Schulz steps (error -> 3/4 error^2); worse ones first go through a Cholesky QR
+            // further Newton-Schulz steps (error -> 3/4 error^2, until it is below 1e-12); worse ones first go through a Cholesky QR
             // (Q1 = Q0 R^-1 with Q0^T Q0 = R^T R).  The last step lands in Q and its input deviation is checked.
             const bool need_chol = !(hd[0] < 0.3);
             if (!need_chol || m <= TNML_CHOL_MAXM) {
@@ -171,7 +171,7 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
                     RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, n, m, m, &one, cur, n, c->sCm, m, &zero, other, n));
                     std::swap(cur, other);
                 }
-                const int nit = need_chol ? 1 : (hd[0] < 0.05 ? 2 : 3);
+                const int nit = need_chol ? 1 : (hd[0] < 1e-3 ? 1 : (hd[0] < 0.05 ? 3 : 4));   // d -> 3/4 d^2 per step; the last input must be < 1e-6
                 for (int it = 0; it <= nit; ++it) {
                     double* dst = it == nit ? Q : other;
                     RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, m, m, n, &one, cur, n, cur, n, &zero, c->sS, m));
@@ -181,7 +181,7 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
                 }
                 HIPCK(c, hipMemcpyAsync(hd, c->sDev, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
                 HIPCK(c, hipStreamSynchronize(st));
-                ok = hd[1] == 0. && hd[0] < 1e-4;
+                ok = hd[1] == 0. && hd[0] < 1e-6;
                 c->svd_last_dev1 = 0.75 * hd[0] * hd[0];
             }
         }
