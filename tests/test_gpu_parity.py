@@ -804,3 +804,37 @@ def test_fixedl_initial_w_from_ten_per_label_files(tmp_path):
     assert m0 and float(m0.group(1)) == pytest.approx(C0, rel=1e-8)
     y = np.eye(10)[lab]
     assert C0 == pytest.approx((np.sum((y - out) ** 2) + 1e-3 * np.sum(o.bond_tensor(1) ** 2)) / len(lab), rel=1e-9)
+
+
+def test_python_multi_gpu_driver_matches_the_cpp_driver(tmp_path):
+    """`python -m tnml_amd.train <inputfile>` (one process per GPU under torch.distributed.run; here a single process) prints
+    the same per-bond lines as the C++ `fixedL` driver for the same input: both are thin loops over tnml_bond_update"""
+    import os
+    import re
+    import subprocess
+    import sys
+    from tnml_amd import hostlib, synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    N, per_label = 16, 12
+    labels = synth.synthetic_labels(10 * per_label, seed=15, per_label=per_label)
+    pixels = np.clip(synth.synthetic_images(N, labels, seed=15).astype(np.int32) * 3, 0, 255).astype(np.uint8)
+    data = str(tmp_path / "data")
+    synth.write_idx(data, pixels, labels)
+    text = ("input\n{\ndatadir = %s\nNtrain = %d\nNbatch = 4\nNsweep = 1\ncutoff = 1E-10\nmaxm = 5\nminm = 2\nninitial = 3\n"
+            "lambda = 1E-3\nNpass = 3\nseed = 5\nfeature_scale = 255\n}\n" % (data, per_label))
+    outs = {}
+    for name, cmd in (("cpp", [os.path.join(root, "tnml_amd", "fixedL"), "input"]), ("py", [sys.executable, "-m", "tnml_amd.train", "input"])):
+        wd = tmp_path / name
+        wd.mkdir()
+        (wd / "input").write_text(text)
+        env = dict(os.environ, PYTHONPATH=root)
+        run = subprocess.run(cmd, capture_output=True, text=True, cwd=wd, timeout=600, env=env)
+        assert run.returncode == 0, run.stdout[-1500:] + run.stderr[-1500:]
+        outs[name] = run.stdout
+        assert os.path.exists(wd / "W") and os.path.exists(wd / "sites")
+    pick = lambda s: re.findall(r"^(SVD trunc err.*|Original m=.*|--> After SVD.*|Percent correct.*|  Cost = .*|Before starting DMRG.*)$", s, re.M)
+    a, b = pick(outs["cpp"]), pick(outs["py"])
+    assert len(a) == len(b) and len(a) > 100
+    assert a == b
+    Wc, Wp = hostlib.read_mps(str(tmp_path / "cpp" / "W")), hostlib.read_mps(str(tmp_path / "py" / "W"))
+    assert all(np.array_equal(x, y) for x, y in zip(Wc, Wp))

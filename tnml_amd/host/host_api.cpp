@@ -66,6 +66,9 @@ int tnmlh_build_initial_single(const char* datadir, long nt_per_label, int label
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
+// `sites` file (SiteSet(N,d), fixedL.cc:619-631)
+int tnmlh_sites_write(const char* file, int N, int d) { try { write_sites(file, N, d); return 0; } catch (const std::exception& e) { g_err = e.what(); return -1; } }
+int tnmlh_sites_read(const char* file, int* N, int* d) { try { read_sites(file, N, d); return 0; } catch (const std::exception& e) { g_err = e.what(); return -1; } }
 // weight file access: dims of site j, then its data (column-major [ml][2][mr][L])
 int tnmlh_mps_info(const char* file, int* N, int* c0) {
     try { HostMPS W = read_mps(file); *N = W.N; *c0 = W.c0; return 0; } catch (const std::exception& e) { g_err = e.what(); return -1; }

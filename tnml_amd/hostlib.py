@@ -26,6 +26,8 @@ def load():
                                             C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int, C.c_double]
         L.tnmlh_reduce.argtypes = [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.tnmlh_build_initial_single.argtypes = [C.c_char_p, C.c_long, C.c_int, C.c_int, C.c_ulonglong, C.c_int, C.c_char_p, C.c_int, C.c_double]
+        L.tnmlh_sites_write.argtypes = [C.c_char_p, C.c_int, C.c_int]
+        L.tnmlh_sites_read.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.tnmlh_mps_info.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.tnmlh_mps_site.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                      C.POINTER(C.c_double)]
@@ -114,3 +116,15 @@ def build_initial_single(datadir, nt_per_label, label, ninitial, seed, normal, o
     """initial W of the per-label variant (single.cc:112-128) written to `out`"""
     if load().tnmlh_build_initial_single(datadir.encode(), nt_per_label, label, ninitial, seed, int(normal), out.encode(), imglen, feature_scale) != 0:
         raise _err()
+
+
+def write_sites(path, N, d=2):
+    if load().tnmlh_sites_write(path.encode(), N, d) != 0:
+        raise _err()
+
+
+def read_sites(path):
+    N, d = C.c_int(), C.c_int()
+    if load().tnmlh_sites_read(path.encode(), N, d) != 0:
+        raise _err()
+    return N.value, d.value
