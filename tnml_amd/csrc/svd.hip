@@ -107,6 +107,21 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
     } else {
         RBCK(c, rocsolver_dsyevd(c->blas, rocblas_evect_original, rocblas_fill_upper, n, c->sG, n, c->sD, c->sE, c->sInfo));
     }
+    double* Q = c->sF;                                   // kept eigenvectors, n x m
+    double* Lf = c->sF + (size_t)c->svd_n * c->maxm;     // left factor when a permutation is still needed
+    double* Q0 = c->sQ1;
+    double* hd = c->h_scal + 2 * c->svd_n + 32;
+    if (own_eig) {
+        // Z (already "largest first") -> U = H_0 H_1 ... Z for all mk candidate columns, then one Newton-Schulz step
+        // Q <- Q (1.5 I - 0.5 Q^T Q); d = max|Q^T Q - I| before the step is checked on the host (after it: ~0.75 d^2).
+        // Queued BEFORE the eigenvalues go to the host, so that the truncation decision costs no idle gap on the device;
+        // the kept columns are the first m of these.
+        TCK(eigh_backtransform(c, c->sV, c->sTau, n, c->sC, n, Q0, n, mk));
+        RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, mk, mk, n, &one, Q0, n, Q0, n, &zero, c->sS, mk));
+        TCK(eigh_ns_matrix(c, c->sS, c->sCm, mk, c->sDev));
+        RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, n, mk, mk, &one, Q0, n, c->sCm, mk, &zero, Q, n));
+        HIPCK(c, hipMemcpyAsync(hd, c->sDev, sizeof(double), hipMemcpyDeviceToHost, st));
+    }
     // eigenvalues -> host: the truncation decision (ITensor truncate()) fixes the new bond dimension
     double* h = c->h_scal;          // pinned, capacity >= 2*svd_n + 64
     HIPCK(c, hipMemcpyAsync(h, evals, sizeof(double) * n, hipMemcpyDeviceToHost, st));
@@ -128,30 +143,18 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
     double* d_isig = c->sE + m;
     HIPCK(c, hipMemcpyAsync(d_sig, hs, sizeof(double) * 2 * m, hipMemcpyHostToDevice, st));
 
-    double* Q = c->sF;                                   // kept eigenvectors, n x m
-    double* Lf = c->sF + (size_t)c->svd_n * c->maxm;     // left factor when a permutation is still needed
     if (own_eig) {
-        // Z (already "largest first") -> U = H_0 H_1 ... Z, then one Newton-Schulz step Q <- Q (1.5 I - 0.5 Q^T Q);
-        // d = max|Q^T Q - I| before the step is checked on the host (after it: ~0.75 d^2).
-        double* Q0 = c->sQ1;
-        TCK(eigh_backtransform(c, c->sV, c->sTau, n, c->sC, n, Q0, n, m));
-        RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, m, m, n, &one, Q0, n, Q0, n, &zero, c->sS, m));
-        TCK(eigh_ns_matrix(c, c->sS, c->sCm, m, c->sDev));
-        RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, n, m, m, &one, Q0, n, c->sCm, m, &zero, Q, n));
-        double* hd = c->h_scal + 2 * c->svd_n + 32;
-        HIPCK(c, hipMemcpyAsync(hd, c->sDev, sizeof(double), hipMemcpyDeviceToHost, st));
-        HIPCK(c, hipStreamSynchronize(st));
         c->svd_last_dev0 = hd[0]; c->svd_last_dev1 = 0.75 * hd[0] * hd[0];      // Newton-Schulz: error -> 3/4 error^2
         bool ok = hd[0] < 1e-6;                                                  // the polish step leaves 3/4 d^2 < 1e-12
         if (!ok) if (const char* dump = getenv("TNML_SVD_DUMP")) {               // debugging aid: the offending tridiagonal problem
             static int dumped = 0;
             if (dumped < 4) {
-                std::vector<double> hb((size_t)3 * n + (size_t)n * m + 2);
-                hb[0] = n; hb[1] = m;
+                std::vector<double> hb((size_t)3 * n + (size_t)n * mk + 2);
+                hb[0] = n; hb[1] = mk;
                 (void)hipMemcpy(hb.data() + 2, c->sD, sizeof(double) * n, hipMemcpyDeviceToHost);
                 (void)hipMemcpy(hb.data() + 2 + n, c->sE2, sizeof(double) * n, hipMemcpyDeviceToHost);
                 (void)hipMemcpy(hb.data() + 2 + 2 * n, c->sW, sizeof(double) * n, hipMemcpyDeviceToHost);
-                (void)hipMemcpy(hb.data() + 2 + 3 * n, c->sC, sizeof(double) * (size_t)n * m, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(hb.data() + 2 + 3 * n, c->sC, sizeof(double) * (size_t)n * mk, hipMemcpyDeviceToHost);
                 char fn[512]; snprintf(fn, sizeof fn, "%s.%d.bin", dump, dumped++);
                 if (FILE* f = fopen(fn, "wb")) { fwrite(hb.data(), sizeof(double), hb.size(), f); fclose(f); }
             }
@@ -162,21 +165,21 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
             // further Newton-Schulz steps (error -> 3/4 error^2, until it is below 1e-12); worse ones first go through a Cholesky QR
             // (Q1 = Q0 R^-1 with Q0^T Q0 = R^T R).  The last step lands in Q and its input deviation is checked.
             const bool need_chol = !(hd[0] < 0.3);
-            if (!need_chol || m <= TNML_CHOL_MAXM) {
+            if (!need_chol || mk <= TNML_CHOL_MAXM) {
                 c->svd_cholqr += 1;
                 double* cur = Q0; double* other = c->sG;                        // the Gram matrix is consumed by now
                 HIPCK(c, hipMemsetAsync(c->sDev + 1, 0, sizeof(double), st));
                 if (need_chol) {
-                    TCK(eigh_chol_rinv(c, c->sS, m, c->sCm, c->sDev + 1));
-                    RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, n, m, m, &one, cur, n, c->sCm, m, &zero, other, n));
+                    TCK(eigh_chol_rinv(c, c->sS, mk, c->sCm, c->sDev + 1));
+                    RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, n, mk, mk, &one, cur, n, c->sCm, mk, &zero, other, n));
                     std::swap(cur, other);
                 }
                 const int nit = need_chol ? 1 : (hd[0] < 1e-3 ? 1 : (hd[0] < 0.05 ? 3 : 4));   // d -> 3/4 d^2 per step; the last input must be < 1e-6
                 for (int it = 0; it <= nit; ++it) {
                     double* dst = it == nit ? Q : other;
-                    RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, m, m, n, &one, cur, n, cur, n, &zero, c->sS, m));
-                    TCK(eigh_ns_matrix(c, c->sS, c->sCm, m, c->sDev));
-                    RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, n, m, m, &one, cur, n, c->sCm, m, &zero, dst, n));
+                    RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, mk, mk, n, &one, cur, n, cur, n, &zero, c->sS, mk));
+                    TCK(eigh_ns_matrix(c, c->sS, c->sCm, mk, c->sDev));
+                    RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, n, mk, mk, &one, cur, n, c->sCm, mk, &zero, dst, n));
                     if (it < nit) std::swap(cur, other);
                 }
                 HIPCK(c, hipMemcpyAsync(hd, c->sDev, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
