@@ -122,6 +122,8 @@ def main():
                     "spectrum of the synthetic data (the reference default max(10, maxm/2) lets trained bonds shrink)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f64_e32", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-label", type=int, default=None, help="bench the per-label variant (single.cc, BASELINE config 4: one such "
+                    "training per label, replicas only) for this label instead of the fixedL sweep")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -151,9 +153,11 @@ def main():
     labels = synth.synthetic_labels(NT)
     pixels = synth.synthetic_images(N, labels)
     W = synth.random_mps(N, maxm, seed=1)
+    if args.single_label is not None:
+        W[N // 2 - 1] = W[N // 2 - 1][..., 0] * 3.0             # plain weight MPS: no Label index
     lo, hi = lib.shard_bounds(NT, world, rank)
     ts = TrainStates(labels[lo:hi], N, maxm, pixels=pixels[lo:hi], device=local_rank, rank=rank, nranks=world,
-                     NT_total=NT, dtype=args.dtype)
+                     NT_total=NT, dtype=args.dtype, single_label=args.single_label)
     del pixels
     if world > 1:
         uid = [TrainStates.comm_unique_id() if rank == 0 else None]
@@ -183,7 +187,7 @@ def main():
 
     def step():
         nonlocal b, ha
-        r = ts.bond_update(b, ha, maxm, minm, cutoff, npass, lam, cconv)
+        r = ts.bond_update(b, ha, maxm, minm, cutoff, npass, lam, cconv, report_costs=args.single_label is not None)
         reports.append(r)
         b, ha = lib.sweepnext(b, ha, N)
         if ha > 2:
@@ -225,13 +229,13 @@ def main():
         # every timed bond calls the feature GEMM 2*npass+1 times with its own (mL, mR); average the flops
         fl = []
         for r in timed:
-            fl.append(2.0 * NTl * (2 * r["mL"]) * (2 * r["mR"]) * (10 if r["label_on_B"] else 1))
+            fl.append(2.0 * NTl * (2 * r["mL"]) * (2 * r["mR"]) * (10 if (r["label_on_B"] and args.single_label is None) else 1))
         flops_per_launch = float(np.mean(fl)) if fl else 0.0
         avg_ms = ms_fg / max(n_fg, 1)
         achieved_tf = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         peak = F64_MFMA_PEAK_TF if args.dtype != "f32" else F32_MFMA_PEAK_TF
         out = {
-            "metric": "two-site bond updates/sec",
+            "metric": "two-site bond updates/sec" if args.single_label is None else "two-site bond updates/sec (per-label variant, label %d)" % args.single_label,
             "value": args.steps / elapsed,
             "unit": "bond updates/s",
             "n_gpus": world,
@@ -269,7 +273,7 @@ def main():
             "last_cost_per_image": timed[-1]["cost"] / NT if timed else None,
             "svd_stats": ts.svd_stats(),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.single_label is None:
             ncore = os.cpu_count() or 1
             out["cpu_baseline"] = cpu_baseline(maxm, npass, lam, cutoff, min(16, ncore), NT)   # paralleldo.h:55-56 caps at 16
         print(json.dumps(out))
