@@ -1,9 +1,9 @@
 import os, re, subprocess, sys, tempfile
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle import pyoracle
 from tnml_amd import hostlib, synth
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 tmp = tempfile.mkdtemp()
 N, per_label = 16, 20
 labels = synth.synthetic_labels(10 * per_label, seed=9, per_label=per_label)

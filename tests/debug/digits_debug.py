@@ -1,10 +1,10 @@
 import os, re, subprocess, sys, tempfile
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from sklearn.datasets import load_digits
 from oracle import pyoracle
 from tnml_amd import hostlib, synth
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 tmp = tempfile.mkdtemp()
 d = load_digits()
 px = np.clip(np.rint(d.images.reshape(-1, 64) * (255.0 / 16.0)), 0, 255).astype(np.uint8)
