@@ -838,3 +838,46 @@ def test_python_multi_gpu_driver_matches_the_cpp_driver(tmp_path):
     assert a == b
     Wc, Wp = hostlib.read_mps(str(tmp_path / "cpp" / "W")), hostlib.read_mps(str(tmp_path / "py" / "W"))
     assert all(np.array_equal(x, y) for x, y in zip(Wc, Wp))
+
+
+def test_properties_at_the_full_baseline_size():
+    """BASELINE config 3 itself (N=784 sites, 60 000 images, m=120, fp64: 250 GB on the one GPU): size-independent
+    properties of the HIP path at the size the benchmark runs -- linearity of the forward map in B, the data cost seen
+    from two neighbouring bonds (gauge invariance), additivity of the gradient over image shards, run-to-run determinism."""
+    from tnml_amd import synth
+    from tnml_amd.fixedl import TrainStates
+    N, NT, m, b0 = 784, 60000, 120, 400
+    labels = synth.synthetic_labels(NT)
+    pixels = synth.synthetic_images(N, labels)
+    W = synth.random_mps(N, m, seed=1)
+
+    def walked(sl):
+        t = TrainStates(labels[sl], N, m, pixels=pixels[sl])
+        t.set_mps(W)
+        t.init()
+        for bb in range(1, b0):
+            t.shiftE(bb, True)
+        t.setBond(b0)
+        return t
+    ts = walked(slice(0, NT))
+    assert ts.device_bytes() > 200e9
+    B1 = ts.bond_tensor(b0)
+    assert B1.shape == (120, 2, 2, 120)
+    B2 = np.random.default_rng(0).standard_normal(B1.shape) * np.abs(B1).max()
+    P1, P2, P12 = ts.forward(B1), ts.forward(B2), ts.forward(B1 + 2.0 * B2)
+    assert _relmax(P12, P1 + 2.0 * P2) < 1e-12
+    G = ts.gradient(B1)
+    assert _relmax(ts.gradient(B1), G) == 0.0                                  # deterministic reductions: bit-identical
+    C, lc, cr, nc = ts.quadcost(B1, 1e-3)
+    ts.shiftE(b0, True)
+    ts.setBond(b0 + 1)
+    C2, lc2, cr2, nc2 = ts.quadcost(ts.bond_tensor(b0 + 1), 1e-3)
+    assert C2 - cr2 == pytest.approx(C - cr, rel=1e-11) and nc2 == nc
+    np.testing.assert_allclose(lc2, lc, rtol=1e-10)
+    ts.close()
+    Gs = np.zeros_like(G)
+    for sl in (slice(0, NT // 2), slice(NT // 2, NT)):
+        t2 = walked(sl)
+        Gs += t2.gradient(B1)
+        t2.close()
+    assert _relmax(Gs, G) < 1e-11
