@@ -29,6 +29,15 @@ def test_input_file_grammar():
         hostlib.input_get("/nonexistent/file", "x")
 
 
+def test_input_file_grammar_of_the_per_label_sample():
+    """layout of sample_inputs/input_single: the group braces and the keys indented"""
+    f = os.path.join(ROOT, "tests", "golden", "input_single_sample")
+    assert hostlib.input_get(f, "datadir") == "/data/MNIST"
+    assert int(hostlib.input_get(f, "label")) == 3 and int(hostlib.input_get(f, "imglen")) == 8
+    assert int(hostlib.input_get(f, "maxm")) == 20 and float(hostlib.input_get(f, "cutoff")) == 1e-9
+    assert float(hostlib.input_get(f, "lambda")) == 1e-8 and hostlib.input_get(f, "feature") is None
+
+
 def test_driver_usage_and_missing_data(tmp_path):
     exe = os.path.join(ROOT, "tnml_amd", "fixedL")
     out = subprocess.run([exe], capture_output=True, text=True)
