@@ -9,10 +9,11 @@ device resident.
 
 Which bonds are timed.  A sweep has four kinds of interior bonds of equal GEMM cost: the Label index sits on
 the right (b < N/2) or left (b > N/2) environment, and the environment built by shiftE after the update
-carries the Label index (10x the work of a Label-free shift) on exactly half of them.  With --steps >=
-2(N-1) the timed region is whole sweeps from bond 1 (the exact sweep average, centre bonds included).  With
-fewer steps it is a run of consecutive interior bonds of the MOST expensive kind (first half-sweep, b > N/2:
-every step pays the Label-carrying shift), so a short run never overstates the sweep average.
+carries the Label index (10x the work of a Label-free shift) on exactly half of them.  The default is one
+whole sweep, 2(N-1) = 1566 consecutive bond updates (the exact sweep average: chain ends, interior and centre
+bonds in their true proportions; 6-7 s).  With --steps < 2(N-1) the timed region is a run of consecutive
+interior bonds of the MOST expensive kind (first half-sweep, b > N/2: every step pays the Label-carrying
+shift), so a short run never overstates the sweep average.
 At --gpus N the 60 000 images are sharded over N ranks (strong scaling) and the gradient / cost
 partials are summed by an RCCL all-reduce inside the library; the control plane (unique-id
 broadcast, barriers, max-over-ranks timing) uses torch.distributed.
@@ -105,14 +106,14 @@ def hbm_roofline(prof_all, NTl, timed, args, world):
     avg_ms = ms_ld / n_ld
     ach = by / (avg_ms * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": "k_labeldot", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-            "traffic": pmc_traffic("void k_labeldot<4, double, double, double>") if args.dtype == "f64" and args.maxm == 120 and args.images == 60000 and world == 1 else None,
+            "traffic": pmc_traffic("void k_labeldot<4, 2, 10, double, double, double>") if args.dtype == "f64" and args.maxm == 120 and args.images == 60000 and world == 1 else None,
             "avg_launch_ms": avg_ms, "launches": n_ld, "bytes_per_launch": by}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=None, help="default: one whole sweep, 2(N-1) bond updates (6-7 s at the default workload)")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--sites", type=int, default=784)
     ap.add_argument("--images", type=int, default=60000)
@@ -125,6 +126,8 @@ def main():
     ap.add_argument("--single-label", type=int, default=None, help="bench the per-label variant (single.cc, BASELINE config 4: one such "
                     "training per label, replicas only) for this label instead of the fixedL sweep")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 2 * (args.sites - 1)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
