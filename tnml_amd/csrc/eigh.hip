@@ -29,35 +29,6 @@ struct TriArgs {
     long long* dbg;                      // TNML_EIGH_PROF builds: per-phase cycle counters
 };
 
-// quad-lane exchange of a double through DPP (lanes 4q..4q+3 hold the 4 column strips of one block)
-template <int CTRL>
-static __device__ __forceinline__ double dpp_quad(double x) {
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
-    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
-    return __hiloint2double(hi, lo);
-}
-template <int CTRL, int ROWMASK>
-static __device__ __forceinline__ double dpp_masked(double x) {       // rows outside ROWMASK receive 0
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWMASK, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-// wave64 sum broadcast to every lane, all in DPP (a ds_bpermute shuffle costs an LDS round trip per
-// step, ~12 of them per reduction; this sits on the serial path of every Householder step)
-static __device__ __forceinline__ double wave_sum(double x) {
-    x += dpp_quad<0xB1>(x);                 // quad_perm [1,0,3,2]
-    x += dpp_quad<0x4E>(x);                 // quad_perm [2,3,0,1]
-    x += dpp_quad<0x141>(x);                // row_half_mirror: 8-lane sums
-    x += dpp_quad<0x140>(x);                // row_mirror: 16-lane (row) sums in every lane
-    x += dpp_masked<0x142, 0xA>(x);         // row_bcast:15 -> rows 1,3 += row 0,2
-    x += dpp_masked<0x143, 0xC>(x);         // row_bcast:31 -> rows 2,3 += rows 0..1
-    const int lo = __builtin_amdgcn_readlane(__double2loint(x), 63);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), 63);
-    return __hiloint2double(hi, lo);
-}
-
 __global__ __launch_bounds__(512) void k_sytrd_onewg(TriArgs T) {
     __shared__ double s_v[TRI_MAXN + TB], s_w[TRI_MAXN + TB], s_x[TRI_MAXN + TB];
     __shared__ double s_red[16];

@@ -579,7 +579,8 @@ __global__ __launch_bounds__(64 * WR * WC) void k_bgemm64(Bgemm64KArgs K) {
     constexpr int NAI = (BMr / 2) * (KTn / 4), NBI = (BNc / 2) * (KTn / 4);
     constexpr int NA = (NAI + T - 1) / T, NB = (NBI + T - 1) / T;
     static_assert(!FUSE || T >= TNML_NL * KTn, "dP tile needs one lane per entry");
-    __shared__ __attribute__((aligned(16))) double lds[(BMr + BNc) * ST + (FUSE ? TNML_NL * KTn : 0)];
+    static_assert(!FUSE || T >= 4 * KTn, "feature tile needs one lane per entry");
+    __shared__ __attribute__((aligned(16))) double lds[(BMr + BNc) * ST + (FUSE ? (TNML_NL + 4) * KTn : 0)];
     double* As = lds;
     double* Bs = lds + BMr * ST;
     const Bgemm64Args& A = K.a;
@@ -609,6 +610,8 @@ __global__ __launch_bounds__(64 * WR * WC) void k_bgemm64(Bgemm64KArgs K) {
     V2<TE> el[FUSE ? NF : 1][FUSE ? TNML_NL : 1];   // Label-carrying env rows of the chunk in flight (FUSE)
     double dpr = 0.;                               // this lane's entry of the dP tile [10][KTn] (FUSE)
     double* dPs = lds + (BMr + BNc) * ST;          // [10][KTn]
+    double phr = 0.;                               // and of the feature tile [phiI s0, s1, phiO s0, s1][KTn]:
+    double* phs = dPs + TNML_NL * KTn;             // staged with dP so the build phase never waits on L2
     auto load_chunk = [&](int nb) {
 #pragma unroll
         for (int q = 0; q < NA; ++q) {
@@ -661,8 +664,15 @@ __global__ __launch_bounds__(64 * WR * WC) void k_bgemm64(Bgemm64KArgs K) {
             }
         }
         if (FUSE && tid < TNML_NL * KTn) dpr = A.dPz[(size_t)(tid / KTn) * NTp + nb + (tid % KTn)];
+        if (FUSE && tid < 4 * KTn) {
+            const int wh = tid / KTn, n = nb + (tid % KTn);
+            phr = (double)((wh < 2 ? phiI : phiO)[(size_t)(wh & 1) * NTp + n]);
+        }
     };
-    auto store_dp = [&]() { if (FUSE && tid < TNML_NL * KTn) dPs[tid] = dpr; };
+    auto store_dp = [&]() {
+        if (FUSE && tid < TNML_NL * KTn) dPs[tid] = dpr;
+        if (FUSE && tid < 4 * KTn) phs[tid] = phr;
+    };
     auto store_chunk = [&](int nb) {
 #pragma unroll
         for (int q = 0; q < NA; ++q) {
@@ -670,14 +680,22 @@ __global__ __launch_bounds__(64 * WR * WC) void k_bgemm64(Bgemm64KArgs K) {
             if (idx < NAI) {
                 const int ar = idx / (KTn / 4), c4 = idx % (KTn / 4);
                 const V4<TE> e = ea[q];
-                const V4<TE> p0 = FUSE ? V4<TE>::load(phiI + nb + c4 * 4) : pa0[q];          // FUSE: register budget,
-                const V4<TE> p1 = FUSE ? V4<TE>::load(phiI + NTp + nb + c4 * 4) : pa1[q];    // the features are cache hot
                 double* x0 = &As[(2 * ar) * ST + c4 * 4];
                 double* x1 = &As[(2 * ar + 1) * ST + c4 * 4];
-                *reinterpret_cast<double2*>(x0) = make_double2(e.x() * p0.x(), e.y() * p0.y());
-                *reinterpret_cast<double2*>(x0 + 2) = make_double2(e.z() * p0.z(), e.w() * p0.w());
-                *reinterpret_cast<double2*>(x1) = make_double2(e.x() * p1.x(), e.y() * p1.y());
-                *reinterpret_cast<double2*>(x1 + 2) = make_double2(e.z() * p1.z(), e.w() * p1.w());
+                if (FUSE) {
+                    const double2 p0a = *reinterpret_cast<const double2*>(&phs[c4 * 4]), p0b = *reinterpret_cast<const double2*>(&phs[c4 * 4 + 2]);
+                    const double2 p1a = *reinterpret_cast<const double2*>(&phs[KTn + c4 * 4]), p1b = *reinterpret_cast<const double2*>(&phs[KTn + c4 * 4 + 2]);
+                    *reinterpret_cast<double2*>(x0) = make_double2(e.x() * p0a.x, e.y() * p0a.y);
+                    *reinterpret_cast<double2*>(x0 + 2) = make_double2(e.z() * p0b.x, e.w() * p0b.y);
+                    *reinterpret_cast<double2*>(x1) = make_double2(e.x() * p1a.x, e.y() * p1a.y);
+                    *reinterpret_cast<double2*>(x1 + 2) = make_double2(e.z() * p1b.x, e.w() * p1b.y);
+                } else {
+                    const V4<TE> p0 = pa0[q], p1 = pa1[q];
+                    *reinterpret_cast<double2*>(x0) = make_double2(e.x() * p0.x(), e.y() * p0.y());
+                    *reinterpret_cast<double2*>(x0 + 2) = make_double2(e.z() * p0.z(), e.w() * p0.w());
+                    *reinterpret_cast<double2*>(x1) = make_double2(e.x() * p1.x(), e.y() * p1.y());
+                    *reinterpret_cast<double2*>(x1 + 2) = make_double2(e.z() * p1.z(), e.w() * p1.w());
+                }
             }
         }
         if (FUSE) {
@@ -693,10 +711,10 @@ __global__ __launch_bounds__(64 * WR * WC) void k_bgemm64(Bgemm64KArgs K) {
                         z0 = fma(el[q][ll].x(), d.x, z0);
                         z1 = fma(el[q][ll].y(), d.y, z1);
                     }
-                    const V2<TE> f0 = V2<TE>::load(phiO + nb + c2 * 2);
-                    const V2<TE> f1 = V2<TE>::load(phiO + NTp + nb + c2 * 2);
-                    *reinterpret_cast<double2*>(&Bs[(2 * qr) * ST + c2 * 2]) = make_double2(z0 * f0.x(), z1 * f0.y());
-                    *reinterpret_cast<double2*>(&Bs[(2 * qr + 1) * ST + c2 * 2]) = make_double2(z0 * f1.x(), z1 * f1.y());
+                    const double2 f0 = *reinterpret_cast<const double2*>(&phs[2 * KTn + c2 * 2]);
+                    const double2 f1 = *reinterpret_cast<const double2*>(&phs[3 * KTn + c2 * 2]);
+                    *reinterpret_cast<double2*>(&Bs[(2 * qr) * ST + c2 * 2]) = make_double2(z0 * f0.x, z1 * f0.y);
+                    *reinterpret_cast<double2*>(&Bs[(2 * qr + 1) * ST + c2 * 2]) = make_double2(z0 * f1.x, z1 * f1.y);
                 }
             }
         } else {
@@ -769,7 +787,8 @@ __global__ void k_slab_reduce64(const double* __restrict__ slab, double* __restr
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     double s = 0.;
-    for (int k = 0; k < nsplit; ++k) s += slab[(size_t)k * n + i];
+#pragma unroll 8
+    for (int k = 0; k < nsplit; ++k) s += slab[(size_t)k * n + i];      // same order, eight loads in flight
     G[i] = s;
 }
 

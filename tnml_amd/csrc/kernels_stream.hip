@@ -16,6 +16,36 @@ template <typename T> struct vec2;
 template <> struct vec2<float> { typedef float2 type; };
 template <> struct vec2<double> { typedef double2 type; };
 
+// Workgroup partial sums [12]: cost bucket of every label (0..9), number correct (10), plain sum (11, the
+// <p|A|p> mode).  Called by whole waves (all 64 lanes active): a fixed DPP tree inside the wave, lane 0
+// leaves the wave's 12 values in s_part[wave][12]; after a barrier sum_wave_partials adds the waves in
+// order -> deterministic for a given launch shape.  (The serial 128-entry LDS walk this replaces
+// was a third of k_pupdate.)
+static __device__ __forceinline__ void wave_bucket_partials(double val, int lab, int cor, bool pap, double* s_part, int wave, int lane) {
+    if (pap) {
+        const double s = wave_sum(val);
+        if (lane < 12) s_part[wave * 12 + lane] = lane == 11 ? s : 0.;
+        return;
+    }
+    double mine = 0.;
+#pragma unroll
+    for (int t = 0; t < TNML_NL; ++t) {
+        const double s = wave_sum(lab == t ? val : 0.);
+        if (lane == t) mine = s;
+    }
+    const double sc = wave_sum((double)cor);
+    if (lane == 10) mine = sc;
+    if (lane < 12) s_part[wave * 12 + lane] = mine;
+}
+static __device__ __forceinline__ void sum_wave_partials(const double* s_part, int nwaves, double* out, int tid) {
+    if (tid < 12) {
+        double s = 0.;
+        for (int w = 0; w < nwaves; ++w) s += s_part[w * 12 + tid];
+        out[tid] = s;
+    }
+}
+
+
 // TA: element type of the label-carrying operand, TB: of the label-free one, TC: arithmetic type
 // IPL: images per lane.  2 (128 images per workgroup, 16-byte loads) is the streaming configuration; 1 with more
 // waves per workgroup keeps enough loads in flight when a rank holds few images (multi-GPU shards, small sets).
@@ -25,9 +55,7 @@ template <int NW, int IPL, int NLT, typename TA, typename TB, typename TC>
 __global__ __launch_bounds__(64 * NW) void k_labeldot(LdotArgs A, double* __restrict__ partials) {
     constexpr int LDI = 64 * IPL;
     __shared__ __attribute__((aligned(16))) TC red[NW * NLT * LDI];
-    __shared__ TC s_val[LDI];
-    __shared__ int s_lab[LDI];
-    __shared__ int s_cor[LDI];
+    __shared__ double s_part[(LDI / 64) * 12];
     typedef typename vec2<TA>::type TA2;
     typedef typename vec2<TB>::type TB2;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -97,21 +125,10 @@ __global__ __launch_bounds__(64 * NW) void k_labeldot(LdotArgs A, double* __rest
             if (A.target < 0) cor = (lab >= 0 && arg == lab) ? 1 : 0;
             else              cor = (lab >= 0 && ((P[0] > (TC)0.5) == (lab == A.target))) ? 1 : 0;
         }
-        s_val[tid] = val; s_lab[tid] = lab; s_cor[tid] = cor;
+        wave_bucket_partials((double)val, lab, cor, A.mode == LD_MODE_PAP, s_part, tid >> 6, tid & 63);
     }
     __syncthreads();
-    // deterministic per-workgroup partial sums: thread l sums its label bucket in image order
-    if (tid < 12) {
-        double s = 0.;
-        if (A.mode == LD_MODE_PAP) {
-            if (tid == 11) for (int i = 0; i < LDI; ++i) s += (double)s_val[i];
-        } else if (tid < TNML_NL) {
-            for (int i = 0; i < LDI; ++i) if (s_lab[i] == tid) s += (double)s_val[i];
-        } else if (tid == 10) {
-            for (int i = 0; i < LDI; ++i) s += (double)s_cor[i];
-        }
-        partials[(size_t)blockIdx.x * 12 + tid] = s;
-    }
+    sum_wave_partials(s_part, LDI / 64, partials + (size_t)blockIdx.x * 12, tid);
 }
 
 __global__ __launch_bounds__(768) void k_reduce_partials(const double* __restrict__ partials, int nblk, double* __restrict__ out) {
@@ -189,9 +206,7 @@ __global__ __launch_bounds__(LD_IMGS) void k_pupdate(T* __restrict__ P, const T*
                                                     const double* __restrict__ alpha, const double* __restrict__ conv,
                                                     double* __restrict__ partials, int nl, int target) {
     if (conv[0] != 0.) return;                             // CG already converged: P must stay as it is
-    __shared__ T s_val[LD_IMGS];
-    __shared__ int s_lab[LD_IMGS];
-    __shared__ int s_cor[LD_IMGS];
+    __shared__ double s_part[(LD_IMGS / 64) * 12];
     const int tid = threadIdx.x;
     const int ni = blockIdx.x * LD_IMGS + tid;
     const T a = (T)alpha[0];
@@ -210,15 +225,10 @@ __global__ __launch_bounds__(LD_IMGS) void k_pupdate(T* __restrict__ P, const T*
             if (l == 0) { best = wgt; p0 = p; } else if (wgt > best) { best = wgt; arg = l; }
         }
     }
-    s_val[tid] = val; s_lab[tid] = lab;
-    s_cor[tid] = target < 0 ? ((lab >= 0 && arg == lab) ? 1 : 0) : ((lab >= 0 && ((p0 > (T)0.5) == (lab == target))) ? 1 : 0);
+    const int cor = target < 0 ? ((lab >= 0 && arg == lab) ? 1 : 0) : ((lab >= 0 && ((p0 > (T)0.5) == (lab == target))) ? 1 : 0);
+    wave_bucket_partials((double)val, lab, cor, false, s_part, tid >> 6, tid & 63);
     __syncthreads();
-    if (tid < 12) {
-        double s = 0.;
-        if (tid < TNML_NL) { for (int i = 0; i < LD_IMGS; ++i) if (s_lab[i] == tid) s += (double)s_val[i]; }
-        else if (tid == 10) { for (int i = 0; i < LD_IMGS; ++i) s += (double)s_cor[i]; }
-        partials[(size_t)blockIdx.x * 12 + tid] = s;
-    }
+    sum_wave_partials(s_part, LD_IMGS / 64, partials + (size_t)blockIdx.x * 12, tid);
 }
 
 int launch_pupdate(tnml_ctx* c, const double* alpha_dev, double* scal_out) {
