@@ -118,26 +118,29 @@ int launch_bond_form(tnml_ctx* c, const SiteT& A1, const SiteT& A2, double* B) {
 // A single workgroup streams at ~25-50 GB/s (one CU), which made the 1-block versions 40-90 us each.
 #define VB 256
 #define VNB_MAX 256
+// workgroup sum (VB lanes, every lane active): DPP tree inside each wave, then the waves in order
 static __device__ __forceinline__ double block_sum(double v, double* sh) {
+    const double w = wave_sum(v);
     const int tid = threadIdx.x;
-    sh[tid] = v;
+    __syncthreads();                                        // readers of a previous call are done with sh
+    if ((tid & 63) == 0) sh[tid >> 6] = w;
     __syncthreads();
-    for (int s = VB / 2; s > 0; s >>= 1) {
-        if (tid < s) sh[tid] += sh[tid + s];
-        __syncthreads();
-    }
-    const double r = sh[0];
-    __syncthreads();
+    double r = 0.;
+#pragma unroll
+    for (int k = 0; k < VB / 64; ++k) r += sh[k];
     return r;
 }
 static __device__ __forceinline__ void slice(size_t n, size_t* lo, size_t* hi) {
     const size_t per = (n + gridDim.x - 1) / gridDim.x;
     *lo = per * blockIdx.x; *hi = *lo + per; if (*hi > n) *hi = n; if (*lo > n) *lo = n;
 }
-static __device__ __forceinline__ void sum_partials(const double* part, int nb, double* s0, double* s1) {
-    double a = 0., b = 0.;
-    for (int k = 0; k < nb; ++k) { a += part[2 * k]; b += part[2 * k + 1]; }   // same order in every workgroup
-    *s0 = a; *s1 = b;
+// sum of the nb <= VB phase-1 partial pairs, by the whole workgroup: lane k takes pair k, then the fixed
+// block_sum tree -> the same value in every workgroup (a serial walk by every lane cost ~6 us per kernel)
+static __device__ __forceinline__ void sum_partials(const double* part, int nb, double* s0, double* s1, double* sh) {
+    const int tid = threadIdx.x;
+    const double a = tid < nb ? part[2 * tid] : 0., b = tid < nb ? part[2 * tid + 1] : 0.;
+    *s0 = block_sum(a, sh);
+    *s1 = block_sum(b, sh);
 }
 
 // r = G - lambda*B (fixedL.cc:385-386); p = r (:388); partial |r|^2
@@ -156,9 +159,10 @@ __global__ __launch_bounds__(VB) void k_cg_init1(const double* __restrict__ G, c
     if (threadIdx.x == 0) { part[2 * blockIdx.x] = s; part[2 * blockIdx.x + 1] = 0.; }
 }
 // cconv0 >= 0 (TNML_MODE_SINGLE): |r| < cconv at entry -> "not optimizing" (single.h:202-206): flag 2 freezes every later kernel
-__global__ void k_cg_init2(const double* __restrict__ part, int nb, double* __restrict__ scal, int rr_out, double cconv0) {
+__global__ __launch_bounds__(VB) void k_cg_init2(const double* __restrict__ part, int nb, double* __restrict__ scal, int rr_out, double cconv0) {
+    __shared__ double sh[VB / 64];
+    double a, b; sum_partials(part, nb, &a, &b, sh);
     if (threadIdx.x == 0) {
-        double a, b; sum_partials(part, nb, &a, &b);
         scal[rr_out] = a; scal[SC_CONV] = (cconv0 >= 0. && sqrt(a) < cconv0) ? 2. : 0.; scal[SC_NPASS] = 0.;
     }
 }
@@ -177,7 +181,8 @@ __global__ __launch_bounds__(VB) void k_cg_step2(double* __restrict__ B, const d
                                                 const double* __restrict__ tail, const double* __restrict__ part, int nb,
                                                 double* __restrict__ scal, int rr_in, double* __restrict__ trace, int pass) {
     if (scal[SC_CONV] != 0.) return;                       // |r| < cconv was hit in an earlier pass (fixedL.cc:432-436)
-    double pn2, unused; sum_partials(part, nb, &pn2, &unused);
+    __shared__ double sh[VB / 64];
+    double pn2, unused; sum_partials(part, nb, &pn2, &unused, sh);
     const double pAp = tail[SC_PP] + lambda * pn2;
     const double a = scal[rr_in] / pAp;
     size_t lo, hi; slice(n, &lo, &hi);
@@ -210,7 +215,8 @@ __global__ __launch_bounds__(VB) void k_cg_resid2(const double* __restrict__ G, 
                                                  double* __restrict__ scal, int rr_in, int rr_out,
                                                  double* __restrict__ trace, int pass) {
     if (scal[SC_CONV] != 0.) return;
-    double nn, bn2; sum_partials(part, nb, &nn, &bn2);
+    __shared__ double sh[VB / 64];
+    double nn, bn2; sum_partials(part, nb, &nn, &bn2, sh);
     const double q = sqrt(nn) / sqrt(scal[rr_in]);
     const double beta = q * q;
     const double rn = sqrt(nn);
@@ -235,8 +241,10 @@ __global__ __launch_bounds__(VB) void k_cg_resid2(const double* __restrict__ G, 
 __global__ void k_cg_commit(double* __restrict__ scal) {
     if (threadIdx.x == 0 && scal[SC_CONV] == 0.) scal[SC_CONV] = scal[SC_CONV_NEXT];
 }
-__global__ void k_norm2(const double* __restrict__ part, int nb, double* __restrict__ out, int nout) {
-    if (threadIdx.x == 0) { double a, b; sum_partials(part, nb, &a, &b); out[0] = a; if (nout > 1) out[1] = b; }
+__global__ __launch_bounds__(VB) void k_norm2(const double* __restrict__ part, int nb, double* __restrict__ out, int nout) {
+    __shared__ double sh[VB / 64];
+    double a, b; sum_partials(part, nb, &a, &b, sh);
+    if (threadIdx.x == 0) { out[0] = a; if (nout > 1) out[1] = b; }
 }
 __global__ __launch_bounds__(VB) void k_diffnorm1(const double* __restrict__ x, const double* __restrict__ y, size_t n, double* __restrict__ part) {
     __shared__ double sh[VB];
@@ -257,7 +265,7 @@ int launch_cg_init(tnml_ctx* c, size_t n, double lambda, double cconv0) {
     const int nb = vec_blocks(n);
     c->rr_slot = 0;
     hipLaunchKernelGGL(k_cg_init1, dim3(nb), dim3(VB), 0, c->stream, c->vG, c->vB, c->vR, c->vP, n, lambda, c->vpart);
-    hipLaunchKernelGGL(k_cg_init2, dim3(1), dim3(64), 0, c->stream, c->vpart, nb, c->scal, (int)SC_RR, cconv0);
+    hipLaunchKernelGGL(k_cg_init2, dim3(1), dim3(VB), 0, c->stream, c->vpart, nb, c->scal, (int)SC_RR, cconv0);
     HIPCK(c, hipGetLastError());
     return 0;
 }
@@ -284,7 +292,7 @@ int launch_sqnorm(tnml_ctx* c, const double* x, size_t n, double* out) {
     ProfScope ps(c, KC_VEC);
     const int nb = vec_blocks(n);
     hipLaunchKernelGGL(k_norm1, dim3(nb), dim3(VB), 0, c->stream, x, (const double*)nullptr, n, c->vpart);
-    hipLaunchKernelGGL(k_norm2, dim3(1), dim3(64), 0, c->stream, c->vpart, nb, out, 1);
+    hipLaunchKernelGGL(k_norm2, dim3(1), dim3(VB), 0, c->stream, c->vpart, nb, out, 1);
     HIPCK(c, hipGetLastError());
     return 0;
 }
@@ -292,7 +300,7 @@ int launch_diffnorm(tnml_ctx* c, const double* x, const double* y, size_t n, dou
     ProfScope ps(c, KC_VEC);
     const int nb = vec_blocks(n);
     hipLaunchKernelGGL(k_diffnorm1, dim3(nb), dim3(VB), 0, c->stream, x, y, n, c->vpart);
-    hipLaunchKernelGGL(k_norm2, dim3(1), dim3(64), 0, c->stream, c->vpart, nb, out2, 2);
+    hipLaunchKernelGGL(k_norm2, dim3(1), dim3(VB), 0, c->stream, c->vpart, nb, out2, 2);
     HIPCK(c, hipGetLastError());
     return 0;
 }
