@@ -95,13 +95,15 @@ def cpu_baseline(maxm, npass, lam, cutoff, nthread, NT_total):
 def hbm_roofline(prof_all, NTl, timed, args, world):
     """the HBM-bound kernel of the path: the label dot P_n[l] = sum_q T[q][n] * E[l][q][n] streams the Label-carrying
     environment (10*m values per image) and the GEMM output (m per image) once; algorithmic bytes per launch from the
-    bond dimensions of the timed bonds, duration from the library's HIP events over the untimed breakdown steps"""
+    bond dimensions of the timed bonds, duration from the library's HIP events (class "labeldot" = the k_labeldot launches
+    alone; the P update and the partial-sum reduction are class "p_update") over the untimed breakdown steps"""
     n_ld, ms_ld = prof_all.get("labeldot", (0, 0.0))
     if not n_ld or not timed:
         return None
     esz = 4 if args.dtype == "f32" else 8
     env_sz = 8 if args.dtype == "f64" else 4
-    by = float(np.mean([NTl * (10 * min(r["mL"], r["mR"]) * (esz if r["label_on_B"] else env_sz) +
+    nl = 1 if args.single_label is not None else 10
+    by = float(np.mean([NTl * (nl * min(r["mL"], r["mR"]) * (esz if r["label_on_B"] else env_sz) +
                               min(r["mL"], r["mR"]) * (env_sz if r["label_on_B"] else esz) + 4) for r in timed]))
     avg_ms = ms_ld / n_ld
     ach = by / (avg_ms * 1e-3) / 1e9

@@ -291,6 +291,11 @@ template <typename T> struct V2;
 template <> struct V2<float> {
     float2 v;
     static __device__ __forceinline__ V2 load(const float* p) { V2 r; r.v = *reinterpret_cast<const float2*>(p); return r; }
+    static __device__ __forceinline__ V2 load_nt(const float* p) {            // streamed once: non-temporal
+        typedef float f2v __attribute__((ext_vector_type(2)));
+        const f2v t = __builtin_nontemporal_load(reinterpret_cast<const f2v*>(p));
+        V2 r; r.v = make_float2(t.x, t.y); return r;
+    }
     static __device__ __forceinline__ V2 zero() { V2 r; r.v = make_float2(0.f, 0.f); return r; }
     __device__ __forceinline__ double x() const { return v.x; }
     __device__ __forceinline__ double y() const { return v.y; }
@@ -298,6 +303,11 @@ template <> struct V2<float> {
 template <> struct V2<double> {
     double2 v;
     static __device__ __forceinline__ V2 load(const double* p) { V2 r; r.v = *reinterpret_cast<const double2*>(p); return r; }
+    static __device__ __forceinline__ V2 load_nt(const double* p) {
+        typedef double d2v __attribute__((ext_vector_type(2)));
+        const d2v t = __builtin_nontemporal_load(reinterpret_cast<const d2v*>(p));
+        V2 r; r.v = make_double2(t.x, t.y); return r;
+    }
     static __device__ __forceinline__ V2 zero() { V2 r; r.v = make_double2(0., 0.); return r; }
     __device__ __forceinline__ double x() const { return v.x; }
     __device__ __forceinline__ double y() const { return v.y; }
@@ -351,7 +361,7 @@ __global__ __launch_bounds__(64 * WR * WC) void k_fgemm64(Fgemm64Args A) {
             const int ar = idx / (BM / 4);
             const int a = k0 / 2 + ar;
             xr[q] = V4<TE>::zero();
-            if (idx < NXI && a < A.mI) xr[q] = V4<TE>::load(E + (size_t)a * NTp + n0 + xc4 * 4);
+            if (idx < NXI && a < A.mI) xr[q] = V4<TE>::load(E + (size_t)a * NTp + n0 + xc4 * 4);   // (non-temporal: no gain, matrix-pipe bound)
         }
 #pragma unroll
         for (int q = 0; q < NM; ++q) {
@@ -483,7 +493,7 @@ __global__ __launch_bounds__(64 * WR * WC) void k_fgemm64(Fgemm64Args A) {
                     const int q = j >> 1;
                     if ((g & 1) == 0 && q < A.mO) out[(size_t)q * NTp + n] = v;
                 } else {
-                    if (j < A.mO) out[(size_t)j * NTp + n] = acc[c][r][e];
+                    if (j < A.mO) out[(size_t)j * NTp + n] = acc[c][r][e];     // (non-temporal stores: no gain)
                 }
             }
         }
@@ -565,6 +575,7 @@ struct Bgemm64KArgs {
     Bgemm64Args a;
     double* slab;
     int nsplit, imgs_per_split;
+    int nt;                       // non-temporal loads of the Label-carrying environment (read once per launch)
 };
 
 // Software pipelined like k_fgemm64: the image chunk n+1 is fetched into registers while chunk n feeds
@@ -634,7 +645,10 @@ __global__ __launch_bounds__(64 * WR * WC) void k_bgemm64(Bgemm64KArgs K) {
 #pragma unroll
                 for (int ll = 0; ll < TNML_NL; ++ll) {
                     el[q][ll] = V2<TE>::zero();
-                    if (idx < NFI && qq < A.mO) el[q][ll] = V2<TE>::load(ELp + (size_t)ll * A.EL_lstride + (size_t)qq * NTp + n);
+                    if (idx < NFI && qq < A.mO) {
+                        const TE* ep = ELp + (size_t)ll * A.EL_lstride + (size_t)qq * NTp + n;
+                        el[q][ll] = K.nt ? V2<TE>::load_nt(ep) : V2<TE>::load(ep);
+                    }
                 }
             }
         } else {
@@ -808,7 +822,8 @@ static int bgemm64_go(tnml_ctx* c, const Bgemm64Args& a, double* G, int default_
     if ((size_t)nsplit * n > cap) return tnml_fail(c, "bgemm64: slab workspace too small");
     int per = ((chunks + nsplit - 1) / nsplit) * 32;
     nsplit = (a.NTp + per - 1) / per;
-    Bgemm64KArgs K{a, (double*)c->slab, nsplit, per};
+    static const int nt = getenv("TNML_BG_NT") ? atoi(getenv("TNML_BG_NT")) : 1;
+    Bgemm64KArgs K{a, (double*)c->slab, nsplit, per, nt};
     {
         ProfScope ps(c, KC_BGEMM);
         dim3 grid((a.Kp + BMr - 1) / BMr, (a.Np + BNc - 1) / BNc, nsplit * a.L);

@@ -31,11 +31,11 @@
 
 enum KClass {
     KC_FGEMM_FWD = 0, KC_FGEMM_SHIFT, KC_LABELDOT, KC_ZPRIME, KC_BGEMM, KC_SLABRED, KC_PACK, KC_VEC,
-    KC_SMALLGEMM, KC_SVD, KC_ALLREDUCE, KC_COUNT
+    KC_SMALLGEMM, KC_SVD, KC_ALLREDUCE, KC_PUPDATE, KC_COUNT
 };
 static const char* const kclass_names[KC_COUNT] = {
     "fgemm_fwd", "fgemm_shift", "labeldot", "zprime", "bgemm", "slab_reduce", "pack", "cg_vec",
-    "small_gemm", "svd", "allreduce"};
+    "small_gemm", "svd", "allreduce", "p_update"};
 
 struct EnvSlot {
     void* ptr = nullptr;    // [L][m][NTp], fp32 or fp64 elements (tnml_ctx::env64)
@@ -220,6 +220,7 @@ struct LdotArgs {
     const int* label;
     void* P; void* dP;                  // [10][NTp] in the context's arithmetic type
     int mode;
+    int nt = 0;                         // non-temporal loads of A (set by launch_labeldot)
 };
 // partial sums -> scal_out[0..11] (device); deterministic
 int launch_labeldot(tnml_ctx* c, const LdotArgs& a, double* scal_out);
