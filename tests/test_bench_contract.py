@@ -1,0 +1,65 @@
+"""bench.py's output contract on a small workload (the full BASELINE config 3 is what the driver runs)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"}
+
+
+def _run(*extra):
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--sites", "24", "--images", "3000", "--maxm", "12",
+                          "--warmup", "2", *extra], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert run.returncode == 0, run.stderr[-2000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, run.stdout[-2000:]                       # ONE JSON line
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_json_line_whole_sweep():
+    d = _run()
+    assert REQUIRED <= set(d), REQUIRED - set(d)
+    assert d["metric"] == "two-site bond updates/sec" and d["unit"] == "bond updates/s"
+    assert d["steps"] == 2 * (24 - 1) and d["warmup"] == 2 and d["n_gpus"] == 1       # default: one whole sweep
+    assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert d["dtype"] == "f64" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 78.6
+    assert r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["traffic"] is None                                       # the PMC summary was taken on the full workload only
+    h = d["roofline_hbm"]
+    assert h["bound"] == "hbm" and h["unit"] == "GB/s" and h["launches"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
+    assert d["last_cost_per_image"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_window_and_variants():
+    d = _run("--steps", "4", "--no-cpu-baseline")
+    assert d["steps"] == 4 and "cpu_baseline" not in d
+    e = _run("--steps", "4", "--no-cpu-baseline", "--dtype", "f64_e32")
+    assert e["dtype"] == "f64_e32"
+    s = _run("--steps", "4", "--no-cpu-baseline", "--single-label", "3")
+    assert s["value"] > 0
+
+
+def test_bench_refuses_without_a_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present")
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert run.returncode != 0 and "no CPU fallback" in (run.stderr + run.stdout)
+
+
+def test_bench_refuses_gpus_without_launcher():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
+    assert run.returncode != 0 and "torch.distributed.run" in (run.stderr + run.stdout)
