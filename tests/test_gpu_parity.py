@@ -883,18 +883,20 @@ def test_properties_at_the_full_baseline_size():
     assert _relmax(Gs, G) < 1e-11
 
 
-def test_bond_dimension_above_120_uses_the_rocsolver_path():
+@pytest.mark.parametrize("m,NT", [(150, 48), (300, 24)])
+def test_bond_dimension_above_120_uses_the_rocsolver_path(m, NT):
     """maxm > 120 (BASELINE config 5 goes to 300): Gram side n = 2m > 240, beyond the in-house tridiagonalisation;
-    the split falls to rocSOLVER dsyevd and the generic GEMM tiles.  One bond update at m = 150 against the oracle."""
-    ts, o = _pair(N=24, NT=48, m=150, maxm=150)
-    _walk(ts, o, 10)                                           # bond 10 of 24: 150 x 150, Label on the right environment (c0 = 12)
+    the split falls to rocSOLVER dsyevd and the generic GEMM tiles.  One bond update at m = 150 and at m = 300
+    (config 5's bond dimension) against the oracle."""
+    ts, o = _pair(N=24, NT=NT, m=m, maxm=m)
+    _walk(ts, o, 10)                                           # bond 10 of 24: m x m, Label on the right environment (c0 = 12)
     B = o.bond_tensor(10)
-    assert B.shape == (150, 2, 2, 150)
+    assert B.shape == (m, 2, 2, m)
     assert _relmax(ts.forward(B), o.forward(B)) < 1e-11
     assert _relmax(ts.gradient(B), o.gradient(B)) < 1e-9
     Bn = B + 0.05 * np.random.default_rng(3).standard_normal(B.shape)
-    mg, teg, svg = ts.svd_split(Bn, 10, 1, 1e-10, 150, 75)
-    mo, teo, svo = o.svd_split(Bn, 10, 1, 1e-10, 150, 75)
+    mg, teg, svg = ts.svd_split(Bn, 10, 1, 1e-10, m, m // 2)
+    mo, teo, svo = o.svd_split(Bn, 10, 1, 1e-10, m, m // 2)
     assert mg == mo
     np.testing.assert_allclose(svg[:mg], svo[:mo], rtol=1e-7, atol=1e-8 * svo[0])
     assert _relmax(ts.bond_tensor(10), o.bond_tensor(10)) < 1e-8
