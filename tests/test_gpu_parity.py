@@ -5,6 +5,9 @@ dtype "f64" (TNML_F64, the default): everything in fp64 like the reference -- th
 fp64 implementations with different summation orders.  dtype "f64_e32" (TNML_F64_E32): fp64 MFMA and fp64
 CG/SVD algebra over fp32-STORED environments -- tolerances set by that storage rounding (~1e-7 per site,
 accumulated along the chain and amplified by the CG).  dtype "f32": the looser study figures of SURVEY.md 8(d)."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -900,3 +903,35 @@ def test_bond_dimension_above_120_uses_the_rocsolver_path(m, NT):
     assert mg == mo
     np.testing.assert_allclose(svg[:mg], svo[:mo], rtol=1e-7, atol=1e-8 * svo[0])
     assert _relmax(ts.bond_tensor(10), o.bond_tensor(10)) < 1e-8
+
+
+def test_lds_dma_gradient_gemm_variant_matches_the_default(tmp_path):
+    """k_bgemm64_dma (TNML_BGF_CFG=5: image stream staged by global_load_lds instead of registers) against the default
+    register-staged kernel on the same state: 4096 images at m = 120, so that every workgroup runs prologue, steady
+    state and drain of the two-stage DMA ring (the knob is read once per process -> two subprocesses)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from tnml_amd import synth\n"
+        "from tnml_amd.fixedl import TrainStates\n"
+        "N, NT, m = 20, 4096, 120\n"
+        "labels = synth.synthetic_labels(NT)\n"
+        "pixels = synth.synthetic_images(N, labels)\n"
+        "W = synth.random_mps(N, m, seed=5)\n"
+        "ts = TrainStates(labels, N, m, pixels=pixels)\n"
+        "ts.set_mps(W); ts.init()\n"
+        "for bb in range(1, 8): ts.shiftE(bb, True)\n"
+        "ts.setBond(8)\n"
+        "B = ts.bond_tensor(8) + 0.05 * np.random.default_rng(1).standard_normal((120, 2, 2, 120))\n"
+        "np.save(sys.argv[1], ts.gradient(B))\n" % root)
+    outs = []
+    for cfg in ("0", "5"):
+        out = tmp_path / ("g%s.npy" % cfg)
+        run = subprocess.run([sys.executable, "-c", script, str(out)], capture_output=True, text=True, timeout=300,
+                             env=dict(os.environ, TNML_BGF_CFG=cfg))
+        assert run.returncode == 0, run.stderr[-1500:]
+        outs.append(np.load(out))
+    assert outs[0].shape == (120, 2, 2, 120)
+    assert _relmax(outs[1], outs[0]) < 1e-12
