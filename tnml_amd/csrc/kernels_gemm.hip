@@ -541,12 +541,16 @@ int launch_fgemm64(tnml_ctx* c, const Fgemm64Args& a) {
             case 18: fgemm64_go<2, 5, 2, 3, 16>(c, a); break;   // 64 x 240, 6 waves
             case 19: fgemm64_go<1, 5, 2, 3, 16>(c, a); break;   // 32 x 240, 6 waves (several workgroups per CU)
             case 20: fgemm64_go<1, 5, 4, 3, 8>(c, a); break;    // 64 x 240, 12 waves, KT 8
+            case 21: fgemm64_go<1, 4, 4, 2, 16>(c, a); break;   // 64 x 128 (two column tiles), 8 waves
+            case 22: fgemm64_go<2, 4, 2, 2, 16>(c, a); break;   // 64 x 128, 4 waves
+            case 23: fgemm64_go<1, 4, 2, 2, 16>(c, a); break;   // 32 x 128, 4 waves
+            case 24: fgemm64_go<2, 4, 4, 2, 16>(c, a); break;   // 128 x 128, 8 waves
             default:
                 // 128 x 240, 12 waves is the best tile when the images fill the chip (profiles/r01_tune_fgemm64.txt); a rank
                 // with few images (multi-GPU shards, small sets) gets smaller row tiles so that every CU has a workgroup
                 if (a.NTp / 128 >= 192)     fgemm64_go<2, 5, 4, 3, 16>(c, a);
                 else if (a.NTp / 64 >= 192) fgemm64_go<1, 5, 4, 3, 16>(c, a);   // 64 x 240, 12 waves
-                else                        fgemm64_go<1, 5, 2, 3, 16>(c, a);   // 32 x 240, 6 waves
+                else                        fgemm64_go<1, 4, 4, 2, 16>(c, a);   // 64 x 128 (two column tiles), 8 waves: 7500 images 30.5 TF vs 26.2 with 32 x 240
                 break;
         }
     }
