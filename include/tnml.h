@@ -126,6 +126,12 @@ const char* tnml_last_error(const tnml_ctx* ctx);      /* ctx may be NULL: error
    stdx::accumulate over per-thread partials, fixedL.cc:333,339,385,402,421,427. */
 int tnml_comm_unique_id(void* id128);
 int tnml_comm_init(tnml_ctx* ctx, const void* id128);
+/* Collective.  Verifies that the communicator really spans cfg.nranks ranks (ncclCommCount) and that every rank holds a
+   bit-identical replica of the weight MPS (a 64-bit fingerprint of all site tensors, max/min-reduced over the ranks);
+   non-zero + tnml_last_error on a mismatch.  The replicated CG/SVD algebra relies on identical replicas the way the
+   reference relies on one shared W (fixedL.cc:451); tnml_bond_update runs the same check on the two site tensors it
+   rewrites after every split (TNML_CHECK_REPLICAS=0 disables that).  nranks_in_comm (nullable) receives the communicator size. */
+int tnml_replica_check(tnml_ctx* ctx, int* nranks_in_comm);
 
 /* ---- training set: TState ctor fixedL.cc:28-47 + feature map :637-642 -------------------- */
 /* raw bytes [NT_local][N] with the reference's feature map phi = [1, byte/(255*255*4)] */
@@ -197,11 +203,30 @@ int tnml_profile_count(tnml_ctx* ctx);
 int tnml_profile_get(tnml_ctx* ctx, int idx, char* name64, int64_t* launches, double* total_ms);
 int tnml_profile_reset(tnml_ctx* ctx);
 int tnml_synchronize(tnml_ctx* ctx);
+/* run-time switches of the algebraic shortcuts and checks (defaults: all 1; the environment variables TNML_FAST_CG,
+   TNML_REUSE_P, TNML_FUSE_Z, TNML_CHECK_REPLICAS set the defaults at tnml_create):
+     "fast_cg"        P <- P + a (p*t.v) instead of re-running the forward GEMM inside cgrad (single.h:290-398 idea)
+     "reuse_p"        the after-SVD quadcost of one bond update provides the first residuals of the next
+     "fuse_z"         the gradient GEMM builds Z = sum_l EL[l] dP[l] itself
+     "check_replicas" multi-rank: fingerprint check of the rewritten site tensors after every split
+     "fg64_cfg", "ldot_cfg"  force a tile configuration of the feature GEMM / the label dot that is otherwise chosen by the
+                      image count (2 / 1 = the large-image-count forms bench.py times; parity tests run them at small sizes)
+   fast_cg = reuse_p = 0 is the reference's literal evaluation order (fixedL.cc:374-421). */
+int tnml_set_option(tnml_ctx* ctx, const char* name, int value);
 /* health of the in-house eigensolver: number of fallbacks to rocSOLVER so far, number of splits whose kept basis
    held an eigenvalue cluster and was re-orthonormalised by Cholesky QR, and max|Q^T Q - I| of the kept basis
    before the first / second Newton-Schulz polish step of the last split */
 int tnml_svd_stats(tnml_ctx* ctx, int64_t* fallbacks, int64_t* cluster_repairs, double* dev_before_polish, double* dev_after_first_polish);
 int64_t tnml_device_bytes(tnml_ctx* ctx);              /* device memory currently owned by ctx */
+
+/* ---- workspace planning (host arithmetic + hipMemGetInfo; used by the drivers before tnml_create) ---------------
+ * The reference treats `maxm` (fixedL.cc:592, default 5000) as an upper bound only; a context sizes its workspaces and
+ * environment slabs by cfg.maxm, so a driver asks for the largest bond dimension that (a) an MPS of N sites can reach
+ * and (b) fits the device, and says so, instead of failing in hipMalloc. */
+int64_t tnml_estimate_bytes(const tnml_config* cfg);  /* device bytes of a context after a sweep has built every environment; -1 on bad cfg */
+int tnml_device_memory(int device, int64_t* free_bytes, int64_t* total_bytes);
+/* largest maxm in [floor_m, wanted] reachable by an N-site MPS whose tnml_estimate_bytes fits budget_bytes (<= 0: no memory bound) */
+int tnml_plan_maxm(const tnml_config* cfg, int wanted, int floor_m, int64_t budget_bytes);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,311 @@
+"""The BASELINE configurations at their STATED shapes, and the kernel instantiations bench.py times, against the oracle.
+
+C1  fixedL N=196 (14x14), 100 images per label, maxm=10, Nsweep=2      -- every one of the 780 bond updates
+C2  fixedL N=784, maxm=20, 1000 images per label                        -- properties + bond updates vs the oracle
+C3  the tile configurations chosen at 60 000 images (feature GEMM 128 x 240 / 12 waves, streaming label dot) run at a
+    size the oracle handles, for all three bond kinds
+accuracy: a 10 000-image test set, so that "test accuracy within 0.1 %" (north_star) is resolvable.
+
+Why C1 is checked in LOCKSTEP.  A free-running sweep is a chaotic map of its rounding errors: the oracle run with 1 and
+with 8 threads (only the summation order of paralleldo.h:51-67 differs) agrees on the per-bond cost to 1e-15 for 10
+bonds, 1e-8 after 50, 1e-4 after 250 and 17 % by the end of the first sweep, although both reach the same final cost to
+~0.4 % (tests/golden/make_golden_c1.py prints the spread).  No tolerance on a free-running trajectory can therefore
+tell a correct implementation from a wrong one after the first ~100 bonds.  The lockstep test removes the accumulation:
+after every bond update the GPU's two site tensors are overwritten with the oracle's and the environment is rebuilt
+from them, so each of the 780 bond updates starts from the same state on both sides and is compared on its own."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD_C1 = os.path.join(ROOT, "tests", "golden", "fixedl_c1.npz")
+
+
+def _c1():
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden_c1 as mg
+    g = np.load(GOLD_C1)
+    W = [g["W%03d" % j] for j in range(1, int(g["N"]) + 1)]
+    return g, mg.features(g["pixels"]), W, dict(mg.PARAMS)
+
+
+def _rel(a, b):
+    return np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300)
+
+
+def test_c1_oracle_reproduces_the_golden_prefix():
+    """the oracle with the generator's thread count (chunking is deterministic in nthread, not in the core count)"""
+    from oracle import pyoracle
+    g, phi, W, p = _c1()
+    o = pyoracle.Oracle(phi, g["labels"], W, nthread=8)
+    o.init()
+    reps = o.mldmrg(p["nsweep"], p["maxm"], p["minm"], p["cutoff"], p["npass"], p["lam"], p["cconv"], max_bonds=60)
+    np.testing.assert_allclose([r["cost"] for r in reps], g["cost"][:60], rtol=1e-9)
+    assert [r["newm"] for r in reps] == list(g["newm"][:60])
+    assert [r["ncorrect"] for r in reps] == list(g["ncorrect"][:60])
+    np.testing.assert_allclose(reps[0]["cg"]["cost"][:p["npass"] - 1], g["cg_cost0"], rtol=1e-12)
+
+
+@pytest.mark.gpu
+def test_c1_every_bond_update_in_lockstep_with_the_oracle():
+    """BASELINE config 1 at full size: 2 sweeps x 390 bond updates, each compared on its own (cost, per-label costs,
+    new bond dimension, truncation error, #correct), then the prediction VECTOR of the trained network
+    (fixedL.cc:321-326, util.h:42-57) from tnml_classify against the oracle's toverlap."""
+    from oracle import pyoracle
+    from tnml_amd import lib
+    from tnml_amd.fixedl import TrainStates
+    g, phi, W, p = _c1()
+    N, NT = int(g["N"]), int(g["NT"])
+    ts = TrainStates(g["labels"], N, p["maxm"], phi=phi)
+    ts.set_mps(W)
+    ts.init()
+    o = pyoracle.Oracle(phi, g["labels"], W, nthread=min(8, os.cpu_count() or 1))
+    o.init()
+    worst = dict(cost=0.0, lc=0.0, te=0.0)
+    nbonds = 0
+    ncorr_mismatch = 0
+    for sw in range(p["nsweep"]):
+        b, ha = 1, 1
+        while ha <= 2:
+            r = ts.bond_update(b, ha, p["maxm"], p["minm"], p["cutoff"], p["npass"], p["lam"], p["cconv"])
+            o.set_bond(b)                                                   # fixedL.cc:488-540 on the oracle
+            B, tr = o.cgrad(o.bond_tensor(b), p["npass"], p["lam"], p["cconv"])
+            newm, te, _ = o.svd_split(B, b, ha, p["cutoff"], p["maxm"], p["minm"])
+            C, lc, cr, nc = o.quadcost(o.bond_tensor(b), p["lam"])
+            o.shiftE(b, ha == 1)
+            assert r["newm"] == newm, (sw, b, ha)
+            worst["cost"] = max(worst["cost"], abs(r["cost"] / C - 1))
+            worst["lc"] = max(worst["lc"], np.abs(r["label_cost"] - lc).max() / C)
+            worst["te"] = max(worst["te"], abs(r["truncerr"] - te))
+            ncorr_mismatch += int(r["ncorrect"] != nc)
+            np.testing.assert_allclose(r["cg"]["cost"], tr["cost"], rtol=1e-7, err_msg="CG cost trace, sweep %d bond %d" % (sw, b))
+            # same state for the next bond update on both sides
+            ts.set_site(b, o.get_site(b))
+            ts.set_site(b + 1, o.get_site(b + 1))
+            ts.shiftE(b, ha == 1)
+            nbonds += 1
+            b, ha = lib.sweepnext(b, ha, N)
+    print("C1 lockstep: %d bond updates; worst rel. cost error %.2e, per-label cost %.2e (of C), trunc. err. %.2e, "
+          "#correct mismatches %d" % (nbonds, worst["cost"], worst["lc"], worst["te"], ncorr_mismatch))
+    assert nbonds == 2 * 2 * (N - 1)
+    assert worst["cost"] < 1e-7 and worst["lc"] < 1e-7 and worst["te"] < 1e-8
+    assert ncorr_mismatch == 0
+    # inference on the trained network: both sides now hold the same W
+    w, pred, cnt, ninc = ts.classify()
+    wo = np.stack([o.toverlap(i) for i in range(NT)])
+    assert _rel(w, wo) < 1e-10
+    po = np.abs(wo).argmax(axis=1)
+    assert (pred == po).all()                                              # the prediction vector, not only its count
+    assert int(ninc.sum()) == int((po != g["labels"]).sum())
+    ts.close()
+
+
+@pytest.mark.gpu
+def test_c1_free_running_against_the_golden_vectors():
+    """the same two sweeps free-running against tests/golden/fixedl_c1.npz: tight where the trajectory is still
+    determined (first 50 bonds), within the oracle's own summation-order spread afterwards"""
+    from tnml_amd.fixedl import TrainStates, mldmrg
+    g, phi, W, p = _c1()
+    NT = int(g["NT"])
+    ts = TrainStates(g["labels"], int(g["N"]), p["maxm"], phi=phi)
+    ts.set_mps(W)
+    ts.init()
+    reps = mldmrg(ts, p["nsweep"], p["maxm"], p["minm"], p["cutoff"], p["npass"], p["lam"], p["cconv"])
+    cost = np.array([r["cost"] for r in reps])
+    assert len(cost) == len(g["cost"])
+    np.testing.assert_allclose(reps[0]["cg"]["cost"], g["cg_cost0"], rtol=1e-9)
+    np.testing.assert_allclose(cost[:50], g["cost"][:50], rtol=1e-6)
+    assert [r["newm"] for r in reps[:100]] == list(g["newm"][:100])
+    assert [r["ncorrect"] for r in reps[:50]] == list(g["ncorrect"][:50])
+    dev = np.abs(cost / g["cost"] - 1)
+    print("C1 free run vs golden: max rel. dev. bonds 0-49 %.1e, 50-249 %.1e, all %.1e; final cost/NT %.6f vs %.6f"
+          % (dev[:50].max(), dev[50:250].max(), dev.max(), cost[-1] / NT, g["cost"][-1] / NT))
+    assert dev[50:250].max() < 1e-2                       # oracle 1 thread vs 8 threads: 1.2e-4 here
+    assert abs(cost[-1] / g["cost"][-1] - 1) < 0.05       # oracle 1 thread vs 8 threads: 0.4 %
+    w, pred, cnt, ninc = ts.classify()
+    assert (pred == g["pred"]).mean() >= 0.995            # decision margins of the golden network are >= 0.67
+    ts.close()
+
+
+@pytest.mark.gpu
+def test_c3_kernel_instantiations_of_the_benchmark_match_the_oracle():
+    """bench.py's 60 000-image run selects k_fgemm64<2,5,4,3,16,...> (128 x 240 tiles, 12 waves) and the streaming
+    k_labeldot<4,2,10>; at oracle-sized image counts the library would pick smaller tiles, so they are forced here
+    ("fg64_cfg" = 2, "ldot_cfg" = 1) and compared with the oracle for all three bond kinds at m = 120: forward map,
+    gradient, cost, the CG and one whole bond update."""
+    from oracle import pyoracle
+    from tnml_amd import synth
+    from tnml_amd.fixedl import TrainStates
+    from conftest import make_problem
+    N, NT, m = 20, 300, 120
+    pixels, labels, phi, W = make_problem(N, NT, m, 3, pixel_boost=200.0)
+    ts = TrainStates(labels, N, m, phi=phi)
+    ts.set_option("fg64_cfg", 2)
+    ts.set_option("ldot_cfg", 1)
+    ts.set_mps(W)
+    ts.init()
+    o = pyoracle.Oracle(phi, labels, W, nthread=min(8, os.cpu_count() or 1))
+    o.init()
+    rng = np.random.default_rng(1)
+    at = 1
+    for b, kind in ((8, "Label on RE"), (9, "Label on B"), (12, "Label on LE")):
+        for bb in range(at, b):
+            ts.shiftE(bb, True); o.shiftE(bb, True)
+        at = b
+        ts.setBond(b); o.set_bond(b)
+        B = o.bond_tensor(b)
+        B = B + 0.05 * rng.standard_normal(B.shape)
+        assert B.shape[:4] == (120, 2, 2, 120)
+        assert _rel(ts.forward(B), o.forward(B)) < 1e-11, kind
+        assert _rel(ts.gradient(B), o.gradient(B)) < 1e-9, kind
+        Cg, lg, _, ng = ts.quadcost(B, 1e-3)
+        Co, lo, _, no = o.quadcost(B, 1e-3)
+        assert Cg == pytest.approx(Co, rel=1e-11) and ng == no, kind
+        Bg, tg = ts.cgrad(B, 3, 1e-3, 1e-10)
+        Bo, to = o.cgrad(B, 3, 1e-3, 1e-10)
+        np.testing.assert_allclose(tg["cost"], to["cost"], rtol=1e-9, err_msg=kind)
+        np.testing.assert_allclose(tg["alpha"], to["alpha"], rtol=1e-5, err_msg=kind)
+        assert _rel(Bg, Bo) < 1e-5, kind
+    # one whole bond update (fast CG + carried outputs on the GPU side) on the last bond
+    r = ts.bond_update(12, 1, m, m // 2, 1e-10, 3, 1e-3, 1e-10)
+    o.set_bond(12)
+    B, _ = o.cgrad(o.bond_tensor(12), 3, 1e-3, 1e-10)
+    newm, te, _ = o.svd_split(B, 12, 1, 1e-10, m, m // 2)
+    C, lc, cr, nc = o.quadcost(o.bond_tensor(12), 1e-3)
+    assert r["newm"] == newm and r["ncorrect"] == nc
+    assert r["cost"] == pytest.approx(C, rel=1e-8)
+    ts.close()
+
+
+@pytest.mark.gpu
+def test_c2_at_its_stated_shape():
+    """BASELINE config 2: N=784, maxm=20, 1000 images per label.  Size-independent properties on the HIP path (linearity
+    of the forward map, gradient additivity over image shards, cost independent of the bond) and, against the oracle on
+    the same inputs, the first two bond updates of a sweep."""
+    from oracle import pyoracle
+    from tnml_amd import synth
+    from tnml_amd.fixedl import TrainStates
+    N, NT, m = 784, 10000, 20
+    labels = synth.synthetic_labels(NT, per_label=NT // 10)
+    pixels = synth.synthetic_images(N, labels)
+    phi = synth.features_series(pixels)
+    phi[..., 1] *= 255.0                                                    # [1, x/4] (README.md:74)
+    W = synth.random_mps(N, m, seed=5)
+    ts = TrainStates(labels, N, m, phi=phi)
+    ts.set_mps(W)
+    ts.init()
+    B1 = ts.bond_tensor(1)
+    rng = np.random.default_rng(0)
+    B2 = rng.standard_normal(B1.shape)
+    P1, P2, P12 = ts.forward(B1), ts.forward(B2), ts.forward(B1 + 2.0 * B2)
+    assert _rel(P12, P1 + 2.0 * P2) < 1e-12
+    G = ts.gradient(B1)
+    half = NT // 2
+    parts = []
+    for sl in (slice(0, half), slice(half, NT)):
+        t2 = TrainStates(labels[sl], N, m, phi=phi[sl])
+        t2.set_mps(W)
+        t2.init()
+        parts.append(t2.gradient(B1))
+        t2.close()
+    assert _rel(parts[0] + parts[1], G) < 1e-11
+    c1 = ts.quadcost(B1, 0.0)[0]
+    # the oracle on the same inputs: initial cost and the first two bond updates
+    o = pyoracle.Oracle(phi, labels, W, nthread=min(16, os.cpu_count() or 1))
+    o.init()
+    assert c1 == pytest.approx(o.quadcost(o.bond_tensor(1), 0.0)[0], rel=1e-11)
+    assert _rel(ts.env(3), o.env(3)) < 1e-12 and _rel(ts.env(N), o.env(N)) < 1e-12
+    ro = o.mldmrg(1, m, m // 2, 1e-10, 4, 1e-3, 1e-10, max_bonds=2)
+    for k, b in enumerate((1, 2)):
+        r = ts.bond_update(b, 1, m, m // 2, 1e-10, 4, 1e-3, 1e-10)
+        assert r["newm"] == ro[k]["newm"] and r["ncorrect"] == ro[k]["ncorrect"]
+        assert r["cost"] == pytest.approx(ro[k]["cost"], rel=1e-8)
+    # the cost does not depend on the bond it is evaluated at (gauge invariance), far into the chain
+    for b in range(3, 41):
+        ts.shiftE(b, True)
+    ts.setBond(41)
+    c41, _, cr41, n41 = ts.quadcost(ts.bond_tensor(41), 1e-3)
+    ts41 = c41 - cr41                                                        # sum_l C_l: a property of the network, not of the bond
+    assert ts41 == pytest.approx(ro[1]["cost"] - ro[1]["reg_cost"], rel=1e-9) and n41 == ro[1]["ncorrect"]
+    ts.close()
+
+
+def _hard_images(N, labels, seed, mix=0.8):
+    """overlapping classes: every image is its label's template blended with another label's (weight `mix`) plus the
+    generator's noise, so that a classifier trained for two sweeps at m = 10 is right on ~90-97 % of the images and a
+    0.1 % difference (10 images of 10 000) is visible"""
+    from tnml_amd import synth
+    labels = np.asarray(labels)
+    rng = np.random.default_rng(seed)
+    other = (labels + rng.integers(1, 10, size=labels.shape)) % 10
+    a = synth.synthetic_images(N, labels, seed=seed).astype(np.float64)
+    b = synth.synthetic_images(N, other, seed=seed + 17).astype(np.float64)
+    w = rng.uniform(0.0, mix, size=(len(labels), 1))
+    return np.clip(np.rint((1.0 - w) * a + w * b), 0, 255).astype(np.uint8)
+
+
+@pytest.mark.gpu
+def test_test_set_accuracy_within_a_tenth_of_a_percent_on_10000_images(tmp_path):
+    """north_star: "test-set accuracy within 0.1 % of the CPU reference".  Training set: C1 shape (N=196, 100 per
+    label, maxm=10, 2 sweeps) on overlapping synthetic classes; test set: 10 000 images of the same distribution, so
+    one image is 0.01 %.  (a) The SAME trained network evaluated by the `fulltest` binary (tnml_classify) and by the
+    oracle's toverlap: identical prediction vectors.  (b) The network trained by the `fixedL` binary vs the one trained
+    by the oracle from the same initial W: test accuracies within 0.1 % + the oracle's own 1-vs-8-thread spread."""
+    from oracle import pyoracle
+    from tnml_amd import hostlib, synth
+    N, per_label, NTEST = 196, 100, 10000
+    ltr = synth.synthetic_labels(10 * per_label, seed=11, per_label=per_label)
+    lte = synth.synthetic_labels(NTEST, seed=12, per_label=NTEST // 10)
+    pall = _hard_images(N, np.concatenate([ltr, lte]), 11)     # one call: the label templates depend on the seed
+    ptr, pte = pall[:len(ltr)], pall[len(ltr):]
+    order = np.argsort(ltr, kind="stable")                       # any file order; the driver keeps the first 100 of each label
+    data = str(tmp_path / "data")
+    synth.write_idx(data, ptr[order], ltr[order], side=14)
+    synth.write_idx(data, pte, lte, train=False, side=14)
+    keys = "datadir = %s\nfeature_scale = 255\n" % data
+    inp = tmp_path / "input"
+    inp.write_text("input\n{\n%sNtrain = %d\nNbatch = 10\nNsweep = 2\ncutoff = 1E-10\nmaxm = 10\nminm = 10\nninitial = 5\n"
+                   "lambda = 1E-3\nNpass = 4\nseed = 3\n}\n" % (keys, per_label))
+    w0 = str(tmp_path / "W0ref")
+    hostlib.build_initial_w(data, per_label, 5, 3, w0, feature_scale=255.0)
+    run = subprocess.run([os.path.join(ROOT, "tnml_amd", "fixedL"), str(inp)], capture_output=True, text=True, cwd=tmp_path, timeout=900)
+    assert run.returncode == 0, run.stdout[-1500:] + run.stderr[-1500:]
+    tin = tmp_path / "input_test"
+    tin.write_text("input\n{\n%s}\n" % keys)
+
+    def fulltest():
+        ev = subprocess.run([os.path.join(ROOT, "tnml_amd", "fulltest"), str(tin)], capture_output=True, text=True, cwd=tmp_path, timeout=900)
+        assert ev.returncode == 0, ev.stdout[-1500:] + ev.stderr[-1500:]
+        mm = re.search(r"(\d+)/(\d+) correct \(([0-9.]+)%\)", ev.stdout)
+        assert mm and int(mm.group(2)) == NTEST
+        return int(mm.group(1))
+    gpu_trained_correct = fulltest()
+
+    def feats(p):
+        gg = p.astype(np.float64) / 255.0
+        return np.stack([np.ones_like(gg), 255.0 * ((gg / 255.0) / 4.0)], axis=-1)
+    trp, trl, _ = hostlib.read_mnist(data, True, per_label)
+    runs = {}
+    for nth in (1, 8):
+        o = pyoracle.Oracle(feats(trp), trl, hostlib.read_mps(w0), nthread=nth)
+        o.init()
+        o.mldmrg(2, 10, 10, 1e-10, 4, 1e-3, 1e-10)
+        Wo = o.get_mps()
+        ot = pyoracle.Oracle(feats(pte), lte, Wo, nthread=1)
+        wt = np.stack([ot.toverlap(i) for i in range(NTEST)])
+        runs[nth] = dict(W=Wo, pred=np.abs(wt).argmax(axis=1), correct=int((np.abs(wt).argmax(axis=1) == lte).sum()))
+    # (a) same network, two inference paths
+    hostlib.write_mps(str(tmp_path / "W"), runs[8]["W"])
+    same_net_correct = fulltest()
+    assert same_net_correct == runs[8]["correct"]
+    # (b) two trainings
+    spread = abs(runs[1]["correct"] - runs[8]["correct"])
+    d = min(abs(gpu_trained_correct - runs[nth]["correct"]) for nth in (1, 8))
+    print("10 000 test images: GPU-trained %d correct, oracle-trained %d (1 thread) / %d (8 threads); same network through "
+          "fulltest and toverlap: %d / %d" % (gpu_trained_correct, runs[1]["correct"], runs[8]["correct"], same_net_correct, runs[8]["correct"]))
+    assert 0.80 * NTEST < runs[8]["correct"] < 0.995 * NTEST             # hard enough to resolve, easy enough to have learned
+    assert d <= 0.001 * NTEST + spread

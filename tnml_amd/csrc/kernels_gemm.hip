@@ -518,7 +518,7 @@ static void fgemm64_go(tnml_ctx* c, const Fgemm64Args& a) {
 int launch_fgemm64(tnml_ctx* c, const Fgemm64Args& a) {
     ProfScope ps(c, a.phiO ? KC_FGEMM_FWD : KC_FGEMM_SHIFT);
     if (a.NTp % TNML_NTPAD) return tnml_fail(c, "fgemm64: NTp not padded");
-    static const int cfg = getenv("TNML_FG64_CFG") ? atoi(getenv("TNML_FG64_CFG")) : 0;   // tuning knob (tools/tune_fgemm.sh)
+    const int cfg = c->opt_fg64_cfg;                         // tuning knob (env TNML_FG64_CFG / tnml_set_option "fg64_cfg"; tools/tune_fgemm.sh)
     if (a.Np == 240 && a.phiO) {                             // m = 120: exactly 15 column tiles, no padding waste
         switch (cfg) {
             case 1:  fgemm64_go<1, 5, 4, 3, 16>(c, a); break;   // 64 x 240, 12 waves

@@ -304,3 +304,28 @@ int launch_diffnorm(tnml_ctx* c, const double* x, const double* y, size_t n, dou
     HIPCK(c, hipGetLastError());
     return 0;
 }
+
+// ---- replica fingerprint (multi-rank runs) ---------------------------------------------------
+// acc[0] += salt * sum_i bits(x_i) * (2 i + 1)  (mod 2^64): order-independent inside the kernel, position- and
+// bit-sensitive, so two replicas of a tensor agree on it iff they are bit-identical (up to 2^-64 collisions).
+// acc[1] is kept as ~acc[0]: max-all-reducing the pair over ranks gives [max h, ~min h].
+__global__ __launch_bounds__(1024) void k_fingerprint(const double* __restrict__ x, size_t n, unsigned long long salt,
+                                                      unsigned long long* __restrict__ acc, int reset) {
+    __shared__ unsigned long long sh[16];
+    unsigned long long h = 0;
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x) h += (unsigned long long)__double_as_longlong(x[i]) * (2ull * i + 1ull);
+    for (int o = 32; o >= 1; o >>= 1) h += __shfl_xor(h, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = h;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[w];
+        const unsigned long long v = (reset ? 0ull : acc[0]) + t * salt;
+        acc[0] = v; acc[1] = ~v;
+    }
+}
+int launch_fingerprint(tnml_ctx* c, const double* x, size_t n, unsigned long long salt, unsigned long long* acc, bool reset) {
+    hipLaunchKernelGGL(k_fingerprint, dim3(1), dim3(1024), 0, c->stream, x, n, salt | 1ull, acc, reset ? 1 : 0);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}

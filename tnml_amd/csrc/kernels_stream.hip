@@ -160,7 +160,7 @@ int launch_labeldot(tnml_ctx* c, const LdotArgs& a_in, double* scal_out) {
     LdotArgs a = a_in;
     a.nt = nt;
     // few images on this rank: 64-image workgroups with 16 (fp64) waves each, so that the chip still has enough loads in flight
-    static const int force = getenv("TNML_LDOT_CFG") ? atoi(getenv("TNML_LDOT_CFG")) : 0;     // 1: streaming form, 2: small-shard form
+    const int force = c->opt_ldot_cfg;                        // 1: streaming form, 2: small-shard form (env TNML_LDOT_CFG / tnml_set_option "ldot_cfg")
     const bool small = force ? force == 2 : a.NTp / 128 < 192;
     const int nblk = a.NTp / (small ? 64 : 128);
     if (nblk > c->partial_cap) return tnml_fail(c, "labeldot: partial buffer too small");

@@ -81,6 +81,9 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
     const int nl = 2 * mL * (labL ? TNML_NL : 1), nr = 2 * mR * (labR ? TNML_NL : 1);
     const int n = nl < nr ? nl : nr;
     if (n > c->svd_n) return tnml_fail(c, "svd_split: matrix side %d exceeds workspace %d (raise maxm)", n, c->svd_n);
+    if (maxm < 1 || minm < 0) return tnml_fail(c, "svd_split: maxm must be >= 1 and minm >= 0");
+    if (maxm > c->maxm) maxm = c->maxm;                  // the workspaces (sS, sCm, sQ1, sF) are sized by the context's maxm
+    if (minm > maxm) minm = maxm;
     hipStream_t st = c->stream;
 
     const double* M = B_it;
@@ -120,9 +123,13 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
         RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, mk, mk, n, &one, Q0, n, Q0, n, &zero, c->sS, mk));
         TCK(eigh_ns_matrix(c, c->sS, c->sCm, mk, c->sDev));
         RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, n, mk, mk, &one, Q0, n, c->sCm, mk, &zero, Q, n));
+        TCK(bcast_rank0(c, c->sDev, 1));
         HIPCK(c, hipMemcpyAsync(hd, c->sDev, sizeof(double), hipMemcpyDeviceToHost, st));
     }
-    // eigenvalues -> host: the truncation decision (ITensor truncate()) fixes the new bond dimension
+    // eigenvalues -> host: the truncation decision (ITensor truncate()) fixes the new bond dimension.  With more than
+    // one rank the decision is made collective: every rank decides on rank 0's eigenvalues (and rank 0's orthogonality
+    // check), so that a last-bit difference between replicas can never produce different bond dimensions.
+    TCK(bcast_rank0(c, const_cast<double*>(evals), n));
     double* h = c->h_scal;          // pinned, capacity >= 2*svd_n + 64
     HIPCK(c, hipMemcpyAsync(h, evals, sizeof(double) * n, hipMemcpyDeviceToHost, st));
     HIPCK(c, hipStreamSynchronize(st));
@@ -182,6 +189,7 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
                     RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, n, mk, mk, &one, cur, n, c->sCm, mk, &zero, dst, n));
                     if (it < nit) std::swap(cur, other);
                 }
+                TCK(bcast_rank0(c, c->sDev, 2));
                 HIPCK(c, hipMemcpyAsync(hd, c->sDev, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
                 HIPCK(c, hipStreamSynchronize(st));
                 ok = hd[1] == 0. && hd[0] < 1e-6;

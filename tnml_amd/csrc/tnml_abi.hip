@@ -62,6 +62,17 @@ int tnml_profile_reset(tnml_ctx* c) {
     for (int i = 0; i < KC_COUNT; ++i) { c->prof_launches[i] = 0; c->prof_ms[i] = 0.; }
     return 0;
 }
+int tnml_set_option(tnml_ctx* c, const char* name, int value) {
+    if (!c || !name) return tnml_fail(c, "tnml_set_option: null argument");
+    if (!strcmp(name, "fast_cg")) c->fast_cg = value != 0;
+    else if (!strcmp(name, "reuse_p")) { c->reuse_p = value != 0; c->p_valid = false; }
+    else if (!strcmp(name, "fuse_z")) c->fuse_z = value != 0;
+    else if (!strcmp(name, "check_replicas")) c->check_replicas = value != 0;
+    else if (!strcmp(name, "fg64_cfg")) c->opt_fg64_cfg = value;
+    else if (!strcmp(name, "ldot_cfg")) c->opt_ldot_cfg = value;
+    else return tnml_fail(c, "tnml_set_option: unknown option %s", name);
+    return 0;
+}
 int tnml_synchronize(tnml_ctx* c) { HIPCK(c, hipStreamSynchronize(c->stream)); return 0; }
 int64_t tnml_device_bytes(tnml_ctx* c) { return c->bytes; }
 int tnml_svd_stats(tnml_ctx* c, int64_t* fallbacks, int64_t* cluster_repairs, double* d0, double* d1) {
@@ -113,6 +124,60 @@ static int dmalloc(tnml_ctx* c, T** p, size_t n) {
 }
 static inline int ru16(int x) { return (x + 15) / 16 * 16; }
 
+// Device memory a context of this configuration will own once a sweep has touched every environment: the workspaces of
+// tnml_create plus the environment slabs (about N/2 Label-carrying + N/2 Label-free environments
+// at any time = 0.55 N slabs of 10*maxm*NTp elements, + the three chain buffers of tnml_classify).
+int64_t tnml_estimate_bytes(const tnml_config* cfg) {
+    if (!cfg || cfg->N < 1 || cfg->NT_local < 1 || cfg->maxm < 1) return -1;
+    const double NTp = (double)((cfg->NT_local + TNML_NTPAD - 1) / TNML_NTPAD * TNML_NTPAD);
+    const double m = cfg->maxm, Kmax = ru16(2 * cfg->maxm), n = 2. * m;
+    const double esz = cfg->dtype != TNML_F32 ? 8 : 4, eesz = cfg->dtype == TNML_F64 ? 8 : 4;
+    const bool single = cfg->mode == TNML_MODE_SINGLE;
+    const double mcap = TNML_NL * Kmax * Kmax;
+    double b = cfg->N * 2. * NTp * eesz + NTp * (4 + eesz);                                  // features, labels, ones
+    b += (TNML_NL * m * NTp + 3. * TNML_NL * NTp + m * NTp) * esz;                          // U, P, dP, Pp, Zp
+    b += mcap * (4 + 6 * 8) + 128. * Kmax * Kmax * 4 * (cfg->dtype != TNML_F32 ? 2 : 1);    // Mf, vB vR vP vG tB tB2, split-K slabs
+    b += 8. * (std::max(40. * m * m, TNML_NL * Kmax * (double)ru16(cfg->maxm)) + 3. * n * n + 7. * n * m + 2. * TNML_NL * m * m + 2. * m * m);   // split workspaces
+    b += 8. * (cfg->N - 1 + TNML_NL) * 2. * m * m;                                            // W replica
+    const double nslab = single ? (cfg->N / 10. + 2.) : (0.55 * cfg->N + 3.);
+    b += nslab * TNML_NL * m * NTp * eesz;
+    return (int64_t)b;
+}
+int tnml_device_memory(int device, int64_t* free_bytes, int64_t* total_bytes) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return tnml_fail(nullptr, "tnml_device_memory: no HIP device %d", device);
+    int cur = 0; (void)hipGetDevice(&cur);
+    size_t f = 0, t = 0;
+    if (hipSetDevice(device) != hipSuccess || hipMemGetInfo(&f, &t) != hipSuccess) return tnml_fail(nullptr, "tnml_device_memory: hipMemGetInfo failed");
+    (void)hipSetDevice(cur);
+    if (free_bytes) *free_bytes = (int64_t)f;
+    if (total_bytes) *total_bytes = (int64_t)t;
+    return 0;
+}
+// Largest bond dimension <= wanted (and >= floor_m) whose context fits into budget_bytes; also bounded by what an MPS of
+// N sites can reach at all: min over the two sides of a bond of the full dimension, 2^j and 10*2^(N-j).
+int tnml_plan_maxm(const tnml_config* cfg, int wanted, int floor_m, int64_t budget_bytes) {
+    if (!cfg || wanted < 1) return -1;
+    long reach = 1;
+    for (int j = 1; j < cfg->N; ++j) {
+        const int l = j, r = cfg->N - j;
+        const double dl = l >= 40 ? 1e12 : (double)(1L << l) * (cfg->mode == TNML_MODE_SINGLE ? 1 : TNML_NL);   // the Label index may sit on either side
+        const double dr = r >= 40 ? 1e12 : (double)(1L << r) * (cfg->mode == TNML_MODE_SINGLE ? 1 : TNML_NL);
+        const double d = dl < dr ? dl : dr;
+        if (d > reach) reach = d > 1e9 ? 1000000000L : (long)d;
+    }
+    int hi = wanted < reach ? wanted : (int)reach;
+    if (hi < floor_m) hi = floor_m;
+    tnml_config t = *cfg;
+    t.maxm = hi;
+    if (budget_bytes <= 0 || tnml_estimate_bytes(&t) <= budget_bytes) return hi;
+    int lo = floor_m < 1 ? 1 : floor_m;
+    t.maxm = lo;
+    if (tnml_estimate_bytes(&t) > budget_bytes) return lo;      // even the floor does not fit: let tnml_create report it
+    while (hi - lo > 1) { const int mid = lo + (hi - lo) / 2; t.maxm = mid; if (tnml_estimate_bytes(&t) <= budget_bytes) lo = mid; else hi = mid; }
+    return lo;
+}
+
 int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     if (!out || !cfg) return tnml_fail(nullptr, "tnml_create: null argument");
     *out = nullptr;
@@ -137,6 +202,8 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(tnml_fail(c, "hipStreamCreate failed"));
     if (rocblas_create_handle(&c->blas) != rocblas_status_success) return bail(tnml_fail(c, "rocblas_create_handle failed"));
     rocblas_set_stream(c->blas, c->stream);
+    // replicas of W must stay bit-identical over the ranks: no atomics-based split-K inside rocBLAS
+    rocblas_set_atomics_mode(c->blas, rocblas_atomics_not_allowed);
     const size_t NTp = c->NTp;
     const int Kmax = ru16(2 * c->maxm);
     c->mcap = (size_t)TNML_NL * Kmax * Kmax;
@@ -158,6 +225,8 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     if (const char* e = getenv("TNML_FAST_CG")) c->fast_cg = atoi(e) != 0;
     if (const char* e = getenv("TNML_FUSE_Z")) c->fuse_z = atoi(e) != 0;
     if (const char* e = getenv("TNML_REUSE_P")) c->reuse_p = atoi(e) != 0;
+    if (const char* e = getenv("TNML_FG64_CFG")) c->opt_fg64_cfg = atoi(e);
+    if (const char* e = getenv("TNML_LDOT_CFG")) c->opt_ldot_cfg = atoi(e);
     if ((rc = dmalloc(c, (char**)&c->Zp, c->small_elems * esz))) return bail(rc);
     if ((rc = dmalloc(c, &c->Mf, c->mcap))) return bail(rc);
     if ((rc = dmalloc(c, (char**)&c->slab, c->slab_bytes))) return bail(rc);
@@ -171,12 +240,17 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     if ((rc = dmalloc(c, &c->cgtrace, (size_t)4 * TNML_MAX_PASS))) return bail(rc);
     if ((rc = dmalloc(c, &c->tB, c->mcap))) return bail(rc);
     if ((rc = dmalloc(c, &c->tB2, c->mcap))) return bail(rc);
-    if ((rc = dmalloc(c, &c->sM, (size_t)40 * c->maxm * c->maxm))) return bail(rc);
+    // sM holds (a) the Label-permuted bond matrix of the split, 40 maxm^2, and (b) the 16-padded site matrix of an
+    // environment shift, L * ru16(2 m) * ru16(m) -- at small maxm the padding of (b) dominates
+    c->sM_cap = std::max((size_t)40 * c->maxm * c->maxm, (size_t)TNML_NL * Kmax * ru16(c->maxm));
+    if ((rc = dmalloc(c, &c->sM, c->sM_cap))) return bail(rc);
     if ((rc = dmalloc(c, &c->sG, (size_t)c->svd_n * c->svd_n))) return bail(rc);
     if ((rc = dmalloc(c, &c->sD, (size_t)c->svd_n))) return bail(rc);
     if ((rc = dmalloc(c, &c->sE, (size_t)2 * c->svd_n))) return bail(rc);
     if ((rc = dmalloc(c, &c->sF, (size_t)c->svd_n * c->maxm + (size_t)2 * TNML_NL * c->maxm * c->maxm))) return bail(rc);
     if ((rc = dmalloc(c, &c->sInfo, 4))) return bail(rc);
+    if ((rc = dmalloc(c, &c->fprint, 2))) return bail(rc);
+    if (const char* e = getenv("TNML_CHECK_REPLICAS")) c->check_replicas = atoi(e) != 0;
     if ((rc = dmalloc(c, &c->sE2, (size_t)c->svd_n))) return bail(rc);
     if ((rc = dmalloc(c, &c->sTau, (size_t)c->svd_n))) return bail(rc);
     if ((rc = dmalloc(c, &c->sV, (size_t)c->svd_n * c->svd_n))) return bail(rc);
@@ -209,7 +283,7 @@ int tnml_destroy(tnml_ctx* c) {
     for (auto& p : c->prof_pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     for (auto e : c->prof_free) (void)hipEventDestroy(e);
     void* ptrs[] = {c->phi, c->label, c->ones, c->U, c->P, c->dP, c->Pp, c->Zp, c->Mf, c->slab, c->partials, c->vB, c->vR, c->vP,
-                    c->vG, c->scal, c->vpart, c->cgtrace, c->tB, c->tB2, c->sM, c->sG, c->sD, c->sE, c->sF, c->sInfo, c->sE2, c->sTau, c->sV, c->sC, c->sW, c->sScr, c->sS, c->sCm, c->sQ1, c->sDev};
+                    c->vG, c->scal, c->vpart, c->cgtrace, c->tB, c->tB2, c->sM, c->sG, c->sD, c->sE, c->sF, c->sInfo, c->sE2, c->sTau, c->sV, c->sC, c->sW, c->sScr, c->sS, c->sCm, c->sQ1, c->sDev, c->fprint};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& s : c->W) if (s.a) (void)hipFree(s.a);
     for (auto& sl : c->slabs) if (sl.base) (void)hipFree(sl.base);
@@ -247,6 +321,39 @@ static int allreduce(tnml_ctx* c, double* buf, size_t count) {
     ProfScope ps(c, KC_ALLREDUCE);
     ncclResult_t r = ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, c->comm, c->stream);
     if (r != ncclSuccess) return tnml_fail(c, "ncclAllReduce failed: %s", ncclGetErrorString(r));
+    return 0;
+}
+int bcast_rank0(tnml_ctx* c, double* buf, size_t count) {
+    if (!c->comm) return 0;
+    ncclResult_t r = ncclBroadcast(buf, buf, count, ncclDouble, 0, c->comm, c->stream);
+    if (r != ncclSuccess) return tnml_fail(c, "ncclBroadcast failed: %s", ncclGetErrorString(r));
+    return 0;
+}
+static int check_W(tnml_ctx* c);
+// fingerprints of the replicated site tensors j0..j1 -> fprint[0..1], max-all-reduced: [max h, ~min h]
+static int replica_fingerprint(tnml_ctx* c, int j0, int j1) {
+    for (int j = j0; j <= j1; ++j) {
+        const SiteT& s = c->W[j];
+        TCK(launch_fingerprint(c, s.a, (size_t)s.ml * 2 * s.mr * s.L, 0x9E3779B97F4A7C15ull * (unsigned long long)(2 * j + 1), c->fprint, j == j0));
+    }
+    ncclResult_t r = ncclAllReduce(c->fprint, c->fprint, 2, ncclUint64, ncclMax, c->comm, c->stream);
+    if (r != ncclSuccess) return tnml_fail(c, "ncclAllReduce failed: %s", ncclGetErrorString(r));
+    return 0;
+}
+int tnml_replica_check(tnml_ctx* c, int* nranks_in_comm) {
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    if (nranks_in_comm) *nranks_in_comm = 1;
+    if (!c->comm) return c->cfg.nranks == 1 ? 0 : tnml_fail(c, "tnml_replica_check: nranks > 1 but tnml_comm_init was not called");
+    int cnt = 0;
+    if (ncclCommCount(c->comm, &cnt) != ncclSuccess) return tnml_fail(c, "ncclCommCount failed");
+    if (nranks_in_comm) *nranks_in_comm = cnt;
+    if (cnt != c->cfg.nranks) return tnml_fail(c, "communicator has %d ranks, context was created for %d", cnt, c->cfg.nranks);
+    TCK(check_W(c));
+    TCK(replica_fingerprint(c, 1, c->N));
+    unsigned long long h[2];
+    HIPCK(c, hipMemcpyAsync(h, c->fprint, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    if (h[0] != ~h[1]) return tnml_fail(c, "replicas of the weight MPS differ between ranks");
     return 0;
 }
 
@@ -370,6 +477,8 @@ static int shift_core(tnml_ctx* c, int cs, bool from_left, const void* src, int 
     if (from_left) { d.nx = A.ml; d.sx = 1; d.ny = A.mr; d.sy = 2 * A.ml; }
     else           { d.nx = A.mr; d.sx = 2 * A.ml; d.ny = A.ml; d.sy = 1; }
     d.Kp = ru16(2 * d.nx); d.Np = ru16(d.ny);
+    if ((size_t)d.L * d.Kp * d.Np > c->sM_cap || (size_t)d.L * d.Kp * d.Np > c->mcap)
+        return tnml_fail(c, "shift: packed site matrix of site %d (%d x %d x %d) exceeds the workspace", cs, d.L, d.Kp, d.Np);
     if (c->env64() || (acc_out && c->f64())) {          // fp64 output: fp64 MFMA shift (M in the free SVD workspace)
         TCK(launch_pack(c, d, A.a, c->sM, nullptr));
         Fgemm64Args f;
@@ -811,7 +920,16 @@ int tnml_bond_update(tnml_ctx* c, int b, int ha, const tnml_sweep_params* sp, tn
     HIPCK(c, hipMemcpyAsync(hq, c->vG + c->plan.msize(), sizeof(double) * 13, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipMemcpyAsync(hq + 16, c->scal + SC_NORMS, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
     TCK(tnml_shift_env(c, b, ha == 1));                               // :540
+    const bool fp_check = c->comm && c->check_replicas;
+    if (fp_check) {                                                   // the two site tensors the split just wrote must be bit-identical on every rank
+        TCK(replica_fingerprint(c, b, b + 1));
+        HIPCK(c, hipMemcpyAsync(hq + 32, c->fprint, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    }
     HIPCK(c, hipStreamSynchronize(c->stream));
+    if (fp_check) {
+        unsigned long long h[2]; memcpy(h, hq + 32, sizeof h);
+        if (h[0] != ~h[1]) return tnml_fail(c, "bond %d: replicas of W.A(%d), W.A(%d) differ between ranks after the split", b, b, b + 1);
+    }
     quadcost_parse(c, hq, sp->lambda_cost, &rep->cost_after_svd, rep->label_cost, &rep->reg_cost, &rep->ncorrect);
     rep->norm_newB = std::sqrt(hq[16]); rep->diff_B_newB = std::sqrt(hq[17]);
     c->p_valid = true;

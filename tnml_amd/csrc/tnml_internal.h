@@ -108,6 +108,7 @@ struct tnml_ctx {
     // recompute with its own forward GEMM + label dot.  p_valid marks P/dP as current; anything that changes W, the data or
     // P itself clears it (env TNML_REUSE_P=0 disables the shortcut).
     bool reuse_p = true, p_valid = false;
+    int opt_fg64_cfg = 0, opt_ldot_cfg = 0;   // kernel-instantiation overrides (0: chosen by the image count)
     void* Zp = nullptr;        // [maxm][NTp]
     float* Mf = nullptr;       // fp32 GEMM operand, M-layout, capacity 10*Kmax*Kmax (env shifts, F32 mode)
     void* slab = nullptr;      // split-K partial slabs
@@ -130,6 +131,7 @@ struct tnml_ctx {
     double *tB = nullptr, *tB2 = nullptr;   // bond tensors in ITensor layout (fp64)
     size_t mcap = 0;           // capacity (elements) of M-layout vectors / bond tensors
     // svd workspaces (fp64)
+    size_t sM_cap = 0;
     double *sM = nullptr, *sG = nullptr, *sD = nullptr, *sE = nullptr, *sF = nullptr;
     double *sE2 = nullptr, *sTau = nullptr, *sV = nullptr, *sC = nullptr;   // eigh.hip: subdiagonal, tau, reflectors, tridiagonal eigenvectors
     double *sW = nullptr, *sScr = nullptr, *sS = nullptr, *sCm = nullptr, *sQ1 = nullptr, *sDev = nullptr;   // own tridiagonal eigensolver + Newton-Schulz polish
@@ -137,6 +139,8 @@ struct tnml_ctx {
     long svd_fallbacks = 0, svd_cholqr = 0;
     double last_bnorm = 0.;         // |B| of the last quadcost
     int* sInfo = nullptr;
+    unsigned long long* fprint = nullptr;   // [2] device: fingerprint of replicated tensors and its complement
+    bool check_replicas = true;             // multi-rank: compare the fingerprints of W[b], W[b+1] after every bond update (env TNML_CHECK_REPLICAS=0 disables)
     int svd_n = 0;
 
     BondPlan plan;
@@ -246,6 +250,7 @@ int launch_sqnorm(tnml_ctx* c, const double* x, size_t n, double* out);    // ou
 int launch_diffnorm(tnml_ctx* c, const double* x, const double* y, size_t n, double* out2);  // out2[0]=|x|^2, out2[1]=|x-y|^2
 int launch_fill_f32(tnml_ctx* c, float* p, float v, size_t n);
 int launch_fill_f64(tnml_ctx* c, double* p, double v, size_t n);
+int launch_fingerprint(tnml_ctx* c, const double* x, size_t n, unsigned long long salt, unsigned long long* acc, bool reset);
 
 // ---- eigh.hip -----------------------------------------------------------------------------
 int eigh_tridiagonalize(tnml_ctx* c, const double* A, int n, double* D, double* E, double* tau, double* V);
@@ -254,6 +259,9 @@ int eigh_ns_matrix(tnml_ctx* c, const double* S, double* Cm, int m, double* dev)
 int eigh_chol_rinv(tnml_ctx* c, const double* S, int m, double* Rinv, double* flag);   // m <= 136
 #define TNML_CHOL_MAXM 136
 int eigh_backtransform(tnml_ctx* c, const double* V, const double* tau, int n, const double* Z, int ldz, double* U, int ldu, int ncols);
+
+// rank 0's values to every rank, in stream order (no-op without a communicator)
+int bcast_rank0(tnml_ctx* c, double* buf, size_t count);
 
 // ---- svd.hip ------------------------------------------------------------------------------
 int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cutoff, int maxm, int minm,

@@ -84,6 +84,15 @@ class TrainStates:
             raise TnmlError("tnml_comm_unique_id failed")
         return buf.raw
 
+    def replica_check(self):
+        """collective: communicator size == nranks and bit-identical W replicas on every rank; returns the communicator size"""
+        n = C.c_int()
+        self._ck(self._L.tnml_replica_check(self._h, C.byref(n)))
+        return n.value
+
+    def set_option(self, name, value):
+        self._ck(self._L.tnml_set_option(self._h, name.encode(), int(value)))
+
     def size(self):
         return self.NT
 
@@ -114,6 +123,10 @@ class TrainStates:
         for j, A in enumerate(W, start=1):
             A = np.asarray(A, dtype=np.float64)
             self._ck(self._L.tnml_set_site(self._h, j, A.shape[0], A.shape[2], int(A.ndim == 4), _lib.dptr(_lib.flat(A))))
+
+    def set_site(self, j, A):
+        A = np.asarray(A, dtype=np.float64)
+        self._ck(self._L.tnml_set_site(self._h, j, A.shape[0], A.shape[2], int(A.ndim == 4), _lib.dptr(_lib.flat(A))))
 
     def get_site(self, j):
         ml, mr, hl = C.c_int(), C.c_int(), C.c_int()

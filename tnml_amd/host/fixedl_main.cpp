@@ -3,16 +3,22 @@
 // Keeps the reference's surface (fixedL.cc:573-767): the input-file grammar and keys, the files in the
 // working directory (sites, W, WRITE_WF, LAMBDA), the idx-ubyte dataset under `datadir`, and the log
 // lines, while the sweep itself (mldmrg, fixedL.cc:451-570) is one
-// tnml_bond_update call per bond.  Extensions (never read by the reference, all optional): `seed`
-// (initial-W RNG), `device` (HIP ordinal), `precision` (f64 = fp64 everywhere [default], mixed = fp64 MFMA over
+// tnml_bond_update call per bond.  Multi-GPU: `ngpu = n` shards the training images over n GPUs (ParallelDo's chunk rule,
+// paralleldo.h:32-43), one host thread and one context per GPU inside this process, gradient / cost sums over RCCL; rank 0
+// prints and writes files, so the log of an n-GPU run is the log of the 1-GPU run.  Extensions (never read by the
+// reference, all optional): `seed` (initial-W RNG), `device` (first HIP ordinal), `ngpu`, `precision` (f64 = fp64 everywhere [default], mixed = fp64 MFMA over
 // fp32-stored environments, f32 = fp32 MFMA study mode), `imglen` (block-mean down-sampling of the images to
 // imglen x imglen; present in the reference's sample input but never read by fixedL.cc), `feature_scale`
 // (multiplies the second feature component; 1 = the reference's double normalisation).
 #include <array>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
+#include <mutex>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "../../include/tnml.h"
 #include "host_mps.h"
@@ -27,6 +33,20 @@ static void die(tnml_ctx* c, const char* what) {
     std::exit(1);
 }
 #define CK(c, call) do { if ((call) != 0) die((c), #call); } while (0)
+
+// the ranks of one process meet here (a generation-counting barrier)
+class HostBarrier {
+    std::mutex mu; std::condition_variable cv; int n, waiting = 0; long gen = 0;
+  public:
+    explicit HostBarrier(int n_) : n(n_) {}
+    void wait() {
+        if (n <= 1) return;
+        std::unique_lock<std::mutex> lk(mu);
+        const long g = gen;
+        if (++waiting == n) { waiting = 0; ++gen; cv.notify_all(); }
+        else cv.wait(lk, [&] { return gen != g; });
+    }
+};
 
 static void upload(tnml_ctx* ctx, const HostMPS& W) {
     for (int j = 1; j <= W.N; ++j) CK(ctx, tnml_set_site(ctx, j, W.A[j].ml, W.A[j].mr, W.A[j].L == NL, W.A[j].a.data()));
@@ -63,7 +83,8 @@ int main(int argc, const char* argv[]) {
         const long Npass = input.getInt("Npass", 4);
         const double cconv = input.getReal("cconv", 1E-10);
         const uint64_t seed = (uint64_t)input.getInt("seed", 1);                         // extension
-        const int device = (int)input.getInt("device", 0);                              // extension
+        const int device = (int)input.getInt("device", 0);                              // extension: first HIP ordinal
+        const long ngpu = input.getInt("ngpu", 1);                                      // extension: GPUs (ranks) to shard the images over; 0 = all visible
         const std::string precision = input.getString("precision", "f64");              // extension: f64 | mixed | f32
         const long imglen = input.getInt("imglen", 0);                                   // extension: 0 = keep the file's size
         const double feature_scale = input.getReal("feature_scale", 1.);                 // extension
@@ -92,8 +113,6 @@ int main(int argc, const char* argv[]) {
             std::printf("totNtrain not commensurate with Nbatch\n");
             return 1;
         }
-        std::printf("Thread %d %d -> %d (%d)\n", 0, 0, totNtrain, totNtrain);           // :94 (one GPU in place of Nthread threads)
-        (void)Nthread;
 
         HostMPS W;
         if (file_exists("W")) {                                                         // :671-681
@@ -125,85 +144,146 @@ int main(int argc, const char* argv[]) {
         for (int j = 1; j <= N; ++j) if ((W.A[j].L == NL) != (j == c)) { std::printf("Label Index not on site %d\n", c); return 1; }   // :734
         int wm = 1; for (int j = 1; j <= N; ++j) wm = std::max(wm, std::max(W.A[j].ml, W.A[j].mr));
 
-        tnml_config cfg{};
-        cfg.device = device; cfg.rank = 0; cfg.nranks = 1; cfg.N = N; cfg.NT_local = totNtrain; cfg.NT_total = totNtrain;
-        cfg.maxm = (int)std::max<long>(std::min<long>(maxm, 4096), wm); cfg.dtype = dtype; cfg.svd_backend = TNML_SVD_SYEVD;
-        tnml_ctx* ctx = nullptr;
-        if (tnml_create(&ctx, &cfg) != 0) die(nullptr, "tnml_create");
-        if (!train.reduced() && feature_scale == 1.) {
-            CK(ctx, tnml_set_data_u8(ctx, train.pixels.data(), train.labels.data()));   // TState ctor, :644-653
-        } else {
-            std::vector<double> phi = all_features(train, false, feature_scale);
-            CK(ctx, tnml_set_data_phi(ctx, phi.data(), train.labels.data()));
+        // ---- ranks: one host thread per GPU (the reference's `nthread` worker threads become GPUs: paralleldo.h:21-68) ----
+        int nranks = (int)ngpu;
+        if (nranks <= 0) {                                                              // ngpu = 0: every visible device from `device` on
+            nranks = 0;
+            int64_t f, t;
+            while (tnml_device_memory(device + nranks, &f, &t) == 0) ++nranks;
+            if (nranks == 0) die(nullptr, "tnml_device_memory");
         }
-        upload(ctx, W);
-        std::printf("Projecting training states..."); std::fflush(stdout);              // :740
-        CK(ctx, tnml_env_init(ctx));                                                    // :741
-        std::printf("done\n");
-        std::printf("Calling quadcost...\n");                                           // :744
-        {
-            int mL, mR, lab; CK(ctx, tnml_bond_dims(ctx, 1, &mL, &mR, &lab));
-            std::vector<double> B((size_t)mL * 4 * mR * (lab ? NL : 1));
-            CK(ctx, tnml_bond_tensor(ctx, 1, B.data()));
-            double C, lc[10], cr; int64_t nc;
-            CK(ctx, tnml_quadcost(ctx, B.data(), lambda, &C, lc, &cr, &nc));            // :745
-            std::printf("Percent correct = %.4f%%, # incorrect = %lld/%d\n", nc * 100. / totNtrain, (long long)(totNtrain - nc), totNtrain);
-            std::printf("Before starting DMRG Cost = %.10f\n", C / totNtrain);          // :746
+        if (nranks > totNtrain) nranks = totNtrain;
+        std::vector<int64_t> lo(nranks), hi(nranks);
+        for (int r = 0; r < nranks; ++r) {
+            tnml_shard_bounds(totNtrain, nranks, r, &lo[r], &hi[r]);
+            std::printf("Thread %d %lld -> %lld (%lld)\n", r, (long long)lo[r], (long long)hi[r], (long long)(hi[r] - lo[r]));   // :94, one GPU per "thread"
         }
-        if (pause_step) { std::printf("PAUSE"); std::fflush(stdout); std::getchar(); }
+        (void)Nthread;
+        // `maxm` is only an upper bound for the reference (default 5000): the contexts are sized by what an N-site MPS can
+        // reach and what every GPU can hold for its shard
+        int ctx_maxm = (int)std::min<long>(maxm, 1 << 20);
+        for (int r = 0; r < nranks; ++r) {
+            tnml_config pc{}; pc.device = device + r; pc.rank = r; pc.nranks = nranks; pc.N = N; pc.NT_local = (int)(hi[r] - lo[r]); pc.NT_total = totNtrain;
+            pc.maxm = ctx_maxm; pc.dtype = dtype;
+            int64_t freeb = 0, totb = 0;
+            if (tnml_device_memory(pc.device, &freeb, &totb) != 0) die(nullptr, "tnml_device_memory");
+            ctx_maxm = std::min(ctx_maxm, tnml_plan_maxm(&pc, ctx_maxm, wm, (int64_t)(0.97 * (double)freeb)));
+        }
+        ctx_maxm = std::max(ctx_maxm, wm);
+        if (ctx_maxm < maxm)
+            std::printf("maxm=%ld is beyond what %d sites can reach or the GPU can hold for %lld images: bond dimensions are capped at %d\n",
+                        maxm, N, (long long)(hi[0] - lo[0]), ctx_maxm);
 
-        const double lambda_cost = lambda;                                              // cargs copy, :467
-        for (long sw = 1; sw <= Nsweep; ++sw) {                                         // mldmrg, :470
-            std::printf("\nSweep %ld maxm=%ld minm=%ld\n", sw, maxm, minm);            // :472
-            for (int b = 1, ha = 1; ha <= 2; tnml_sweepnext(&b, &ha, N)) {              // :478
-                tnml_sweep_params sp{(int)std::min<long>(maxm, cfg.maxm), (int)minm, cutoff, (int)Npass, lambda, lambda_cost, cconv, 0};
-                tnml_bond_report r;
-                CK(ctx, tnml_bond_update(ctx, b, ha, &sp, &r));
-                std::printf("Sweep %ld Half %d Bond %d\n", sw, ha, r.c);                // :490
-                std::printf("In cgrad, lambda = %.3E\n", lambda);                       // :358
-                for (int p = 0; p < r.cg.npass_done; ++p) {
-                    std::printf("  Conj grad pass %d\n", p + 1);                        // :391
-                    const bool has_cost = r.cg.converged ? true : p + 1 < r.cg.npass_done || r.cg.npass_done < Npass;
-                    if (has_cost && (p + 1 < Npass)) {
-                        std::printf("  Cost = %.10f\n", r.cg.cost[p] / totNtrain);      // :429
-                        if (r.cg.converged && p + 1 == r.cg.npass_done) std::printf("  |r| = %.1E < %.1E, breaking\n", r.cg.rnorm[p], cconv);   // :434
-                        else std::printf("  |r| = %.1E\n", r.cg.rnorm[p]);              // :439
-                    }
+        std::vector<double> phi_all;
+        const bool use_u8 = !train.reduced() && feature_scale == 1.;
+        if (!use_u8) phi_all = all_features(train, false, feature_scale);
+        unsigned char uid[128] = {0};
+        if (nranks > 1 && tnml_comm_unique_id(uid) != 0) die(nullptr, "tnml_comm_unique_id");
+
+        HostBarrier bar(nranks);
+        double lambda_shared = lambda;
+        bool write_wf = false;
+        auto rank_main = [&](int r) {
+            const bool root = r == 0;
+            tnml_config cfg{};
+            cfg.device = device + r; cfg.rank = r; cfg.nranks = nranks; cfg.N = N; cfg.NT_local = (int)(hi[r] - lo[r]); cfg.NT_total = totNtrain;
+            cfg.maxm = ctx_maxm; cfg.dtype = dtype; cfg.svd_backend = TNML_SVD_SYEVD;
+            tnml_ctx* ctx = nullptr;
+            if (tnml_create(&ctx, &cfg) != 0) die(nullptr, "tnml_create");
+            if (use_u8) CK(ctx, tnml_set_data_u8(ctx, train.pixels.data() + (size_t)lo[r] * N, train.labels.data() + lo[r]));   // TState ctor, :644-653
+            else        CK(ctx, tnml_set_data_phi(ctx, phi_all.data() + (size_t)lo[r] * N * 2, train.labels.data() + lo[r]));
+            if (nranks > 1) CK(ctx, tnml_comm_init(ctx, uid));
+            upload(ctx, W);
+            if (nranks > 1) { int cnt = 0; CK(ctx, tnml_replica_check(ctx, &cnt)); if (root) std::printf("RCCL communicator of %d ranks, W replicas identical\n", cnt); }
+            if (root) { std::printf("Projecting training states..."); std::fflush(stdout); }   // :740
+            CK(ctx, tnml_env_init(ctx));                                                    // :741
+            if (root) { std::printf("done\n"); std::printf("Calling quadcost...\n"); }     // :744
+            {
+                int mL, mR, lab; CK(ctx, tnml_bond_dims(ctx, 1, &mL, &mR, &lab));
+                std::vector<double> B((size_t)mL * 4 * mR * (lab ? NL : 1));
+                CK(ctx, tnml_bond_tensor(ctx, 1, B.data()));
+                double C, lc[10], cr; int64_t nc;
+                CK(ctx, tnml_quadcost(ctx, B.data(), lambda, &C, lc, &cr, &nc));            // :745
+                if (root) {
+                    std::printf("Percent correct = %.4f%%, # incorrect = %lld/%d\n", nc * 100. / totNtrain, (long long)(totNtrain - nc), totNtrain);
+                    std::printf("Before starting DMRG Cost = %.10f\n", C / totNtrain);      // :746
                 }
-                std::printf("Sweep %ld Half %d Bond %d\n", sw, ha, r.c);                // :510
-                std::printf("SVD trunc err = %.2E\n", r.truncerr);                      // :523
-                std::printf("Original m=%d, New m=%d\n", r.origm, r.newm);              // :525
-                std::printf("norm(newB) = %.12g\n", r.norm_newB);                       // :528
-                std::printf("rank(newB) = %d\n", r.label_on_B ? 5 : 4);                 // :529 (tensor order)
-                std::printf("|B-newB| = %.3E\n", r.diff_B_newB);                        // :530
-                for (int l = 0; l < 10; ++l) std::printf("  Label l=%d C%d = %.10f\n", l, l, r.label_cost[l] / totNtrain);   // :334
-                std::printf("  Reg. cost CR = %.10f\n", r.reg_cost / totNtrain);        // :337
-                std::printf("Percent correct = %.4f%%, # incorrect = %lld/%d\n", r.ncorrect * 100. / totNtrain,
-                            (long long)(totNtrain - r.ncorrect), totNtrain);            // :341-342
-                std::printf("--> After SVD, Cost = %.10f\n", r.cost_after_svd / totNtrain);   // :533
-                const int cs = ha == 1 ? b : b + 1, prevc = ha == 1 ? b - 1 : b + 2;    // :196-209
-                if (prevc >= 1 && prevc <= N) std::printf("## Advancing E from %d to %d\n", prevc, cs);
-                else std::printf("## Making new E at %d\n", cs);
-                if (file_exists("WRITE_WF")) {                                          // :542-548
-                    std::printf("File WRITE_WF found\n");
-                    std::remove("WRITE_WF");
-                    std::printf("Writing W to disk\n");
-                    write_mps("W", download(ctx, N));
-                }
-                if (file_exists("LAMBDA")) {                                            // :550-559
-                    std::ifstream lf("LAMBDA"); lf >> lambda; lf.close();
-                    std::remove("LAMBDA");
-                    std::cout << "new lambda = " << lambda << std::endl;
-                }
-                if (pause_step) { std::printf("PAUSE"); std::fflush(stdout); std::getchar(); }   // :561
-                std::fflush(stdout);
             }
-            std::printf("Writing W to disk\n");                                         // :565
-            write_mps("W", download(ctx, N));                                           // :566
-        }
-        std::printf("Writing W to disk\n");                                             // :763
-        write_mps("W", download(ctx, N));                                               // :764
-        tnml_destroy(ctx);
+            if (root && pause_step) { std::printf("PAUSE"); std::fflush(stdout); std::getchar(); }
+            bar.wait();
+
+            double lam = lambda;
+            const double lambda_cost = lambda;                                              // cargs copy, :467
+            for (long sw = 1; sw <= Nsweep; ++sw) {                                         // mldmrg, :470
+                if (root) std::printf("\nSweep %ld maxm=%ld minm=%ld\n", sw, maxm, minm);  // :472
+                for (int b = 1, ha = 1; ha <= 2; tnml_sweepnext(&b, &ha, N)) {              // :478
+                    tnml_sweep_params sp{(int)std::min<long>(maxm, cfg.maxm), (int)std::min<long>(minm, cfg.maxm), cutoff, (int)Npass, lam, lambda_cost, cconv, 0};
+                    tnml_bond_report rep;
+                    CK(ctx, tnml_bond_update(ctx, b, ha, &sp, &rep));
+                    if (root) {
+                        const tnml_bond_report& r_ = rep;
+                        std::printf("Sweep %ld Half %d Bond %d\n", sw, ha, r_.c);           // :490
+                        std::printf("In cgrad, lambda = %.3E\n", lam);                      // :358
+                        for (int p = 0; p < r_.cg.npass_done; ++p) {
+                            std::printf("  Conj grad pass %d\n", p + 1);                    // :391
+                            const bool has_cost = r_.cg.converged ? true : p + 1 < r_.cg.npass_done || r_.cg.npass_done < Npass;
+                            if (has_cost && (p + 1 < Npass)) {
+                                std::printf("  Cost = %.10f\n", r_.cg.cost[p] / totNtrain); // :429
+                                if (r_.cg.converged && p + 1 == r_.cg.npass_done) std::printf("  |r| = %.1E < %.1E, breaking\n", r_.cg.rnorm[p], cconv);   // :434
+                                else std::printf("  |r| = %.1E\n", r_.cg.rnorm[p]);         // :439
+                            }
+                        }
+                        std::printf("Sweep %ld Half %d Bond %d\n", sw, ha, r_.c);           // :510
+                        std::printf("SVD trunc err = %.2E\n", r_.truncerr);                 // :523
+                        std::printf("Original m=%d, New m=%d\n", r_.origm, r_.newm);        // :525
+                        std::printf("norm(newB) = %.12g\n", r_.norm_newB);                  // :528
+                        std::printf("rank(newB) = %d\n", r_.label_on_B ? 5 : 4);            // :529 (tensor order)
+                        std::printf("|B-newB| = %.3E\n", r_.diff_B_newB);                   // :530
+                        for (int l = 0; l < 10; ++l) std::printf("  Label l=%d C%d = %.10f\n", l, l, r_.label_cost[l] / totNtrain);   // :334
+                        std::printf("  Reg. cost CR = %.10f\n", r_.reg_cost / totNtrain);   // :337
+                        std::printf("Percent correct = %.4f%%, # incorrect = %lld/%d\n", r_.ncorrect * 100. / totNtrain,
+                                    (long long)(totNtrain - r_.ncorrect), totNtrain);       // :341-342
+                        std::printf("--> After SVD, Cost = %.10f\n", r_.cost_after_svd / totNtrain);   // :533
+                        const int cs = ha == 1 ? b : b + 1, prevc = ha == 1 ? b - 1 : b + 2;    // :196-209
+                        if (prevc >= 1 && prevc <= N) std::printf("## Advancing E from %d to %d\n", prevc, cs);
+                        else std::printf("## Making new E at %d\n", cs);
+                        // file hooks: rank 0 looks, every rank follows
+                        write_wf = false;
+                        if (file_exists("WRITE_WF")) {                                      // :542-548
+                            std::printf("File WRITE_WF found\n");
+                            std::remove("WRITE_WF");
+                            std::printf("Writing W to disk\n");
+                            write_mps("W", download(ctx, N));
+                        }
+                        if (file_exists("LAMBDA")) {                                        // :550-559
+                            std::ifstream lf("LAMBDA"); lf >> lambda_shared; lf.close();
+                            std::remove("LAMBDA");
+                            std::cout << "new lambda = " << lambda_shared << std::endl;
+                        }
+                        if (pause_step) { std::printf("PAUSE"); std::fflush(stdout); std::getchar(); }   // :561
+                        std::fflush(stdout);
+                    }
+                    if (nranks > 1) bar.wait();
+                    lam = lambda_shared;
+                    if (nranks > 1) bar.wait();                                             // nobody re-enters the hooks before everyone has read lambda
+                }
+                if (root) {
+                    std::printf("Writing W to disk\n");                                     // :565
+                    write_mps("W", download(ctx, N));                                       // :566
+                }
+            }
+            if (root) {
+                std::printf("Writing W to disk\n");                                         // :763
+                write_mps("W", download(ctx, N));                                           // :764
+            }
+            if (nranks > 1) { CK(ctx, tnml_replica_check(ctx, nullptr)); bar.wait(); }
+            tnml_destroy(ctx);
+        };
+        (void)write_wf;
+        std::vector<std::thread> workers;
+        for (int r = 1; r < nranks; ++r) workers.emplace_back(rank_main, r);
+        rank_main(0);
+        for (auto& t : workers) t.join();
     } catch (const std::exception& e) {
         std::fprintf(stderr, "Error: %s\n", e.what());
         return 1;

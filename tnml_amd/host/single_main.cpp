@@ -128,8 +128,14 @@ int main(int argc, const char* argv[]) {
 
         tnml_config cfg{};
         cfg.device = device; cfg.rank = 0; cfg.nranks = 1; cfg.N = N; cfg.NT_local = totNtrain; cfg.NT_total = totNtrain;
-        cfg.maxm = (int)std::max<long>(std::min<long>(maxm, 4096), wm); cfg.dtype = dtype; cfg.svd_backend = TNML_SVD_SYEVD;
+        cfg.maxm = (int)std::min<long>(maxm, 1 << 20); cfg.dtype = dtype; cfg.svd_backend = TNML_SVD_SYEVD;
         cfg.mode = TNML_MODE_SINGLE; cfg.target_label = L;
+        {   // `maxm` is only an upper bound for the reference: size the context by what N sites can reach and the GPU can hold
+            int64_t freeb = 0, totb = 0;
+            if (tnml_device_memory(device, &freeb, &totb) != 0) die(nullptr, "tnml_device_memory");
+            cfg.maxm = std::max(wm, tnml_plan_maxm(&cfg, cfg.maxm, wm, (int64_t)(0.97 * (double)freeb)));
+            if (cfg.maxm < maxm) std::printf("maxm=%ld is beyond what %d sites can reach or the GPU can hold for %d images: bond dimensions are capped at %d\n", maxm, N, totNtrain, cfg.maxm);
+        }
         tnml_ctx* ctx = nullptr;
         if (tnml_create(&ctx, &cfg) != 0) die(nullptr, "tnml_create");
         CK(ctx, tnml_set_data_phi(ctx, phi.data(), labels.data()));
@@ -150,7 +156,7 @@ int main(int argc, const char* argv[]) {
         for (long sw = 1; sw <= Nsweep; ++sw) {                                         // single.h:546
             std::printf("Sweep %ld maxm=%ld\n", sw, maxm);                              // :548
             for (int b = 1, ha = 1; ha <= 2; tnml_sweepnext(&b, &ha, N)) {              // :554
-                tnml_sweep_params sp{(int)std::min<long>(maxm, cfg.maxm), (int)minm, cutoff, (int)Npass, lambda, lambda, cconv, 1};
+                tnml_sweep_params sp{(int)std::min<long>(maxm, cfg.maxm), (int)std::min<long>(minm, cfg.maxm), cutoff, (int)Npass, lambda, lambda, cconv, 1};
                 tnml_bond_report r;
                 CK(ctx, tnml_bond_update(ctx, b, ha, &sp, &r));
                 std::printf("Sweep %ld Half %d Bond %d\n", sw, ha, r.c);                // :566

@@ -25,7 +25,8 @@ EXPORTS = [
     "tnml_bond_dims", "tnml_bond_tensor", "tnml_forward", "tnml_gradient", "tnml_quadcost",
     "tnml_cgrad", "tnml_svd_split", "tnml_bond_update", "tnml_truncate", "tnml_sweepnext",
     "tnml_shard_bounds", "tnml_profile_enable", "tnml_profile_select", "tnml_profile_count", "tnml_profile_get",
-    "tnml_profile_reset", "tnml_synchronize", "tnml_device_bytes", "tnml_svd_stats", "tnml_classify",
+    "tnml_profile_reset", "tnml_synchronize", "tnml_device_bytes", "tnml_svd_stats", "tnml_classify", "tnml_replica_check",
+    "tnml_estimate_bytes", "tnml_device_memory", "tnml_plan_maxm", "tnml_set_option",
 ]
 
 
@@ -106,6 +107,12 @@ def load():
     L.tnml_device_bytes.argtypes = [vp]
     L.tnml_classify.argtypes = [vp, dp, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.tnml_device_bytes.restype = C.c_int64
+    L.tnml_replica_check.argtypes = [vp, ip]
+    L.tnml_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+    L.tnml_estimate_bytes.argtypes = [C.POINTER(Config)]
+    L.tnml_estimate_bytes.restype = C.c_int64
+    L.tnml_device_memory.argtypes = [C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.tnml_plan_maxm.argtypes = [C.POINTER(Config), C.c_int, C.c_int, C.c_int64]
     _lib = L
     return L
 
@@ -130,6 +137,24 @@ def sweepnext(b, ha, N):
     bb, hh = C.c_int(b), C.c_int(ha)
     load().tnml_sweepnext(C.byref(bb), C.byref(hh), N)
     return bb.value, hh.value
+
+
+def plan_maxm(N, NT_local, wanted, floor_m=1, dtype="f64", device=None, single=False, budget_bytes=None):
+    """largest bond dimension <= wanted that an N-site MPS can reach and whose context fits the device (or budget_bytes)"""
+    L = load()
+    cfg = Config(device or 0, 0, 1, N, NT_local, NT_local, wanted, DTYPES[dtype], 0, 1 if single else 0, 0)
+    if budget_bytes is None:
+        budget_bytes = 0
+        if device is not None:
+            f, t = C.c_int64(), C.c_int64()
+            if L.tnml_device_memory(device, C.byref(f), C.byref(t)) == 0:
+                budget_bytes = int(f.value * 0.97)
+    return L.tnml_plan_maxm(C.byref(cfg), wanted, floor_m, budget_bytes)
+
+
+def estimate_bytes(N, NT_local, maxm, dtype="f64", single=False):
+    cfg = Config(0, 0, 1, N, NT_local, NT_local, maxm, DTYPES[dtype], 0, 1 if single else 0, 0)
+    return load().tnml_estimate_bytes(C.byref(cfg))
 
 
 def shard_bounds(NT_total, nranks, rank):

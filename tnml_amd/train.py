@@ -109,7 +109,15 @@ def main(argv=None):
         say("Expected W to have Label type Index at site %d" % c)
         return 1
     wm = max(max(A.shape[0], A.shape[2]) for A in W)
-    ctx_maxm = max(min(maxm, 4096), wm)
+    # `maxm` is only an upper bound for the reference (default 5000): size the context by what an N-site MPS can reach
+    # and what fits this GPU for this shard, and say so
+    ctx_maxm = lib.plan_maxm(N, hi - lo, maxm, floor_m=wm, dtype=dtype, device=local_rank)
+    if world > 1:
+        t = torch.tensor([ctx_maxm], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ctx_maxm = max(int(t[0]), wm)
+    if ctx_maxm < maxm:
+        say("maxm=%d is beyond what %d sites can reach or this GPU can hold for %d images: bond dimensions are capped at %d" % (maxm, N, hi - lo, ctx_maxm))
 
     if vals is None and feature_scale == 1.0:
         ts = TrainStates(lab[lo:hi], N, ctx_maxm, pixels=px[lo:hi], device=local_rank, rank=rank, nranks=world, NT_total=NT, dtype=dtype)
