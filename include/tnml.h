@@ -126,6 +126,11 @@ const char* tnml_last_error(const tnml_ctx* ctx);      /* ctx may be NULL: error
    stdx::accumulate over per-thread partials, fixedL.cc:333,339,385,402,421,427. */
 int tnml_comm_unique_id(void* id128);
 int tnml_comm_init(tnml_ctx* ctx, const void* id128);
+/* In-process communicator for n ranks that share ONE device (RCCL refuses two ranks on a GPU): ctxs[r] must have been
+   created as rank r of n on the same device; call once, from one thread, before the ranks start.  Afterwards every
+   collective entry point must be driven by one host thread per rank (they meet in a host barrier).  Same results as
+   RCCL (rank-ordered sums, bit-identical on every rank); a correctness vehicle for one-GPU boxes, not a fast path. */
+int tnml_comm_init_local(tnml_ctx** ctxs, int n);
 /* Collective.  Verifies that the communicator really spans cfg.nranks ranks (ncclCommCount) and that every rank holds a
    bit-identical replica of the weight MPS (a 64-bit fingerprint of all site tensors, max/min-reduced over the ranks);
    non-zero + tnml_last_error on a mismatch.  The replicated CG/SVD algebra relies on identical replicas the way the

@@ -1,0 +1,145 @@
+"""The library's multi-rank path (image shards, packed [G | cost | ncorrect | pAp] all-reduce, collective truncation
+decision, replica fingerprints -- tnml_abi.hip: grad_eval / cgrad_device / quadcost_launch / tnml_bond_update, svd.hip)
+with MORE THAN ONE RANK on the one GPU a test box has: every rank gets its own context and host thread, the ranks are
+joined by the in-process communicator (tnml_comm_init_local; RCCL itself refuses two ranks on one device and is covered
+by test_rccl_path_with_a_one_rank_communicator).  Replaces paralleldo.h:21-68 + the stdx::accumulate reductions
+fixedL.cc:333,339,385,402,421,427; the results must not depend on the number of ranks beyond summation order."""
+import os
+import re
+import subprocess
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import make_problem
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_ranks(nranks, labels, phi, W, N, maxm, body):
+    """one context + one host thread per rank on device 0; returns body(ts, rank) of every rank"""
+    from tnml_amd import lib
+    from tnml_amd.fixedl import TrainStates
+    NT = len(labels)
+    states = []
+    for r in range(nranks):
+        lo, hi = lib.shard_bounds(NT, nranks, r)
+        states.append(TrainStates(labels[lo:hi], N, maxm, phi=phi[lo:hi], rank=r, nranks=nranks, NT_total=NT))
+    if nranks > 1:
+        TrainStates.comm_init_local(states)
+    out, err = [None] * nranks, [None] * nranks
+
+    def work(r):
+        try:
+            ts = states[r]
+            ts.set_mps(W)
+            out[r] = body(ts, r)
+        except Exception as e:                                   # noqa: BLE001
+            err[r] = e
+    th = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    assert not any(t.is_alive() for t in th), "a rank hung"
+    for e in err:
+        if e is not None:
+            raise e
+    for ts in states:
+        ts.close()
+    return out
+
+
+@pytest.mark.parametrize("nranks,NT", [(2, 151), (3, 150), (4, 257)])
+def test_sweep_on_several_ranks_matches_one_rank_and_the_oracle(nranks, NT):
+    from oracle import pyoracle
+    from tnml_amd.fixedl import mldmrg
+    N, m = 12, 6
+    pixels, labels, phi, W = make_problem(N, NT, m, 3, pixel_boost=200.0)
+    args = (1, m, m // 2, 1e-10, 3, 1e-3, 1e-10)
+
+    def body(ts, r):
+        n = ts.replica_check()
+        ts.init()
+        B1 = ts.bond_tensor(1)
+        G = ts.gradient(B1)                                      # collective: the sum over ALL ranks' images
+        C0 = ts.quadcost(B1, 1e-3)
+        reps = mldmrg(ts, *args)
+        ts.replica_check()
+        return dict(n=n, G=G, C0=C0, reps=reps, W=ts.get_mps())
+    multi = _run_ranks(nranks, labels, phi, W, N, m, body)
+    single = _run_ranks(1, labels, phi, W, N, m, body)[0]
+    o = pyoracle.Oracle(phi, labels, W)
+    o.init()
+    ro = o.mldmrg(*args)
+    assert all(x["n"] == nranks for x in multi)
+    for x in multi[1:]:                                          # every rank holds the same bits
+        assert np.array_equal(x["G"], multi[0]["G"])
+        assert [r["cost"] for r in x["reps"]] == [r["cost"] for r in multi[0]["reps"]]
+        assert all(np.array_equal(a, b) for a, b in zip(x["W"], multi[0]["W"]))
+    x = multi[0]
+    assert np.abs(x["G"] - single["G"]).max() <= 1e-12 * np.abs(single["G"]).max()
+    assert x["C0"][0] == pytest.approx(single["C0"][0], rel=1e-13) and x["C0"][3] == single["C0"][3]
+    assert [r["newm"] for r in x["reps"]] == [r["newm"] for r in single["reps"]] == [r["newm"] for r in ro]
+    assert [r["ncorrect"] for r in x["reps"]] == [r["ncorrect"] for r in ro]
+    np.testing.assert_allclose([r["cost"] for r in x["reps"]], [r["cost"] for r in single["reps"]], rtol=1e-9)
+    np.testing.assert_allclose([r["cost"] for r in x["reps"]], [r["cost"] for r in ro], rtol=1e-8)
+    np.testing.assert_allclose(np.stack([r["label_cost"] for r in x["reps"]]), np.stack([r["label_cost"] for r in ro]),
+                               rtol=1e-7, atol=1e-8 * ro[0]["cost"])
+
+
+def test_two_ranks_at_m120_share_the_truncation_decision():
+    """m = 120: the in-house eigensolver path with the eigenvalues broadcast from rank 0; two ranks of 300 images"""
+    N, NT, m = 20, 600, 120
+    pixels, labels, phi, W = make_problem(N, NT, m, 3, pixel_boost=200.0)
+
+    def body(ts, r):
+        ts.init()
+        for bb in range(1, 8):
+            ts.shiftE(bb, True)
+        reps = [ts.bond_update(b, 1, m, m // 2, 1e-10, 3, 1e-3, 1e-10) for b in (8, 9, 10)]   # Label on RE, on B, on B
+        ts.replica_check()
+        return reps
+    multi = _run_ranks(2, labels, phi, W, N, m, body)
+    single = _run_ranks(1, labels, phi, W, N, m, body)[0]
+    assert [r["cost"] for r in multi[0]] == [r["cost"] for r in multi[1]]
+    assert [r["newm"] for r in multi[0]] == [r["newm"] for r in single]
+    assert [r["ncorrect"] for r in multi[0]] == [r["ncorrect"] for r in single]
+    np.testing.assert_allclose([r["cost"] for r in multi[0]], [r["cost"] for r in single], rtol=1e-9)
+
+
+def test_cpp_driver_with_two_ranks_prints_the_one_rank_log(tmp_path):
+    """`fixedL` with ngpu = 2 (one host thread + one context per rank; share_device = yes puts both on the one GPU):
+    same log lines as the 1-rank run, costs equal up to the summation order of the image shards"""
+    from tnml_amd import synth
+    N, per_label = 16, 30
+    labels = synth.synthetic_labels(10 * per_label, seed=5, per_label=per_label)
+    pixels = synth.synthetic_images(N, labels, seed=5)
+    data = str(tmp_path / "data")
+    synth.write_idx(data, pixels[np.argsort(labels, kind="stable")], np.sort(labels), side=4)
+    logs = {}
+    for tag, extra in (("one", ""), ("two", "ngpu = 2\nshare_device = yes\n")):
+        wd = tmp_path / tag
+        wd.mkdir()
+        inp = wd / "input"
+        inp.write_text("input\n{\ndatadir = %s\nfeature_scale = 255\nNtrain = %d\nNbatch = 10\nNsweep = 1\ncutoff = 1E-10\nmaxm = 6\n"
+                       "minm = 3\nninitial = 4\nlambda = 1E-3\nNpass = 3\nseed = 3\n%s}\n" % (data, per_label, extra))
+        run = subprocess.run([os.path.join(ROOT, "tnml_amd", "fixedL"), str(inp)], capture_output=True, text=True, cwd=wd, timeout=600)
+        assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+        logs[tag] = run.stdout
+    assert "in-process communicator of 2 ranks" in logs["two"]
+    assert "Thread 1 150 -> 300 (150)" in logs["two"]
+
+    def costs(s):
+        return np.array([float(x) for x in re.findall(r"--> After SVD, Cost = ([0-9.eE+-]+)", s)])
+
+    def skeleton(s):                                             # the log with the numbers blanked
+        keep = [ln for ln in s.splitlines() if not ln.startswith(("Thread ", "in-process")) and "communicator" not in ln]
+        return [re.sub(r"[-+]?[0-9]*\.?[0-9]+([eE][-+]?[0-9]+)?", "#", ln) for ln in keep]
+    c1, c2 = costs(logs["one"]), costs(logs["two"])
+    assert len(c1) == 2 * (N - 1) and len(c2) == len(c1)
+    np.testing.assert_allclose(c2, c1, rtol=1e-6)
+    assert skeleton(logs["one"]) == skeleton(logs["two"])
+    assert re.findall(r"New m=(\d+)", logs["one"]) == re.findall(r"New m=(\d+)", logs["two"])

@@ -280,6 +280,7 @@ int tnml_destroy(tnml_ctx* c) {
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) ncclCommDestroy(c->comm);
+    local_comm_release(c);
     for (auto& p : c->prof_pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     for (auto e : c->prof_free) (void)hipEventDestroy(e);
     void* ptrs[] = {c->phi, c->label, c->ones, c->U, c->P, c->dP, c->Pp, c->Zp, c->Mf, c->slab, c->partials, c->vB, c->vR, c->vP,
@@ -314,6 +315,7 @@ int tnml_comm_init(tnml_ctx* c, const void* id128) {
 }
 // sum over ranks of a fp64 device buffer, in stream order (replaces stdx::accumulate, fixedL.cc:385,402,421,427)
 static int allreduce(tnml_ctx* c, double* buf, size_t count) {
+    if (c->local) { ProfScope ps(c, KC_ALLREDUCE); return local_comm_exchange(c, buf, count, 0); }
     if (!c->comm) {
         if (c->cfg.nranks == 1) return 0;
         return tnml_fail(c, "nranks > 1 but tnml_comm_init was not called");
@@ -324,6 +326,7 @@ static int allreduce(tnml_ctx* c, double* buf, size_t count) {
     return 0;
 }
 int bcast_rank0(tnml_ctx* c, double* buf, size_t count) {
+    if (c->local) return local_comm_exchange(c, buf, count, 1);
     if (!c->comm) return 0;
     ncclResult_t r = ncclBroadcast(buf, buf, count, ncclDouble, 0, c->comm, c->stream);
     if (r != ncclSuccess) return tnml_fail(c, "ncclBroadcast failed: %s", ncclGetErrorString(r));
@@ -336,6 +339,7 @@ static int replica_fingerprint(tnml_ctx* c, int j0, int j1) {
         const SiteT& s = c->W[j];
         TCK(launch_fingerprint(c, s.a, (size_t)s.ml * 2 * s.mr * s.L, 0x9E3779B97F4A7C15ull * (unsigned long long)(2 * j + 1), c->fprint, j == j0));
     }
+    if (c->local) return local_comm_exchange(c, reinterpret_cast<double*>(c->fprint), 2, 2);
     ncclResult_t r = ncclAllReduce(c->fprint, c->fprint, 2, ncclUint64, ncclMax, c->comm, c->stream);
     if (r != ncclSuccess) return tnml_fail(c, "ncclAllReduce failed: %s", ncclGetErrorString(r));
     return 0;
@@ -343,9 +347,10 @@ static int replica_fingerprint(tnml_ctx* c, int j0, int j1) {
 int tnml_replica_check(tnml_ctx* c, int* nranks_in_comm) {
     HIPCK(c, hipSetDevice(c->cfg.device));
     if (nranks_in_comm) *nranks_in_comm = 1;
-    if (!c->comm) return c->cfg.nranks == 1 ? 0 : tnml_fail(c, "tnml_replica_check: nranks > 1 but tnml_comm_init was not called");
+    if (!c->comm && !c->local) return c->cfg.nranks == 1 ? 0 : tnml_fail(c, "tnml_replica_check: nranks > 1 but tnml_comm_init was not called");
     int cnt = 0;
-    if (ncclCommCount(c->comm, &cnt) != ncclSuccess) return tnml_fail(c, "ncclCommCount failed");
+    if (c->local) cnt = local_comm_size(c);
+    else if (ncclCommCount(c->comm, &cnt) != ncclSuccess) return tnml_fail(c, "ncclCommCount failed");
     if (nranks_in_comm) *nranks_in_comm = cnt;
     if (cnt != c->cfg.nranks) return tnml_fail(c, "communicator has %d ranks, context was created for %d", cnt, c->cfg.nranks);
     TCK(check_W(c));
@@ -920,7 +925,7 @@ int tnml_bond_update(tnml_ctx* c, int b, int ha, const tnml_sweep_params* sp, tn
     HIPCK(c, hipMemcpyAsync(hq, c->vG + c->plan.msize(), sizeof(double) * 13, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipMemcpyAsync(hq + 16, c->scal + SC_NORMS, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
     TCK(tnml_shift_env(c, b, ha == 1));                               // :540
-    const bool fp_check = c->comm && c->check_replicas;
+    const bool fp_check = (c->comm || c->local) && c->check_replicas;
     if (fp_check) {                                                   // the two site tensors the split just wrote must be bit-identical on every rank
         TCK(replica_fingerprint(c, b, b + 1));
         HIPCK(c, hipMemcpyAsync(hq + 32, c->fprint, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));

@@ -82,6 +82,7 @@ struct tnml_ctx {
     hipStream_t stream = nullptr;
     rocblas_handle blas = nullptr;
     ncclComm_t comm = nullptr;
+    struct LocalComm* local = nullptr;   // in-process communicator of ranks sharing one device (local_comm.hip)
     std::string err;
     int64_t bytes = 0;
 
@@ -259,6 +260,11 @@ int eigh_ns_matrix(tnml_ctx* c, const double* S, double* Cm, int m, double* dev)
 int eigh_chol_rinv(tnml_ctx* c, const double* S, int m, double* Rinv, double* flag);   // m <= 136
 #define TNML_CHOL_MAXM 136
 int eigh_backtransform(tnml_ctx* c, const double* V, const double* tau, int n, const double* Z, int ldz, double* U, int ldu, int ncols);
+
+// ---- local_comm.hip ----
+void local_comm_release(tnml_ctx* c);
+int local_comm_size(const tnml_ctx* c);
+int local_comm_exchange(tnml_ctx* c, double* buf, size_t count, int op);   // 0 sum, 1 broadcast from rank 0, 2 max of uint64 patterns
 
 // rank 0's values to every rank, in stream order (no-op without a communicator)
 int bcast_rank0(tnml_ctx* c, double* buf, size_t count);

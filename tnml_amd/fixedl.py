@@ -78,6 +78,14 @@ class TrainStates:
         self._ck(self._L.tnml_comm_init(self._h, buf))
 
     @staticmethod
+    def comm_init_local(states):
+        """in-process communicator for ranks sharing one device (tnml_comm_init_local); afterwards drive every rank from its
+        own host thread"""
+        arr = (C.c_void_p * len(states))(*[s._h for s in states])
+        if _lib.load().tnml_comm_init_local(arr, len(states)) != 0:
+            raise TnmlError(_lib.load().tnml_last_error(None).decode() or "tnml_comm_init_local failed")
+
+    @staticmethod
     def comm_unique_id() -> bytes:
         buf = C.create_string_buffer(128)
         if _lib.load().tnml_comm_unique_id(buf) != 0:

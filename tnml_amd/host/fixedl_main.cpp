@@ -85,6 +85,7 @@ int main(int argc, const char* argv[]) {
         const uint64_t seed = (uint64_t)input.getInt("seed", 1);                         // extension
         const int device = (int)input.getInt("device", 0);                              // extension: first HIP ordinal
         const long ngpu = input.getInt("ngpu", 1);                                      // extension: GPUs (ranks) to shard the images over; 0 = all visible
+        const bool share_device = input.getYesNo("share_device", false);                // extension: all ranks on `device` (in-process communicator; one-GPU boxes)
         const std::string precision = input.getString("precision", "f64");              // extension: f64 | mixed | f32
         const long imglen = input.getInt("imglen", 0);                                   // extension: 0 = keep the file's size
         const double feature_scale = input.getReal("feature_scale", 1.);                 // extension
@@ -146,6 +147,7 @@ int main(int argc, const char* argv[]) {
 
         // ---- ranks: one host thread per GPU (the reference's `nthread` worker threads become GPUs: paralleldo.h:21-68) ----
         int nranks = (int)ngpu;
+        if (nranks <= 0 && share_device) nranks = 1;
         if (nranks <= 0) {                                                              // ngpu = 0: every visible device from `device` on
             nranks = 0;
             int64_t f, t;
@@ -163,10 +165,11 @@ int main(int argc, const char* argv[]) {
         // reach and what every GPU can hold for its shard
         int ctx_maxm = (int)std::min<long>(maxm, 1 << 20);
         for (int r = 0; r < nranks; ++r) {
-            tnml_config pc{}; pc.device = device + r; pc.rank = r; pc.nranks = nranks; pc.N = N; pc.NT_local = (int)(hi[r] - lo[r]); pc.NT_total = totNtrain;
+            tnml_config pc{}; pc.device = share_device ? device : device + r; pc.rank = r; pc.nranks = nranks; pc.N = N; pc.NT_local = (int)(hi[r] - lo[r]); pc.NT_total = totNtrain;
             pc.maxm = ctx_maxm; pc.dtype = dtype;
             int64_t freeb = 0, totb = 0;
             if (tnml_device_memory(pc.device, &freeb, &totb) != 0) die(nullptr, "tnml_device_memory");
+            if (share_device) freeb /= nranks;
             ctx_maxm = std::min(ctx_maxm, tnml_plan_maxm(&pc, ctx_maxm, wm, (int64_t)(0.97 * (double)freeb)));
         }
         ctx_maxm = std::max(ctx_maxm, wm);
@@ -178,7 +181,8 @@ int main(int argc, const char* argv[]) {
         const bool use_u8 = !train.reduced() && feature_scale == 1.;
         if (!use_u8) phi_all = all_features(train, false, feature_scale);
         unsigned char uid[128] = {0};
-        if (nranks > 1 && tnml_comm_unique_id(uid) != 0) die(nullptr, "tnml_comm_unique_id");
+        if (nranks > 1 && !share_device && tnml_comm_unique_id(uid) != 0) die(nullptr, "tnml_comm_unique_id");
+        std::vector<tnml_ctx*> all_ctx(nranks, nullptr);
 
         HostBarrier bar(nranks);
         double lambda_shared = lambda;
@@ -186,15 +190,21 @@ int main(int argc, const char* argv[]) {
         auto rank_main = [&](int r) {
             const bool root = r == 0;
             tnml_config cfg{};
-            cfg.device = device + r; cfg.rank = r; cfg.nranks = nranks; cfg.N = N; cfg.NT_local = (int)(hi[r] - lo[r]); cfg.NT_total = totNtrain;
+            cfg.device = share_device ? device : device + r; cfg.rank = r; cfg.nranks = nranks; cfg.N = N; cfg.NT_local = (int)(hi[r] - lo[r]); cfg.NT_total = totNtrain;
             cfg.maxm = ctx_maxm; cfg.dtype = dtype; cfg.svd_backend = TNML_SVD_SYEVD;
             tnml_ctx* ctx = nullptr;
             if (tnml_create(&ctx, &cfg) != 0) die(nullptr, "tnml_create");
             if (use_u8) CK(ctx, tnml_set_data_u8(ctx, train.pixels.data() + (size_t)lo[r] * N, train.labels.data() + lo[r]));   // TState ctor, :644-653
             else        CK(ctx, tnml_set_data_phi(ctx, phi_all.data() + (size_t)lo[r] * N * 2, train.labels.data() + lo[r]));
-            if (nranks > 1) CK(ctx, tnml_comm_init(ctx, uid));
+            if (nranks > 1 && !share_device) CK(ctx, tnml_comm_init(ctx, uid));                // RCCL over xGMI, one rank per GPU
+            if (nranks > 1 && share_device) {                                               // in-process communicator on one GPU
+                all_ctx[r] = ctx;
+                bar.wait();
+                if (root && tnml_comm_init_local(all_ctx.data(), nranks) != 0) die(nullptr, "tnml_comm_init_local");
+                bar.wait();
+            }
             upload(ctx, W);
-            if (nranks > 1) { int cnt = 0; CK(ctx, tnml_replica_check(ctx, &cnt)); if (root) std::printf("RCCL communicator of %d ranks, W replicas identical\n", cnt); }
+            if (nranks > 1) { int cnt = 0; CK(ctx, tnml_replica_check(ctx, &cnt)); if (root) std::printf("%s communicator of %d ranks, W replicas identical\n", share_device ? "in-process" : "RCCL", cnt); }
             if (root) { std::printf("Projecting training states..."); std::fflush(stdout); }   // :740
             CK(ctx, tnml_env_init(ctx));                                                    // :741
             if (root) { std::printf("done\n"); std::printf("Calling quadcost...\n"); }     // :744
