@@ -37,29 +37,60 @@ F32_MFMA_PEAK_TF = 157.3     # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md "HBM3E peak BW"
 
 
-def pmc_traffic(kernel_prefix):
-    """HBM bytes per launch of a kernel from the committed PMC summary (tools/pmc_bench.sh: rocprofv3 --pmc FETCH_SIZE and
-    --pmc WRITE_SIZE in separate passes over this same workload).  FETCH_SIZE is doubled as MI355X_MICROARCH.md "HBM"
-    prescribes for wide streaming reads on gfx950; the label-dot kernel, whose byte count is known exactly
-    (635.5 MB per launch), calibrates it: 310 398 KB reported = half.  Returns None when no summary is present."""
-    import csv
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.csv")
-    if not os.path.exists(path):
-        return None
-    for r in csv.DictReader(open(path)):
-        if r["kernel"].startswith(kernel_prefix):
-            return (2.0 * float(r["fetch_size_mean"]) + float(r["write_size_mean"])) * 1024.0
-    return None
+def kernel_source_sha16():
+    """fingerprint of the kernel sources a PMC measurement belongs to"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("kernels_gemm.hip", "kernels_stream.hip"):
+        h.update(open(os.path.join(ROOT, "tnml_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
-def cpu_baseline(maxm, npass, lam, cutoff, nthread, NT_total):
-    """The CPU oracle (dense t.v restatement of fixedL.cc) timed on the host cores on a bounded
-    sample: N=20 sites (a bond update costs O(NT m^2), independent of N -- SURVEY.md section 5),
-    interior bonds 8..9 at the full bond dimension, NT_s images; the rate is scaled to NT_total."""
+def pmc_traffic(kernel_class):
+    """HBM bytes per launch of a kernel class from the newest committed PMC record (profiles/r*_pmc_traffic.json, written
+    by tools/pmc_summary.py from rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes over this same workload; FETCH_SIZE
+    doubled as MI355X_MICROARCH.md "HBM" prescribes for wide streaming reads on gfx950 -- the label dot, whose byte count
+    is known exactly, calibrates the factor).  The record carries the kernel symbol and the sha of the kernel sources it
+    was taken at: when the sources have changed since, the number is stale and None is returned."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        rec = json.load(open(files[-1]))
+    except (OSError, ValueError):
+        return None, None
+    if rec.get("kernels_src_sha16") != kernel_source_sha16():
+        return None, None, None
+    e = rec.get("kernels", {}).get(kernel_class)
+    if not e:
+        return None, None
+    return e["bytes_per_launch"], {"kernel": e["kernel"], "commit": rec.get("commit"), "kernels_src_sha16": rec.get("kernels_src_sha16"),
+                                   "file": "profiles/" + os.path.basename(files[-1])}
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(maxm, npass, lam, cutoff, nthread, NT_total, full=False):
+    """The CPU oracle (dense t.v restatement of fixedL.cc, paralleldo.h chunking, `nthread` <= 16 threads) timed on the host
+    cores on a bounded sample of the same workload: N=20 sites (a bond update costs O(NT m^2), independent of N --
+    SURVEY.md section 5), consecutive interior bonds 8, 9, ... at the full bond dimension on NT_s images; the rate is scaled
+    to NT_total (work per bond update is linear in the image count).  Default: NT_s = 960 (480 for m > 200) and as many
+    bond updates as fit ~20 s (>= 2); full=True: the SURVEY.md 8(d) sample, NT_s = 2000 and 20 bonds (minutes)."""
     from oracle import pyoracle
     from tnml_amd import synth
-    N = 20
-    NT_s = 240 if maxm >= 100 else 2000
+    if full:
+        N, NT_s, nb_max, budget = 44, 2000, 20, 1e9
+    else:
+        N, NT_s, nb_max, budget = 36, (960 if maxm <= 200 else 240) if maxm >= 100 else 4000, 20, 18.0
     NT_s = (NT_s // nthread) * nthread
     labels = synth.synthetic_labels(NT_s, seed=7)
     pixels = synth.synthetic_images(N, labels, seed=7)
@@ -67,28 +98,35 @@ def cpu_baseline(maxm, npass, lam, cutoff, nthread, NT_total):
     W = synth.random_mps(N, maxm, seed=1)
     o = pyoracle.Oracle(phi, labels, W, nthread=nthread, nbatch=1)
     o.init()
-    b0 = 8
+    b0 = 8                                             # bonds 8.. are m x m on both sides for m <= 128
     for bb in range(1, b0):
         o.shiftE(bb, True)
-    nb = 2
+    nb = 0
     t0 = time.time()
-    for b in range(b0, b0 + nb):                      # the mldmrg loop body, fixedL.cc:482-540
-        o.set_bond(b)
+    b = b0
+    while nb < nb_max and (nb < 2 or time.time() - t0 < budget) and b < N - 8:
+        o.set_bond(b)                                  # the mldmrg loop body, fixedL.cc:482-540
         B = o.bond_tensor(b)
         B, _ = o.cgrad(B, npass, lam, 1e-10)
         o.svd_split(B, b, 1, cutoff, maxm, maxm // 2)
         o.quadcost(o.bond_tensor(b), lam)
         o.shiftE(b, True)
+        nb += 1
+        b += 1
     dt = time.time() - t0
     rate_sample = nb / dt
     return {
         "value": rate_sample * NT_s / NT_total,
         "unit": "bond updates/s",
         "cores": nthread,
+        "cpu_model": cpu_model(),
+        "host_cores": os.cpu_count(),
         "kind": "port",
-        "sample": "oracle (dense t.v fp64 restatement of fixedL.cc, %d threads): %d bond updates at m=%d on %d images took "
-                  "%.2f s (%.3f bond updates/s); value = that rate x %d/%d (work per bond update is linear in the "
-                  "image count)" % (nthread, nb, maxm, NT_s, dt, rate_sample, NT_s, NT_total),
+        "image_bond_updates_per_s": rate_sample * NT_s,
+        "sample": "oracle (dense t.v fp64 restatement of fixedL.cc, %d threads): %d consecutive bond updates (bonds %d..%d of a %d-site chain, "
+                  "Label on RE / on B) at m=%d on %d images took %.2f s (%.4f bond updates/s = %.1f image-bond-updates/s); value = that rate "
+                  "x %d/%d (work per bond update is linear in the image count)" % (nthread, nb, b0, b0 + nb - 1, N, maxm, NT_s, dt, rate_sample,
+                                                                                 rate_sample * NT_s, NT_s, NT_total),
     }
 
 
@@ -107,9 +145,38 @@ def hbm_roofline(prof_all, NTl, timed, args, world):
                               min(r["mL"], r["mR"]) * (env_sz if r["label_on_B"] else esz) + 4) for r in timed]))
     avg_ms = ms_ld / n_ld
     ach = by / (avg_ms * 1e-3) / 1e9
+    tr, src = pmc_traffic("labeldot") if args.dtype == "f64" and args.maxm == 120 and args.images == 60000 and world == 1 else (None, None)
     return {"bound": "hbm", "kernel": "k_labeldot", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-            "traffic": pmc_traffic("void k_labeldot<4, 2, 10, double, double, double>") if args.dtype == "f64" and args.maxm == 120 and args.images == 60000 and world == 1 else None,
-            "avg_launch_ms": avg_ms, "launches": n_ld, "bytes_per_launch": by}
+            "traffic": tr, "traffic_source": src, "avg_launch_ms": avg_ms, "launches": n_ld, "bytes_per_launch": by}
+
+
+def self_launch(ngpus):
+    """`python bench.py --gpus N` without a launcher: re-run this command as N ranks under torch.distributed.run on this
+    node (127.0.0.1 rendezvous on a free port) and hand its output through -- rank 0's JSON line is the result."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def shift_flops(r, NTl, N, single):
+    """flops of the shiftE that ends bond update r: 2 NT (2 m_in) m_out, x10 when the new environment carries the Label index"""
+    c0 = -1 if single else N // 2
+    b, ha = r["bond"], r["half"]
+    if ha == 1:
+        cs, m_in, m_out = b, r["mL"], r["newm"]
+        lab = (not single) and cs >= c0
+    else:
+        cs, m_in, m_out = b + 1, r["mR"], r["newm"]
+        lab = (not single) and cs <= c0
+    return 2.0 * NTl * (2 * m_in) * m_out * (10 if lab else 1)
 
 
 def main():
@@ -125,50 +192,77 @@ def main():
                     "spectrum of the synthetic data (the reference default max(10, maxm/2) lets trained bonds shrink)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f64_e32", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="the SURVEY.md 8(d) CPU sample (2000 images, 20 bonds: minutes) instead of the bounded one")
+    ap.add_argument("--literal-steps", type=int, default=None, help="bond updates timed in the reference's literal evaluation order "
+                    "(fast CG and carried outputs off) after the main window; default min(steps, 100), 0 = skip")
+    ap.add_argument("--workload", default="default", choices=["default", "8d"], help="8d: SURVEY.md 8(d) literally -- one untimed warm-up "
+                    "sweep with minm = maxm/2 from the random-init W, then the timed bonds with minm = maxm/2")
     ap.add_argument("--single-label", type=int, default=None, help="bench the per-label variant (single.cc, BASELINE config 4: one such "
                     "training per label, replicas only) for this label instead of the fixedL sweep")
+    ap.add_argument("--dry-run", action="store_true", help="control plane only (launcher, rendezvous, shard bounds, max-over-ranks clock): no GPU work")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 2 * (args.sites - 1)
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
 
     import torch
     import torch.distributed as dist
     from tnml_amd import lib, synth
-    from tnml_amd.fixedl import TrainStates
-
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     N, NT, maxm = args.sites, args.images, args.maxm
     lam, cutoff, cconv, npass = 1e-3, 1e-10, 1e-10, args.npass
-    minm = args.minm if args.minm is not None else maxm
+    minm = args.minm if args.minm is not None else (maxm // 2 if args.workload == "8d" else maxm)
+    lo, hi = lib.shard_bounds(NT, world, rank)
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    if args.dry_run:
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        cnt = torch.tensor([hi - lo], dtype=torch.int64)
+        if world > 1:
+            dist.barrier()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(cnt)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "max_over_ranks": float(t[0]), "images_over_ranks": int(cnt[0]),
+                              "shard_of_rank0": [lo, hi]}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    from tnml_amd.fixedl import TrainStates
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d needs HIP device %d but only %d are visible" % (rank, local_rank, torch.cuda.device_count()))
+    torch.cuda.set_device(local_rank)
 
     labels = synth.synthetic_labels(NT)
     pixels = synth.synthetic_images(N, labels)
     W = synth.random_mps(N, maxm, seed=1)
-    if args.single_label is not None:
+    single = args.single_label is not None
+    if single:
         W[N // 2 - 1] = W[N // 2 - 1][..., 0] * 3.0             # plain weight MPS: no Label index
-    lo, hi = lib.shard_bounds(NT, world, rank)
     ts = TrainStates(labels[lo:hi], N, maxm, pixels=pixels[lo:hi], device=local_rank, rank=rank, nranks=world,
                      NT_total=NT, dtype=args.dtype, single_label=args.single_label)
     del pixels
+    comm_ranks = 1
     if world > 1:
         uid = [TrainStates.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         ts.comm_init(uid[0])
     ts.set_mps(W)
+    if world > 1:
+        comm_ranks = ts.replica_check()                          # ncclCommCount == world and bit-identical W replicas
+        assert comm_ranks == world, (comm_ranks, world)
     t_init = time.time()
     ts.init()
     ts.synchronize()
@@ -181,22 +275,31 @@ def main():
             dist.barrier()
 
     b, ha = 1, 1
+    reports = []
+
+    def step():
+        nonlocal b, ha
+        r = ts.bond_update(b, ha, maxm, minm, cutoff, npass, lam, cconv, report_costs=single)
+        reports.append(r)
+        b, ha = lib.sweepnext(b, ha, N)
+        if ha > 2:
+            b, ha = 1, 1
+
     full_sweeps = args.steps >= 2 * (N - 1)
-    if not full_sweeps and N >= 64:
+    if args.workload == "8d":
+        for _ in range(2 * (N - 1)):                             # the warm-up sweep of SURVEY.md 8(d): bonds grow to their trained size
+            step()
+        reports.clear()
+        if not full_sweeps and N >= 64:                          # timed window: consecutive interior bonds of the second sweep, b < N/2
+            for _ in range(max(8, min(N // 4, N // 2 - 8 - args.warmup - args.steps))):
+                step()
+            reports.clear()
+    elif not full_sweeps and N >= 64:
         # left environments up to the window start, as a sweep would have left them (setup, untimed)
         b0 = max(N // 2 + 8, min(N // 2 + 8 + (N // 2 - 24 - args.warmup - args.steps) // 2, N - 1))
         for bb in range(1, b0):
             ts.shiftE(bb, True)
         b = b0
-    reports = []
-
-    def step():
-        nonlocal b, ha
-        r = ts.bond_update(b, ha, maxm, minm, cutoff, npass, lam, cconv, report_costs=args.single_label is not None)
-        reports.append(r)
-        b, ha = lib.sweepnext(b, ha, N)
-        if ha > 2:
-            b, ha = 1, 1
 
     for _ in range(args.warmup):
         step()
@@ -212,6 +315,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ts.profile(False)
     prof = ts.profile_read()
+    n_timed_end = len(reports)
     # untimed extra steps with every kernel class timed: the per-class breakdown
     ts.profile(True)
     ts.profile_reset()
@@ -220,67 +324,108 @@ def main():
         step()
     ts.profile(False)
     prof_all = ts.profile_read()
+    # the reference's literal evaluation order (every forward pass of fixedL.cc:374-421 executed), timed the same way
+    nlit = min(args.steps, 100) if args.literal_steps is None else args.literal_steps
+    elapsed_lit = None
+    if nlit > 0:
+        ts.set_option("fast_cg", 0)
+        ts.set_option("reuse_p", 0)
+        step()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(nlit):
+            step()
+        sync()
+        elapsed_lit = time.perf_counter() - t1
+        ts.set_option("fast_cg", 1)
+        ts.set_option("reuse_p", 1)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64)
+        t = torch.tensor([elapsed, elapsed_lit or 0.0], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
+        elapsed_lit = float(t[1]) if nlit > 0 else None
+        ts.replica_check()
 
     if rank == 0:
-        timed = reports[args.warmup:args.warmup + args.steps]
+        timed = reports[n_timed_end - args.steps:n_timed_end]
         NTl = hi - lo
         # dominant kernel: the feature GEMM (T = X*B_mat).  Algorithmic flops per launch = SURVEY.md 8(d)
         # GEMM term 2*NT*(2mL)*(2mR) for the images one launch processes (x10 on the two Label-on-B bonds).
         n_fg, ms_fg = prof.get("fgemm_fwd", (0, 0.0))
-        # every timed bond calls the feature GEMM 2*npass+1 times with its own (mL, mR); average the flops
-        fl = []
-        for r in timed:
-            fl.append(2.0 * NTl * (2 * r["mL"]) * (2 * r["mR"]) * (10 if (r["label_on_B"] and args.single_label is None) else 1))
+        # every timed bond calls the feature GEMM with its own (mL, mR); average the flops
+        fl = [2.0 * NTl * (2 * r["mL"]) * (2 * r["mR"]) * (10 if (r["label_on_B"] and not single) else 1) for r in timed]
         flops_per_launch = float(np.mean(fl)) if fl else 0.0
         avg_ms = ms_fg / max(n_fg, 1)
         achieved_tf = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         peak = F64_MFMA_PEAK_TF if args.dtype != "f32" else F32_MFMA_PEAK_TF
+        ms_per_step = 1e3 * elapsed / args.steps
+        kms = {k: v[1] / nbreak for k, v in prof_all.items() if v[0]}
+        # whole-step MFMA fraction.  executed: the GEMM launches a bond update really issues (5 forward + 4 gradient with the two
+        # shortcuts on) + its shiftE; algorithmic: SURVEY.md 8(d), (3P+1) passes of 2 NT (2m)^2 + 2 NT 2m 10, the shift, 22 (2m)^3
+        nf_step = prof_all.get("fgemm_fwd", (0, 0))[0] / max(nbreak, 1)
+        nb_step = prof_all.get("bgemm", (0, 0))[0] / max(nbreak, 1)
+        sh = float(np.mean([shift_flops(r, NTl, N, single) for r in timed])) if timed else 0.0
+        exec_gf = ((nf_step + nb_step) * flops_per_launch + sh) / 1e9
+        m_avg = float(np.mean([0.5 * (r["mL"] + r["mR"]) for r in timed])) if timed else 0.0
+        alg_gf = ((3 * npass + 1) * (flops_per_launch + 2.0 * NTl * 2 * m_avg * (1 if single else 10)) + sh + 22.0 * (2 * m_avg) ** 3) / 1e9
+        grad_classes = ("fgemm_fwd", "labeldot", "p_update", "bgemm", "slab_reduce", "zprime", "allreduce")
+        tr_fg, src_fg = pmc_traffic("fgemm_fwd") if args.dtype == "f64" and maxm == 120 and NT == 60000 and world == 1 else (None, None)
+        shortcuts_on = os.environ.get("TNML_FAST_CG", "1") != "0" or os.environ.get("TNML_REUSE_P", "1") != "0"
         out = {
-            "metric": "two-site bond updates/sec" if args.single_label is None else "two-site bond updates/sec (per-label variant, label %d)" % args.single_label,
+            "metric": "two-site bond updates/sec" if not single else "two-site bond updates/sec (per-label variant, label %d)" % args.single_label,
             "value": args.steps / elapsed,
             "unit": "bond updates/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step": ms_per_step,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
+            "parity": "unpinned-oracle (no reference-held vectors exist and ITensor is absent: GPU results are checked against "
+                      "oracle/, a line-cited restatement of fixedL.cc cross-checked by an independent numpy restatement)",
             "config": {"workload": "fixedL N=%d, maxm=%d, %d images (BASELINE config 3), Npass=%d, lambda=%g, minm=%d, "
-                                   "%s; timed bonds %d..%d (%s, m=%d)" % (N, maxm, NT, npass, lam, minm,
+                                   "%s; %s; timed bonds %d..%d (%s, m=%.0f)" % (N, maxm, NT, npass, lam, minm,
                                                                                {"f64": "fp64 throughout", "f64_e32": "fp64 MFMA over fp32-stored environments", "f32": "fp32 study mode"}[args.dtype],
+                                                                               "random-init W at m=maxm" if args.workload == "default" else "SURVEY 8(d): after one warm-up sweep from the random-init W",
                                                                                timed[0]["bond"] if timed else 0,
                                                                                timed[-1]["bond"] if timed else 0,
                                                                                "whole sweeps" if full_sweeps else
-                                                                               "consecutive interior bonds, Label-carrying shiftE on each",
-                                                                               maxm),
-                       "global_images": NT, "sites": N, "maxm": maxm, "parallelism": "dp%d (image sharding + RCCL all-reduce)" % world},
+                                                                               ("consecutive interior bonds, Label-carrying shiftE on each" if args.workload == "default" else "consecutive interior bonds of the second sweep"),
+                                                                               m_avg),
+                       "global_images": NT, "sites": N, "maxm": maxm, "parallelism": "dp%d (image sharding + RCCL all-reduce)" % world,
+                       "rccl_ranks": comm_ranks},
             "roofline": {"bound": "mfma", "kernel": "k_fgemm64" if args.dtype != "f32" else "k_fgemm",
                          "achieved": achieved_tf, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved_tf / peak,
-                         "traffic": pmc_traffic("void k_fgemm64<2, 5, 4, 3, 16, 0, 0, double, 2>") if args.dtype == "f64" and maxm == 120 and NT == 60000 and world == 1 else None,
+                         "traffic": tr_fg, "traffic_source": src_fg,
                          "avg_launch_ms": avg_ms, "launches": n_fg, "flops_per_launch": flops_per_launch},
-            "kernel_ms_per_step": {k: v[1] / nbreak for k, v in prof_all.items() if v[0]},
+            "roofline_step": {"bound": "mfma", "peak": peak, "unit": "TFLOP/s",
+                              "executed_gflop_per_step": exec_gf, "executed": exec_gf / ms_per_step, "frac_executed": exec_gf / ms_per_step / peak,
+                              "algorithmic_gflop_per_step": alg_gf, "algorithmic": alg_gf / ms_per_step, "frac_algorithmic": alg_gf / ms_per_step / peak,
+                              "note": "whole bond update (GEMMs + label dot + CG vectors + split + shiftE) against the MFMA peak; executed = the GEMM "
+                                      "launches issued with the algebraic shortcuts on, algorithmic = SURVEY.md 8(d)'s count for the literal order"},
+            "kernel_ms_per_step": kms,
+            "gradient_phase_ms": sum(kms.get(k, 0.0) for k in grad_classes),
+            "svd_ms": kms.get("svd", 0.0),
             "roofline_hbm": hbm_roofline(prof_all, NTl, timed, args, world),
             "algebraic_shortcuts": [
                 "fast CG: B*t.v is linear in B, so P <- P + a (p*t.v) replaces Npass-1 forward GEMMs per bond (TNML_FAST_CG=0 disables)",
                 "the network outputs P_n do not depend on the bond they are evaluated at: the after-SVD quadcost of one bond update "
                 "provides the residuals of the next one's first gradient, replacing 1 forward GEMM + label dot per bond (TNML_REUSE_P=0 disables)",
-            ] if os.environ.get("TNML_FAST_CG", "1") != "0" or os.environ.get("TNML_REUSE_P", "1") != "0" else [],
+            ] if shortcuts_on else [],
+            "value_literal_order": (nlit / elapsed_lit) if elapsed_lit else None,
+            "literal_order_steps": nlit,
             "env_init_s": t_init,
             "device_gb": ts.device_bytes() / 1e9,
             "last_cost_per_image": timed[-1]["cost"] / NT if timed else None,
             "svd_stats": ts.svd_stats(),
         }
-        if world == 1 and not args.no_cpu_baseline and args.single_label is None:
+        if world == 1 and not args.no_cpu_baseline and not single:
             ncore = os.cpu_count() or 1
-            out["cpu_baseline"] = cpu_baseline(maxm, npass, lam, cutoff, min(16, ncore), NT)   # paralleldo.h:55-56 caps at 16
+            out["cpu_baseline"] = cpu_baseline(maxm, npass, lam, cutoff, min(16, ncore), NT, full=args.cpu_baseline_full)   # paralleldo.h:55-56 caps at 16
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -33,11 +33,16 @@ def test_bench_json_line_whole_sweep():
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 78.6
     assert r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert r["traffic"] is None                                       # the PMC summary was taken on the full workload only
+    assert r["traffic"] is None                                       # the PMC record belongs to the full workload only
+    rs = d["roofline_step"]
+    assert rs["executed"] > 0 and rs["algorithmic"] >= rs["executed"] and abs(rs["frac_executed"] - rs["executed"] / rs["peak"]) < 1e-12
+    assert d["value_literal_order"] > 0 and d["value_literal_order"] < 1.2 * d["value"]
+    assert d["gradient_phase_ms"] > 0 and d["parity"].startswith("unpinned-oracle")
     h = d["roofline_hbm"]
     assert h["bound"] == "hbm" and h["unit"] == "GB/s" and h["launches"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
+    assert c["cpu_model"] and c["image_bond_updates_per_s"] > 0
     assert d["last_cost_per_image"] > 0
 
 
@@ -59,7 +64,26 @@ def test_bench_refuses_without_a_device():
     assert run.returncode != 0 and "no CPU fallback" in (run.stderr + run.stdout)
 
 
-def test_bench_refuses_gpus_without_launcher():
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
-    assert run.returncode != 0 and "torch.distributed.run" in (run.stderr + run.stdout)
+def test_bench_gpus_n_without_a_launcher_starts_n_ranks():
+    """`python bench.py --gpus 2` (no torch.distributed.run around it) launches its own two ranks: world-size-2 gloo
+    rendezvous on 127.0.0.1, shard bounds, max-over-ranks reduction and ONE JSON line from rank 0 (--dry-run: the control
+    plane only, there is no GPU in this test)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--images", "61"],
+                         capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
+    assert run.returncode == 0, (run.stderr + run.stdout)[-2000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, run.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d == {"dry_run": True, "n_gpus": 2, "max_over_ranks": 2.0, "images_over_ranks": 61, "shard_of_rank0": [0, 30]}
+
+
+def test_bench_under_the_launcher_form_the_driver_uses():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"],
+                         capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert run.returncode == 0, (run.stderr + run.stdout)[-2000:]
+    d = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["images_over_ranks"] == 60000 and d["shard_of_rank0"] == [0, 30000]

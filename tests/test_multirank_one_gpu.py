@@ -84,7 +84,8 @@ def test_sweep_on_several_ranks_matches_one_rank_and_the_oracle(nranks, NT):
     assert x["C0"][0] == pytest.approx(single["C0"][0], rel=1e-13) and x["C0"][3] == single["C0"][3]
     assert [r["newm"] for r in x["reps"]] == [r["newm"] for r in single["reps"]] == [r["newm"] for r in ro]
     assert [r["ncorrect"] for r in x["reps"]] == [r["ncorrect"] for r in ro]
-    np.testing.assert_allclose([r["cost"] for r in x["reps"]], [r["cost"] for r in single["reps"]], rtol=1e-9)
+    # a different image partition is a different summation order: the same 1e-8 as against the oracle (4 ranks: 1.8e-9 seen)
+    np.testing.assert_allclose([r["cost"] for r in x["reps"]], [r["cost"] for r in single["reps"]], rtol=1e-8)
     np.testing.assert_allclose([r["cost"] for r in x["reps"]], [r["cost"] for r in ro], rtol=1e-8)
     np.testing.assert_allclose(np.stack([r["label_cost"] for r in x["reps"]]), np.stack([r["label_cost"] for r in ro]),
                                rtol=1e-7, atol=1e-8 * ro[0]["cost"])
