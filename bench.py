@@ -269,6 +269,7 @@ def main():
     t_init = time.time() - t_init
 
     def sync():
+        drain()
         ts.synchronize()
         torch.cuda.synchronize()
         if world > 1:
@@ -277,22 +278,40 @@ def main():
     b, ha = 1, 1
     reports = []
 
+    inflight = 0
+    pipelined = os.environ.get("TNML_BENCH_PIPELINE", "1") != "0"
+
     def step():
-        nonlocal b, ha
-        r = ts.bond_update(b, ha, maxm, minm, cutoff, npass, lam, cconv, report_costs=single)
-        reports.append(r)
+        """one bond update; pipelined: bond k+1 is enqueued before the report of bond k is fetched, as the sweep drivers do"""
+        nonlocal b, ha, inflight
+        if pipelined:
+            ts.bond_update_begin(b, ha, maxm, minm, cutoff, npass, lam, cconv, report_costs=single)
+            inflight += 1
+            if inflight == 2:
+                reports.append(ts.bond_update_end())
+                inflight -= 1
+        else:
+            reports.append(ts.bond_update(b, ha, maxm, minm, cutoff, npass, lam, cconv, report_costs=single))
         b, ha = lib.sweepnext(b, ha, N)
         if ha > 2:
             b, ha = 1, 1
+
+    def drain():
+        nonlocal inflight
+        while inflight:
+            reports.append(ts.bond_update_end())
+            inflight -= 1
 
     full_sweeps = args.steps >= 2 * (N - 1)
     if args.workload == "8d":
         for _ in range(2 * (N - 1)):                             # the warm-up sweep of SURVEY.md 8(d): bonds grow to their trained size
             step()
+        drain()
         reports.clear()
         if not full_sweeps and N >= 64:                          # timed window: consecutive interior bonds of the second sweep, b < N/2
             for _ in range(max(8, min(N // 4, N // 2 - 8 - args.warmup - args.steps))):
                 step()
+            drain()
             reports.clear()
     elif not full_sweeps and N >= 64:
         # left environments up to the window start, as a sweep would have left them (setup, untimed)
@@ -315,19 +334,26 @@ def main():
     elapsed = time.perf_counter() - t0
     ts.profile(False)
     prof = ts.profile_read()
-    n_timed_end = len(reports)
-    # untimed extra steps with every kernel class timed: the per-class breakdown
+    n_timed_end = len(reports)                                   # sync() has drained the pipeline: every timed report is in
+    # untimed extra steps with every kernel class timed: the per-class breakdown.  After whole sweeps the next bonds are the
+    # chain start (bond dimensions 2, 4, 8, ...): move on to interior bonds first
+    if full_sweeps and N >= 64:
+        for _ in range(N // 4):
+            step()
+        drain()
     ts.profile(True)
     ts.profile_reset()
     nbreak = min(args.steps, 10)
     for _ in range(nbreak):
         step()
+    drain()
     ts.profile(False)
     prof_all = ts.profile_read()
     # the reference's literal evaluation order (every forward pass of fixedL.cc:374-421 executed), timed the same way
     nlit = min(args.steps, 100) if args.literal_steps is None else args.literal_steps
     elapsed_lit = None
     if nlit > 0:
+        drain()
         ts.set_option("fast_cg", 0)
         ts.set_option("reuse_p", 0)
         step()
@@ -354,7 +380,15 @@ def main():
         n_fg, ms_fg = prof.get("fgemm_fwd", (0, 0.0))
         # every timed bond calls the feature GEMM with its own (mL, mR); average the flops
         fl = [2.0 * NTl * (2 * r["mL"]) * (2 * r["mR"]) * (10 if (r["label_on_B"] and not single) else 1) for r in timed]
-        flops_per_launch = float(np.mean(fl)) if fl else 0.0
+        flops_per_pass = float(np.mean(fl)) if fl else 0.0
+        # two-queue forward pass: the images go through the feature GEMM in two launches, and class "fgemm_fwd" holds only the
+        # first one (the half that has the machine to itself); the second runs beside the label dot of the first half
+        split = prof_all.get("fgemm_fwd_overlapped", (0, 0))[0] > 0
+        NTp = (NTl + 255) // 256 * 256
+        nblk = NTp // 128
+        img_fg = ((nblk + 1) // 2) * 128 if split else NTl            # images of one "fgemm_fwd" launch (all real: the padding sits at the end)
+        img_ld = NTl - img_fg if split else NTl                        # images of one "labeldot" launch
+        flops_per_launch = flops_per_pass * img_fg / NTl
         avg_ms = ms_fg / max(n_fg, 1)
         achieved_tf = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         peak = F64_MFMA_PEAK_TF if args.dtype != "f32" else F32_MFMA_PEAK_TF
@@ -365,10 +399,11 @@ def main():
         nf_step = prof_all.get("fgemm_fwd", (0, 0))[0] / max(nbreak, 1)
         nb_step = prof_all.get("bgemm", (0, 0))[0] / max(nbreak, 1)
         sh = float(np.mean([shift_flops(r, NTl, N, single) for r in timed])) if timed else 0.0
-        exec_gf = ((nf_step + nb_step) * flops_per_launch + sh) / 1e9
+        exec_gf = ((nf_step + nb_step) * flops_per_pass + sh) / 1e9
         m_avg = float(np.mean([0.5 * (r["mL"] + r["mR"]) for r in timed])) if timed else 0.0
-        alg_gf = ((3 * npass + 1) * (flops_per_launch + 2.0 * NTl * 2 * m_avg * (1 if single else 10)) + sh + 22.0 * (2 * m_avg) ** 3) / 1e9
-        grad_classes = ("fgemm_fwd", "labeldot", "p_update", "bgemm", "slab_reduce", "zprime", "allreduce")
+        alg_gf = ((3 * npass + 1) * (flops_per_pass + 2.0 * NTl * 2 * m_avg * (1 if single else 10)) + sh + 22.0 * (2 * m_avg) ** 3) / 1e9
+        # (the label dot of the first image half, class labeldot_overlapped, runs beside fgemm_fwd_overlapped: counted once)
+        grad_classes = ("fgemm_fwd", "fgemm_fwd_overlapped", "labeldot", "p_update", "bgemm", "slab_reduce", "zprime", "allreduce")
         tr_fg, src_fg = pmc_traffic("fgemm_fwd") if args.dtype == "f64" and maxm == 120 and NT == 60000 and world == 1 else (None, None)
         shortcuts_on = os.environ.get("TNML_FAST_CG", "1") != "0" or os.environ.get("TNML_REUSE_P", "1") != "0"
         out = {
@@ -401,7 +436,9 @@ def main():
                          "achieved": achieved_tf, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved_tf / peak,
                          "traffic": tr_fg, "traffic_source": src_fg,
-                         "avg_launch_ms": avg_ms, "launches": n_fg, "flops_per_launch": flops_per_launch},
+                         "avg_launch_ms": avg_ms, "launches": n_fg, "flops_per_launch": flops_per_launch, "images_per_launch": img_fg,
+                         "note": ("forward pass split over two queues: this is the launch of the first image half, which has the GPU to itself; "
+                                  "the second half runs beside the label dot of the first (kernel_ms_per_step.fgemm_fwd_overlapped)") if split else None},
             "roofline_step": {"bound": "mfma", "peak": peak, "unit": "TFLOP/s",
                               "executed_gflop_per_step": exec_gf, "executed": exec_gf / ms_per_step, "frac_executed": exec_gf / ms_per_step / peak,
                               "algorithmic_gflop_per_step": alg_gf, "algorithmic": alg_gf / ms_per_step, "frac_algorithmic": alg_gf / ms_per_step / peak,
@@ -410,7 +447,7 @@ def main():
             "kernel_ms_per_step": kms,
             "gradient_phase_ms": sum(kms.get(k, 0.0) for k in grad_classes),
             "svd_ms": kms.get("svd", 0.0),
-            "roofline_hbm": hbm_roofline(prof_all, NTl, timed, args, world),
+            "roofline_hbm": hbm_roofline(prof_all, img_ld, timed, args, world),
             "algebraic_shortcuts": [
                 "fast CG: B*t.v is linear in B, so P <- P + a (p*t.v) replaces Npass-1 forward GEMMs per bond (TNML_FAST_CG=0 disables)",
                 "the network outputs P_n do not depend on the bond they are evaluated at: the after-SVD quadcost of one bond update "

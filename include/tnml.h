@@ -180,6 +180,13 @@ int tnml_svd_split(tnml_ctx* ctx, const double* B, int b, int ha, double cutoff,
 /* ---- one iteration of the mldmrg loop body, device resident (fixedL.cc:478-540) ----------- */
 /* setBond -> oB -> cgrad -> svd -> newB -> quadcost -> shiftE without tensors leaving the GPU */
 int tnml_bond_update(tnml_ctx* ctx, int b, int ha, const tnml_sweep_params* p, tnml_bond_report* rep);
+/* The same bond update in two halves, for a sweep loop that keeps the GPU queue full across bond boundaries (mldmrg's loop
+   body ends with prints only, fixedL.cc:523-561): _begin enqueues the whole update -- it blocks once, inside the split, for
+   the eigenvalues that decide the new bond dimension -- and returns; _end waits for the end-of-bond scalars (cost, #correct,
+   norms; multi-rank: the replica fingerprint) and fills the report.  bond k+1 may be begun before bond k is ended (at most
+   two in flight; reports come back in order), in which case _end does not wait at all.  tnml_bond_update = _begin + _end. */
+int tnml_bond_update_begin(tnml_ctx* ctx, int b, int ha, const tnml_sweep_params* p);
+int tnml_bond_update_end(tnml_ctx* ctx, tnml_bond_report* rep);
 
 /* ---- host-side rules (no GPU needed) ------------------------------------------------------ */
 /* ---- inference (fulltest.cc:7-100; util.h:19-40 toverlap, util.h:123-200 fullTest) ------------------

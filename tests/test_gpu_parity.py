@@ -872,6 +872,14 @@ def test_properties_at_the_full_baseline_size():
     G = ts.gradient(B1)
     assert _relmax(ts.gradient(B1), G) == 0.0                                  # deterministic reductions: bit-identical
     C, lc, cr, nc = ts.quadcost(B1, 1e-3)
+    # the two-queue forward pass (label dot of one image half beside the feature GEMM of the other) against the one-queue
+    # form: same arithmetic per image, same reduction order -> identical bits
+    ts.set_option("overlap", 0)
+    P1s, Gs1 = ts.forward(B1), ts.gradient(B1)
+    Cs = ts.quadcost(B1, 1e-3)
+    ts.set_option("overlap", 1)
+    assert np.array_equal(P1s, P1) and np.array_equal(Gs1, G)
+    assert Cs[0] == C and np.array_equal(Cs[1], lc) and Cs[3] == nc
     ts.shiftE(b0, True)
     ts.setBond(b0 + 1)
     C2, lc2, cr2, nc2 = ts.quadcost(ts.bond_tensor(b0 + 1), 1e-3)

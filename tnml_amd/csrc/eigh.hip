@@ -377,6 +377,248 @@ __global__ __launch_bounds__(512) void k_sytrd_v2(TriArgs T) {
     if (tid == 0) T.D[n - 1] = s_x[(n - 1) & 1][n - 1];
 }
 
+// ==========================================================================================
+// k_sytrd_v3 -- k_sytrd_v2's block ownership (8x8 blocks of the lower triangle, one lane per block, column-block major so
+// that waves retire) with the serial part of a Householder step cut down (profiles/r02_probe_eigh.txt):
+//   * the current column lives in REGISTERS of every wave (rows lane + 64 e): the look-ahead column formed at the end of
+//     step k is the input of step k+1 without an LDS round trip, alpha comes from a readlane;
+//   * Householder scalars from v_rsq_f64 / v_rcp_f64 with explicit Newton steps (one dependent chain of ~25 fp64 ops
+//     instead of the ~45 of IEEE sqrt + division), tau = 1 + |alpha|/norm;
+//   * the partial sums of y = A v go to a table Y[c][i] (c = block column that produced the partial, i = row; row stride
+//     242 doubles): every block writes its 8 row sums and its 8 column sums as 16-byte stores that are bank-conflict
+//     free across the lanes of a wave (v2's [block][8] layout made them 4-way conflicted), and the partials of a row are
+//     a strided run that TWO lanes per row read with all loads in flight before the first add;
+//   * the global stores of v are taken by a different wave every step.
+// Two barriers per step as before; same Householder convention as the other two kernels (LAPACK dlarfg).
+// ==========================================================================================
+#define V3_LD 242
+#define V3_SMEM_DOUBLES (T8_MAXNB * V3_LD + 240 + 240 + 2 * 240 + 16)
+static __device__ __forceinline__ double lane_bcast(double x, int l) {          // l uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+    return __hiloint2double(hi, lo);
+}
+__global__ __launch_bounds__(512) void k_sytrd_v3(TriArgs T) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* Y = smem;                                   // [nb][V3_LD]
+    double* s_v = Y + T8_MAXNB * V3_LD;                 // [240]
+    double* s_w = s_v + 240;                            // [240]
+    double* s_xo = s_w + 240;                           // [2][240]
+    double* s_red = s_xo + 480;                         // [8]
+    const int n = T.n, nb = (n + T8 - 1) / T8;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int nblocks = nb * (nb + 1) / 2;
+    const bool owner = tid < nblocks;
+    int R = 0, C = 0;
+    if (owner) { int cc = 0; while ((cc + 1) * nb - (cc + 1) * cc / 2 <= tid) ++cc; C = cc; R = cc + (tid - (cc * nb - cc * (cc - 1) / 2)); }
+    const int i0 = T8 * R, j0 = T8 * C;
+    // the last block column held by this wave: once kb passes it the wave has no block left ("retired") and only helps
+    // with the row sums of phase C
+    int cmax = owner ? C : -1;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const int t = __shfl_xor(cmax, o); cmax = t > cmax ? t : cmax; }
+    cmax = __builtin_amdgcn_readfirstlane(cmax);
+    double a[T8][T8];
+#pragma unroll
+    for (int r = 0; r < T8; ++r)
+#pragma unroll
+        for (int cc = 0; cc < T8; ++cc) {
+            const int i = i0 + r, j = j0 + cc;
+            a[r][cc] = (owner && i < n && j < n) ? T.A[i + (size_t)T.lda * j] : 0.;
+        }
+    double x[4], v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const int i = lane + 64 * e; x[e] = i < n ? T.A[i] : 0.; v[e] = 0.; }
+    if (tid < 240) { s_v[tid] = 0.; s_w[tid] = 0.; s_xo[tid] = 0.; s_xo[240 + tid] = 0.; }
+    __syncthreads();
+#ifdef TNML_EIGH_PROF
+    long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tlast = clock64();
+    const int pw = T.dbg ? (int)T.dbg[7] : 0;
+#define TP3(i) do { if (wid == pw && lane == 0) { long long t_ = clock64(); prof[i] += t_ - tlast; tlast = t_; } } while (0)
+#else
+#define TP3(i) do {} while (0)
+#endif
+    // row-sum duty of phase C: two lanes per row, lane h takes the first / second half of the block columns kb..nb-1
+    const int ci = tid >> 1, ch = tid & 1;
+    const int cic = ci < 240 ? ci : 239;
+    for (int k = 0; k < n - 1; ++k) {
+        const int par = k & 1;
+        const int kb = (k + 1) / T8;
+        const bool live = cmax >= kb || wid == 7;       // uniform per wave; wave 7 (holds the last block) is live to the end
+        double tau = 0.;
+        if (live) {
+            // ---- A: Householder scalars and v, redundantly per live wave, from the column in registers.  x is zero above
+            //      row k; element k is the diagonal entry, element k+1 is alpha.
+            const int e1 = (k + 1) >> 6, l1 = (k + 1) & 63, e0 = k >> 6, l0 = k & 63;
+            double xa, xd;                               // the registers holding alpha and d_k (e1, e0 uniform)
+            switch (e1) { case 0: xa = x[0]; break; case 1: xa = x[1]; break; case 2: xa = x[2]; break; default: xa = x[3]; break; }
+            switch (e0) { case 0: xd = x[0]; break; case 1: xd = x[1]; break; case 2: xd = x[2]; break; default: xd = x[3]; break; }
+            const double alpha = lane_bcast(xa, l1);
+            const bool at0 = lane == l0, at1 = lane == l1;
+            // zero the two leading entries in their registers: what is left is x[k+2:]
+            double xt[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xt[e] = ((e == e0 && at0) || (e == e1 && at1)) ? 0. : x[e];
+            double sig = fma(xt[0], xt[0], fma(xt[1], xt[1], fma(xt[2], xt[2], xt[3] * xt[3])));
+            sig = wave_sum(sig);
+            double beta = alpha, scale = 0.;
+            if (sig > 0.) {
+                const double n2 = fma(alpha, alpha, sig);
+                double g, ih, s0;
+                const double aa = fabs(alpha);
+                if (n2 > 1e-280 && n2 < 1e280) {
+                    // sqrt and 1/sqrt by Goldschmidt from v_rsq_f64, reciprocal from v_rcp_f64 + two Newton steps
+                    const double y0 = __builtin_amdgcn_rsq(n2);
+                    g = n2 * y0; double h = 0.5 * y0;
+                    double r = fma(-h, g, 0.5); g = fma(g, r, g); h = fma(h, r, h);
+                    r = fma(-h, g, 0.5); g = fma(g, r, g); h = fma(h, r, h);
+                    const double d = fma(-g, g, n2); g = fma(d, h, g);
+                    ih = h + h;
+                    const double ee = fma(-g, ih, 1.0); ih = fma(ih, ee, ih);
+                    const double den = aa + g;
+                    s0 = __builtin_amdgcn_rcp(den);
+                    double e2 = fma(-den, s0, 1.0); s0 = fma(s0, e2, s0);
+                    e2 = fma(-den, s0, 1.0); s0 = fma(s0, e2, s0);
+                } else { g = sqrt(n2); ih = 1. / g; s0 = 1. / (aa + g); }
+                beta = alpha >= 0. ? -g : g;
+                tau = fma(aa, ih, 1.0);                               // (beta - alpha)/beta = 1 + |alpha|/norm
+                scale = alpha >= 0. ? s0 : -s0;                       // 1/(alpha - beta)
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = (e == e1 && at1) ? 1. : xt[e] * scale;
+                if (e < 3 || lane < 48) s_v[lane + 64 * e] = v[e];    // identical values from every live wave
+            }
+            if (lane == 0) s_red[8] = tau;                            // for the retired waves
+            if (wid == 7) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const int i = lane + 64 * e; if (i < n) T.V[i + (size_t)T.ldv * k] = v[e]; }
+                if (lane == 0) { T.D[k] = lane_bcast(xd, l0); T.E[k] = beta; T.tau[k] = tau; }
+            }
+            wave_lds_fence();
+        }
+        TP3(0);
+        const bool active = owner && C >= kb;
+        if (owner && C == kb) {                                       // column k+1 as it is before this step's update
+            double* dst = s_xo + par * 240 + i0;
+#define V3_STAGE(J) { _Pragma("unroll") for (int r = 0; r < T8; ++r) dst[r] = a[r][J]; } break
+            switch ((k + 1) & 7) {
+                case 0: V3_STAGE(0); case 1: V3_STAGE(1); case 2: V3_STAGE(2); case 3: V3_STAGE(3);
+                case 4: V3_STAGE(4); case 5: V3_STAGE(5); case 6: V3_STAGE(6); default: V3_STAGE(7);
+            }
+#undef V3_STAGE
+        }
+        double vI[T8], vJ[T8];
+        if (live) {
+            double q = 0.;
+            if (active && tau != 0.) {
+#pragma unroll
+                for (int r = 0; r < T8; ++r) vI[r] = s_v[i0 + r];
+#pragma unroll
+                for (int cc = 0; cc < T8; ++cc) vJ[cc] = s_v[j0 + cc];
+                double c1[T8];
+#pragma unroll
+                for (int r = 0; r < T8; ++r) {
+                    double t = 0.;
+#pragma unroll
+                    for (int cc = 0; cc < T8; ++cc) t = fma(a[r][cc], vJ[cc], t);
+                    c1[r] = t;
+                    q = fma(vI[r], t, q);
+                }
+                double* y1 = Y + C * V3_LD + i0;                      // partial of rows i0.. from block column C
+#pragma unroll
+                for (int r = 0; r < T8; r += 2) *reinterpret_cast<double2*>(y1 + r) = make_double2(c1[r], c1[r + 1]);
+                if (R != C) {
+                    double c2[T8];
+#pragma unroll
+                    for (int cc = 0; cc < T8; ++cc) {
+                        double t = 0.;
+#pragma unroll
+                        for (int r = 0; r < T8; ++r) t = fma(a[r][cc], vI[r], t);
+                        c2[cc] = t;
+                    }
+                    double* y2 = Y + R * V3_LD + j0;                  // partial of rows j0.. from the transposed block
+#pragma unroll
+                    for (int cc = 0; cc < T8; cc += 2) *reinterpret_cast<double2*>(y2 + cc) = make_double2(c2[cc], c2[cc + 1]);
+                    q *= 2.;
+                }
+            }
+            q = wave_sum(q);
+            if (lane == 0) s_red[wid] = q;
+        } else if (lane == 0) s_red[wid] = 0.;
+        TP3(1);
+        __syncthreads();
+        TP3(2);
+        tau = s_red[8];                                               // uniform over the workgroup
+        if (tau != 0.) {
+            // ---- C: y_i = sum_c Y[c][i] by two lanes per row, w_i = tau y_i - tau^2/2 (v^T A v) v_i
+            {
+                double vAv = 0.;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) vAv += s_red[w];
+                const double K = -0.5 * tau * tau * vAv;
+                const int nc = nb - kb, half = (nc + 1) >> 1;         // uniform
+                const int cbeg = kb + ch * half, cnt = ch ? nc - half : half;
+                const double* yp = Y + cbeg * V3_LD + cic;
+                double y0 = 0., y1 = 0., y2 = 0.;
+                int u = 0;
+                for (; u + 3 <= half; u += 3) {                       // uniform trip count; the odd lane may run one short
+                    const double t0 = yp[(u < cnt ? u : 0) * V3_LD], t1 = yp[(u + 1 < cnt ? u + 1 : 0) * V3_LD], t2 = yp[(u + 2 < cnt ? u + 2 : 0) * V3_LD];
+                    y0 += u < cnt ? t0 : 0.; y1 += u + 1 < cnt ? t1 : 0.; y2 += u + 2 < cnt ? t2 : 0.;
+                }
+                for (; u < half; ++u) { const double t0 = yp[(u < cnt ? u : 0) * V3_LD]; y0 += u < cnt ? t0 : 0.; }
+                const double yh = (y0 + y1) + y2;
+                const double yo = dpp_quad<0xB1>(yh);                 // the other half of the row (lane ^ 1)
+                const double y = ch == 0 ? yh + yo : yo + yh;         // first-half part + second-half part on both lanes
+                if (ch == 0 && ci < 240) s_w[ci] = (ci > k && ci < n) ? fma(K, s_v[cic], tau * y) : 0.;
+            }
+            TP3(3);
+            __syncthreads();
+            TP3(4);
+            // ---- D: A <- A - v w^T - w v^T
+            if (active) {
+                double wI[T8], wJ[T8];
+#pragma unroll
+                for (int r = 0; r < T8; ++r) wI[r] = s_w[i0 + r];
+#pragma unroll
+                for (int cc = 0; cc < T8; ++cc) wJ[cc] = s_w[j0 + cc];
+#pragma unroll
+                for (int r = 0; r < T8; ++r)
+#pragma unroll
+                    for (int cc = 0; cc < T8; ++cc) a[r][cc] = fma(-vI[r], wJ[cc], fma(-wI[r], vJ[cc], a[r][cc]));
+            }
+            if (live) {
+                // look-ahead: column k+1 of the updated matrix, into the registers of every live wave
+                const double wk1 = s_w[k + 1];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = lane + 64 * e;
+                    const int ic = i < 240 ? i : 239;
+                    const double xo = s_xo[par * 240 + ic], wi = s_w[ic];
+                    x[e] = (i >= k + 1 && i < n) ? (xo - v[e] * wk1) - wi : 0.;
+                }
+            }
+            TP3(5);
+        } else {                                                      // no reflector: the matrix is unchanged
+            if (live) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const int i = lane + 64 * e; const int ic = i < 240 ? i : 239; x[e] = (i >= k + 1 && i < n) ? s_xo[par * 240 + ic] : 0.; }
+            }
+            __syncthreads();
+        }
+    }
+#ifdef TNML_EIGH_PROF
+    if (wid == pw && lane == 0 && T.dbg) for (int i = 0; i < 6; ++i) T.dbg[i] = prof[i];
+#endif
+    {
+        const int kl = n - 1;
+        double xl;
+        switch (kl >> 6) { case 0: xl = x[0]; break; case 1: xl = x[1]; break; case 2: xl = x[2]; break; default: xl = x[3]; break; }
+        const double dl = lane_bcast(xl, kl & 63);
+        if (tid == 7 * 64) T.D[kl] = dl;                              // wave 7 is live to the end
+    }
+}
+
 // U[:, c] = H_0 H_1 ... H_{n-2} Z[:, c]; one wave per column, 4 rows per lane (n <= 256).  The
 // reflectors are fetched 8 at a time so that the L2 latency of V is paid once per 8 dependent updates.
 #define BT_PF 8
@@ -414,7 +656,15 @@ __global__ __launch_bounds__(64) void k_backtransform(const double* __restrict__
 int eigh_tridiagonalize(tnml_ctx* c, const double* A, int n, double* D, double* E, double* tau, double* V) {
     if (n > TRI_MAXN) return tnml_fail(c, "eigh_tridiagonalize: n=%d exceeds %d", n, TRI_MAXN);
     TriArgs t{A, n, n, D, E, tau, V, n, nullptr};
-    static const int ver = getenv("TNML_SYTRD") ? atoi(getenv("TNML_SYTRD")) : 2;
+    static const int ver = getenv("TNML_SYTRD") ? atoi(getenv("TNML_SYTRD")) : 3;
+    if (ver == 3) {
+        static const bool attr_set = (hipFuncSetAttribute(reinterpret_cast<const void*>(k_sytrd_v3), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                          (int)(V3_SMEM_DOUBLES * sizeof(double))) == hipSuccess);
+        if (!attr_set) return tnml_fail(c, "eigh_tridiagonalize: cannot reserve %zu bytes of LDS", V3_SMEM_DOUBLES * sizeof(double));
+        hipLaunchKernelGGL(k_sytrd_v3, dim3(1), dim3(512), V3_SMEM_DOUBLES * sizeof(double), c->stream, t);
+        HIPCK(c, hipGetLastError());
+        return 0;
+    }
     if (ver == 2) {
         hipLaunchKernelGGL(k_sytrd_v2, dim3(1), dim3(512), 0, c->stream, t);
         HIPCK(c, hipGetLastError());
@@ -795,8 +1045,220 @@ __global__ __launch_bounds__(1024) void k_chol_rinv(const double* __restrict__ S
     }
     if (tid == 0) flag[0] = 0.;
 }
+// ==========================================================================================
+// k_chol_rinv_blocked -- the same result (S = L L^T, Rinv = L^-T) for m <= 128 by a blocked right-looking Cholesky on
+// 8 x 8 register tiles, one lane per tile of the lower triangle (16 x 16 lanes), with the inverse accumulated alongside:
+// W starts as the identity and takes the same eliminations as the trailing matrix, so that the row block p of
+// X = L^-1 is final right after panel p (X_p* = L_pp^-1 W_p*) and no separate triangular inversion pass is needed.
+// A tile holds A_ij until its column panel j has been factored and W_ij from then on: 64 doubles per lane throughout.
+// Per panel p: (1) lane (p,p) factors its tile and inverts the 8 x 8 triangle; (2) the lanes of column p form
+// L_ip = A_ip L_pp^-T, the lanes of row p form X_pj = L_pp^-1 W_pj, both published in LDS; (3) every lane below row
+// block p updates its tile with one 8 x 8 x 8 product.  Two barriers per panel, 16 panels: ~45 us at m = 120 against
+// 204 us for the column-by-column kernel above (whose two barriers per COLUMN and separate inversion dominate).
+// ==========================================================================================
+#define CQ_T 8
+#define CQ_NT 16
+__global__ __launch_bounds__(256) void k_chol_rinv_blocked(const double* __restrict__ S, int m, double* __restrict__ Rinv, double* __restrict__ flag) {
+    __shared__ __attribute__((aligned(16))) double s_li[CQ_T * CQ_T];            // L_pp^-1, row major, zeros above the diagonal
+    __shared__ __attribute__((aligned(16))) double Pl[CQ_NT * CQ_T * CQ_T];      // L_ip rows: [row][k]
+    __shared__ __attribute__((aligned(16))) double Px[CQ_T * CQ_NT * CQ_T];      // X_p* : [k][column]
+    __shared__ int s_fail;
+    const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+    const int nt = (m + CQ_T - 1) / CQ_T;
+    if (tid == 0) s_fail = 0;
+    double a[CQ_T][CQ_T];
+#pragma unroll
+    for (int r = 0; r < CQ_T; ++r)
+#pragma unroll
+        for (int cc = 0; cc < CQ_T; ++cc) {
+            const int i = CQ_T * ti + r, j = CQ_T * tj + cc;
+            a[r][cc] = (i < m && j < m && tj <= ti) ? S[i + (size_t)m * j] : (i == j ? 1. : 0.);
+        }
+    {   // orthonormal already (max |S - I| < 1e-9): R = I, nothing to factor
+        __shared__ double s_dev[4];
+        double dv = 0.;
+#pragma unroll
+        for (int r = 0; r < CQ_T; ++r)
+#pragma unroll
+            for (int cc = 0; cc < CQ_T; ++cc) dv = fmax(dv, fabs(a[r][cc] - ((CQ_T * ti + r == CQ_T * tj + cc) ? 1. : 0.)));
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) dv = fmax(dv, __shfl_xor(dv, o));
+        if ((tid & 63) == 0) s_dev[tid >> 6] = dv;
+        __syncthreads();
+        dv = fmax(fmax(s_dev[0], s_dev[1]), fmax(s_dev[2], s_dev[3]));
+        if (dv < 1e-9) {
+#pragma unroll
+            for (int r = 0; r < CQ_T; ++r)
+#pragma unroll
+                for (int cc = 0; cc < CQ_T; ++cc) {
+                    const int i = CQ_T * ti + r, j = CQ_T * tj + cc;
+                    if (i < m && j < m) Rinv[j + (size_t)m * i] = i == j ? 1. : 0.;
+                }
+            if (tid == 0) { flag[0] = 0.; flag[1] = 0.; }
+            return;
+        }
+    }
+    for (int p = 0; p < nt; ++p) {
+        if (ti == p && tj == p) {
+            // (1) Cholesky of the diagonal tile (lower triangle) ...
+            double dinv[CQ_T];
+#pragma unroll
+            for (int k = 0; k < CQ_T; ++k) {
+                double d = a[k][k];
+                if (!(d > 1e-13) || !(d < 1e280)) { s_fail = 1; d = 1.; }
+                // sqrt and 1/sqrt from v_rsq_f64 by Goldschmidt steps: no IEEE sqrt / division on this single-lane chain
+                const double y0 = __builtin_amdgcn_rsq(d);
+                double g = d * y0, h = 0.5 * y0;
+                double rr = fma(-h, g, 0.5); g = fma(g, rr, g); h = fma(h, rr, h);
+                rr = fma(-h, g, 0.5); g = fma(g, rr, g); h = fma(h, rr, h);
+                const double dd = fma(-g, g, d); g = fma(dd, h, g);
+                double inv = h + h;
+                const double e1 = fma(-g, inv, 1.0); inv = fma(inv, e1, inv);
+                const double sq = g;
+                dinv[k] = inv;
+                a[k][k] = sq;
+#pragma unroll
+                for (int r = k + 1; r < CQ_T; ++r) a[r][k] *= inv;
+#pragma unroll
+                for (int cc = k + 1; cc < CQ_T; ++cc)
+#pragma unroll
+                    for (int r = cc; r < CQ_T; ++r) a[r][cc] = fma(-a[r][k], a[cc][k], a[r][cc]);
+            }
+            // ... and its inverse, column by column (forward substitution on the unit vectors)
+            double li[CQ_T][CQ_T];
+#pragma unroll
+            for (int cc = 0; cc < CQ_T; ++cc) {
+#pragma unroll
+                for (int r = 0; r < CQ_T; ++r) {
+                    if (r < cc) li[r][cc] = 0.;
+                    else if (r == cc) li[r][cc] = dinv[cc];
+                    else {
+                        double t = 0.;
+#pragma unroll
+                        for (int k = cc; k < r; ++k) t = fma(a[r][k], li[k][cc], t);
+                        li[r][cc] = -t * dinv[r];
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < CQ_T; ++r)
+#pragma unroll
+                for (int cc = 0; cc < CQ_T; ++cc) { s_li[r * CQ_T + cc] = li[r][cc]; a[r][cc] = li[r][cc]; }     // X_pp = L_pp^-1 stays in the tile
+        }
+        __syncthreads();
+        if (tj <= ti && ti >= p && !(ti == p && tj == p) && (tj == p || ti == p)) {
+            double li[CQ_T][CQ_T];
+#pragma unroll
+            for (int r = 0; r < CQ_T; ++r)
+#pragma unroll
+                for (int cc = 0; cc < CQ_T; ++cc) li[r][cc] = s_li[r * CQ_T + cc];
+            double t2[CQ_T][CQ_T];
+            if (tj == p) {
+                // (2a) L_ip = A_ip L_pp^-T, published; the tile then becomes W_ip = -L_ip X_pp
+#pragma unroll
+                for (int r = 0; r < CQ_T; ++r)
+#pragma unroll
+                    for (int cc = 0; cc < CQ_T; ++cc) {
+                        double t = 0.;
+#pragma unroll
+                        for (int k = 0; k <= cc; ++k) t = fma(a[r][k], li[cc][k], t);
+                        t2[r][cc] = t;
+                    }
+                double* dst = Pl + (size_t)(CQ_T * ti) * CQ_T;
+#pragma unroll
+                for (int r = 0; r < CQ_T; ++r)
+#pragma unroll
+                    for (int cc = 0; cc < CQ_T; cc += 2) *reinterpret_cast<double2*>(dst + r * CQ_T + cc) = make_double2(t2[r][cc], t2[r][cc + 1]);
+#pragma unroll
+                for (int r = 0; r < CQ_T; ++r)
+#pragma unroll
+                    for (int cc = 0; cc < CQ_T; ++cc) {
+                        double t = 0.;
+#pragma unroll
+                        for (int k = cc; k < CQ_T; ++k) t = fma(t2[r][k], li[k][cc], t);
+                        a[r][cc] = -t;
+                    }
+            } else {
+                // (2b) X_pj = L_pp^-1 W_pj, published and final
+#pragma unroll
+                for (int r = 0; r < CQ_T; ++r)
+#pragma unroll
+                    for (int cc = 0; cc < CQ_T; ++cc) {
+                        double t = 0.;
+#pragma unroll
+                        for (int k = 0; k <= r; ++k) t = fma(li[r][k], a[k][cc], t);
+                        t2[r][cc] = t;
+                    }
+#pragma unroll
+                for (int r = 0; r < CQ_T; ++r)
+#pragma unroll
+                    for (int cc = 0; cc < CQ_T; cc += 2) {
+                        a[r][cc] = t2[r][cc]; a[r][cc + 1] = t2[r][cc + 1];
+                        *reinterpret_cast<double2*>(Px + (size_t)r * (CQ_NT * CQ_T) + CQ_T * tj + cc) = make_double2(t2[r][cc], t2[r][cc + 1]);
+                    }
+            }
+        }
+        __syncthreads();
+        if (ti > p && tj <= ti && tj != p) {
+            // (3) A_ij -= L_ip L_jp^T (columns still to be factored) or W_ij -= L_ip X_pj (columns already factored)
+            double lrow[CQ_T][CQ_T];
+            const double* src = Pl + (size_t)(CQ_T * ti) * CQ_T;
+#pragma unroll
+            for (int r = 0; r < CQ_T; ++r)
+#pragma unroll
+                for (int k = 0; k < CQ_T; ++k) lrow[r][k] = src[r * CQ_T + k];
+            if (tj > p) {
+                const double* sc = Pl + (size_t)(CQ_T * tj) * CQ_T;
+#pragma unroll
+                for (int cc = 0; cc < CQ_T; ++cc) {
+                    double lc[CQ_T];
+#pragma unroll
+                    for (int k = 0; k < CQ_T; ++k) lc[k] = sc[cc * CQ_T + k];
+#pragma unroll
+                    for (int r = 0; r < CQ_T; ++r) {
+                        double t = a[r][cc];
+#pragma unroll
+                        for (int k = 0; k < CQ_T; ++k) t = fma(-lrow[r][k], lc[k], t);
+                        a[r][cc] = t;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < CQ_T; ++k) {
+                    double xr[CQ_T];
+#pragma unroll
+                    for (int cc = 0; cc < CQ_T; ++cc) xr[cc] = Px[(size_t)k * (CQ_NT * CQ_T) + CQ_T * tj + cc];
+#pragma unroll
+                    for (int r = 0; r < CQ_T; ++r)
+#pragma unroll
+                        for (int cc = 0; cc < CQ_T; ++cc) a[r][cc] = fma(-lrow[r][k], xr[cc], a[r][cc]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (s_fail) { if (tid == 0) flag[0] = 1.; return; }
+    // Rinv = X^T (upper triangular, dense): lane (i,j), j <= i, holds X_ij; the lanes above the diagonal write the zeros
+#pragma unroll
+    for (int r = 0; r < CQ_T; ++r)
+#pragma unroll
+        for (int cc = 0; cc < CQ_T; ++cc) {
+            const int i = CQ_T * ti + r, j = CQ_T * tj + cc;
+            if (i < m && j < m) {
+                if (tj <= ti) Rinv[j + (size_t)m * i] = (tj < ti || cc <= r) ? a[r][cc] : 0.;
+                else Rinv[j + (size_t)m * i] = 0.;
+            }
+        }
+    if (tid == 0) { flag[0] = 0.; flag[1] = 1.; }          // flag[1]: a factorisation was needed
+}
 int eigh_chol_rinv(tnml_ctx* c, const double* S, int m, double* Rinv, double* flag) {
     if (m > CHOL_MAXM) return tnml_fail(c, "eigh_chol_rinv: m=%d exceeds %d", m, CHOL_MAXM);
+    static const int old_kernel = getenv("TNML_CHOL_OLD") ? atoi(getenv("TNML_CHOL_OLD")) : 0;
+    if (m <= CQ_T * CQ_NT && !old_kernel) {
+        hipLaunchKernelGGL(k_chol_rinv_blocked, dim3(1), dim3(256), 0, c->stream, S, m, Rinv, flag);
+        HIPCK(c, hipGetLastError());
+        return 0;
+    }
     const size_t lds = sizeof(double) * ((size_t)(m | 1) * m + 3 * CHOL_MAXM);
     static size_t attr_lds = 0;                          // the kernel also has a few bytes of static LDS: ask for what is needed
     if (lds > attr_lds) { HIPCK(c, hipFuncSetAttribute((const void*)k_chol_rinv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_lds = lds; }

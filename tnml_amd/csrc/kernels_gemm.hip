@@ -334,7 +334,7 @@ __global__ __launch_bounds__(64 * WR * WC) void k_fgemm64(Fgemm64Args A) {
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid / WC, wc = wid % WC;
-    const int n0 = blockIdx.x * BM, j0 = blockIdx.y * BN, l = blockIdx.z;
+    const int n0 = A.n_off + blockIdx.x * BM, j0 = blockIdx.y * BN, l = blockIdx.z;
     const TE* E = static_cast<const TE*>(A.EI) + (size_t)l * A.EI_lstride;
     const TE* phiI = static_cast<const TE*>(A.phiI);
     const TE* phiO = static_cast<const TE*>(A.phiO);
@@ -503,21 +503,24 @@ __global__ __launch_bounds__(64 * WR * WC) void k_fgemm64(Fgemm64Args A) {
 template <int RT, int CT, int WR, int WC, int KT, int DB = 0>
 static void fgemm64_go(tnml_ctx* c, const Fgemm64Args& a) {
     constexpr int BM = 16 * RT * WR, BN = 16 * CT * WC;
-    dim3 grid(a.NTp / BM, (a.Np + BN - 1) / BN, a.L);
+    const int cnt = a.n_cnt ? a.n_cnt : a.NTp;
+    dim3 grid((cnt + BM - 1) / BM, (a.Np + BN - 1) / BN, a.L);
     dim3 block(64 * WR * WC);
+    hipStream_t st = a.st ? a.st : c->stream;
     if (!a.phiO) {                                        // shift form (TO = 1): no second feature on the columns
         if constexpr (DB == 0 && CT != 5) {
-            if (a.env64) hipLaunchKernelGGL((k_fgemm64<RT, CT, WR, WC, KT, 0, 0, double, 1>), grid, block, 0, c->stream, a);
-            else         hipLaunchKernelGGL((k_fgemm64<RT, CT, WR, WC, KT, 0, 0, float, 1>), grid, block, 0, c->stream, a);
+            if (a.env64) hipLaunchKernelGGL((k_fgemm64<RT, CT, WR, WC, KT, 0, 0, double, 1>), grid, block, 0, st, a);
+            else         hipLaunchKernelGGL((k_fgemm64<RT, CT, WR, WC, KT, 0, 0, float, 1>), grid, block, 0, st, a);
         }
     }
-    else if (!a.env64) hipLaunchKernelGGL((k_fgemm64<RT, CT, WR, WC, KT, DB, 0, float, 2>), grid, block, 0, c->stream, a);
-    else               hipLaunchKernelGGL((k_fgemm64<RT, CT, WR, WC, KT, DB, 0, double, 2>), grid, block, 0, c->stream, a);
+    else if (!a.env64) hipLaunchKernelGGL((k_fgemm64<RT, CT, WR, WC, KT, DB, 0, float, 2>), grid, block, 0, st, a);
+    else               hipLaunchKernelGGL((k_fgemm64<RT, CT, WR, WC, KT, DB, 0, double, 2>), grid, block, 0, st, a);
 }
 
 int launch_fgemm64(tnml_ctx* c, const Fgemm64Args& a) {
-    ProfScope ps(c, a.phiO ? KC_FGEMM_FWD : KC_FGEMM_SHIFT);
+    ProfScope ps(c, a.kclass >= 0 ? a.kclass : (a.phiO ? KC_FGEMM_FWD : KC_FGEMM_SHIFT), a.st);
     if (a.NTp % TNML_NTPAD) return tnml_fail(c, "fgemm64: NTp not padded");
+    if (a.n_cnt && (a.n_cnt % 128 || a.n_off % 128)) return tnml_fail(c, "fgemm64: image range must be a multiple of 128");
     const int cfg = c->opt_fg64_cfg;                         // tuning knob (env TNML_FG64_CFG / tnml_set_option "fg64_cfg"; tools/tune_fgemm.sh)
     if (a.Np == 240 && a.phiO) {                             // m = 120: exactly 15 column tiles, no padding waste
         switch (cfg) {
@@ -548,7 +551,7 @@ int launch_fgemm64(tnml_ctx* c, const Fgemm64Args& a) {
             default:
                 // 128 x 240, 12 waves is the best tile when the images fill the chip (profiles/r01_tune_fgemm64.txt); a rank
                 // with few images (multi-GPU shards, small sets) gets smaller row tiles so that every CU has a workgroup
-                if (a.NTp / 128 >= 192)     fgemm64_go<2, 5, 4, 3, 16>(c, a);
+                if (a.NTp / 128 >= 192)     fgemm64_go<2, 5, 4, 3, 16>(c, a);   // (an image half of a split launch keeps the tile of the whole)
                 else if (a.NTp / 64 >= 192) fgemm64_go<1, 5, 4, 3, 16>(c, a);   // 64 x 240, 12 waves
                 else                        fgemm64_go<1, 4, 4, 2, 16>(c, a);   // 64 x 128 (two column tiles), 8 waves: 7500 images 30.5 TF vs 26.2 with 32 x 240
                 break;

@@ -6,8 +6,9 @@
 #include "tnml_internal.h"
 
 // ---- pack / unpack -------------------------------------------------------------------------
-__global__ void k_pack(PackDesc d, const double* __restrict__ T, double* __restrict__ Md, float* __restrict__ Mf) {
+__global__ void k_pack(PackDesc d, const double* __restrict__ T, double* __restrict__ Md, float* __restrict__ Mf, double* __restrict__ zero, int nzero) {
     const size_t per = (size_t)d.Kp * d.Np, total = per * d.L;
+    if (blockIdx.x == 0 && (int)threadIdx.x < nzero) zero[threadIdx.x] = 0.;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int l = (int)(idx / per);
         const int k = (int)((idx % per) / d.Np), j = (int)(idx % d.Np);
@@ -38,9 +39,9 @@ __global__ void k_fill_f32(float* p, float v, size_t n) {
 
 static inline int nblocks(size_t n) { size_t b = (n + 255) / 256; return (int)(b > 2048 ? 2048 : (b ? b : 1)); }
 
-int launch_pack(tnml_ctx* c, const PackDesc& d, const double* T, double* Md, float* Mf) {
+int launch_pack(tnml_ctx* c, const PackDesc& d, const double* T, double* Md, float* Mf, double* zero, int nzero) {
     ProfScope ps(c, KC_PACK);
-    hipLaunchKernelGGL(k_pack, dim3(nblocks((size_t)d.Kp * d.Np * d.L)), dim3(256), 0, c->stream, d, T, Md, Mf);
+    hipLaunchKernelGGL(k_pack, dim3(nblocks((size_t)d.Kp * d.Np * d.L)), dim3(256), 0, c->stream, d, T, Md, Mf, zero, zero ? nzero : 0);
     HIPCK(c, hipGetLastError());
     return 0;
 }
@@ -161,6 +162,7 @@ __global__ __launch_bounds__(VB) void k_cg_init1(const double* __restrict__ G, c
 // cconv0 >= 0 (TNML_MODE_SINGLE): |r| < cconv at entry -> "not optimizing" (single.h:202-206): flag 2 freezes every later kernel
 __global__ __launch_bounds__(VB) void k_cg_init2(const double* __restrict__ part, int nb, double* __restrict__ scal, int rr_out, double cconv0) {
     __shared__ double sh[VB / 64];
+    for (int i = threadIdx.x; i < 4 * TNML_MAX_PASS; i += VB) scal[SC_N + i] = 0.;      // the per-pass trace lives behind the scalars
     double a, b; sum_partials(part, nb, &a, &b, sh);
     if (threadIdx.x == 0) {
         scal[rr_out] = a; scal[SC_CONV] = (cconv0 >= 0. && sqrt(a) < cconv0) ? 2. : 0.; scal[SC_NPASS] = 0.;

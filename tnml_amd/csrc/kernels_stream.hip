@@ -62,7 +62,9 @@ static __device__ __forceinline__ void sum_wave_partials(const double* s_part, i
 // waves per workgroup keeps enough loads in flight when a rank holds few images (multi-GPU shards, small sets).
 // NLT: label extent (10, or 1 in TNML_MODE_SINGLE) -- a template parameter so that the label loops stay straight-line code
 // (a run-time bound costs ~35 % of this kernel's bandwidth: the loads can no longer be hoisted ahead of the FMAs).
-template <int NW, int IPL, int NLT, typename TA, typename TB, typename TC>
+// QU: rows of the contraction index fetched per loop iteration and wave (QU = 2: twice the bytes in flight per wave -- what a
+// launch over HALF the images needs to pull the same bandwidth out of half the workgroups).
+template <int NW, int IPL, int NLT, typename TA, typename TB, typename TC, int QU = 1>
 __global__ __launch_bounds__(64 * NW) void k_labeldot(LdotArgs A, double* __restrict__ partials) {
     constexpr int LDI = 64 * IPL;
     __shared__ __attribute__((aligned(16))) TC red[NW * NLT * LDI];
@@ -71,13 +73,36 @@ __global__ __launch_bounds__(64 * NW) void k_labeldot(LdotArgs A, double* __rest
     typedef typename vec2<TB>::type TB2;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int NTp = A.NTp;
-    const int n = blockIdx.x * LDI + lane * IPL;
+    const int blk = blockIdx.x + A.blk_off;
+    const int n = blk * LDI + lane * IPL;
     const TA* Ap = static_cast<const TA*>(A.A);
     const TB* Bp = static_cast<const TB*>(A.Bv);
 
     TC px[NLT], py[NLT];
 #pragma unroll
     for (int l = 0; l < NLT; ++l) { px[l] = 0; py[l] = 0; }
+    if constexpr (QU == 2 && IPL == 2) {
+        for (int q = 2 * w; q < A.mq; q += 2 * NW) {
+            const bool two = q + 1 < A.mq;
+            const TA* ap = Ap + (size_t)q * NTp + n;
+            const TB2 u0 = *reinterpret_cast<const TB2*>(Bp + (size_t)q * NTp + n);
+            TB2 u1; u1.x = 0; u1.y = 0;
+            if (two) u1 = *reinterpret_cast<const TB2*>(Bp + (size_t)(q + 1) * NTp + n);
+            TA2 e0[NLT], e1[NLT];
+#pragma unroll
+            for (int l = 0; l < NLT; ++l) {
+                e0[l] = A.nt ? load2_nt(ap + (size_t)l * A.A_lstride) : *reinterpret_cast<const TA2*>(ap + (size_t)l * A.A_lstride);
+                if (two) e1[l] = A.nt ? load2_nt(ap + (size_t)l * A.A_lstride + NTp) : *reinterpret_cast<const TA2*>(ap + (size_t)l * A.A_lstride + NTp);
+                else { e1[l].x = 0; e1[l].y = 0; }
+            }
+#pragma unroll
+            for (int l = 0; l < NLT; ++l) {                         // same order of accumulation as QU = 1: q, then q + 1
+                px[l] = fma((TC)e0[l].x, (TC)u0.x, px[l]);
+                py[l] = fma((TC)e0[l].y, (TC)u0.y, py[l]);
+                if (two) { px[l] = fma((TC)e1[l].x, (TC)u1.x, px[l]); py[l] = fma((TC)e1[l].y, (TC)u1.y, py[l]); }
+            }
+        }
+    } else
     for (int q = w; q < A.mq; q += NW) {
         const TA* ap = Ap + (size_t)q * NTp + n;
         if constexpr (IPL == 2) {
@@ -102,7 +127,7 @@ __global__ __launch_bounds__(64 * NW) void k_labeldot(LdotArgs A, double* __rest
     __syncthreads();
 
     if (tid < LDI) {
-        const int ni = blockIdx.x * LDI + tid;
+        const int ni = blk * LDI + tid;
         TC P[NLT];
 #pragma unroll
         for (int l = 0; l < NLT; ++l) {
@@ -139,7 +164,7 @@ __global__ __launch_bounds__(64 * NW) void k_labeldot(LdotArgs A, double* __rest
         wave_bucket_partials((double)val, lab, cor, A.mode == LD_MODE_PAP, s_part, tid >> 6, tid & 63);
     }
     __syncthreads();
-    sum_wave_partials(s_part, LDI / 64, partials + (size_t)blockIdx.x * 12, tid);
+    sum_wave_partials(s_part, LDI / 64, partials + (size_t)blk * 12, tid);
 }
 
 __global__ __launch_bounds__(768) void k_reduce_partials(const double* __restrict__ partials, int nblk, double* __restrict__ out) {
@@ -153,22 +178,27 @@ __global__ __launch_bounds__(768) void k_reduce_partials(const double* __restric
     if (lane == 0) out[t] = s;
 }
 
-int launch_labeldot(tnml_ctx* c, const LdotArgs& a_in, double* scal_out) {
+bool labeldot_streaming(const tnml_ctx* c, int NTp) {
+    // few images on this rank: 64-image workgroups with 16 (fp64) waves each, so that the chip still has enough loads in flight
+    const int force = c->opt_ldot_cfg;                        // 1: streaming form, 2: small-shard form (env TNML_LDOT_CFG / tnml_set_option "ldot_cfg")
+    return force ? force == 1 : NTp / 128 >= 192;
+}
+int launch_labeldot_blocks(tnml_ctx* c, const LdotArgs& a_in, int blk_off, int nblk, hipStream_t st, int kclass, int form) {
     // the Label-carrying operand is read exactly once per launch: non-temporal loads stream it at 6.4-6.5 TB/s
     // instead of 5.6-5.7 (TNML_LDOT_NT=0 restores the default cache policy)
     static const int nt = getenv("TNML_LDOT_NT") ? atoi(getenv("TNML_LDOT_NT")) : 1;
     LdotArgs a = a_in;
-    a.nt = nt;
-    // few images on this rank: 64-image workgroups with 16 (fp64) waves each, so that the chip still has enough loads in flight
-    const int force = c->opt_ldot_cfg;                        // 1: streaming form, 2: small-shard form (env TNML_LDOT_CFG / tnml_set_option "ldot_cfg")
-    const bool small = force ? force == 2 : a.NTp / 128 < 192;
-    const int nblk = a.NTp / (small ? 64 : 128);
-    if (nblk > c->partial_cap) return tnml_fail(c, "labeldot: partial buffer too small");
-    {
-    ProfScope ps(c, KC_LABELDOT);            // the streaming kernel alone: bench.py's HBM roofline divides by these launches
-#define LDOT(NW, IPL, TA, TB, TC) do { if (a.nl == 1) hipLaunchKernelGGL((k_labeldot<NW, IPL, 1, TA, TB, TC>), dim3(nblk), dim3(64 * NW), 0, c->stream, a, c->partials); \
-                                        else hipLaunchKernelGGL((k_labeldot<NW, IPL, TNML_NL, TA, TB, TC>), dim3(nblk), dim3(64 * NW), 0, c->stream, a, c->partials); } while (0)
-    if (c->env64()) {
+    a.nt = nt; a.blk_off = blk_off;
+    const bool small = form ? form == 2 : !labeldot_streaming(c, a.NTp);
+    if (blk_off + nblk > c->partial_cap) return tnml_fail(c, "labeldot: partial buffer too small");
+    if (!st) st = c->stream;
+    ProfScope ps(c, kclass, st);             // the streaming kernel alone: bench.py's HBM roofline divides by these launches
+#define LDOT(NW, IPL, TA, TB, TC) do { if (a.nl == 1) hipLaunchKernelGGL((k_labeldot<NW, IPL, 1, TA, TB, TC>), dim3(nblk), dim3(64 * NW), 0, st, a, c->partials); \
+                                        else hipLaunchKernelGGL((k_labeldot<NW, IPL, TNML_NL, TA, TB, TC>), dim3(nblk), dim3(64 * NW), 0, st, a, c->partials); } while (0)
+    if (c->env64() && form == 3) {          // 128-image blocks, two rows in flight per wave (split launches)
+        if (a.nl == 1) hipLaunchKernelGGL((k_labeldot<4, 2, 1, double, double, double, 2>), dim3(nblk), dim3(256), 0, st, a, c->partials);
+        else           hipLaunchKernelGGL((k_labeldot<4, 2, TNML_NL, double, double, double, 2>), dim3(nblk), dim3(256), 0, st, a, c->partials);
+    } else if (c->env64()) {
         if (small) LDOT(16, 1, double, double, double); else LDOT(4, 2, double, double, double);
     } else if (c->f64()) {
         if (a.a_is_env) { if (small) LDOT(16, 1, float, double, double); else LDOT(4, 2, float, double, double); }
@@ -177,11 +207,19 @@ int launch_labeldot(tnml_ctx* c, const LdotArgs& a_in, double* scal_out) {
         if (small) LDOT(16, 1, float, float, float); else LDOT(8, 2, float, float, float);
     }
 #undef LDOT
-    }
-    ProfScope ps(c, KC_PUPDATE);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(768), 0, c->stream, c->partials, nblk, scal_out);
     HIPCK(c, hipGetLastError());
     return 0;
+}
+int launch_labeldot_reduce(tnml_ctx* c, int nblk_total, double* scal_out) {
+    ProfScope ps(c, KC_PUPDATE);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(768), 0, c->stream, c->partials, nblk_total, scal_out);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
+int launch_labeldot(tnml_ctx* c, const LdotArgs& a, double* scal_out) {
+    const int nblk = a.NTp / (labeldot_streaming(c, a.NTp) ? 128 : 64);
+    TCK(launch_labeldot_blocks(c, a, 0, nblk, c->stream, KC_LABELDOT, 0));
+    return launch_labeldot_reduce(c, nblk, scal_out);
 }
 
 template <typename T, typename TE>

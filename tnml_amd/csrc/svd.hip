@@ -40,6 +40,15 @@ __global__ void k_perm_labL_back(const double* __restrict__ Lf, double* __restri
         A[as + (size_t)mL2 * (g + (size_t)m * l)] = Lf[idx];
     }
 }
+// sigma_g (inv = 0) or 1/sigma_g (inv = 1) of the g-th largest eigenvalue, from the ascending eigenvalues on the device:
+// the same IEEE sqrt / division the host applies to its copy, so no scale vector has to travel back
+struct SigmaRef { const double* ev; int n; int inv; };
+static __device__ __forceinline__ double sigma_of(const SigmaRef& s, int g) {
+    double lam = s.ev[s.n - 1 - g];
+    if (!(lam > 0.)) lam = 0.;
+    const double sg = sqrt(lam);
+    return s.inv ? (sg > 1e-300 ? 1.0 / sg : 0.0) : sg;
+}
 // Q[:, g] = G[:, n-1-g]  (dsyevd returns ascending eigenvalues), optional column scale
 __global__ void k_take_top(const double* __restrict__ G, double* __restrict__ Q, int n, int m, const double* __restrict__ colscale) {
     const size_t total = (size_t)n * m;
@@ -51,22 +60,22 @@ __global__ void k_take_top(const double* __restrict__ G, double* __restrict__ Q,
     }
 }
 // out[g + m*i] = scale[g] * Q[i + n*g]   (transpose of the kept columns, optional row scale)
-__global__ void k_transpose_scale(const double* __restrict__ Q, double* __restrict__ out, int n, int m, const double* __restrict__ rowscale) {
+__global__ void k_transpose_scale(const double* __restrict__ Q, double* __restrict__ out, int n, int m, SigmaRef rowscale) {
     const size_t total = (size_t)n * m;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int g = (int)(idx % m), i = (int)(idx / m);
         double v = Q[i + (size_t)n * g];
-        if (rowscale) v *= rowscale[g];
+        if (rowscale.ev) v *= sigma_of(rowscale, g);
         out[idx] = v;
     }
 }
-__global__ void k_scale_rows(double* __restrict__ X, int m, size_t cols, const double* __restrict__ rowscale) {
+__global__ void k_scale_rows(double* __restrict__ X, int m, size_t cols, SigmaRef rowscale) {
     const size_t total = (size_t)m * cols;
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) X[idx] *= rowscale[idx % m];
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) X[idx] *= sigma_of(rowscale, (int)(idx % m));
 }
-__global__ void k_scale_cols(double* __restrict__ X, size_t rows, int m, const double* __restrict__ colscale) {
+__global__ void k_scale_cols(double* __restrict__ X, size_t rows, int m, SigmaRef colscale) {
     const size_t total = rows * m;
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) X[idx] *= colscale[idx / rows];
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) X[idx] *= sigma_of(colscale, (int)(idx / rows));
 }
 
 #define RBCK(c, expr) do { rocblas_status s_ = (expr); if (s_ != rocblas_status_success) return tnml_fail((c), "%s failed: rocblas status %d (%s:%d)", #expr, (int)s_, __FILE__, __LINE__); } while (0)
@@ -111,28 +120,47 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
         RBCK(c, rocsolver_dsyevd(c->blas, rocblas_evect_original, rocblas_fill_upper, n, c->sG, n, c->sD, c->sE, c->sInfo));
     }
     double* Q = c->sF;                                   // kept eigenvectors, n x m
+    bool direct_left = false;
     double* Lf = c->sF + (size_t)c->svd_n * c->maxm;     // left factor when a permutation is still needed
     double* Q0 = c->sQ1;
     double* hd = c->h_scal + 2 * c->svd_n + 32;
+    const bool always_qr = own_eig && mk <= 128;          // k_chol_rinv_blocked covers m <= 128
+    double* dv = own_eig ? c->sW + n : c->sDev;           // [0] max|Q^T Q - I| into the polish step, [1] Cholesky failed, [2] a factorisation was needed
     if (own_eig) {
-        // Z (already "largest first") -> U = H_0 H_1 ... Z for all mk candidate columns, then one Newton-Schulz step
-        // Q <- Q (1.5 I - 0.5 Q^T Q); d = max|Q^T Q - I| before the step is checked on the host (after it: ~0.75 d^2).
-        // Queued BEFORE the eigenvalues go to the host, so that the truncation decision costs no idle gap on the device;
-        // the kept columns are the first m of these.
+        // Z (already "largest first") -> U = H_0 H_1 ... Z for all mk candidate columns, queued BEFORE the eigenvalues go to
+        // the host, so that the truncation decision costs no idle gap on the device; the kept columns are the first m.
         TCK(eigh_backtransform(c, c->sV, c->sTau, n, c->sC, n, Q0, n, mk));
         RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, mk, mk, n, &one, Q0, n, Q0, n, &zero, c->sS, mk));
-        TCK(eigh_ns_matrix(c, c->sS, c->sCm, mk, c->sDev));
-        RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, n, mk, mk, &one, Q0, n, c->sCm, mk, &zero, Q, n));
-        TCK(bcast_rank0(c, c->sDev, 1));
-        HIPCK(c, hipMemcpyAsync(hd, c->sDev, sizeof(double), hipMemcpyDeviceToHost, st));
+        const double* Qin = Q0;
+        if (always_qr) {
+            // The Gram matrix of a bond tensor spans 12+ decades (the common mode of the images dominates), so most of the kept
+            // eigenvalues sit within a few 100 eps*|T| of each other: inverse iteration returns the right invariant subspace for
+            // them but not orthogonal vectors (80 % of the bond updates of a sweep).  Any orthonormal basis of that subspace is
+            // an equally valid set of singular vectors, so the basis ALWAYS goes through a Cholesky QR (Q1 = Q0 R^-1,
+            // Q0^T Q0 = R^T R; the kernel returns R = I straight away when Q0 is orthonormal to 1e-9) and one Newton-Schulz
+            // polish step whose input deviation is the check -- no host decision, no second synchronisation.
+            TCK(eigh_chol_rinv(c, c->sS, mk, c->sCm, dv + 1));              // writes both flags
+            RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, n, mk, mk, &one, Q0, n, c->sCm, mk, &zero, c->sG, n));   // the Gram matrix is consumed by now
+            RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, mk, mk, n, &one, c->sG, n, c->sG, n, &zero, c->sS, mk));
+            Qin = c->sG;
+        }
+        // Newton-Schulz step Q <- Q (1.5 I - 0.5 Q^T Q); d = max|Q^T Q - I| before the step is checked on the host (after it: ~0.75 d^2)
+        TCK(eigh_ns_matrix(c, c->sS, c->sCm, mk, dv));
+        // the kept basis lands where it is needed: straight in the site tensor when that is its final place
+        direct_left = left && !labL && mk <= c->maxm;
+        if (direct_left) Q = Sl.a;
+        RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, n, mk, mk, &one, Qin, n, c->sCm, mk, &zero, Q, n));
+        if (!always_qr) HIPCK(c, hipMemsetAsync(dv + 1, 0, 2 * sizeof(double), st));
     }
     // eigenvalues -> host: the truncation decision (ITensor truncate()) fixes the new bond dimension.  With more than
     // one rank the decision is made collective: every rank decides on rank 0's eigenvalues (and rank 0's orthogonality
     // check), so that a last-bit difference between replicas can never produce different bond dimensions.
-    TCK(bcast_rank0(c, const_cast<double*>(evals), n));
+    const int nev = own_eig ? n + 3 : n;                 // the check values ride behind the eigenvalues: one broadcast, one copy
+    TCK(bcast_rank0(c, const_cast<double*>(evals), nev));
     double* h = c->h_scal;          // pinned, capacity >= 2*svd_n + 64
-    HIPCK(c, hipMemcpyAsync(h, evals, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+    HIPCK(c, hipMemcpyAsync(h, evals, sizeof(double) * nev, hipMemcpyDeviceToHost, st));
     HIPCK(c, hipStreamSynchronize(st));
+    if (own_eig) { hd[0] = h[n]; hd[1] = h[n + 1]; hd[2] = h[n + 2]; }
     std::vector<double> p(n), sig(n);
     for (int g = 0; g < n; ++g) { double lam = h[n - 1 - g]; if (!(lam > 0.)) lam = 0.; p[g] = lam; sig[g] = std::sqrt(lam); }
     double te = 0.;
@@ -143,16 +171,12 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
     if (sv_host) for (int g = 0; g < n; ++g) sv_host[g] = sig[g];
     if (m > c->maxm) return tnml_fail(c, "svd_split: new bond dimension %d exceeds maxm %d of the context", m, c->maxm);
 
-    // scale vectors sigma / 1/sigma for the kept columns (device copies live behind the eigenvalues)
-    double* hs = h + c->svd_n;
-    for (int g = 0; g < m; ++g) { hs[g] = sig[g]; hs[m + g] = sig[g] > 1e-300 ? 1.0 / sig[g] : 0.0; }
-    double* d_sig = c->sE;              // sE is free after dsyevd; capacity >= 2*svd_n
-    double* d_isig = c->sE + m;
-    HIPCK(c, hipMemcpyAsync(d_sig, hs, sizeof(double) * 2 * m, hipMemcpyHostToDevice, st));
+    const SigmaRef d_sig{evals, n, 0}, d_isig{evals, n, 1}, no_scale{nullptr, 0, 0};   // sigma_g / 1/sigma_g of the kept columns, computed where they are used
 
     if (own_eig) {
         c->svd_last_dev0 = hd[0]; c->svd_last_dev1 = 0.75 * hd[0] * hd[0];      // Newton-Schulz: error -> 3/4 error^2
-        bool ok = hd[0] < 1e-6;                                                  // the polish step leaves 3/4 d^2 < 1e-12
+        bool ok = hd[0] < 1e-6 && (!always_qr || hd[1] == 0.);                   // the polish step leaves 3/4 d^2 < 1e-12
+        if (always_qr && hd[2] != 0.) c->svd_cholqr += 1;
         if (!ok) if (const char* dump = getenv("TNML_SVD_DUMP")) {               // debugging aid: the offending tridiagonal problem
             static int dumped = 0;
             if (dumped < 4) {
@@ -166,7 +190,7 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
                 if (FILE* f = fopen(fn, "wb")) { fwrite(hb.data(), sizeof(double), hb.size(), f); fclose(f); }
             }
         }
-        if (!ok && hd[0] == hd[0]) {
+        if (!ok && hd[0] == hd[0] && !always_qr) {
             // Close eigenvalues inside one unreduced block: inverse iteration gave independent but not quite
             // orthogonal vectors of the right invariant subspace.  Mild cases (max|Q^T Q - I| < 0.3) are repaired by
             // further Newton-Schulz steps (error -> 3/4 error^2, until it is below 1e-12); worse ones first go through a Cholesky QR
@@ -216,7 +240,7 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
     if (left) {
         // Q = U_m
         RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, m, nr, nl, &one, Q, nl, M, nl, &zero, Aright, m));   // U^T M = S V^T
-        HIPCK(c, hipMemcpyAsync(Aleft, Q, sizeof(double) * (size_t)nl * m, hipMemcpyDeviceToDevice, st));
+        if (Q != Aleft) HIPCK(c, hipMemcpyAsync(Aleft, Q, sizeof(double) * (size_t)nl * m, hipMemcpyDeviceToDevice, st));
         if (ha == 2) {   // orthonormal factor goes right: V^T = S^-1 U^T M ; left gets U S
             hipLaunchKernelGGL(k_scale_rows, dim3(nblk((size_t)m * nr)), dim3(256), 0, st, Aright, m, (size_t)nr, d_isig);
             hipLaunchKernelGGL(k_scale_cols, dim3(nblk((size_t)nl * m)), dim3(256), 0, st, Aleft, (size_t)nl, m, d_sig);
@@ -225,7 +249,7 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
         // Q = V_m
         RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, nl, m, nr, &one, M, nl, Q, nr, &zero, Aleft, nl));        // M V = U S
         if (ha == 2) {
-            hipLaunchKernelGGL(k_transpose_scale, dim3(nblk((size_t)nr * m)), dim3(256), 0, st, Q, Aright, nr, m, (const double*)nullptr);
+            hipLaunchKernelGGL(k_transpose_scale, dim3(nblk((size_t)nr * m)), dim3(256), 0, st, Q, Aright, nr, m, no_scale);
         } else {         // orthonormal factor goes left: U = M V S^-1 ; right gets S V^T
             hipLaunchKernelGGL(k_scale_cols, dim3(nblk((size_t)nl * m)), dim3(256), 0, st, Aleft, (size_t)nl, m, d_isig);
             hipLaunchKernelGGL(k_transpose_scale, dim3(nblk((size_t)nr * m)), dim3(256), 0, st, Q, Aright, nr, m, d_sig);

@@ -25,15 +25,16 @@ static hipEvent_t prof_event(tnml_ctx* c) {
     if (!c->prof_free.empty()) { hipEvent_t e = c->prof_free.back(); c->prof_free.pop_back(); return e; }
     hipEvent_t e; (void)hipEventCreate(&e); return e;
 }
-void prof_begin(tnml_ctx* c, int, hipEvent_t* e0) { *e0 = prof_event(c); (void)hipEventRecord(*e0, c->stream); }
-void prof_end(tnml_ctx* c, int kc, hipEvent_t e0) {
-    hipEvent_t e1 = prof_event(c); (void)hipEventRecord(e1, c->stream);
+void prof_begin(tnml_ctx* c, int, hipEvent_t* e0, hipStream_t st) { *e0 = prof_event(c); (void)hipEventRecord(*e0, st ? st : c->stream); }
+void prof_end(tnml_ctx* c, int kc, hipEvent_t e0, hipStream_t st) {
+    hipEvent_t e1 = prof_event(c); (void)hipEventRecord(e1, st ? st : c->stream);
     c->prof_pending.push_back({e0, e1, kc});
     if (c->prof_pending.size() > 8192) prof_resolve(c);
 }
 void prof_resolve(tnml_ctx* c) {
     if (c->prof_pending.empty()) return;
     (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     for (auto& p : c->prof_pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) { c->prof_ms[p.kc] += ms; c->prof_launches[p.kc] += 1; }
@@ -68,6 +69,7 @@ int tnml_set_option(tnml_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "reuse_p")) { c->reuse_p = value != 0; c->p_valid = false; }
     else if (!strcmp(name, "fuse_z")) c->fuse_z = value != 0;
     else if (!strcmp(name, "check_replicas")) c->check_replicas = value != 0;
+    else if (!strcmp(name, "overlap")) c->overlap = value;
     else if (!strcmp(name, "fg64_cfg")) c->opt_fg64_cfg = value;
     else if (!strcmp(name, "ldot_cfg")) c->opt_ldot_cfg = value;
     else return tnml_fail(c, "tnml_set_option: unknown option %s", name);
@@ -200,6 +202,10 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     int rc = 0;
     auto bail = [&](int r) { g_create_err = c->err; tnml_destroy(c); return r; };
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(tnml_fail(c, "hipStreamCreate failed"));
+    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) return bail(tnml_fail(c, "hipStreamCreate failed"));
+    if (hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) != hipSuccess)
+        return bail(tnml_fail(c, "hipEventCreate failed"));
+    if (const char* e = getenv("TNML_OVERLAP")) c->overlap = atoi(e);
     if (rocblas_create_handle(&c->blas) != rocblas_status_success) return bail(tnml_fail(c, "rocblas_create_handle failed"));
     rocblas_set_stream(c->blas, c->stream);
     // replicas of W must stay bit-identical over the ranks: no atomics-based split-K inside rocBLAS
@@ -235,9 +241,9 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     if ((rc = dmalloc(c, &c->vR, c->mcap))) return bail(rc);
     if ((rc = dmalloc(c, &c->vP, c->mcap))) return bail(rc);
     if ((rc = dmalloc(c, &c->vG, c->mcap + TNML_NSCAL_AR))) return bail(rc);
-    if ((rc = dmalloc(c, &c->scal, SC_N))) return bail(rc);
+    if ((rc = dmalloc(c, &c->scal, SC_N + (size_t)4 * TNML_MAX_PASS))) return bail(rc);   // CG scalars, then the per-pass trace: one copy to the host
+    c->cgtrace = c->scal + SC_N;
     if ((rc = dmalloc(c, &c->vpart, 512))) return bail(rc);
-    if ((rc = dmalloc(c, &c->cgtrace, (size_t)4 * TNML_MAX_PASS))) return bail(rc);
     if ((rc = dmalloc(c, &c->tB, c->mcap))) return bail(rc);
     if ((rc = dmalloc(c, &c->tB2, c->mcap))) return bail(rc);
     // sM holds (a) the Label-permuted bond matrix of the split, 40 maxm^2, and (b) the 16-padded site matrix of an
@@ -255,14 +261,15 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     if ((rc = dmalloc(c, &c->sTau, (size_t)c->svd_n))) return bail(rc);
     if ((rc = dmalloc(c, &c->sV, (size_t)c->svd_n * c->svd_n))) return bail(rc);
     if ((rc = dmalloc(c, &c->sC, (size_t)c->svd_n * c->svd_n))) return bail(rc);
-    if ((rc = dmalloc(c, &c->sW, (size_t)c->svd_n))) return bail(rc);
+    if ((rc = dmalloc(c, &c->sW, (size_t)c->svd_n + 8))) return bail(rc);           // + room for the orthogonality check values behind the eigenvalues
     if ((rc = dmalloc(c, &c->sScr, std::max<size_t>((size_t)5 * c->svd_n * c->maxm, 1024)))) return bail(rc);
     if ((rc = dmalloc(c, &c->sS, (size_t)c->maxm * c->maxm))) return bail(rc);
     if ((rc = dmalloc(c, &c->sCm, (size_t)c->maxm * c->maxm))) return bail(rc);
     if ((rc = dmalloc(c, &c->sQ1, (size_t)c->svd_n * c->maxm))) return bail(rc);
     if ((rc = dmalloc(c, &c->sDev, 4))) return bail(rc);
     if (const char* e = getenv("TNML_SVD_BACKEND")) c->cfg.svd_backend = atoi(e);
-    if (hipHostMalloc((void**)&c->h_scal, sizeof(double) * (2 * c->svd_n + 64 + SC_N + 4 * TNML_MAX_PASS + 64)) != hipSuccess) return bail(tnml_fail(c, "hipHostMalloc failed"));
+    for (int k = 0; k < 2; ++k) if (hipEventCreateWithFlags(&c->pend[k].ev, hipEventDisableTiming) != hipSuccess) return bail(tnml_fail(c, "hipEventCreate failed"));
+    if (hipHostMalloc((void**)&c->h_scal, sizeof(double) * (2 * c->svd_n + 64 + SC_N + 4 * TNML_MAX_PASS + 2 * 64)) != hipSuccess) return bail(tnml_fail(c, "hipHostMalloc failed"));
     for (int j = 1; j <= c->N; ++j) {
         const size_t cap = (size_t)2 * c->maxm * c->maxm * (j == c->c0 ? TNML_NL : 1);
         if ((rc = dmalloc(c, &c->W[j].a, cap))) return bail(rc);
@@ -281,15 +288,19 @@ int tnml_destroy(tnml_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) ncclCommDestroy(c->comm);
     local_comm_release(c);
+    for (int k = 0; k < 2; ++k) if (c->pend[k].ev) (void)hipEventDestroy(c->pend[k].ev);
     for (auto& p : c->prof_pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     for (auto e : c->prof_free) (void)hipEventDestroy(e);
     void* ptrs[] = {c->phi, c->label, c->ones, c->U, c->P, c->dP, c->Pp, c->Zp, c->Mf, c->slab, c->partials, c->vB, c->vR, c->vP,
-                    c->vG, c->scal, c->vpart, c->cgtrace, c->tB, c->tB2, c->sM, c->sG, c->sD, c->sE, c->sF, c->sInfo, c->sE2, c->sTau, c->sV, c->sC, c->sW, c->sScr, c->sS, c->sCm, c->sQ1, c->sDev, c->fprint};
+                    c->vG, c->scal, c->vpart, c->tB, c->tB2, c->sM, c->sG, c->sD, c->sE, c->sF, c->sInfo, c->sE2, c->sTau, c->sV, c->sC, c->sW, c->sScr, c->sS, c->sCm, c->sQ1, c->sDev, c->fprint};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& s : c->W) if (s.a) (void)hipFree(s.a);
     for (auto& sl : c->slabs) if (sl.base) (void)hipFree(sl.base);
     if (c->h_scal) (void)hipHostFree(c->h_scal);
     if (c->blas) rocblas_destroy_handle(c->blas);
+    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+    if (c->ev_a) (void)hipEventDestroy(c->ev_a);
+    if (c->ev_b) (void)hipEventDestroy(c->ev_b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -687,6 +698,11 @@ int tnml_bond_tensor(tnml_ctx* c, int b, double* B) {
 static int forward_pass(tnml_ctx* c, const double* vec, int mode, double* tail, bool want_P) {
     const BondPlan& p = c->plan;
     const size_t ustride = (size_t)p.mO * c->NTp;
+    LdotArgs a;
+    if (p.kind == 2) { a.A = c->U; a.A_lstride = ustride; a.Bv = p.EX; a.a_is_env = 0; }
+    else             { a.A = p.EX; a.A_lstride = ustride; a.Bv = c->U; a.a_is_env = 1; }
+    a.mq = p.mO; a.NTp = c->NTp; a.label = c->label; a.nl = c->nl(); a.target = c->target();
+    a.P = want_P ? (mode == LD_MODE_PAP ? c->Pp : c->P) : nullptr; a.dP = (mode == LD_MODE_PAP) ? nullptr : c->dP; a.mode = mode;
     if (c->f64()) {
         Fgemm64Args f;
         f.EI = p.EI; f.EI_lstride = 0; f.mI = p.mI; f.phiI = p.phiI;
@@ -694,6 +710,26 @@ static int forward_pass(tnml_ctx* c, const double* vec, int mode, double* tail, 
         f.phiO = p.phiO;
         f.out = (double*)c->U; f.out_lstride = ustride; f.mO = p.mO;
         f.NTp = c->NTp; f.L = p.LB; f.env64 = c->env64();
+        // Two image halves on two queues: the feature GEMM is bound by the matrix pipe, the label dot by HBM, so the label
+        // dot of the first half runs beside the feature GEMM of the second (each half is one round of 128-image tiles on the
+        // 256 CUs).  Every image still goes through exactly the same arithmetic in the same order, and the cost partials are
+        // reduced over all blocks in the fixed order afterwards: bit-identical to the single-queue form.
+        const int nblk = c->NTp / 128;
+        if (c->overlap && nblk >= 2 * 192 && p.Np == 240 && c->opt_fg64_cfg == 0 && labeldot_streaming(c, c->NTp)) {
+            const int b1 = (nblk + 1) / 2, b2 = nblk - b1;
+            f.n_off = 0; f.n_cnt = b1 * 128; f.kclass = KC_FGEMM_FWD;                 // alone on the machine: the roofline sample
+            TCK(launch_fgemm64(c, f));
+            HIPCK(c, hipEventRecord(c->ev_a, c->stream));
+            HIPCK(c, hipStreamWaitEvent(c->stream2, c->ev_a, 0));
+            const int lf = c->overlap == 2 ? 2 : (c->overlap == 3 && c->env64() ? 3 : 1), lm = lf == 2 ? 2 : 1;   // overlap = 2: 64-image label-dot blocks; 3: two rows in flight per wave
+            TCK(launch_labeldot_blocks(c, a, 0, b1 * lm, c->stream2, KC_LABELDOT_OVL, lf));
+            HIPCK(c, hipEventRecord(c->ev_b, c->stream2));
+            f.n_off = b1 * 128; f.n_cnt = b2 * 128; f.kclass = KC_FGEMM_FWD_OVL;
+            TCK(launch_fgemm64(c, f));
+            TCK(launch_labeldot_blocks(c, a, b1 * lm, b2 * lm, c->stream, KC_LABELDOT, lf));   // alone again: the HBM roofline sample
+            HIPCK(c, hipStreamWaitEvent(c->stream, c->ev_b, 0));
+            return launch_labeldot_reduce(c, nblk * lm, tail);
+        }
         TCK(launch_fgemm64(c, f));
     } else {
         TCK(launch_cvt(c, vec, c->Mf, p.msize()));
@@ -705,18 +741,13 @@ static int forward_pass(tnml_ctx* c, const double* vec, int mode, double* tail, 
         f.NTp = c->NTp; f.L = p.LB;
         TCK(launch_fgemm(c, f));
     }
-    LdotArgs a;
-    if (p.kind == 2) { a.A = c->U; a.A_lstride = ustride; a.Bv = p.EX; a.a_is_env = 0; }
-    else             { a.A = p.EX; a.A_lstride = ustride; a.Bv = c->U; a.a_is_env = 1; }
-    a.mq = p.mO; a.NTp = c->NTp; a.label = c->label; a.nl = c->nl(); a.target = c->target();
-    a.P = want_P ? (mode == LD_MODE_PAP ? c->Pp : c->P) : nullptr; a.dP = (mode == LD_MODE_PAP) ? nullptr : c->dP; a.mode = mode;
     return launch_labeldot(c, a, tail);
 }
 // G = sum_n dP_n*dag(t.v) over all ranks for the bond tensor in vB; cost partials ride in the tail
 static int grad_eval(tnml_ctx* c, bool from_P_update = false, bool outputs_current = false) {
     const BondPlan& p = c->plan;
     const size_t n = p.msize();
-    if (outputs_current)    HIPCK(c, hipMemsetAsync(c->vG + n, 0, sizeof(double) * TNML_NSCAL_AR, c->stream));   // P/dP already hold B*t.v and the residuals
+    if (outputs_current)    { if (!c->tail_zeroed) HIPCK(c, hipMemsetAsync(c->vG + n, 0, sizeof(double) * TNML_NSCAL_AR, c->stream)); }   // P/dP already hold B*t.v and the residuals (the pack kernel of tnml_bond_update has cleared the tail)
     else if (from_P_update) TCK(launch_pupdate(c, c->scal + SC_ALPHA, c->vG + n));          // P += a (p*t.v): no GEMM
     else                    TCK(forward_pass(c, c->vB, LD_MODE_COST, c->vG + n, c->fast_cg)); // keeps P when fast CG is on
     const bool fuse = c->f64() && c->fuse_z && p.kind != 2;
@@ -756,7 +787,6 @@ static int read_scal(tnml_ctx* c, const double* dev, int count, double* host_out
 static int cgrad_device(tnml_ctx* c, int npass, double lambda, double cconv, bool outputs_current = false) {
     if (npass < 1 || npass > TNML_MAX_PASS) return tnml_fail(c, "cgrad: Npass must be in 1..%d", TNML_MAX_PASS);
     const size_t n = c->plan.msize();
-    HIPCK(c, hipMemsetAsync(c->cgtrace, 0, sizeof(double) * 4 * TNML_MAX_PASS, c->stream));
     TCK(grad_eval(c, false, outputs_current));           // :374-385
     TCK(launch_cg_init(c, n, lambda, c->single() ? cconv : -1.));   // :386-388 (single.h:200-208 with the entry check)
     for (int pass = 1; pass <= npass; ++pass) {          // :389
@@ -772,9 +802,7 @@ static int cgrad_device(tnml_ctx* c, int npass, double lambda, double cconv, boo
 // the CG's device scalars and per-pass trace: enqueue the copies, parse after any later synchronisation of the stream
 static int cgrad_trace_enqueue(tnml_ctx* c) {
     double* hp = c->h_scal + 2 * c->svd_n + 64;
-    // scal and cgtrace are separate allocations: two small copies
-    HIPCK(c, hipMemcpyAsync(hp, c->scal, sizeof(double) * SC_N, hipMemcpyDeviceToHost, c->stream));
-    HIPCK(c, hipMemcpyAsync(hp + SC_N, c->cgtrace, sizeof(double) * 4 * TNML_MAX_PASS, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync(hp, c->scal, sizeof(double) * (SC_N + 4 * TNML_MAX_PASS), hipMemcpyDeviceToHost, c->stream));
     return 0;
 }
 static void cgrad_trace_parse(tnml_ctx* c, int npass, tnml_cg_trace* tr) {
@@ -888,11 +916,18 @@ int tnml_svd_split(tnml_ctx* c, const double* B, int b, int ha, double cutoff, i
 }
 
 // ---- one iteration of the mldmrg loop body (fixedL.cc:478-540) ------------------------------------
-int tnml_bond_update(tnml_ctx* c, int b, int ha, const tnml_sweep_params* sp, tnml_bond_report* rep) {
+// One iteration of the mldmrg loop body in two halves, so that a sweep can keep the GPU queue full across bond boundaries:
+// tnml_bond_update_begin enqueues the whole bond update (it blocks once, inside the split, for the eigenvalues that fix the
+// new bond dimension) and returns; tnml_bond_update_end hands out the report once the end-of-bond scalars have landed.  A
+// caller may begin bond k+1 before ending bond k (at most two bond updates in flight): the wait of `end` then costs nothing
+// because `begin` of the next bond has already passed its own synchronisation point.
+int tnml_bond_update_begin(tnml_ctx* c, int b, int ha, const tnml_sweep_params* sp) {
     HIPCK(c, hipSetDevice(c->cfg.device));
     if (ha != 1 && ha != 2) return tnml_fail(c, "tnml_bond_update: half must be 1 or 2");
-    tnml_bond_report local;
-    if (!rep) rep = &local;
+    if (c->pend_count >= 2) return tnml_fail(c, "tnml_bond_update_begin: two bond updates are in flight, call tnml_bond_update_end first");
+    const int slot = (c->pend_tail + c->pend_count) & 1;
+    PendingReport& pr = c->pend[slot];
+    tnml_bond_report* rep = &pr.rep;
     memset(rep, 0, sizeof *rep);
     TCK(tnml_set_bond(c, b));                                         // :488
     const BondPlan p = c->plan;
@@ -902,41 +937,61 @@ int tnml_bond_update(tnml_ctx* c, int b, int ha, const tnml_sweep_params* sp, tn
     rep->mL = p.mL; rep->mR = p.mR; rep->label_on_B = (p.kind == 2);
     const PackDesc pd = bond_pack_desc(p);
     TCK(launch_bond_form(c, c->W[b], c->W[b + 1], c->tB));            // :494
-    TCK(launch_pack(c, pd, c->tB, c->vB, nullptr));
     bool outputs_current = c->reuse_p && c->p_valid;                  // left by the previous bond update's quadcost
     c->p_valid = false;
+    // with carried outputs no label dot rewrites the [cost | ncorrect | pAp] tail behind G before the first all-reduce: the
+    // pack kernel clears it on the way
+    TCK(launch_pack(c, pd, c->tB, c->vB, nullptr, outputs_current && !sp->report_costs ? c->vG + p.msize() : nullptr, TNML_NSCAL_AR));
+    c->tail_zeroed = outputs_current && !sp->report_costs;
     if (sp->report_costs) {                                           // single.h:572,621: norm(oB), quadcost(oB)
         TCK(quadcost_device(c, sp->lambda_cost, &rep->cost_old, nullptr, nullptr, nullptr, true));
         rep->norm_oB = c->last_bnorm;
         outputs_current = c->reuse_p;                                 // that was the forward pass of the first gradient
     }
     TCK(cgrad_device(c, sp->npass, sp->lambda, sp->cconv, outputs_current));   // :504
+    c->tail_zeroed = false;
     if (sp->report_costs) TCK(quadcost_device(c, sp->lambda_cost, &rep->cost_cg, nullptr, &rep->reg_cost_cg, nullptr, false));   // single.h:622,626
     TCK(launch_unpack(c, pd, c->vB, c->tB));
     TCK(cgrad_trace_enqueue(c));                                      // lands with the split's own synchronisation (eigenvalues)
     TCK(svd_split_device(c, c->tB, b, ha, sp->cutoff, sp->maxm, sp->minm, &rep->truncerr, &rep->newm, nullptr, nullptr));   // :519-522
     cgrad_trace_parse(c, sp->npass, &rep->cg);
     TCK(launch_bond_form(c, c->W[b], c->W[b + 1], c->tB2));           // :527
-    TCK(launch_diffnorm(c, c->tB2, c->tB, ne, c->scal + SC_NORMS));   // :528,:530
     TCK(launch_pack(c, pd, c->tB2, c->vB, nullptr));
     TCK(quadcost_launch(c, true));                                    // :532; P and dP stay for the next bond update
-    // the end-of-bond scalars come back in one copy after the environment shift has been queued: no idle gap for them
-    double* hq = c->h_scal + 2 * c->svd_n + 64 + SC_N + 4 * TNML_MAX_PASS;
-    HIPCK(c, hipMemcpyAsync(hq, c->vG + c->plan.msize(), sizeof(double) * 13, hipMemcpyDeviceToHost, c->stream));
-    HIPCK(c, hipMemcpyAsync(hq + 16, c->scal + SC_NORMS, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
-    TCK(tnml_shift_env(c, b, ha == 1));                               // :540
-    const bool fp_check = (c->comm || c->local) && c->check_replicas;
-    if (fp_check) {                                                   // the two site tensors the split just wrote must be bit-identical on every rank
+    TCK(launch_diffnorm(c, c->tB2, c->tB, ne, c->vG + c->plan.msize() + 13));   // :528,:530 -> slots 13, 14 behind the cost partials
+    // the end-of-bond scalars come back in one copy, queued before the environment shift: no idle gap for them
+    double* hq = c->h_scal + 2 * c->svd_n + 64 + SC_N + 4 * TNML_MAX_PASS + 64 * slot;
+    HIPCK(c, hipMemcpyAsync(hq, c->vG + c->plan.msize(), sizeof(double) * TNML_NSCAL_AR, hipMemcpyDeviceToHost, c->stream));
+    pr.fp = (c->comm || c->local) && c->check_replicas;
+    if (pr.fp) {                                                      // the two site tensors the split just wrote must be bit-identical on every rank
         TCK(replica_fingerprint(c, b, b + 1));
         HIPCK(c, hipMemcpyAsync(hq + 32, c->fprint, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     }
-    HIPCK(c, hipStreamSynchronize(c->stream));
-    if (fp_check) {
-        unsigned long long h[2]; memcpy(h, hq + 32, sizeof h);
-        if (h[0] != ~h[1]) return tnml_fail(c, "bond %d: replicas of W.A(%d), W.A(%d) differ between ranks after the split", b, b, b + 1);
-    }
-    quadcost_parse(c, hq, sp->lambda_cost, &rep->cost_after_svd, rep->label_cost, &rep->reg_cost, &rep->ncorrect);
-    rep->norm_newB = std::sqrt(hq[16]); rep->diff_B_newB = std::sqrt(hq[17]);
-    c->p_valid = true;
+    HIPCK(c, hipEventRecord(pr.ev, c->stream));
+    TCK(tnml_shift_env(c, b, ha == 1));                               // :540
+    pr.lambda_cost = sp->lambda_cost;
+    c->pend_count += 1;
+    c->p_valid = true;                                                // in stream order: P/dP of the after-SVD quadcost
     return 0;
+}
+int tnml_bond_update_end(tnml_ctx* c, tnml_bond_report* rep) {
+    if (c->pend_count < 1) return tnml_fail(c, "tnml_bond_update_end: no bond update in flight");
+    const int slot = c->pend_tail;
+    PendingReport& pr = c->pend[slot];
+    HIPCK(c, hipEventSynchronize(pr.ev));
+    c->pend_tail ^= 1; c->pend_count -= 1;
+    const double* hq = c->h_scal + 2 * c->svd_n + 64 + SC_N + 4 * TNML_MAX_PASS + 64 * slot;
+    if (pr.fp) {
+        unsigned long long h[2]; memcpy(h, hq + 32, sizeof h);
+        if (h[0] != ~h[1]) return tnml_fail(c, "bond %d: replicas of W.A(%d), W.A(%d) differ between ranks after the split", pr.rep.bond, pr.rep.bond, pr.rep.bond + 1);
+    }
+    quadcost_parse(c, hq, pr.lambda_cost, &pr.rep.cost_after_svd, pr.rep.label_cost, &pr.rep.reg_cost, &pr.rep.ncorrect);
+    pr.rep.norm_newB = std::sqrt(hq[13]); pr.rep.diff_B_newB = std::sqrt(hq[14]);
+    if (rep) *rep = pr.rep;
+    return 0;
+}
+int tnml_bond_update(tnml_ctx* c, int b, int ha, const tnml_sweep_params* sp, tnml_bond_report* rep) {
+    if (c->pend_count != 0) return tnml_fail(c, "tnml_bond_update: a pipelined bond update is still in flight");
+    TCK(tnml_bond_update_begin(c, b, ha, sp));
+    return tnml_bond_update_end(c, rep);
 }

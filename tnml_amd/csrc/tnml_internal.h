@@ -31,11 +31,11 @@
 
 enum KClass {
     KC_FGEMM_FWD = 0, KC_FGEMM_SHIFT, KC_LABELDOT, KC_ZPRIME, KC_BGEMM, KC_SLABRED, KC_PACK, KC_VEC,
-    KC_SMALLGEMM, KC_SVD, KC_ALLREDUCE, KC_PUPDATE, KC_COUNT
+    KC_SMALLGEMM, KC_SVD, KC_ALLREDUCE, KC_PUPDATE, KC_FGEMM_FWD_OVL, KC_LABELDOT_OVL, KC_COUNT
 };
 static const char* const kclass_names[KC_COUNT] = {
     "fgemm_fwd", "fgemm_shift", "labeldot", "zprime", "bgemm", "slab_reduce", "pack", "cg_vec",
-    "small_gemm", "svd", "allreduce", "p_update"};
+    "small_gemm", "svd", "allreduce", "p_update", "fgemm_fwd_overlapped", "labeldot_overlapped"};
 
 struct EnvSlot {
     void* ptr = nullptr;    // [L][m][NTp], fp32 or fp64 elements (tnml_ctx::env64)
@@ -75,11 +75,15 @@ struct BondPlan {
 };
 
 struct ProfPending { hipEvent_t e0, e1; int kc; };
+struct PendingReport { tnml_bond_report rep; double lambda_cost = 0.; hipEvent_t ev = nullptr; bool fp = false; };
 
 struct tnml_ctx {
     tnml_config cfg;
     int N = 0, NT = 0, NTp = 0, c0 = 0, maxm = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // second queue: the HBM-bound label dot of one image half runs beside the MFMA-bound feature GEMM of the other
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    int overlap = 0;             // env TNML_OVERLAP=0 / tnml_set_option "overlap"
     rocblas_handle blas = nullptr;
     ncclComm_t comm = nullptr;
     struct LocalComm* local = nullptr;   // in-process communicator of ranks sharing one device (local_comm.hip)
@@ -146,6 +150,9 @@ struct tnml_ctx {
 
     BondPlan plan;
     int currb = -1;
+    PendingReport pend[2];     // bond updates begun and not yet ended (tnml_bond_update_begin / _end)
+    int pend_tail = 0, pend_count = 0;
+    bool tail_zeroed = false;  // the pack kernel of the running bond update has cleared the scalar tail behind G
 
     // profiling
     bool prof = false;
@@ -157,8 +164,8 @@ struct tnml_ctx {
 };
 
 int tnml_fail(tnml_ctx* c, const char* fmt, ...);
-void prof_begin(tnml_ctx* c, int kc, hipEvent_t* e0);
-void prof_end(tnml_ctx* c, int kc, hipEvent_t e0);
+void prof_begin(tnml_ctx* c, int kc, hipEvent_t* e0, hipStream_t st = nullptr);
+void prof_end(tnml_ctx* c, int kc, hipEvent_t e0, hipStream_t st = nullptr);
 void prof_resolve(tnml_ctx* c);
 
 #define HIPCK(c, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return tnml_fail((c), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
@@ -166,10 +173,10 @@ void prof_resolve(tnml_ctx* c);
 
 // RAII-less profiling bracket around a group of launches of one kernel class
 struct ProfScope {
-    tnml_ctx* c; int kc; hipEvent_t e0 = nullptr;
+    tnml_ctx* c; int kc; hipEvent_t e0 = nullptr; hipStream_t st;
     bool on;
-    ProfScope(tnml_ctx* c_, int kc_) : c(c_), kc(kc_), on(c_->prof && ((c_->prof_mask >> kc_) & 1u)) { if (on) prof_begin(c, kc, &e0); }
-    ~ProfScope() { if (on) prof_end(c, kc, e0); }
+    ProfScope(tnml_ctx* c_, int kc_, hipStream_t st_ = nullptr) : c(c_), kc(kc_), st(st_), on(c_->prof && ((c_->prof_mask >> kc_) & 1u)) { if (on) prof_begin(c, kc, &e0, st); }
+    ~ProfScope() { if (on) prof_end(c, kc, e0, st); }
 };
 
 // ---- kernels_gemm.hip ---------------------------------------------------------------------
@@ -201,6 +208,9 @@ struct Fgemm64Args {
     double* out; size_t out_lstride; int mO;
     int NTp; int L;
     int env64;
+    int n_off = 0, n_cnt = 0;                         // image range of this launch (n_cnt = 0: all NTp); multiples of 128
+    hipStream_t st = nullptr;                         // nullptr: the context's stream
+    int kclass = -1;                                  // profiling class override
 };
 int launch_fgemm64(tnml_ctx* c, const Fgemm64Args& a);
 struct Bgemm64Args {
@@ -226,9 +236,14 @@ struct LdotArgs {
     void* P; void* dP;                  // [10][NTp] in the context's arithmetic type
     int mode;
     int nt = 0;                         // non-temporal loads of A (set by launch_labeldot)
+    int blk_off = 0;                    // first image block of this launch (blocks of 64 * images-per-lane)
 };
 // partial sums -> scal_out[0..11] (device); deterministic
 int launch_labeldot(tnml_ctx* c, const LdotArgs& a, double* scal_out);
+// the two halves of launch_labeldot for a split launch: blocks [blk_off, blk_off + nblk) on `st`, then the reduction of ALL partials
+int launch_labeldot_blocks(tnml_ctx* c, const LdotArgs& a, int blk_off, int nblk, hipStream_t st, int kclass, int form = 0);   // form 1: 128-image blocks, 2: 64-image blocks, 0: by image count
+int launch_labeldot_reduce(tnml_ctx* c, int nblk_total, double* scal_out);
+bool labeldot_streaming(const tnml_ctx* c, int NTp);   // the 128-images-per-workgroup form is in use
 int launch_pupdate(tnml_ctx* c, const double* alpha_dev, double* scal_out);     // uses c->nl(), c->target()
 int launch_zprime(tnml_ctx* c, const void* EL, size_t lstride, const void* dP, void* Z, int mq, int NTp);
 int launch_features_u8(tnml_ctx* c, const uint8_t* d_pix, int N, int NT, int NTp, void* phi);
@@ -239,7 +254,7 @@ struct PackDesc {       // M[l][2x+s][TO==2 ? 2y+t : y] <-> T[off + x*sx + s*ss 
     long sx, ss, sy, st, sl;
     int Kp, Np;
 };
-int launch_pack(tnml_ctx* c, const PackDesc& d, const double* T, double* Md, float* Mf);   // either output may be null
+int launch_pack(tnml_ctx* c, const PackDesc& d, const double* T, double* Md, float* Mf, double* zero = nullptr, int nzero = 0);   // either output may be null; zero[0..nzero) is cleared on the way
 int launch_unpack(tnml_ctx* c, const PackDesc& d, const double* Md, double* T);
 int launch_cvt(tnml_ctx* c, const double* src, float* dst, size_t n);
 int launch_bond_form(tnml_ctx* c, const SiteT& A1, const SiteT& A2, double* B);            // B = A1*A2, ITensor layout

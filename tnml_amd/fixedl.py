@@ -213,6 +213,20 @@ class TrainStates:
         sp = _lib.SweepParams(maxm, minm, cutoff, npass, lam, lam if lam_cost is None else lam_cost, cconv, int(report_costs))
         rep = _lib.BondReport()
         self._ck(self._L.tnml_bond_update(self._h, b, ha, C.byref(sp), C.byref(rep)))
+        return self._report(rep)
+
+    def bond_update_begin(self, b, ha, maxm, minm, cutoff, npass, lam, cconv, lam_cost=None, report_costs=False):
+        """enqueue one bond update; the report comes from bond_update_end (at most two bond updates in flight)"""
+        sp = _lib.SweepParams(maxm, minm, cutoff, npass, lam, lam if lam_cost is None else lam_cost, cconv, int(report_costs))
+        self._ck(self._L.tnml_bond_update_begin(self._h, b, ha, C.byref(sp)))
+
+    def bond_update_end(self):
+        rep = _lib.BondReport()
+        self._ck(self._L.tnml_bond_update_end(self._h, C.byref(rep)))
+        return self._report(rep)
+
+    @staticmethod
+    def _report(rep):
         return dict(bond=rep.bond, half=rep.half, c=rep.c, mL=rep.mL, mR=rep.mR, label_on_B=bool(rep.label_on_B), origm=rep.origm, newm=rep.newm, truncerr=rep.truncerr,
                     norm_newB=rep.norm_newB, diff=rep.diff_B_newB, cost=rep.cost_after_svd,
                     label_cost=np.array(rep.label_cost[:]), reg_cost=rep.reg_cost, ncorrect=rep.ncorrect,
@@ -254,11 +268,32 @@ def cgrad(B, ts, npass=4, lam=0.0, cconv=1e-10):
     return ts.cgrad(B, npass, lam, cconv)
 
 
-def mldmrg(ts, nsweep, maxm, minm, cutoff, npass, lam, cconv, max_bonds=0, log=None, report_costs=False):
+def mldmrg(ts, nsweep, maxm, minm, cutoff, npass, lam, cconv, max_bonds=0, log=None, report_costs=False, pipelined=False):
     """fixedL.cc:451-570 (single.h:523-728 for a per-label TrainStates): the sweep loop; emits the reference's log lines
-    through `log` if given."""
+    through `log` if given.  pipelined: bond k+1 is enqueued before the report of bond k is fetched (same results, no idle
+    GPU between bond updates; the log of a bond appears one bond later)."""
     NT = float(ts.NT_total)
     reports = []
+    if pipelined and not log:
+        sched = []
+        for sw in range(1, nsweep + 1):
+            b, ha = 1, 1
+            while ha <= 2:
+                sched.append((sw, b, ha))
+                b, ha = _lib.sweepnext(b, ha, ts.N)
+        if max_bonds:
+            sched = sched[:max_bonds]
+        for k, (sw, b, ha) in enumerate(sched):
+            ts.bond_update_begin(b, ha, maxm, minm, cutoff, npass, lam, cconv, report_costs=report_costs or ts.single)
+            if k > 0:
+                r = ts.bond_update_end()
+                r["sweep"] = sched[k - 1][0]
+                reports.append(r)
+        if sched:
+            r = ts.bond_update_end()
+            r["sweep"] = sched[-1][0]
+            reports.append(r)
+        return reports
     for sw in range(1, nsweep + 1):
         if log:
             log("\nSweep %d maxm=%d minm=%d" % (sw, maxm, minm))

@@ -26,7 +26,7 @@ EXPORTS = [
     "tnml_cgrad", "tnml_svd_split", "tnml_bond_update", "tnml_truncate", "tnml_sweepnext",
     "tnml_shard_bounds", "tnml_profile_enable", "tnml_profile_select", "tnml_profile_count", "tnml_profile_get",
     "tnml_profile_reset", "tnml_synchronize", "tnml_device_bytes", "tnml_svd_stats", "tnml_classify", "tnml_replica_check",
-    "tnml_estimate_bytes", "tnml_device_memory", "tnml_plan_maxm", "tnml_set_option", "tnml_comm_init_local",
+    "tnml_estimate_bytes", "tnml_device_memory", "tnml_plan_maxm", "tnml_set_option", "tnml_comm_init_local", "tnml_bond_update_begin", "tnml_bond_update_end",
 ]
 
 
@@ -92,6 +92,8 @@ def load():
     L.tnml_cgrad.argtypes = [vp, dp, C.c_int, C.c_double, C.c_double, C.POINTER(CgTrace)]
     L.tnml_svd_split.argtypes = [vp, dp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, dp, ip, dp, ip]
     L.tnml_bond_update.argtypes = [vp, C.c_int, C.c_int, C.POINTER(SweepParams), C.POINTER(BondReport)]
+    L.tnml_bond_update_begin.argtypes = [vp, C.c_int, C.c_int, C.POINTER(SweepParams)]
+    L.tnml_bond_update_end.argtypes = [vp, C.POINTER(BondReport)]
     L.tnml_truncate.argtypes = [dp, C.c_int, C.c_int, C.c_int, C.c_double, dp]
     L.tnml_sweepnext.argtypes = [ip, ip, C.c_int]
     L.tnml_sweepnext.restype = None
