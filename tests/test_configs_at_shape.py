@@ -105,6 +105,54 @@ def test_c1_every_bond_update_in_lockstep_with_the_oracle():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f64_e32", "f32"])
+def test_c1_lockstep_in_the_reduced_precision_modes(dtype):
+    """The tolerance study of BASELINE config 5 on the HIP kernels themselves (not an emulation), with the accumulation of a
+    free-running sweep taken out: every bond update of C1 starts from the oracle's state and is compared on its own.
+      f64_e32  fp64 MFMA over fp32-STORED environments / features       -> gated: per-bond cost within 1e-5
+      f32      v_mfma_f32 with fp32 storage (the 2x-rate matrix pipe)    -> interior bonds gated at 1e-3, the Label-on-B
+               bonds (where the CG resolves the small Hessian directions only in fp64) reported
+    The per-bond-kind maxima are printed; they are the measured basis of the per-bond precision policy in DESIGN.md."""
+    from oracle import pyoracle
+    from tnml_amd import lib
+    from tnml_amd.fixedl import TrainStates
+    g, phi, W, p = _c1()
+    N = int(g["N"])
+    ts = TrainStates(g["labels"], N, p["maxm"], phi=phi, dtype=dtype)
+    ts.set_mps(W)
+    ts.init()
+    o = pyoracle.Oracle(phi, g["labels"], W, nthread=min(8, os.cpu_count() or 1))
+    o.init()
+    worst = {"interior": 0.0, "label_on_B": 0.0}
+    newm_diff = ncorr_diff = nb = 0
+    for sw in range(1):                                                        # one sweep is 390 bond updates of every kind
+        b, ha = 1, 1
+        while ha <= 2:
+            r = ts.bond_update(b, ha, p["maxm"], p["minm"], p["cutoff"], p["npass"], p["lam"], p["cconv"])
+            o.set_bond(b)
+            B, tr = o.cgrad(o.bond_tensor(b), p["npass"], p["lam"], p["cconv"])
+            newm, te, _ = o.svd_split(B, b, ha, p["cutoff"], p["maxm"], p["minm"])
+            C, lc, cr, nc = o.quadcost(o.bond_tensor(b), p["lam"])
+            o.shiftE(b, ha == 1)
+            kind = "label_on_B" if r["label_on_B"] else "interior"
+            worst[kind] = max(worst[kind], abs(r["cost"] / C - 1))
+            newm_diff += int(r["newm"] != newm)
+            ncorr_diff += abs(int(r["ncorrect"]) - int(nc))
+            ts.set_site(b, o.get_site(b))
+            ts.set_site(b + 1, o.get_site(b + 1))
+            ts.shiftE(b, ha == 1)
+            nb += 1
+            b, ha = lib.sweepnext(b, ha, N)
+    print("C1 lockstep in %s: %d bond updates; worst rel. cost error interior %.2e, Label on B %.2e; bond-dimension mismatches %d, "
+          "#correct differences (sum) %d" % (dtype, nb, worst["interior"], worst["label_on_B"], newm_diff, ncorr_diff))
+    if dtype == "f64_e32":
+        assert max(worst.values()) < 1e-5 and newm_diff == 0 and ncorr_diff <= 2
+    else:
+        assert worst["interior"] < 1e-3
+    ts.close()
+
+
+@pytest.mark.gpu
 def test_c1_free_running_against_the_golden_vectors():
     """the same two sweeps free-running against tests/golden/fixedl_c1.npz: tight where the trajectory is still
     determined (first 50 bonds), within the oracle's own summation-order spread afterwards"""

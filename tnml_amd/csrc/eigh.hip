@@ -627,7 +627,7 @@ __global__ __launch_bounds__(64) void k_backtransform(const double* __restrict__
     const int c = blockIdx.x, lane = threadIdx.x;
     double z[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { const int i = lane + 64 * e; z[e] = i < n ? Z[i + (size_t)ldz * c] : 0.; }
+    for (int e = 0; e < 4; ++e) { const int i = lane + 64 * e; z[e] = i < n ? (Z ? Z[i + (size_t)ldz * c] : (i == c ? 1. : 0.)) : 0.; }   // Z == nullptr: the identity (forms H_0 ... H_{n-2} itself)
     for (int k0 = n - 2; k0 >= 0; k0 -= BT_PF) {
         double v[BT_PF][4], t[BT_PF];
 #pragma unroll
@@ -678,8 +678,8 @@ int eigh_tridiagonalize(tnml_ctx* c, const double* A, int n, double* D, double* 
     HIPCK(c, hipGetLastError());
     return 0;
 }
-int eigh_backtransform(tnml_ctx* c, const double* V, const double* tau, int n, const double* Z, int ldz, double* U, int ldu, int ncols) {
-    hipLaunchKernelGGL(k_backtransform, dim3(ncols), dim3(64), 0, c->stream, V, n, tau, n, Z, ldz, U, ldu);
+int eigh_backtransform(tnml_ctx* c, const double* V, const double* tau, int n, const double* Z, int ldz, double* U, int ldu, int ncols, hipStream_t st) {
+    hipLaunchKernelGGL(k_backtransform, dim3(ncols), dim3(64), 0, st ? st : c->stream, V, n, tau, n, Z, ldz, U, ldu);
     HIPCK(c, hipGetLastError());
     return 0;
 }

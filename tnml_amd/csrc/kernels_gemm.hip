@@ -1,25 +1,20 @@
-// kernels_gemm.hip -- the two MFMA kernels of the bond contraction (gfx950, exact-fp32 MFMA).
+// kernels_gemm.hip -- the MFMA kernels of the bond contraction (gfx950).
 //
-// k_fgemm  ("feature GEMM", forward):   replaces B*t.v (fixedL.cc:318,377,399,416) and the
-//          per-image (t.A(c)*W.A(c))*E products of init/shiftE (fixedL.cc:144-148,223-227).
+// k_fgemm64 ("feature GEMM", forward): replaces B*t.v (fixedL.cc:318,377,399,416) and, in its shift form, the per-image
+//          (t.A(c)*W.A(c))*E products of init/shiftE (fixedL.cc:144-148,223-227).
 //   out[l][q][n] = sum_t phiO[t][n] * sum_{a,s} phiI[s][n] * EI[l?][a][n] * M[l?][2a+s][2q+t]
-//   i.e. T = X*M with X_n = EI_n (x) phiI_n built on the fly in LDS (the dense t.v of the
-//   reference is never formed), followed by the contraction with the output-site feature.
-//   GEMM shape: (NTp images) x (Np = 2*mO) x (Kp = 2*mI);  MFMA = v_mfma_f32_16x16x4_f32,
-//   rows = images, so each lane's 4 accumulator values are 4 consecutive images -> float4 stores
-//   into the image-fastest output.
+//   i.e. T = X*M with X_n = EI_n (x) phiI_n built on the fly in LDS (the dense t.v of the reference is never formed),
+//   followed by the contraction with the output-site feature.  GEMM shape: (NTp images) x (Np = 2*mO) x (Kp = 2*mI).
+// k_bgemm64 ("gradient GEMM", backward): replaces tensors[nt] += dP*dag(t.v) (fixedL.cc:379,418)
+//   G[l][2a+s][2q+t] = sum_n (phiI[s][n] EI[a][n]) * (w[l][n] phiO[t][n] Zq[q][n]),  Zq = sum_l EL[l] dP[l] built in the
+//   operand staging; GEMM shape Kp x Np with the reduction over images (split-K over image ranges into fp64 slabs that
+//   k_slab_reduce64 sums in a fixed order -> deterministic).
 //
-// k_bgemm  ("gradient GEMM", backward): replaces tensors[nt] += dP*dag(t.v) (fixedL.cc:379,418)
-//   G[l][2a+s][2q+t] = sum_n (phiI[s][n] EI[a][n]) * (w[l][n] phiO[t][n] Zq[q][n])
-//   GEMM shape: Kp x Np with the reduction over images (split-K over image ranges; fp32 partial
-//   slabs reduced in a fixed order in fp64 -> deterministic).
-//
-// Each kernel exists in two arithmetic flavours over the same fp32 environment storage:
-//   *64 : v_mfma_f64_16x16x4_f64 (fp64 operands + accumulation, 77.4 TF measured ceiling) -- default;
-//   f32 : v_mfma_f32_16x16x4_f32 (exact fp32, 154.5 TF) -- env shifts, and the TNML_F32 study mode.
-// The f64 forms put the IMAGES on the MFMA column index: the f64 C fragment is
-// col = lane&15, row = (lane>>4) + 4*reg, so 16 consecutive lanes hold 16 consecutive images of one
-// output row -> 128-byte coalesced stores into the image-fastest output.
+// Arithmetic: v_mfma_f64_16x16x4_f64 (fp64 operands and accumulation, 78.6 TF peak) is the default and the parity path
+// (TNML_F64: fp64 storage; TNML_F64_E32: environments and features stored in fp32, widened while staging).  The f64 kernels
+// put the IMAGES on the MFMA column index: the f64 C fragment is col = lane&15, row = (lane>>4) + 4*reg, so 16 consecutive
+// lanes hold 16 consecutive images of one output row -> 128-byte coalesced stores into the image-fastest output.
+// k_fgemm / k_bgemm are the v_mfma_f32_16x16x4_f32 counterparts over fp32 storage (TNML_F32, the tolerance-study mode).
 #include <cstdlib>
 
 #include "tnml_internal.h"
@@ -571,7 +566,18 @@ int launch_fgemm64(tnml_ctx* c, const Fgemm64Args& a) {
             default: fgemm64_go<2, 4, 4, 2, 8>(c, a); break;    // 128 x 128, 8 waves, KT 8: best of tools/tune_shift.sh (profiles/r01_tune_shift.txt)
         }
     }
-    else if (a.Np > 64)   fgemm64_go<2, 4, 2, 2, 16>(c, a);     // 64 x 128
+    else if (a.Np > 64) {                                     // forward pass at 32 < m <= 64 (bonds that have shrunk towards minm)
+        static const int gcfg = getenv("TNML_FG64_GEN_CFG") ? atoi(getenv("TNML_FG64_GEN_CFG")) : 0;   // tools/tune_m60.sh, profiles/r02_tune_m60.txt
+        switch (gcfg) {
+            case 2:  fgemm64_go<2, 4, 4, 2, 16>(c, a); break;   // 128 x 128, 8 waves
+            case 3:  fgemm64_go<1, 4, 4, 2, 16>(c, a); break;   // 64 x 128, 8 waves
+            case 4:  fgemm64_go<2, 2, 4, 4, 16>(c, a); break;   // 128 x 128, 16 waves
+            case 5:  fgemm64_go<2, 4, 2, 2, 16>(c, a); break;   // 64 x 128, 4 waves (the round-1 choice: 53 us at m = 60)
+            default: if (a.NTp >= 128 * 192) fgemm64_go<2, 4, 4, 2, 8>(c, a);   // 128 x 128, 8 waves, KT 8: 46 us at m = 60, 60 000 images
+                     else                    fgemm64_go<2, 4, 2, 2, 16>(c, a);
+                     break;
+        }
+    }
     else if (a.Np > 32)   fgemm64_go<2, 2, 2, 2, 16>(c, a);     // 64 x 64
     else                  fgemm64_go<2, 1, 2, 2, 16>(c, a);     // 64 x 32
     HIPCK(c, hipGetLastError());
@@ -1046,6 +1052,13 @@ int launch_bgemm64(tnml_ctx* c, const Bgemm64Args& a, double* G) {
             return bgemm64_go<5, 1, 3, 4, 1>(c, a, G, 256 * a.L);                  // 240 x 64, 12 waves: 187 us vs 153+90 unfused
         }
         if (a.Kp % 80 == 0 && a.Np % 80 == 0) return bgemm64_go<1, 5, 5, 1, 1>(c, a, G);               // 80 x 80, 5 waves
+        static const int gcfg = getenv("TNML_BGF_GEN_CFG") ? atoi(getenv("TNML_BGF_GEN_CFG")) : 0;
+        if (a.Kp % 128 == 0 && a.Np % 64 == 0) {                                                       // m = 33..64
+            if (gcfg == 1) return bgemm64_go<4, 1, 2, 4, 1>(c, a, G);                                  // 128 x 64, 8 waves
+            if (gcfg == 3) return bgemm64_go<4, 2, 2, 4, 1>(c, a, G);                                  // 128 x 128, 8 waves: 151 us
+            if (gcfg == 4) return bgemm64_go<2, 2, 4, 4, 1>(c, a, G);                                  // 128 x 128, 16 waves: 124 us
+            if (gcfg != 7) return bgemm64_go<2, 2, 4, 2, 1>(c, a, G);                                  // 128 x 64, 8 waves: 70 us at m = 60 (96 x 64 tiles: 133 us)
+        }
         return bgemm64_go<2, 2, 3, 2, 1>(c, a, G);                                                     // 96 x 64, 6 waves
     }
     if (a.Kp % 240 == 0 && a.Np % 240 == 0) {

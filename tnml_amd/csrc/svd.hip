@@ -10,6 +10,7 @@
 //   sigma = sqrt(lambda), truncation rule on the host (tnml_truncate), kept factors by dgemm:
 //   the site the sweep leaves gets the orthonormal factor, the site it moves to gets S*V
 //   ("W.Aref(c+dc) *= S", fixedL.cc:521).
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -112,8 +113,20 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
     bool own_eig = tri && c->cfg.svd_backend == TNML_SVD_SYEVD;
     const int mk = maxm < n ? maxm : n;                   // the truncation never keeps more than maxm
     const double* evals = c->sD;                          // ascending eigenvalues of rho
+    double* qh = nullptr;                                 // H_0 ... H_{n-2}, formed beside the tridiagonal eigenproblem
     if (tri) {
         TCK(eigh_tridiagonalize(c, c->sG, n, c->sD, c->sE2, c->sTau, c->sV));
+        // The reflectors are known as soon as the tridiagonalisation ends, the eigenvectors of T only ~200 us later: the product
+        // H_0 ... H_{n-2} is formed on the second queue meanwhile (n independent columns, the same latency chain as the back
+        // transformation of the eigenvectors), and the back transformation itself becomes one dgemm.
+        static const int use_qh = getenv("TNML_SVD_QH") ? atoi(getenv("TNML_SVD_QH")) : 0;   // measured: no gain (profiles/r02_ab_svd_qh.txt), off
+        qh = use_qh && own_eig && (size_t)n * n + 2048 <= std::max<size_t>((size_t)5 * c->svd_n * c->maxm, 1024) ? c->sScr + 2048 : nullptr;
+        if (qh) {
+            HIPCK(c, hipEventRecord(c->ev_a, st));
+            HIPCK(c, hipStreamWaitEvent(c->stream2, c->ev_a, 0));
+            TCK(eigh_backtransform(c, c->sV, c->sTau, n, nullptr, n, qh, n, n, c->stream2));
+            HIPCK(c, hipEventRecord(c->ev_b, c->stream2));
+        }
         if (own_eig) { TCK(eigh_tridiag_eig(c, c->sD, c->sE2, n, c->sW, mk, c->sC, n, c->sScr)); evals = c->sW; }
         else RBCK(c, rocsolver_dstedc(c->blas, rocblas_evect_tridiagonal, n, c->sD, c->sE2, c->sC, n, c->sInfo));
     } else {
@@ -129,7 +142,10 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
     if (own_eig) {
         // Z (already "largest first") -> U = H_0 H_1 ... Z for all mk candidate columns, queued BEFORE the eigenvalues go to
         // the host, so that the truncation decision costs no idle gap on the device; the kept columns are the first m.
-        TCK(eigh_backtransform(c, c->sV, c->sTau, n, c->sC, n, Q0, n, mk));
+        if (qh) {
+            HIPCK(c, hipStreamWaitEvent(st, c->ev_b, 0));
+            RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, n, mk, n, &one, qh, n, c->sC, n, &zero, Q0, n));
+        } else TCK(eigh_backtransform(c, c->sV, c->sTau, n, c->sC, n, Q0, n, mk));
         RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, mk, mk, n, &one, Q0, n, Q0, n, &zero, c->sS, mk));
         const double* Qin = Q0;
         if (always_qr) {

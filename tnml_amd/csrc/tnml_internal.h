@@ -274,7 +274,7 @@ int eigh_tridiag_eig(tnml_ctx* c, const double* D, const double* E, int n, doubl
 int eigh_ns_matrix(tnml_ctx* c, const double* S, double* Cm, int m, double* dev);
 int eigh_chol_rinv(tnml_ctx* c, const double* S, int m, double* Rinv, double* flag);   // m <= 136
 #define TNML_CHOL_MAXM 136
-int eigh_backtransform(tnml_ctx* c, const double* V, const double* tau, int n, const double* Z, int ldz, double* U, int ldu, int ncols);
+int eigh_backtransform(tnml_ctx* c, const double* V, const double* tau, int n, const double* Z, int ldz, double* U, int ldu, int ncols, hipStream_t st = nullptr);   // Z == nullptr: U = H_0 ... H_{n-2}
 
 // ---- local_comm.hip ----
 void local_comm_release(tnml_ctx* c);
