@@ -230,6 +230,47 @@ def test_c3_kernel_instantiations_of_the_benchmark_match_the_oracle():
 
 
 @pytest.mark.gpu
+def test_m60_kernel_instantiations_match_the_oracle():
+    """bonds that have shrunk to minm = maxm/2 = 60 (the reference default, fixedL.cc:593) run their own tiles: 128 x 128
+    feature-GEMM tiles (forced here as for C3: at 60 000 images they are the default), 128 x 64 gradient-GEMM tiles"""
+    from oracle import pyoracle
+    from tnml_amd.fixedl import TrainStates
+    from conftest import make_problem
+    N, NT, m = 20, 300, 60
+    pixels, labels, phi, W = make_problem(N, NT, m, 5, pixel_boost=200.0)
+    ts = TrainStates(labels, N, m, phi=phi)
+    ts.set_option("fg64_cfg", 2)
+    ts.set_option("ldot_cfg", 1)
+    ts.set_mps(W)
+    ts.init()
+    o = pyoracle.Oracle(phi, labels, W, nthread=min(8, os.cpu_count() or 1))
+    o.init()
+    rng = np.random.default_rng(2)
+    at = 1
+    for b, kind in ((8, "Label on RE"), (9, "Label on B"), (12, "Label on LE")):
+        for bb in range(at, b):
+            ts.shiftE(bb, True); o.shiftE(bb, True)
+        at = b
+        ts.setBond(b); o.set_bond(b)
+        B = o.bond_tensor(b)
+        B = B + 0.05 * rng.standard_normal(B.shape)
+        assert B.shape[:4] == (60, 2, 2, 60)
+        assert _rel(ts.forward(B), o.forward(B)) < 1e-11, kind
+        assert _rel(ts.gradient(B), o.gradient(B)) < 1e-9, kind
+        Bg, tg = ts.cgrad(B, 3, 1e-3, 1e-10)
+        Bo, to = o.cgrad(B, 3, 1e-3, 1e-10)
+        np.testing.assert_allclose(tg["cost"], to["cost"], rtol=1e-9, err_msg=kind)
+        assert _rel(Bg, Bo) < 1e-5, kind
+    r = ts.bond_update(12, 1, m, m // 2, 1e-10, 3, 1e-3, 1e-10)
+    o.set_bond(12)
+    B, _ = o.cgrad(o.bond_tensor(12), 3, 1e-3, 1e-10)
+    newm, te, _ = o.svd_split(B, 12, 1, 1e-10, m, m // 2)
+    C, lc, cr, nc = o.quadcost(o.bond_tensor(12), 1e-3)
+    assert r["newm"] == newm and r["ncorrect"] == nc and r["cost"] == pytest.approx(C, rel=1e-8)
+    ts.close()
+
+
+@pytest.mark.gpu
 def test_c2_at_its_stated_shape():
     """BASELINE config 2: N=784, maxm=20, 1000 images per label.  Size-independent properties on the HIP path (linearity
     of the forward map, gradient additivity over image shards, cost independent of the bond) and, against the oracle on

@@ -573,7 +573,7 @@ int launch_fgemm64(tnml_ctx* c, const Fgemm64Args& a) {
             case 3:  fgemm64_go<1, 4, 4, 2, 16>(c, a); break;   // 64 x 128, 8 waves
             case 4:  fgemm64_go<2, 2, 4, 4, 16>(c, a); break;   // 128 x 128, 16 waves
             case 5:  fgemm64_go<2, 4, 2, 2, 16>(c, a); break;   // 64 x 128, 4 waves (the round-1 choice: 53 us at m = 60)
-            default: if (a.NTp >= 128 * 192) fgemm64_go<2, 4, 4, 2, 8>(c, a);   // 128 x 128, 8 waves, KT 8: 46 us at m = 60, 60 000 images
+            default: if (a.NTp >= 128 * 192 || c->opt_fg64_cfg == 2) fgemm64_go<2, 4, 4, 2, 8>(c, a);   // 128 x 128, 8 waves, KT 8: 46 us at m = 60, 60 000 images ("fg64_cfg" = 2 forces it for parity tests)
                      else                    fgemm64_go<2, 4, 2, 2, 16>(c, a);
                      break;
         }

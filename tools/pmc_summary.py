@@ -31,3 +31,25 @@ with open(out + "/pmc_summary.csv", "w") as g:
         g.write('"%s",%d,%.3f,%.3f,%.3f,%.1f,%.1f,%.1f,%.1f\n' % (k, fs[1], fs[0], fs[2], ws[0], mf[0], mf[1], mf[2], mf[3]))
         if mf[3] > 0 and mf[0] > 0:
             print("      MFMA busy %.3e cyc (64.0 per v_mfma_f64_16x16x4: %.3e instructions = %.3f GFLOP), GUI active %.3e summed over the 8 XCDs = %.0f cycles of kernel time\n      -> matrix pipe busy %.1f %% of the time (busy / (gui_active / 8 * 1024 SIMDs))" % (mf[0], mf[1] * 512 / 2048, mf[1] * 512 / 1e9, mf[3], mf[3] / 8, 100 * mf[0] / (mf[3] / 8 * 1024)))
+
+# ---- stamped traffic record for bench.py (roofline.traffic): bytes per launch of the kernels the bench line names, tagged with
+# the kernel symbol, the sha of the kernel sources and the commit they were measured at; bench.py drops the number when the
+# sources have changed since.  FETCH_SIZE is doubled (MI355X_MICROARCH.md "HBM": wide streaming reads are reported at half on
+# gfx950; the label dot, whose byte count is known exactly, calibrates the factor), both counters are in KB.
+import hashlib, json, os, subprocess
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+h = hashlib.sha256()
+for f in ("kernels_gemm.hip", "kernels_stream.hip"):
+    h.update(open(os.path.join(root, "tnml_amd", "csrc", f), "rb").read())
+classes = {"fgemm_fwd": "k_fgemm64<2, 5, 4, 3, 16, 0, 0, double, 2>", "fgemm_shift": "k_fgemm64<2, 4, 4, 2, 8, 0, 0, double, 1>",
+           "labeldot": "k_labeldot<4, 2, 10, double, double, double", "bgemm": "k_bgemm64<5, 1, 3, 4, 1, double>"}
+rec = {"kernels_src_sha16": h.hexdigest()[:16], "commit": os.environ.get("TNML_COMMIT", "unknown"),
+       "workload": "bench.py default (BASELINE config 3, 60000 images, maxm 120, fp64)", "kernels": {}}
+for cls, pat in classes.items():
+    for k, v in res.items():
+        if pat in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            rec["kernels"][cls] = {"kernel": k, "bytes_per_launch": (2.0 * v["FETCH_SIZE"][0] + v["WRITE_SIZE"][0]) * 1024.0,
+                                   "fetch_size_kb": v["FETCH_SIZE"][0], "write_size_kb": v["WRITE_SIZE"][0], "launches": v["FETCH_SIZE"][1]}
+            break
+json.dump(rec, open(out + "/pmc_traffic.json", "w"), indent=1)
+print("wrote", out + "/pmc_traffic.json", {k: round(v["bytes_per_launch"] / 1e6, 1) for k, v in rec["kernels"].items()}, "MB per launch")
