@@ -137,6 +137,7 @@ int tnml_comm_init_local(tnml_ctx** ctxs, int n);
    reference relies on one shared W (fixedL.cc:451); tnml_bond_update runs the same check on the two site tensors it
    rewrites after every split (TNML_CHECK_REPLICAS=0 disables that).  nranks_in_comm (nullable) receives the communicator size. */
 int tnml_replica_check(tnml_ctx* ctx, int* nranks_in_comm);
+int64_t tnml_replica_repairs(tnml_ctx* ctx);           /* re-broadcasts so far in check_replicas mode 2 */
 
 /* ---- training set: TState ctor fixedL.cc:28-47 + feature map :637-642 -------------------- */
 /* raw bytes [NT_local][N] with the reference's feature map phi = [1, byte/(255*255*4)] */
@@ -220,7 +221,8 @@ int tnml_synchronize(tnml_ctx* ctx);
      "fast_cg"        P <- P + a (p*t.v) instead of re-running the forward GEMM inside cgrad (single.h:290-398 idea)
      "reuse_p"        the after-SVD quadcost of one bond update provides the first residuals of the next
      "fuse_z"         the gradient GEMM builds Z = sum_l EL[l] dP[l] itself
-     "check_replicas" multi-rank: fingerprint check of the rewritten site tensors after every split
+     "check_replicas" multi-rank: fingerprint check of the rewritten site tensors after every split (1: a mismatch is an
+                      error; 2: rank 0's two site tensors are re-broadcast, the sweep continues, tnml_replica_repairs counts)
      "fg64_cfg", "ldot_cfg"  force a tile configuration of the feature GEMM / the label dot that is otherwise chosen by the
                       image count (2 / 1 = the large-image-count forms bench.py times; parity tests run them at small sizes)
    fast_cg = reuse_p = 0 is the reference's literal evaluation order (fixedL.cc:374-421). */

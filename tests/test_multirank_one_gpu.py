@@ -144,3 +144,35 @@ def test_cpp_driver_with_two_ranks_prints_the_one_rank_log(tmp_path):
     np.testing.assert_allclose(c2, c1, rtol=1e-6)
     assert skeleton(logs["one"]) == skeleton(logs["two"])
     assert re.findall(r"New m=(\d+)", logs["one"]) == re.findall(r"New m=(\d+)", logs["two"])
+
+
+def test_a_diverging_replica_is_detected_and_can_be_repaired():
+    """one rank's copy of W.A(b) is moved by one ulp after every split (test hook): with check_replicas = 1 the bond update
+    fails on every rank, with check_replicas = 2 rank 0's tensors are re-broadcast, the sweep finishes with identical
+    replicas and the costs of the undisturbed run"""
+    from tnml_amd.fixedl import TnmlError, mldmrg
+    N, NT, m = 12, 150, 6
+    pixels, labels, phi, W = make_problem(N, NT, m, 3, pixel_boost=200.0)
+    args = (1, m, m // 2, 1e-10, 3, 1e-3, 1e-10)
+
+    def body(mode, nudge):
+        def run(ts, r):
+            ts.set_option("check_replicas", mode)
+            ts.set_option("debug_nudge_rank", nudge)
+            ts.init()
+            try:
+                reps = mldmrg(ts, *args)
+            except TnmlError as e:
+                return dict(error=str(e))
+            ts.replica_check()
+            return dict(cost=[x["cost"] for x in reps], repairs=ts.replica_repairs())
+        return run
+    clean = _run_ranks(2, labels, phi, W, N, m, body(1, -1))
+    assert all("error" not in x and x["repairs"] == 0 for x in clean)
+    strict = _run_ranks(2, labels, phi, W, N, m, body(1, 1))
+    assert all("replicas of W.A" in x.get("error", "") for x in strict)
+    repaired = _run_ranks(2, labels, phi, W, N, m, body(2, 1))
+    assert all("error" not in x for x in repaired)
+    assert repaired[0]["repairs"] == repaired[1]["repairs"] == 2 * (N - 1)
+    assert repaired[0]["cost"] == repaired[1]["cost"]
+    np.testing.assert_allclose(repaired[0]["cost"], clean[0]["cost"], rtol=1e-9)

@@ -331,3 +331,11 @@ int launch_fingerprint(tnml_ctx* c, const double* x, size_t n, unsigned long lon
     HIPCK(c, hipGetLastError());
     return 0;
 }
+
+// test hook (tnml_set_option "debug_nudge_rank"): the first element of a replicated tensor moves by one ulp
+__global__ void k_nudge(double* p) { if (threadIdx.x == 0 && blockIdx.x == 0) p[0] = __longlong_as_double(__double_as_longlong(p[0]) + 1); }
+int launch_nudge(tnml_ctx* c, double* p) {
+    hipLaunchKernelGGL(k_nudge, dim3(1), dim3(64), 0, c->stream, p);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}

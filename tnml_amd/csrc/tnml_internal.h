@@ -145,6 +145,9 @@ struct tnml_ctx {
     double last_bnorm = 0.;         // |B| of the last quadcost
     int* sInfo = nullptr;
     unsigned long long* fprint = nullptr;   // [2] device: fingerprint of replicated tensors and its complement
+    int check_replicas_mode = 1;            // 1: a mismatch is an error; 2: rank 0's site tensors are re-broadcast and the event is counted
+    long replica_repairs = 0;
+    int debug_nudge_rank = -1;              // test hook: this rank's copy of W.A(b) is moved by one ulp after every split
     bool check_replicas = true;             // multi-rank: compare the fingerprints of W[b], W[b+1] after every bond update (env TNML_CHECK_REPLICAS=0 disables)
     int svd_n = 0;
 
@@ -266,6 +269,7 @@ int launch_sqnorm(tnml_ctx* c, const double* x, size_t n, double* out);    // ou
 int launch_diffnorm(tnml_ctx* c, const double* x, const double* y, size_t n, double* out2);  // out2[0]=|x|^2, out2[1]=|x-y|^2
 int launch_fill_f32(tnml_ctx* c, float* p, float v, size_t n);
 int launch_fill_f64(tnml_ctx* c, double* p, double v, size_t n);
+int launch_nudge(tnml_ctx* c, double* p);
 int launch_fingerprint(tnml_ctx* c, const double* x, size_t n, unsigned long long salt, unsigned long long* acc, bool reset);
 
 // ---- eigh.hip -----------------------------------------------------------------------------

@@ -98,6 +98,9 @@ class TrainStates:
         self._ck(self._L.tnml_replica_check(self._h, C.byref(n)))
         return n.value
 
+    def replica_repairs(self):
+        return self._L.tnml_replica_repairs(self._h)
+
     def set_option(self, name, value):
         self._ck(self._L.tnml_set_option(self._h, name.encode(), int(value)))
 

@@ -26,7 +26,7 @@ EXPORTS = [
     "tnml_cgrad", "tnml_svd_split", "tnml_bond_update", "tnml_truncate", "tnml_sweepnext",
     "tnml_shard_bounds", "tnml_profile_enable", "tnml_profile_select", "tnml_profile_count", "tnml_profile_get",
     "tnml_profile_reset", "tnml_synchronize", "tnml_device_bytes", "tnml_svd_stats", "tnml_classify", "tnml_replica_check",
-    "tnml_estimate_bytes", "tnml_device_memory", "tnml_plan_maxm", "tnml_set_option", "tnml_comm_init_local", "tnml_bond_update_begin", "tnml_bond_update_end",
+    "tnml_estimate_bytes", "tnml_device_memory", "tnml_plan_maxm", "tnml_set_option", "tnml_comm_init_local", "tnml_bond_update_begin", "tnml_bond_update_end", "tnml_replica_repairs",
 ]
 
 
@@ -110,6 +110,8 @@ def load():
     L.tnml_classify.argtypes = [vp, dp, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.tnml_device_bytes.restype = C.c_int64
     L.tnml_replica_check.argtypes = [vp, ip]
+    L.tnml_replica_repairs.argtypes = [vp]
+    L.tnml_replica_repairs.restype = C.c_int64
     L.tnml_comm_init_local.argtypes = [C.POINTER(vp), C.c_int]
     L.tnml_set_option.argtypes = [vp, C.c_char_p, C.c_int]
     L.tnml_estimate_bytes.argtypes = [C.POINTER(Config)]
