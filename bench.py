@@ -61,7 +61,7 @@ def pmc_traffic(kernel_class):
     except (OSError, ValueError):
         return None, None
     if rec.get("kernels_src_sha16") != kernel_source_sha16():
-        return None, None, None
+        return None, None
     e = rec.get("kernels", {}).get(kernel_class)
     if not e:
         return None, None
