@@ -165,7 +165,8 @@ __global__ __launch_bounds__(VB) void k_cg_init2(const double* __restrict__ part
     for (int i = threadIdx.x; i < 4 * TNML_MAX_PASS; i += VB) scal[SC_N + i] = 0.;      // the per-pass trace lives behind the scalars
     double a, b; sum_partials(part, nb, &a, &b, sh);
     if (threadIdx.x == 0) {
-        scal[rr_out] = a; scal[SC_CONV] = (cconv0 >= 0. && sqrt(a) < cconv0) ? 2. : 0.; scal[SC_NPASS] = 0.;
+        const double cv = (cconv0 >= 0. && sqrt(a) < cconv0) ? 2. : 0.;
+        scal[rr_out] = a; scal[SC_CONV] = cv; scal[SC_CONVP] = cv; scal[SC_NPASS] = 0.;      // slot 0: the state before pass 1
     }
 }
 // partial |x|^2 (and |y|^2)
@@ -182,9 +183,11 @@ __global__ __launch_bounds__(VB) void k_norm1(const double* __restrict__ x, cons
 __global__ __launch_bounds__(VB) void k_cg_step2(double* __restrict__ B, const double* __restrict__ Pv, size_t n, double lambda,
                                                 const double* __restrict__ tail, const double* __restrict__ part, int nb,
                                                 double* __restrict__ scal, int rr_in, double* __restrict__ trace, int pass) {
-    if (scal[SC_CONV] != 0.) return;                       // |r| < cconv was hit in an earlier pass (fixedL.cc:432-436)
+    if (scal[SC_CONVP + ((pass - 1) & 1)] != 0.) return;   // |r| < cconv was hit in an earlier pass (fixedL.cc:432-436)
     __shared__ double sh[VB / 64];
-    double pn2, unused; sum_partials(part, nb, &pn2, &unused, sh);
+    // |p|^2: p = r in pass 1 (fixedL.cc:388), afterwards the partial sums left by k_cg_resid2 when it formed p = r + beta p
+    double pn2, unused;
+    if (pass == 1) pn2 = scal[rr_in]; else sum_partials(part, nb, &pn2, &unused, sh);
     const double pAp = tail[SC_PP] + lambda * pn2;
     const double a = scal[rr_in] / pAp;
     size_t lo, hi; slice(n, &lo, &hi);
@@ -215,21 +218,28 @@ __global__ __launch_bounds__(VB) void k_cg_resid2(const double* __restrict__ G, 
                                                  double* __restrict__ Pv, size_t n, double lambda, double cconv,
                                                  const double* __restrict__ tail, const double* __restrict__ part, int nb,
                                                  double* __restrict__ scal, int rr_in, int rr_out,
-                                                 double* __restrict__ trace, int pass) {
-    if (scal[SC_CONV] != 0.) return;
-    __shared__ double sh[VB / 64];
+                                                 double* __restrict__ trace, int pass, double* __restrict__ part_p) {
+    const double was = scal[SC_CONVP + ((pass - 1) & 1)];
+    if (was != 0.) {                                       // already converged: hand the flag on to the next pass's slot
+        if (blockIdx.x == 0 && threadIdx.x == 0) scal[SC_CONVP + (pass & 1)] = was;
+        return;
+    }
+    __shared__ double sh[VB];
     double nn, bn2; sum_partials(part, nb, &nn, &bn2, sh);
     const double q = sqrt(nn) / sqrt(scal[rr_in]);
     const double beta = q * q;
     const double rn = sqrt(nn);
     const int conv = rn < cconv;
     size_t lo, hi; slice(n, &lo, &hi);
+    double pacc = 0.;
     for (size_t i = lo + threadIdx.x; i < hi; i += VB) {
         double nr = G[i];
         if (lambda != 0.) nr = nr - lambda * B[i];
         R[i] = nr;
-        if (!conv) Pv[i] = nr + beta * Pv[i];
+        if (!conv) { const double pv = nr + beta * Pv[i]; Pv[i] = pv; pacc += pv * pv; }
     }
+    const double ps = block_sum(pacc, sh);                 // partial |p|^2 of the next pass (k_cg_step2 sums them in block order)
+    if (threadIdx.x == 0) { part_p[2 * blockIdx.x] = ps; part_p[2 * blockIdx.x + 1] = 0.; }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         double cs = 0.;
         for (int l = 0; l < TNML_NL; ++l) cs += tail[SC_COST0 + l];
@@ -237,11 +247,9 @@ __global__ __launch_bounds__(VB) void k_cg_resid2(const double* __restrict__ G, 
         scal[SC_BNORM2] = bn2; scal[SC_BETA] = beta; scal[SC_RNORM] = rn;
         scal[rr_out] = nn;
         trace[4 * (pass - 1) + 2] = cs + lambda * bn2; trace[4 * (pass - 1) + 3] = rn;
-        scal[SC_CONV_NEXT] = (double)conv;                 // becomes visible to the next kernels through k_cg_commit
+        scal[SC_CONVP + (pass & 1)] = (double)conv;        // read by the kernels of the next pass; this pass's readers use the other slot
+        scal[SC_CONV] = (double)conv;                      // host copy
     }
-}
-__global__ void k_cg_commit(double* __restrict__ scal) {
-    if (threadIdx.x == 0 && scal[SC_CONV] == 0.) scal[SC_CONV] = scal[SC_CONV_NEXT];
 }
 __global__ __launch_bounds__(VB) void k_norm2(const double* __restrict__ part, int nb, double* __restrict__ out, int nout) {
     __shared__ double sh[VB / 64];
@@ -274,8 +282,7 @@ int launch_cg_init(tnml_ctx* c, size_t n, double lambda, double cconv0) {
 int launch_cg_step(tnml_ctx* c, size_t n, double lambda, int pass) {
     ProfScope ps(c, KC_VEC);
     const int nb = vec_blocks(n);
-    hipLaunchKernelGGL(k_norm1, dim3(nb), dim3(VB), 0, c->stream, c->vP, (const double*)nullptr, n, c->vpart);
-    hipLaunchKernelGGL(k_cg_step2, dim3(nb), dim3(VB), 0, c->stream, c->vB, c->vP, n, lambda, c->vG + n, c->vpart, nb, c->scal, SC_RR + c->rr_slot, c->cgtrace, pass);
+    hipLaunchKernelGGL(k_cg_step2, dim3(nb), dim3(VB), 0, c->stream, c->vB, c->vP, n, lambda, c->vG + n, c->vpart + 512, nb, c->scal, SC_RR + c->rr_slot, c->cgtrace, pass);
     HIPCK(c, hipGetLastError());
     return 0;
 }
@@ -284,8 +291,7 @@ int launch_cg_resid(tnml_ctx* c, size_t n, double lambda, double cconv, int pass
     const int nb = vec_blocks(n);
     const int in = SC_RR + c->rr_slot, out = SC_RR + (c->rr_slot ^ 1);
     hipLaunchKernelGGL(k_cg_resid1, dim3(nb), dim3(VB), 0, c->stream, c->vG, c->vB, n, lambda, c->vpart);
-    hipLaunchKernelGGL(k_cg_resid2, dim3(nb), dim3(VB), 0, c->stream, c->vG, c->vB, c->vR, c->vP, n, lambda, cconv, c->vG + n, c->vpart, nb, c->scal, in, out, c->cgtrace, pass);
-    hipLaunchKernelGGL(k_cg_commit, dim3(1), dim3(64), 0, c->stream, c->scal);
+    hipLaunchKernelGGL(k_cg_resid2, dim3(nb), dim3(VB), 0, c->stream, c->vG, c->vB, c->vR, c->vP, n, lambda, cconv, c->vG + n, c->vpart, nb, c->scal, in, out, c->cgtrace, pass, c->vpart + 512);
     c->rr_slot ^= 1;
     HIPCK(c, hipGetLastError());
     return 0;

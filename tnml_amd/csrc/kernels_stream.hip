@@ -291,8 +291,8 @@ __global__ __launch_bounds__(LD_IMGS) void k_pupdate(T* __restrict__ P, const T*
 int launch_pupdate(tnml_ctx* c, const double* alpha_dev, double* scal_out) {
     ProfScope ps(c, KC_PUPDATE);
     const int nblk = c->NTp / LD_IMGS;
-    if (c->f64()) hipLaunchKernelGGL(k_pupdate<double>, dim3(nblk), dim3(LD_IMGS), 0, c->stream, (double*)c->P, (const double*)c->Pp, (double*)c->dP, c->label, c->NTp, alpha_dev, c->scal + SC_CONV, c->partials, c->nl(), c->target());
-    else          hipLaunchKernelGGL(k_pupdate<float>, dim3(nblk), dim3(LD_IMGS), 0, c->stream, (float*)c->P, (const float*)c->Pp, (float*)c->dP, c->label, c->NTp, alpha_dev, c->scal + SC_CONV, c->partials, c->nl(), c->target());
+    if (c->f64()) hipLaunchKernelGGL(k_pupdate<double>, dim3(nblk), dim3(LD_IMGS), 0, c->stream, (double*)c->P, (const double*)c->Pp, (double*)c->dP, c->label, c->NTp, alpha_dev, c->scal + SC_CONVP + ((c->cg_pass - 1) & 1), c->partials, c->nl(), c->target());
+    else          hipLaunchKernelGGL(k_pupdate<float>, dim3(nblk), dim3(LD_IMGS), 0, c->stream, (float*)c->P, (const float*)c->Pp, (float*)c->dP, c->label, c->NTp, alpha_dev, c->scal + SC_CONVP + ((c->cg_pass - 1) & 1), c->partials, c->nl(), c->target());
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(768), 0, c->stream, c->partials, nblk, scal_out);
     HIPCK(c, hipGetLastError());
     return 0;

@@ -245,7 +245,7 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     if ((rc = dmalloc(c, &c->vG, c->mcap + TNML_NSCAL_AR))) return bail(rc);
     if ((rc = dmalloc(c, &c->scal, SC_N + (size_t)4 * TNML_MAX_PASS))) return bail(rc);   // CG scalars, then the per-pass trace: one copy to the host
     c->cgtrace = c->scal + SC_N;
-    if ((rc = dmalloc(c, &c->vpart, 512))) return bail(rc);
+    if ((rc = dmalloc(c, &c->vpart, 1024))) return bail(rc);   // [256][2] phase-1 partials, then [256][2] for |p|^2 of the next pass
     if ((rc = dmalloc(c, &c->tB, c->mcap))) return bail(rc);
     if ((rc = dmalloc(c, &c->tB2, c->mcap))) return bail(rc);
     // sM holds (a) the Label-permuted bond matrix of the split, 40 maxm^2, and (b) the 16-padded site matrix of an
@@ -792,6 +792,7 @@ static int cgrad_device(tnml_ctx* c, int npass, double lambda, double cconv, boo
     TCK(grad_eval(c, false, outputs_current));           // :374-385
     TCK(launch_cg_init(c, n, lambda, c->single() ? cconv : -1.));   // :386-388 (single.h:200-208 with the entry check)
     for (int pass = 1; pass <= npass; ++pass) {          // :389
+        c->cg_pass = pass;
         TCK(forward_pass(c, c->vP, LD_MODE_PAP, c->vG + n, c->fast_cg));   // :394-401 (keeps p*t.v for the fast update)
         TCK(allreduce(c, c->vG + n, TNML_NSCAL_AR));                  // :402
         TCK(launch_cg_step(c, n, lambda, pass));         // :403-407

@@ -59,7 +59,7 @@ struct SiteT {
 
 // scalar slots of the device-side CG state (doubles)
 enum { SC_COST0 = 0, /* ..9 */ SC_NCORR = 10, SC_PP = 11, SC_RR = 12, /* 13: second |r|^2 slot */ SC_ALPHA = 14, SC_BETA = 15,
-       SC_PNORM2 = 16, SC_BNORM2 = 17, SC_PAP = 18, SC_RNORM = 19, SC_COST = 20, SC_CONV = 21, SC_CONV_NEXT = 22, SC_NPASS = 23,
+       SC_PNORM2 = 16, SC_BNORM2 = 17, SC_PAP = 18, SC_RNORM = 19, SC_COST = 20, SC_CONV = 21 /* host copy of the flag */, SC_CONV_NEXT = 22, SC_NPASS = 23, SC_CONVP = 24 /* ,25: the flag by pass parity */,
        SC_NORMS = 28 /* |newB|^2, |B-newB|^2 */, SC_N = 32 };
 #define TNML_NSCAL_AR 16   /* scalars that ride behind G in the all-reduce buffer */
 
@@ -131,6 +131,7 @@ struct tnml_ctx {
     double* scal = nullptr;    // device scalars [SC_N]
     double* cgtrace = nullptr; // device CG trace [TNML_MAX_PASS][4] = pAp, alpha, cost, |r|
     double* vpart = nullptr;   // per-workgroup partial sums of the CG vector kernels [256][2]
+    int cg_pass = 0;           // CG pass being issued (selects the parity slot of the convergence flag)
     int rr_slot = 0;           // which of scal[SC_RR], scal[SC_RR+1] holds the current |r|^2
     double* h_scal = nullptr;  // pinned host mirror
     double *tB = nullptr, *tB2 = nullptr;   // bond tensors in ITensor layout (fp64)
