@@ -652,6 +652,100 @@ __global__ __launch_bounds__(64) void k_backtransform(const double* __restrict__
     for (int e = 0; e < 4; ++e) { const int i = lane + 64 * e; if (i < n) U[i + (size_t)ldu * c] = z[e]; }
 }
 
+// ------------------------------------------------------------------------------------------
+// Blocked back transformation.  Eight consecutive reflectors are applied as one compact-WY block,
+//   H_a H_{a+1} ... H_{a+7} = I - V T V^T      (V = [v_a .. v_{a+7}], T upper triangular, LAPACK dlarft 'F','C'),
+// so that a column needs 8 INDEPENDENT dot products per block (their wave reductions interleave) instead of 8 dependent
+// dot -> reduce -> update rounds: the one-wave-per-column kernel above is a latency chain of n-1 wave reductions.
+// k_bt_tfactors: one wave per block forms T from the Gram matrix of the block's vectors and tau.
+// ------------------------------------------------------------------------------------------
+#define BTW 8
+__global__ __launch_bounds__(64) void k_bt_tfactors(const double* __restrict__ V, int ldv, const double* __restrict__ tau, int n, double* __restrict__ Tf) {
+    const int blk = blockIdx.x, lane = threadIdx.x, a = blk * BTW;
+    double v[BTW][4], t[BTW];
+#pragma unroll
+    for (int q = 0; q < BTW; ++q) {
+        const int k = a + q;
+        t[q] = k < n - 1 ? tau[k] : 0.;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int i = lane + 64 * e; v[q][e] = (k < n - 1 && i < n && i > k) ? V[i + (size_t)ldv * k] : 0.; }
+    }
+    double g[BTW][BTW];                                   // g[i][j] = v_i . v_j, i < j
+#pragma unroll
+    for (int i = 0; i < BTW; ++i)
+#pragma unroll
+        for (int j = i + 1; j < BTW; ++j) {
+            double d = 0.;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d = fma(v[i][e], v[j][e], d);
+            g[i][j] = wave_sum(d);
+        }
+    // T(0:j-1, j) = -tau_j T(0:j-1, 0:j-1) (V(:, 0:j-1)^T v_j),  T(j,j) = tau_j      -- every lane, identical values
+    double T[BTW][BTW];
+#pragma unroll
+    for (int i = 0; i < BTW; ++i)
+#pragma unroll
+        for (int j = 0; j < BTW; ++j) T[i][j] = 0.;
+#pragma unroll
+    for (int j = 0; j < BTW; ++j) {
+#pragma unroll
+        for (int i = 0; i < j; ++i) {
+            double acc = 0.;
+#pragma unroll
+            for (int k = i; k < j; ++k) acc = fma(T[i][k], g[k][j], acc);
+            T[i][j] = -t[j] * acc;
+        }
+        T[j][j] = t[j];
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < BTW; ++i)
+#pragma unroll
+            for (int j = 0; j < BTW; ++j) Tf[(size_t)blk * BTW * BTW + i * BTW + j] = T[i][j];
+    }
+}
+__global__ __launch_bounds__(64) void k_backtransform_wy(const double* __restrict__ V, int ldv, const double* __restrict__ Tf, int n,
+                                                        const double* __restrict__ Z, int ldz, double* __restrict__ U, int ldu) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    double z[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const int i = lane + 64 * e; z[e] = i < n ? Z[i + (size_t)ldz * c] : 0.; }
+    const int nblk = (n - 1 + BTW - 1) / BTW;
+    for (int blk = nblk - 1; blk >= 0; --blk) {
+        const int a = blk * BTW;
+        double v[BTW][4], w[BTW];
+#pragma unroll
+        for (int q = 0; q < BTW; ++q) {
+            const int k = a + q;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const int i = lane + 64 * e; v[q][e] = (k < n - 1 && i < n && i > k) ? V[i + (size_t)ldv * k] : 0.; }
+        }
+        const double* Tb = Tf + (size_t)blk * BTW * BTW;
+        double T[BTW][BTW];
+#pragma unroll
+        for (int i = 0; i < BTW; ++i)
+#pragma unroll
+            for (int j = i; j < BTW; ++j) T[i][j] = Tb[i * BTW + j];          // the same address in every lane: a broadcast load
+#pragma unroll
+        for (int q = 0; q < BTW; ++q) {
+            double d = 0.;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d = fma(v[q][e], z[e], d);
+            w[q] = wave_sum(d);                                               // eight independent reductions
+        }
+#pragma unroll
+        for (int i = 0; i < BTW; ++i) {                                       // y = T w, then z -= V y
+            double y = 0.;
+#pragma unroll
+            for (int j = i; j < BTW; ++j) y = fma(T[i][j], w[j], y);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) z[e] = fma(-y, v[i][e], z[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const int i = lane + 64 * e; if (i < n) U[i + (size_t)ldu * c] = z[e]; }
+}
+
 // A (n x n symmetric, device) -> D, E, tau, V on the context's stream.  n <= TRI_MAXN.
 int eigh_tridiagonalize(tnml_ctx* c, const double* A, int n, double* D, double* E, double* tau, double* V) {
     if (n > TRI_MAXN) return tnml_fail(c, "eigh_tridiagonalize: n=%d exceeds %d", n, TRI_MAXN);
@@ -679,6 +773,14 @@ int eigh_tridiagonalize(tnml_ctx* c, const double* A, int n, double* D, double* 
     return 0;
 }
 int eigh_backtransform(tnml_ctx* c, const double* V, const double* tau, int n, const double* Z, int ldz, double* U, int ldu, int ncols, hipStream_t st) {
+    static const int wy = getenv("TNML_BT_WY") ? atoi(getenv("TNML_BT_WY")) : 0;   // measured slower than the one-reflector-at-a-time kernel (profiles/r02_ab_bt_wy.txt), off
+    if (wy && Z && c->sBT && n <= 256) {
+        const int nblk = (n - 1 + BTW - 1) / BTW;
+        hipLaunchKernelGGL(k_bt_tfactors, dim3(nblk), dim3(64), 0, st ? st : c->stream, V, n, tau, n, c->sBT);
+        hipLaunchKernelGGL(k_backtransform_wy, dim3(ncols), dim3(64), 0, st ? st : c->stream, V, n, (const double*)c->sBT, n, Z, ldz, U, ldu);
+        HIPCK(c, hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(k_backtransform, dim3(ncols), dim3(64), 0, st ? st : c->stream, V, n, tau, n, Z, ldz, U, ldu);
     HIPCK(c, hipGetLastError());
     return 0;
