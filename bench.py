@@ -26,6 +26,12 @@ import os
 import sys
 import time
 
+# The GPU boxes expose 256 hardware threads under a CPU quota of 16 (cgroup cpu.max): numpy / OpenBLAS / OpenMP pools sized
+# by the thread count spin through that quota in the set-up phase and the kernel then throttles the whole process in
+# 40-100 ms stalls -- which land inside a 20-step timed region (one stall = +50 % on ms_per_step).  Small host pools.
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+    os.environ.setdefault(_v, "8")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -67,6 +73,18 @@ def pmc_traffic(kernel_class):
         return None, None
     return e["bytes_per_launch"], {"kernel": e["kernel"], "commit": rec.get("commit"), "kernels_src_sha16": rec.get("kernels_src_sha16"),
                                    "file": "profiles/" + os.path.basename(files[-1])}
+
+
+def cpu_quota():
+    """CPUs this process may use: the cgroup quota when there is one, else the hardware thread count"""
+    n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def cpu_model():
@@ -121,6 +139,7 @@ def cpu_baseline(maxm, npass, lam, cutoff, nthread, NT_total, full=False):
         "cores": nthread,
         "cpu_model": cpu_model(),
         "host_cores": os.cpu_count(),
+        "host_cpu_quota": cpu_quota(),
         "kind": "port",
         "image_bond_updates_per_s": rate_sample * NT_s,
         "sample": "oracle (dense t.v fp64 restatement of fixedL.cc, %d threads): %d consecutive bond updates (bonds %d..%d of a %d-site chain, "
@@ -214,6 +233,7 @@ def main():
     import torch
     import torch.distributed as dist
     from tnml_amd import lib, synth
+    torch.set_num_threads(min(8, torch.get_num_threads()))
 
     N, NT, maxm = args.sites, args.images, args.maxm
     lam, cutoff, cconv, npass = 1e-3, 1e-10, 1e-10, args.npass
@@ -329,10 +349,15 @@ def main():
     ts.profile_reset()
     sync()
     t0 = time.perf_counter()
+    step_marks = []
     for _ in range(args.steps):
         step()
+        if os.environ.get("TNML_BENCH_STEPTIMES"):
+            step_marks.append(time.perf_counter() - t0)
     sync()
     elapsed = time.perf_counter() - t0
+    if step_marks and rank == 0:
+        print("host time at the end of each timed step (ms):", " ".join("%.2f" % (1e3 * t) for t in step_marks), "| total %.2f" % (1e3 * elapsed), file=sys.stderr)
     ts.profile(False)
     prof = ts.profile_read()
     n_timed_end = len(reports)                                   # sync() has drained the pipeline: every timed report is in
@@ -462,7 +487,7 @@ def main():
             "replica_repairs": ts.replica_repairs(),
         }
         if world == 1 and not args.no_cpu_baseline and not single:
-            ncore = os.cpu_count() or 1
+            ncore = cpu_quota()
             out["cpu_baseline"] = cpu_baseline(maxm, npass, lam, cutoff, min(16, ncore), NT, full=args.cpu_baseline_full)   # paralleldo.h:55-56 caps at 16
         print(json.dumps(out))
     if world > 1:
