@@ -47,7 +47,7 @@ def kernel_source_sha16():
     """fingerprint of the kernel sources a PMC measurement belongs to"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("kernels_gemm.hip", "kernels_stream.hip"):
+    for f in ("kernels_gemm.hip", "kernels_stream.hip", "kernels_fused.hip"):
         h.update(open(os.path.join(ROOT, "tnml_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -155,6 +155,16 @@ def hbm_roofline(prof_all, NTl, timed, args, world):
     bond dimensions of the timed bonds, duration from the library's HIP events (class "labeldot" = the k_labeldot launches
     alone; the P update and the partial-sum reduction are class "p_update") over the untimed breakdown steps"""
     n_ld, ms_ld = prof_all.get("labeldot", (0, 0.0))
+    n_ff, ms_ff = prof_all.get("fwd_fused", (0, 0.0))
+    if n_ff > n_ld and timed:
+        # the label dot runs inside k_fwd_fused: per launch it streams the Label-carrying environment (10 m values per image) and the
+        # Label-free one (m per image) once; the GEMM output never goes to HBM.  MFMA-bound kernel, so this is its HBM share.
+        by = float(np.mean([NTl * (11 * min(r["mL"], r["mR"]) * 8 + 2 * 2 * 8 + 4) for r in timed]))
+        avg_ms = ms_ff / n_ff
+        ach = by / (avg_ms * 1e-3) / 1e9
+        tr, src = pmc_traffic("fwd_fused") if args.dtype == "f64" and args.maxm == 120 and args.images == 60000 and world == 1 else (None, None)
+        return {"bound": "hbm", "kernel": "k_fwd_fused (environment streams beside the feature GEMM)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "traffic": tr, "traffic_source": src, "avg_launch_ms": avg_ms, "launches": n_ff, "bytes_per_launch": by}
     if not n_ld or not timed:
         return None
     esz = 4 if args.dtype == "f32" else 8
@@ -345,7 +355,7 @@ def main():
         step()
     # timed region: HIP events only around the roofline kernel (two event records per launch cost host
     # time; timing all ~70 launches of a bond update would lower the very throughput being measured)
-    ts.profile(os.environ.get("TNML_BENCH_NOPROF", "0") != "1", only="fgemm_fwd")
+    ts.profile(os.environ.get("TNML_BENCH_NOPROF", "0") != "1", only="fgemm_fwd,fwd_fused")
     ts.profile_reset()
     sync()
     t0 = time.perf_counter()
@@ -391,6 +401,19 @@ def main():
         elapsed_lit = time.perf_counter() - t1
         ts.set_option("fast_cg", 1)
         ts.set_option("reuse_p", 1)
+    # the two kernels k_fwd_fused replaces, timed in the same run (untimed steps): stand-alone feature GEMM and label dot
+    unfused = None
+    if prof_all.get("fwd_fused", (0, 0))[0] > 0:
+        drain()
+        ts.set_option("fused_fwd", 0)
+        ts.profile(True, only="fgemm_fwd,labeldot")
+        ts.profile_reset()
+        for _ in range(nbreak):
+            step()
+        drain()
+        ts.profile(False)
+        unfused = ts.profile_read()
+        ts.set_option("fused_fwd", 1)
     if world > 1:
         t = torch.tensor([elapsed, elapsed_lit or 0.0], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -403,6 +426,10 @@ def main():
         # dominant kernel: the feature GEMM (T = X*B_mat).  Algorithmic flops per launch = SURVEY.md 8(d)
         # GEMM term 2*NT*(2mL)*(2mR) for the images one launch processes (x10 on the two Label-on-B bonds).
         n_fg, ms_fg = prof.get("fgemm_fwd", (0, 0.0))
+        n_ff, ms_ff = prof.get("fwd_fused", (0, 0.0))
+        fused = n_ff > n_fg                                     # the forward pass runs as one persistent kernel (kernels_fused.hip)
+        if fused:
+            n_fg, ms_fg = n_ff, ms_ff
         # every timed bond calls the feature GEMM with its own (mL, mR); average the flops
         fl = [2.0 * NTl * (2 * r["mL"]) * (2 * r["mR"]) * (10 if (r["label_on_B"] and not single) else 1) for r in timed]
         flops_per_pass = float(np.mean(fl)) if fl else 0.0
@@ -421,15 +448,15 @@ def main():
         kms = {k: v[1] / nbreak for k, v in prof_all.items() if v[0]}
         # whole-step MFMA fraction.  executed: the GEMM launches a bond update really issues (5 forward + 4 gradient with the two
         # shortcuts on) + its shiftE; algorithmic: SURVEY.md 8(d), (3P+1) passes of 2 NT (2m)^2 + 2 NT 2m 10, the shift, 22 (2m)^3
-        nf_step = prof_all.get("fgemm_fwd", (0, 0))[0] / max(nbreak, 1)
+        nf_step = (prof_all.get("fgemm_fwd", (0, 0))[0] + prof_all.get("fwd_fused", (0, 0))[0]) / max(nbreak, 1)
         nb_step = prof_all.get("bgemm", (0, 0))[0] / max(nbreak, 1)
         sh = float(np.mean([shift_flops(r, NTl, N, single) for r in timed])) if timed else 0.0
         exec_gf = ((nf_step + nb_step) * flops_per_pass + sh) / 1e9
         m_avg = float(np.mean([0.5 * (r["mL"] + r["mR"]) for r in timed])) if timed else 0.0
         alg_gf = ((3 * npass + 1) * (flops_per_pass + 2.0 * NTl * 2 * m_avg * (1 if single else 10)) + sh + 22.0 * (2 * m_avg) ** 3) / 1e9
         # (the label dot of the first image half, class labeldot_overlapped, runs beside fgemm_fwd_overlapped: counted once)
-        grad_classes = ("fgemm_fwd", "fgemm_fwd_overlapped", "labeldot", "p_update", "bgemm", "slab_reduce", "zprime", "allreduce")
-        tr_fg, src_fg = pmc_traffic("fgemm_fwd") if args.dtype == "f64" and maxm == 120 and NT == 60000 and world == 1 else (None, None)
+        grad_classes = ("fgemm_fwd", "fgemm_fwd_overlapped", "fwd_fused", "labeldot", "p_update", "bgemm", "slab_reduce", "zprime", "allreduce")
+        tr_fg, src_fg = pmc_traffic("fwd_fused" if fused else "fgemm_fwd") if args.dtype == "f64" and maxm == 120 and NT == 60000 and world == 1 else (None, None)
         shortcuts_on = os.environ.get("TNML_FAST_CG", "1") != "0" or os.environ.get("TNML_REUSE_P", "1") != "0"
         out = {
             "metric": "two-site bond updates/sec" if not single else "two-site bond updates/sec (per-label variant, label %d)" % args.single_label,
@@ -457,12 +484,14 @@ def main():
                                                                                m_avg),
                        "global_images": NT, "sites": N, "maxm": maxm, "parallelism": "dp%d (image sharding + RCCL all-reduce)" % world,
                        "rccl_ranks": comm_ranks},
-            "roofline": {"bound": "mfma", "kernel": "k_fgemm64" if args.dtype != "f32" else "k_fgemm",
+            "roofline": {"bound": "mfma", "kernel": "k_fwd_fused" if fused else ("k_fgemm64" if args.dtype != "f32" else "k_fgemm"),
                          "achieved": achieved_tf, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved_tf / peak,
                          "traffic": tr_fg, "traffic_source": src_fg,
                          "avg_launch_ms": avg_ms, "launches": n_fg, "flops_per_launch": flops_per_launch, "images_per_launch": img_fg,
-                         "note": ("forward pass split over two queues: this is the launch of the first image half, which has the GPU to itself; "
+                         "note": ("k_fwd_fused = the feature GEMM (these flops) with the label dot of the previous 64-image tile running on four extra "
+                                  "waves of the same workgroup: its launch time replaces feature GEMM + label dot (kernel_ms_per_step.fwd_fused); "
+                                  "bytes streamed beside the flops: roofline_hbm") if fused else ("forward pass split over two queues: this is the launch of the first image half, which has the GPU to itself; "
                                   "the second half runs beside the label dot of the first (kernel_ms_per_step.fgemm_fwd_overlapped)") if split else None},
             "roofline_step": {"bound": "mfma", "peak": peak, "unit": "TFLOP/s",
                               "executed_gflop_per_step": exec_gf, "executed": exec_gf / ms_per_step, "frac_executed": exec_gf / ms_per_step / peak,
@@ -478,6 +507,12 @@ def main():
                 "the network outputs P_n do not depend on the bond they are evaluated at: the after-SVD quadcost of one bond update "
                 "provides the residuals of the next one's first gradient, replacing 1 forward GEMM + label dot per bond (TNML_REUSE_P=0 disables)",
             ] if shortcuts_on else [],
+            "unfused_forward": None if not unfused or not unfused.get("fgemm_fwd", (0, 0))[0] else {
+                "note": "the same forward pass as two kernels (tnml_set_option fused_fwd = 0), timed in this run on untimed extra steps",
+                "fgemm_fwd_ms_per_launch": unfused["fgemm_fwd"][1] / unfused["fgemm_fwd"][0],
+                "fgemm_fwd_frac_of_mfma_peak": flops_per_pass / (unfused["fgemm_fwd"][1] / unfused["fgemm_fwd"][0] * 1e-3) / 1e12 / peak,
+                "labeldot_ms_per_launch": unfused["labeldot"][1] / max(unfused["labeldot"][0], 1),
+                "fused_ms_per_launch": avg_ms},
             "value_literal_order": (nlit / elapsed_lit) if elapsed_lit else None,
             "literal_order_steps": nlit,
             "env_init_s": t_init,

@@ -209,7 +209,7 @@ void tnml_shard_bounds(int64_t NT_total, int nranks, int rank, int64_t* begin, i
 /* ---- measurement -------------------------------------------------------------------------- */
 /* per-kernel-class HIP-event timing on the context's stream (bench.py roofline figures) */
 int tnml_profile_enable(tnml_ctx* ctx, int on);
-/* restrict the timing to one kernel class (e.g. "fgemm_fwd"), or NULL / "" for all classes: two event
+/* restrict the timing to one kernel class (e.g. "fgemm_fwd") or a comma-separated list of classes, or NULL / "" for all classes: two event
    records per timed launch cost host time, so a throughput measurement should time only what it reports */
 int tnml_profile_select(tnml_ctx* ctx, const char* class_name);
 int tnml_profile_count(tnml_ctx* ctx);
@@ -225,6 +225,10 @@ int tnml_synchronize(tnml_ctx* ctx);
                       error; 2: rank 0's two site tensors are re-broadcast, the sweep continues, tnml_replica_repairs counts)
      "fg64_cfg", "ldot_cfg"  force a tile configuration of the feature GEMM / the label dot that is otherwise chosen by the
                       image count (2 / 1 = the large-image-count forms bench.py times; parity tests run them at small sizes)
+     "fused_fwd"      the forward pass of a Label-on-environment bond at m = 120 as one persistent kernel (feature GEMM +
+                      label dot of the previous tile, kernels_fused.hip): 1 = from 32 768 images per rank on (default),
+                      0 = never, 2 = always (parity tests at small sizes), > 2 = always with that many workgroups at most
+     "overlap"        two-queue forward pass (measured slower, default 0)
    fast_cg = reuse_p = 0 is the reference's literal evaluation order (fixedL.cc:374-421). */
 int tnml_set_option(tnml_ctx* ctx, const char* name, int value);
 /* health of the in-house eigensolver: number of fallbacks to rocSOLVER so far, number of splits whose kept basis

@@ -230,6 +230,57 @@ def test_c3_kernel_instantiations_of_the_benchmark_match_the_oracle():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("NT", [300, 1100])
+def test_fused_forward_kernel_matches_the_oracle(NT):
+    """k_fwd_fused (feature GEMM + label dot of the previous tile in one persistent workgroup; option "fused_fwd") forced at
+    an oracle-sized image count: 300 images = 8 tiles on 8 workgroups (one tile + the drain round each), 1100 images = 20 tiles
+    on 20 workgroups; with a grid cap of 4 workgroups (fused_fwd = 4) every workgroup runs several rounds.  Forward map,
+    gradient, cost / #correct, the CG (its pAp passes use the |P|^2 mode) and a bond update, for both bond kinds it serves."""
+    from oracle import pyoracle
+    from tnml_amd.fixedl import TrainStates
+    from conftest import make_problem
+    N, m = 20, 120
+    pixels, labels, phi, W = make_problem(N, NT, m, 7, pixel_boost=200.0)
+    ts = TrainStates(labels, N, m, phi=phi)
+    ts.set_option("fused_fwd", 4 if NT > 1000 else 2)
+    ts.set_mps(W)
+    ts.init()
+    o = pyoracle.Oracle(phi, labels, W, nthread=min(8, os.cpu_count() or 1))
+    o.init()
+    rng = np.random.default_rng(1)
+    at = 1
+    for b, kind in ((8, "Label on RE"), (12, "Label on LE")):
+        for bb in range(at, b):
+            ts.shiftE(bb, True); o.shiftE(bb, True)
+        at = b
+        ts.setBond(b); o.set_bond(b)
+        B = o.bond_tensor(b)
+        B = B + 0.05 * rng.standard_normal(B.shape)
+        assert _rel(ts.forward(B), o.forward(B)) < 1e-11, kind
+        assert _rel(ts.gradient(B), o.gradient(B)) < 1e-9, kind
+        Cg, lg, _, ng = ts.quadcost(B, 1e-3)
+        Co, lo, _, no = o.quadcost(B, 1e-3)
+        assert Cg == pytest.approx(Co, rel=1e-11) and ng == no, kind
+        np.testing.assert_allclose(lg, lo, rtol=1e-9, atol=1e-12 * Co)
+        Bg, tg = ts.cgrad(B, 3, 1e-3, 1e-10)
+        Bo, to = o.cgrad(B, 3, 1e-3, 1e-10)
+        np.testing.assert_allclose(tg["cost"], to["cost"], rtol=1e-9, err_msg=kind)
+        np.testing.assert_allclose(tg["alpha"], to["alpha"], rtol=1e-5, err_msg=kind)
+        assert _rel(Bg, Bo) < 1e-5, kind
+    prof0 = None
+    ts.profile(True)
+    r = ts.bond_update(12, 1, m, m // 2, 1e-10, 3, 1e-3, 1e-10)
+    ts.profile(False)
+    assert ts.profile_read()["fwd_fused"][0] > 0                      # the fused kernel really ran
+    o.set_bond(12)
+    B, _ = o.cgrad(o.bond_tensor(12), 3, 1e-3, 1e-10)
+    newm, te, _ = o.svd_split(B, 12, 1, 1e-10, m, m // 2)
+    C, lc, cr, nc = o.quadcost(o.bond_tensor(12), 1e-3)
+    assert r["newm"] == newm and r["ncorrect"] == nc and r["cost"] == pytest.approx(C, rel=1e-8)
+    ts.close()
+
+
+@pytest.mark.gpu
 def test_m60_kernel_instantiations_match_the_oracle():
     """bonds that have shrunk to minm = maxm/2 = 60 (the reference default, fixedL.cc:593) run their own tiles: 128 x 128
     feature-GEMM tiles (forced here as for C3: at 60 000 images they are the default), 128 x 64 gradient-GEMM tiles"""

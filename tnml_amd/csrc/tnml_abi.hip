@@ -46,8 +46,18 @@ int tnml_profile_enable(tnml_ctx* c, int on) { prof_resolve(c); c->prof = on != 
 int tnml_profile_select(tnml_ctx* c, const char* class_name) {
     prof_resolve(c);
     if (!class_name || !*class_name) { c->prof_mask = 0xffffffffu; return 0; }
-    for (int i = 0; i < KC_COUNT; ++i) if (!strcmp(class_name, kclass_names[i])) { c->prof_mask = 1u << i; return 0; }
-    return tnml_fail(c, "tnml_profile_select: unknown kernel class %s", class_name);
+    unsigned mask = 0;                                    // one class name, or several separated by commas
+    const char* s = class_name;
+    while (*s) {
+        const char* e = strchr(s, ',');
+        const size_t len = e ? (size_t)(e - s) : strlen(s);
+        bool found = false;
+        for (int i = 0; i < KC_COUNT; ++i) if (strlen(kclass_names[i]) == len && !strncmp(s, kclass_names[i], len)) { mask |= 1u << i; found = true; }
+        if (!found) return tnml_fail(c, "tnml_profile_select: unknown kernel class in %s", class_name);
+        s = e ? e + 1 : s + len;
+    }
+    c->prof_mask = mask;
+    return 0;
 }
 int tnml_profile_count(tnml_ctx*) { return KC_COUNT; }
 int tnml_profile_get(tnml_ctx* c, int idx, char* name64, int64_t* launches, double* total_ms) {
@@ -70,6 +80,7 @@ int tnml_set_option(tnml_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "fuse_z")) c->fuse_z = value != 0;
     else if (!strcmp(name, "check_replicas")) { c->check_replicas = value != 0; c->check_replicas_mode = value; }
     else if (!strcmp(name, "overlap")) c->overlap = value;
+    else if (!strcmp(name, "fused_fwd")) c->fused_fwd = value;
     else if (!strcmp(name, "debug_nudge_rank")) c->debug_nudge_rank = value;
     else if (!strcmp(name, "fg64_cfg")) c->opt_fg64_cfg = value;
     else if (!strcmp(name, "ldot_cfg")) c->opt_ldot_cfg = value;
@@ -208,6 +219,7 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     if (hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) != hipSuccess)
         return bail(tnml_fail(c, "hipEventCreate failed"));
     if (const char* e = getenv("TNML_OVERLAP")) c->overlap = atoi(e);
+    if (const char* e = getenv("TNML_FUSED_FWD")) c->fused_fwd = atoi(e);
     if (rocblas_create_handle(&c->blas) != rocblas_status_success) return bail(tnml_fail(c, "rocblas_create_handle failed"));
     rocblas_set_stream(c->blas, c->stream);
     // replicas of W must stay bit-identical over the ranks: no atomics-based split-K inside rocBLAS
@@ -717,6 +729,15 @@ static int forward_pass(tnml_ctx* c, const double* vec, int mode, double* tail, 
         // dot of the first half runs beside the feature GEMM of the second (each half is one round of 128-image tiles on the
         // 256 CUs).  Every image still goes through exactly the same arithmetic in the same order, and the cost partials are
         // reduced over all blocks in the fixed order afterwards: bit-identical to the single-queue form.
+        if (c->fused_fwd && c->env64() && !c->single() && p.kind != 2 && p.Kp == 240 && p.Np == 240 && p.mI == 120 && p.mO == 120 &&
+            (c->fused_fwd >= 2 || c->NTp / 64 >= 2 * 256)) {
+            FwdFusedArgs ff;
+            ff.EI = (const double*)p.EI; ff.mI = p.mI; ff.phiI = (const double*)p.phiI; ff.M = vec; ff.Kp = p.Kp; ff.Np = p.Np;
+            ff.phiO = (const double*)p.phiO; ff.EL = (const double*)p.EX; ff.EL_lstride = ustride; ff.mO = p.mO; ff.NTp = c->NTp; ff.ntiles = c->NTp / 64;
+            ff.label = c->label; ff.P = (double*)a.P; ff.dP = (double*)a.dP; ff.mode = mode; ff.partials = c->partials;
+            TCK(launch_fwd_fused(c, ff));
+            return launch_labeldot_reduce(c, ff.ntiles, tail);
+        }
         const int nblk = c->NTp / 128;
         if (c->overlap && nblk >= 2 * 192 && p.Np == 240 && c->opt_fg64_cfg == 0 && labeldot_streaming(c, c->NTp)) {
             const int b1 = (nblk + 1) / 2, b2 = nblk - b1;

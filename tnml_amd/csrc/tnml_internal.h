@@ -31,11 +31,11 @@
 
 enum KClass {
     KC_FGEMM_FWD = 0, KC_FGEMM_SHIFT, KC_LABELDOT, KC_ZPRIME, KC_BGEMM, KC_SLABRED, KC_PACK, KC_VEC,
-    KC_SMALLGEMM, KC_SVD, KC_ALLREDUCE, KC_PUPDATE, KC_FGEMM_FWD_OVL, KC_LABELDOT_OVL, KC_COUNT
+    KC_SMALLGEMM, KC_SVD, KC_ALLREDUCE, KC_PUPDATE, KC_FGEMM_FWD_OVL, KC_LABELDOT_OVL, KC_FWD_FUSED, KC_COUNT
 };
 static const char* const kclass_names[KC_COUNT] = {
     "fgemm_fwd", "fgemm_shift", "labeldot", "zprime", "bgemm", "slab_reduce", "pack", "cg_vec",
-    "small_gemm", "svd", "allreduce", "p_update", "fgemm_fwd_overlapped", "labeldot_overlapped"};
+    "small_gemm", "svd", "allreduce", "p_update", "fgemm_fwd_overlapped", "labeldot_overlapped", "fwd_fused"};
 
 struct EnvSlot {
     void* ptr = nullptr;    // [L][m][NTp], fp32 or fp64 elements (tnml_ctx::env64)
@@ -83,7 +83,8 @@ struct tnml_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // second queue: the HBM-bound label dot of one image half runs beside the MFMA-bound feature GEMM of the other
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
-    int overlap = 0;             // env TNML_OVERLAP=0 / tnml_set_option "overlap"
+    int overlap = 0;
+    int fused_fwd = 1;               // forward pass as one persistent kernel (kernels_fused.hip); env TNML_FUSED_FWD / option "fused_fwd"             // env TNML_OVERLAP=0 / tnml_set_option "overlap"
     rocblas_handle blas = nullptr;
     ncclComm_t comm = nullptr;
     struct LocalComm* local = nullptr;   // in-process communicator of ranks sharing one device (local_comm.hip)
@@ -252,6 +253,20 @@ bool labeldot_streaming(const tnml_ctx* c, int NTp);   // the 128-images-per-wor
 int launch_pupdate(tnml_ctx* c, const double* alpha_dev, double* scal_out);     // uses c->nl(), c->target()
 int launch_zprime(tnml_ctx* c, const void* EL, size_t lstride, const void* dP, void* Z, int mq, int NTp);
 int launch_features_u8(tnml_ctx* c, const uint8_t* d_pix, int N, int NT, int NTp, void* phi);
+
+// ---- kernels_fused.hip ----
+struct FwdFusedArgs {
+    const double* EI; int mI; const double* phiI;     // Label-free input environment [mI][NTp] and its site features [2][NTp]
+    const double* M; int Kp, Np;                      // bond matrix, M-layout [Kp][Np]
+    const double* phiO;                               // output-site features [2][NTp]
+    const double* EL; size_t EL_lstride;              // Label-carrying environment [10][mO][NTp]
+    int mO, NTp, ntiles;                              // ntiles = NTp / 64
+    const int* label;
+    double* P; double* dP;                            // [10][NTp], either may be null
+    int mode;                                         // LD_MODE_*
+    double* partials;                                 // [ntiles][12]
+};
+int launch_fwd_fused(tnml_ctx* c, const FwdFusedArgs& a);
 
 // ---- kernels_small.hip --------------------------------------------------------------------
 struct PackDesc {       // M[l][2x+s][TO==2 ? 2y+t : y] <-> T[off + x*sx + s*ss + y*sy + t*st + l*sl]
