@@ -15,8 +15,9 @@
 //                  GEMM's own barriers: wave s takes q = s, s+4, ..., one of them per barrier interval (two per 16-deep reduction
 //                  chunk), the loads of the next one in flight across the barrier; after the last chunk the four partial sums meet in LDS and 64
 //                  lanes finish the tile exactly like k_labeldot (dP, per-label cost partials, argmax count, |P|^2).
-//   Every wave executes the same barrier sequence (2 per chunk + 2 per tile); one extra "drain" round lets the streaming waves
-//   finish the last tile.  Deterministic: fixed summation order per image, per-tile partials reduced by k_reduce_partials.
+//   Every wave executes the same barrier sequence (2 per chunk + 2 per tile); one extra "drain" round (two barriers, no pacing) lets
+//   the streaming waves finish the last tile.  A double-buffered 8-deep variant with the chunk stream continuous across tiles was
+//   measured slower (3.75-3.79 vs 3.66-3.68 ms per bond update, profiles/r02_ab_fused_variants.txt) and is not kept.  Deterministic: fixed summation order per image, per-tile partials reduced by k_reduce_partials.
 #include "tnml_internal.h"
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -169,27 +170,17 @@ static __device__ __forceinline__ void ff_stream_role(const FwdFusedArgs& A, con
 #pragma unroll
             for (int l = 0; l < TNML_NL; ++l) px[l] = fma(e[l], u, px[l]);
         };
-        if (tile >= A.ntiles) {
-            // drain round (the GEMM waves only pass the two barriers): no pacing, three rows in flight
-            __syncthreads();
-            if (has) {
-                double ec[TNML_NL];
-                stream_load(0, ea); stream_load(1, eb);
-                for (int k = 0; k < 2 * NCH; k += 3) {               // 30 rows
-                    stream_load(k + 2 < 2 * NCH ? k + 2 : k, ec); consume(k, ea);
-                    stream_load(k + 3 < 2 * NCH ? k + 3 : k, ea); consume(k + 1, eb);
-                    stream_load(k + 4 < 2 * NCH ? k + 4 : k, eb); consume(k + 2, ec);
-                }
-            }
-        } else {
-            if (has) stream_load(0, ea);
-            __syncthreads();
-            for (int ch = 0; ch < NCH; ++ch) {
-                if (has) { stream_load(2 * ch + 1, eb); consume(2 * ch, ea); }
-                __syncthreads();
-                if (has) { if (ch + 1 < NCH) stream_load(2 * ch + 2, ea); consume(2 * ch + 1, eb); }
-                __syncthreads();
-            }
+        // one loop for both kinds of round (a separate drain loop made the register allocator spill): in the drain round (the GEMM
+        // waves only pass its two barriers) the rows follow each other without pacing, otherwise one row per barrier interval
+        const bool drain = tile >= A.ntiles;
+        if (has) stream_load(0, ea);
+        __syncthreads();
+#pragma unroll 1
+        for (int ch = 0; ch < NCH; ++ch) {
+            if (has) { stream_load(2 * ch + 1, eb); consume(2 * ch, ea); }
+            if (!drain) __syncthreads();
+            if (has) { if (ch + 1 < NCH) stream_load(2 * ch + 2, ea); consume(2 * ch + 1, eb); }
+            if (!drain) __syncthreads();
         }
         if (has) {
 #pragma unroll
