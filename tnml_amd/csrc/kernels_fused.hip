@@ -170,17 +170,28 @@ static __device__ __forceinline__ void ff_stream_role(const FwdFusedArgs& A, con
 #pragma unroll
             for (int l = 0; l < TNML_NL; ++l) px[l] = fma(e[l], u, px[l]);
         };
-        // one loop for both kinds of round (a separate drain loop made the register allocator spill): in the drain round (the GEMM
-        // waves only pass its two barriers) the rows follow each other without pacing, otherwise one row per barrier interval
-        const bool drain = tile >= A.ntiles;
-        if (has) stream_load(0, ea);
-        __syncthreads();
-#pragma unroll 1
-        for (int ch = 0; ch < NCH; ++ch) {
-            if (has) { stream_load(2 * ch + 1, eb); consume(2 * ch, ea); }
-            if (!drain) __syncthreads();
-            if (has) { if (ch + 1 < NCH) stream_load(2 * ch + 2, ea); consume(2 * ch + 1, eb); }
-            if (!drain) __syncthreads();
+        if (tile >= A.ntiles) {
+            // drain round (the GEMM waves only pass the two barriers): no pacing, three rows in flight -- with two the round is
+            // latency bound and a forward pass 30 us longer (this loop costs 25 spilled VGPRs, used here only)
+            __syncthreads();
+            if (has) {
+                double ec[TNML_NL];
+                stream_load(0, ea); stream_load(1, eb);
+                for (int k = 0; k < 2 * NCH; k += 3) {               // 30 rows
+                    stream_load(k + 2 < 2 * NCH ? k + 2 : k, ec); consume(k, ea);
+                    stream_load(k + 3 < 2 * NCH ? k + 3 : k, ea); consume(k + 1, eb);
+                    stream_load(k + 4 < 2 * NCH ? k + 4 : k, eb); consume(k + 2, ec);
+                }
+            }
+        } else {
+            if (has) stream_load(0, ea);
+            __syncthreads();
+            for (int ch = 0; ch < NCH; ++ch) {
+                if (has) { stream_load(2 * ch + 1, eb); consume(2 * ch, ea); }
+                __syncthreads();
+                if (has) { if (ch + 1 < NCH) stream_load(2 * ch + 2, ea); consume(2 * ch + 1, eb); }
+                __syncthreads();
+            }
         }
         if (has) {
 #pragma unroll
