@@ -64,84 +64,87 @@ static __device__ __forceinline__ void ff_gemm_role(const FwdFusedArgs& A, doubl
     constexpr int NM = (NMI + FF_NMMA - 1) / FF_NMMA;       // 3
     constexpr int NCH = 240 / FF_KT;                        // 15 chunks
     const int xc4 = tid % (FF_BM / 4), xar = tid / (FF_BM / 4);
-    for (int tile = blockIdx.x; tile < A.ntiles + G; tile += G) {
-        const bool has = tile < A.ntiles;
-        if (!has) { __syncthreads(); __syncthreads(); continue; }     // drain round: the streaming waves run free between two barriers
-        const int n0 = tile * FF_BM;
-        f64x4 acc[FF_CT];
-#pragma unroll
-        for (int c = 0; c < FF_CT; ++c) acc[c] = f64x4{0., 0., 0., 0.};
-        double xr[4] = {0., 0., 0., 0.}; double2 mr[NM];
-        double p0[4] = {0., 0., 0., 0.}, p1[4] = {0., 0., 0., 0.};
-        if (has && tid < NXI) {
+    const int g = lane >> 4;
+    double xr[4] = {0., 0., 0., 0.}; double2 mr[NM];
+    double p0[4] = {0., 0., 0., 0.}, p1[4] = {0., 0., 0., 0.};
+    auto load_phi = [&](int n0) {
+        if (tid < NXI) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { p0[e] = A.phiI[n0 + xc4 * 4 + e]; p1[e] = A.phiI[NTp + n0 + xc4 * 4 + e]; }
         }
-        auto load_chunk = [&](int k0) {
-            if (tid < NXI) {
-                const int a = k0 / 2 + xar;
-                const double2 ea = ld2(A.EI + (size_t)a * NTp + n0 + xc4 * 4), eb = ld2(A.EI + (size_t)a * NTp + n0 + xc4 * 4 + 2);
-                xr[0] = ea.x; xr[1] = ea.y; xr[2] = eb.x; xr[3] = eb.y;
-            }
+    };
+    auto load_chunk = [&](int n0, int k0) {
+        if (tid < NXI) {
+            const int a = k0 / 2 + xar;
+            const double2 ea = ld2(A.EI + (size_t)a * NTp + n0 + xc4 * 4), eb = ld2(A.EI + (size_t)a * NTp + n0 + xc4 * 4 + 2);
+            xr[0] = ea.x; xr[1] = ea.y; xr[2] = eb.x; xr[3] = eb.y;
+        }
 #pragma unroll
-            for (int q = 0; q < NM; ++q) {
-                const int idx = tid + q * FF_NMMA;
-                const int r = idx / (FF_BN / 2), c2 = idx % (FF_BN / 2);
-                mr[q] = make_double2(0., 0.);
-                if (idx < NMI) mr[q] = ld2(A.M + (size_t)(k0 + r) * A.Np + c2 * 2);
-            }
-        };
-        auto store_chunk = [&]() {
-            if (tid < NXI) {
-                double* x0 = &Xs[(2 * xar) * FF_XS + xc4 * 4];
-                double* x1 = &Xs[(2 * xar + 1) * FF_XS + xc4 * 4];
-                *reinterpret_cast<double2*>(x0) = make_double2(xr[0] * p0[0], xr[1] * p0[1]);
-                *reinterpret_cast<double2*>(x0 + 2) = make_double2(xr[2] * p0[2], xr[3] * p0[3]);
-                *reinterpret_cast<double2*>(x1) = make_double2(xr[0] * p1[0], xr[1] * p1[1]);
-                *reinterpret_cast<double2*>(x1 + 2) = make_double2(xr[2] * p1[2], xr[3] * p1[3]);
-            }
+        for (int q = 0; q < NM; ++q) {
+            const int idx = tid + q * FF_NMMA;
+            const int r = idx / (FF_BN / 2), c2 = idx % (FF_BN / 2);
+            mr[q] = make_double2(0., 0.);
+            if (idx < NMI) mr[q] = ld2(A.M + (size_t)(k0 + r) * A.Np + c2 * 2);
+        }
+    };
+    auto store_chunk = [&]() {
+        if (tid < NXI) {
+            double* x0 = &Xs[(2 * xar) * FF_XS + xc4 * 4];
+            double* x1 = &Xs[(2 * xar + 1) * FF_XS + xc4 * 4];
+            *reinterpret_cast<double2*>(x0) = make_double2(xr[0] * p0[0], xr[1] * p0[1]);
+            *reinterpret_cast<double2*>(x0 + 2) = make_double2(xr[2] * p0[2], xr[3] * p0[3]);
+            *reinterpret_cast<double2*>(x1) = make_double2(xr[0] * p1[0], xr[1] * p1[1]);
+            *reinterpret_cast<double2*>(x1 + 2) = make_double2(xr[2] * p1[2], xr[3] * p1[3]);
+        }
 #pragma unroll
-            for (int q = 0; q < NM; ++q) {
-                const int idx = tid + q * FF_NMMA;
-                if (idx < NMI) { const int r = idx / (FF_BN / 2), c2 = idx % (FF_BN / 2); *reinterpret_cast<double2*>(&Ms[r * FF_MS + c2 * 2]) = mr[q]; }
-            }
-        };
-        if (has) { load_chunk(0); store_chunk(); }
+        for (int q = 0; q < NM; ++q) {
+            const int idx = tid + q * FF_NMMA;
+            if (idx < NMI) { const int r = idx / (FF_BN / 2), c2 = idx % (FF_BN / 2); *reinterpret_cast<double2*>(&Ms[r * FF_MS + c2 * 2]) = mr[q]; }
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < A.ntiles) { load_phi(tile * FF_BM); load_chunk(tile * FF_BM, 0); }
+    for (; tile < A.ntiles + G; tile += G) {
+        const bool has = tile < A.ntiles;
+        if (!has) { __syncthreads(); __syncthreads(); continue; }     // drain round: the streaming waves run free between two barriers
+        const int n0 = tile * FF_BM;
+        const bool has_next = tile + G < A.ntiles;
+        // the output-site feature of this lane's image, needed by the epilogue: fetched now, off the tile's critical path
+        const double ph = A.phiO[(size_t)(g & 1) * NTp + n0 + wr * 16 + (lane & 15)];
+        f64x4 acc[FF_CT];
+#pragma unroll
+        for (int c = 0; c < FF_CT; ++c) acc[c] = f64x4{0., 0., 0., 0.};
+        store_chunk();                                       // chunk 0: its loads were issued before the previous tile's epilogue
         __syncthreads();
         for (int ch = 0; ch < NCH; ++ch) {
-            if (has) {
-                if (ch + 1 < NCH) load_chunk((ch + 1) * FF_KT);
+            if (ch + 1 < NCH) load_chunk(n0, (ch + 1) * FF_KT);
 #pragma unroll
-                for (int ks = 0; ks < FF_KT / 4; ++ks) {
-                    const int krow = 4 * ks + (lane >> 4);
-                    const double xf = Xs[krow * FF_XS + wr * 16 + (lane & 15)];
+            for (int ks = 0; ks < FF_KT / 4; ++ks) {
+                const int krow = 4 * ks + (lane >> 4);
+                const double xf = Xs[krow * FF_XS + wr * 16 + (lane & 15)];
 #pragma unroll
-                    for (int c = 0; c < FF_CT; ++c) {
-                        const double mf = Ms[krow * FF_MS + (wc * FF_CT + c) * 16 + (lane & 15)];
-                        acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(mf, xf, acc[c], 0, 0, 0);
-                    }
+                for (int c = 0; c < FF_CT; ++c) {
+                    const double mf = Ms[krow * FF_MS + (wc * FF_CT + c) * 16 + (lane & 15)];
+                    acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(mf, xf, acc[c], 0, 0, 0);
                 }
             }
             __syncthreads();                                 // every GEMM wave is done reading this chunk
-            if (has && ch + 1 < NCH) store_chunk();
+            if (ch + 1 < NCH) store_chunk();
             __syncthreads();
         }
-        if (has) {
-            // lane (g = lane>>4, i = lane&15) holds rows g+4e of column tile c for image i; rows 2q, 2q+1 (site index t = 0,1 of
-            // output link q) sit on lane groups g and g^1
-            const int g = lane >> 4;
-            const int n = n0 + wr * 16 + (lane & 15);
-            const double ph = A.phiO[(size_t)(g & 1) * NTp + n];
+        // the first chunk of this workgroup's next tile: its loads fly during the epilogue and the tile barrier
+        if (has_next) { load_phi((tile + G) * FF_BM); load_chunk((tile + G) * FF_BM, 0); }
+        // lane (g = lane>>4, i = lane&15) holds rows g+4e of column tile c for image i; rows 2q, 2q+1 (site index t = 0,1 of
+        // output link q) sit on lane groups g and g^1
 #pragma unroll
-            for (int c = 0; c < FF_CT; ++c)
+        for (int c = 0; c < FF_CT; ++c)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int j = (wc * FF_CT + c) * 16 + g + 4 * e;
-                    double v = acc[c][e] * ph;
-                    v += __shfl_xor(v, 16);
-                    if ((g & 1) == 0) Ub[(j >> 1) * FF_BM + wr * 16 + (lane & 15)] = v;
-                }
-        }
+            for (int e = 0; e < 4; ++e) {
+                const int j = (wc * FF_CT + c) * 16 + g + 4 * e;
+                double v = acc[c][e] * ph;
+                v += __shfl_xor(v, 16);
+                if ((g & 1) == 0) Ub[(j >> 1) * FF_BM + wr * 16 + (lane & 15)] = v;
+            }
         __syncthreads();
     }
 }
