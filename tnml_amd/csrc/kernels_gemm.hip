@@ -1041,8 +1041,15 @@ static int bgemm64_go(tnml_ctx* c, const Bgemm64Args& a, double* G, int default_
     return 0;
 }
 
+void launch_slab_reduce64(tnml_ctx* c, const double* slab, double* G, size_t n, int nsplit) {
+    hipLaunchKernelGGL(k_slab_reduce64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, slab, G, n, nsplit);
+}
+
 int launch_bgemm64(tnml_ctx* c, const Bgemm64Args& a, double* G) {
     static const int cfg = getenv("TNML_BG64_CFG") ? atoi(getenv("TNML_BG64_CFG")) : 0;
+    // producer / consumer form (kernels_fused.hip) for the shape of BASELINE config 3 when the images fill the chip
+    if (c->bgemm_ps && a.EL && a.dPz && a.env64 && !a.w && a.Kp == 240 && a.Np == 240 && a.L == 1 && a.mI == 120 && a.mO == 120 &&
+        (c->bgemm_ps >= 2 || a.NTp >= 128 * 192)) return launch_bgemm_ps(c, a, G);
     if (a.EL) {                                             // fused Z build: >= 320 lanes per workgroup
         static const int fcfg = getenv("TNML_BGF_CFG") ? atoi(getenv("TNML_BGF_CFG")) : 0;
         if (a.Kp % 240 == 0 && a.Np % 240 == 0) {

@@ -81,6 +81,7 @@ int tnml_set_option(tnml_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "check_replicas")) { c->check_replicas = value != 0; c->check_replicas_mode = value; }
     else if (!strcmp(name, "overlap")) c->overlap = value;
     else if (!strcmp(name, "fused_fwd")) c->fused_fwd = value;
+    else if (!strcmp(name, "bgemm_ps")) c->bgemm_ps = value;
     else if (!strcmp(name, "debug_nudge_rank")) c->debug_nudge_rank = value;
     else if (!strcmp(name, "fg64_cfg")) c->opt_fg64_cfg = value;
     else if (!strcmp(name, "ldot_cfg")) c->opt_ldot_cfg = value;
@@ -220,6 +221,7 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
         return bail(tnml_fail(c, "hipEventCreate failed"));
     if (const char* e = getenv("TNML_OVERLAP")) c->overlap = atoi(e);
     if (const char* e = getenv("TNML_FUSED_FWD")) c->fused_fwd = atoi(e);
+    if (const char* e = getenv("TNML_BGEMM_PS")) c->bgemm_ps = atoi(e);
     if (rocblas_create_handle(&c->blas) != rocblas_status_success) return bail(tnml_fail(c, "rocblas_create_handle failed"));
     rocblas_set_stream(c->blas, c->stream);
     // replicas of W must stay bit-identical over the ranks: no atomics-based split-K inside rocBLAS

@@ -84,7 +84,8 @@ struct tnml_ctx {
     hipStream_t stream2 = nullptr;   // second queue: the HBM-bound label dot of one image half runs beside the MFMA-bound feature GEMM of the other
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     int overlap = 0;
-    int fused_fwd = 1;               // forward pass as one persistent kernel (kernels_fused.hip); env TNML_FUSED_FWD / option "fused_fwd"             // env TNML_OVERLAP=0 / tnml_set_option "overlap"
+    int fused_fwd = 1;
+    int bgemm_ps = 0;                // gradient GEMM with producer / consumer waves (kernels_fused.hip); env TNML_BGEMM_PS / option "bgemm_ps"               // forward pass as one persistent kernel (kernels_fused.hip); env TNML_FUSED_FWD / option "fused_fwd"             // env TNML_OVERLAP=0 / tnml_set_option "overlap"
     rocblas_handle blas = nullptr;
     ncclComm_t comm = nullptr;
     struct LocalComm* local = nullptr;   // in-process communicator of ranks sharing one device (local_comm.hip)
@@ -228,6 +229,8 @@ struct Bgemm64Args {
     int env64;
 };
 int launch_bgemm64(tnml_ctx* c, const Bgemm64Args& a, double* G);
+int launch_bgemm_ps(tnml_ctx* c, const Bgemm64Args& a, double* G);      // kernels_fused.hip: producer / consumer waves
+void launch_slab_reduce64(tnml_ctx* c, const double* slab, double* G, size_t n, int nsplit);
 
 // ---- kernels_stream.hip -------------------------------------------------------------------
 enum { LD_MODE_COST = 0, LD_MODE_PAP = 1, LD_MODE_FWD = 2 };
