@@ -27,6 +27,8 @@ struct TriArgs {
     double* D; double* E; double* tau;   // outputs: diagonal n, subdiagonal n-1, tau n-1
     double* V; int ldv;                  // Householder vectors: column k holds v_k (v_k[k+1] = 1, zeros above)
     long long* dbg;                      // TNML_EIGH_PROF builds: per-phase cycle counters
+    double* nref;                        // out (may be null): number of reflectors formed (n-1 unless k_sytrd_v3 stopped early)
+    double psd_tol;                      // k_sytrd_v3, positive semidefinite input only: stop once trace(trailing block) <= psd_tol * trace(A); 0 = never
 };
 
 __global__ __launch_bounds__(512) void k_sytrd_onewg(TriArgs T) {
@@ -183,6 +185,7 @@ __global__ __launch_bounds__(512) void k_sytrd_onewg(TriArgs T) {
 #ifdef TNML_EIGH_PROF
     if (tid == 0 && T.dbg) { for (int i = 0; i < 6; ++i) T.dbg[i] = prof[i]; T.dbg[6] = wall_clock64() - w0; }
 #endif
+    if (tid == 0 && T.nref) T.nref[0] = (double)(n - 1);
     // last diagonal entry
     const int kl = n - 1;
     if (owner && C == kl / TB && R == C && u == (kl % TB) / TU) {
@@ -374,7 +377,7 @@ __global__ __launch_bounds__(512) void k_sytrd_v2(TriArgs T) {
 #ifdef TNML_EIGH_PROF
     if (tid == 0 && T.dbg) for (int i = 0; i < 6; ++i) T.dbg[i] = prof[i];
 #endif
-    if (tid == 0) T.D[n - 1] = s_x[(n - 1) & 1][n - 1];
+    if (tid == 0) { T.D[n - 1] = s_x[(n - 1) & 1][n - 1]; if (T.nref) T.nref[0] = (double)(n - 1); }
 }
 
 // ==========================================================================================
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(512) void k_sytrd_v2(TriArgs T) {
 // Two barriers per step as before; same Householder convention as the other two kernels (LAPACK dlarfg).
 // ==========================================================================================
 #define V3_LD 242
-#define V3_SMEM_DOUBLES (T8_MAXNB * V3_LD + 240 + 240 + 2 * 240 + 16)
+#define V3_SMEM_DOUBLES (T8_MAXNB * V3_LD + 240 + 240 + 2 * 240 + 32)
 static __device__ __forceinline__ double lane_bcast(double x, int l) {          // l uniform
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
@@ -404,7 +407,7 @@ __global__ __launch_bounds__(512) void k_sytrd_v3(TriArgs T) {
     double* s_v = Y + T8_MAXNB * V3_LD;                 // [240]
     double* s_w = s_v + 240;                            // [240]
     double* s_xo = s_w + 240;                           // [2][240]
-    double* s_red = s_xo + 480;                         // [8]
+    double* s_red = s_xo + 480;                         // [32]: 0..7 v^T A v partials, 8 tau, 9 exact-trace flag, 16..23 trailing-trace partials, 24..31 trace(A) partials
     const int n = T.n, nb = (n + T8 - 1) / T8;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int nblocks = nb * (nb + 1) / 2;
@@ -430,7 +433,28 @@ __global__ __launch_bounds__(512) void k_sytrd_v3(TriArgs T) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) { const int i = lane + 64 * e; x[e] = i < n ? T.A[i] : 0.; v[e] = 0.; }
     if (tid < 240) { s_v[tid] = 0.; s_w[tid] = 0.; s_xo[tid] = 0.; s_xo[240 + tid] = 0.; }
+    {   // trace(A) (rank-adaptive early exit below)
+        double dg = 0.;
+        if (owner && R == C) {
+#pragma unroll
+            for (int r = 0; r < T8; ++r) dg += a[r][r];
+        }
+        dg = wave_sum(dg);
+        if (lane == 0) s_red[24 + wid] = dg;
+    }
     __syncthreads();
+    double t0 = 0.;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) t0 += s_red[24 + w];
+    // Rank-adaptive exit (psd_tol > 0, positive semidefinite A): the trailing block A_k[k+1:, k+1:] of a PSD matrix is PSD, so
+    // every entry of it is bounded by its trace.  The trace follows the recursion t_{k+1} = t_k - d_k (a similarity leaves the
+    // trace alone); once that estimate is within 100x of the threshold the diagonal is summed exactly each step, and when the
+    // exact trace is <= psd_tol * trace(A) the block is dropped: D, E, tau of the remaining rows are zero and T.nref says how many
+    // reflectors exist.  A bond tensor B_old + (a few CG corrections) has numerical rank ~ m + 10 of n = 2m, so its Gram matrix
+    // stops after ~half of the n-2 steps of this latency-bound chain (profiles/r02_sytrd_early_exit.txt).
+    const double t_exit = T.psd_tol * t0, t_screen = 100. * t_exit;
+    double trem = t0;                                   // trace(A_k[k:, k:]), tracked by the live waves
+    int kexit = -1;
 #ifdef TNML_EIGH_PROF
     long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tlast = clock64();
     const int pw = T.dbg ? (int)T.dbg[7] : 0;
@@ -446,6 +470,7 @@ __global__ __launch_bounds__(512) void k_sytrd_v3(TriArgs T) {
         const int kb = (k + 1) / T8;
         const bool live = cmax >= kb || wid == 7;       // uniform per wave; wave 7 (holds the last block) is live to the end
         double tau = 0.;
+        bool need_exact = false;
         if (live) {
             // ---- A: Householder scalars and v, redundantly per live wave, from the column in registers.  x is zero above
             //      row k; element k is the diagonal entry, element k+1 is alpha.
@@ -489,11 +514,14 @@ __global__ __launch_bounds__(512) void k_sytrd_v3(TriArgs T) {
                 v[e] = (e == e1 && at1) ? 1. : xt[e] * scale;
                 if (e < 3 || lane < 48) s_v[lane + 64 * e] = v[e];    // identical values from every live wave
             }
-            if (lane == 0) s_red[8] = tau;                            // for the retired waves
+            const double dk = lane_bcast(xd, l0);
+            trem -= dk;                                               // trace of rows k+1.. (before and after this step's update)
+            need_exact = T.psd_tol > 0. && trem <= t_screen;
+            if (lane == 0) { s_red[8] = tau; s_red[9] = need_exact ? 1. : 0.; }   // for the retired waves
             if (wid == 7) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { const int i = lane + 64 * e; if (i < n) T.V[i + (size_t)T.ldv * k] = v[e]; }
-                if (lane == 0) { T.D[k] = lane_bcast(xd, l0); T.E[k] = beta; T.tau[k] = tau; }
+                if (lane == 0) { T.D[k] = dk; T.E[k] = beta; T.tau[k] = tau; }
             }
             wave_lds_fence();
         }
@@ -545,11 +573,27 @@ __global__ __launch_bounds__(512) void k_sytrd_v3(TriArgs T) {
             }
             q = wave_sum(q);
             if (lane == 0) s_red[wid] = q;
-        } else if (lane == 0) s_red[wid] = 0.;
+            if (need_exact) {                                         // uniform over the live waves
+                double dg = 0.;
+                if (owner && R == C && C >= kb) {
+#pragma unroll
+                    for (int r = 0; r < T8; ++r) dg += (i0 + r >= k + 1) ? a[r][r] : 0.;
+                }
+                dg = wave_sum(dg);
+                if (lane == 0) s_red[16 + wid] = dg;
+            }
+        } else if (lane == 0) { s_red[wid] = 0.; s_red[16 + wid] = 0.; }
         TP3(1);
         __syncthreads();
         TP3(2);
         tau = s_red[8];                                               // uniform over the workgroup
+        if (s_red[9] != 0.) {
+            double te = 0.;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) te += s_red[16 + w];
+            trem = te;                                                // the exact value replaces the recursion
+            if (te <= t_exit) { kexit = k; break; }                   // uniform: reflector k exists, rows k+1.. are dropped
+        }
         if (tau != 0.) {
             // ---- C: y_i = sum_c Y[c][i] by two lanes per row, w_i = tau y_i - tau^2/2 (v^T A v) v_i
             {
@@ -610,12 +654,15 @@ __global__ __launch_bounds__(512) void k_sytrd_v3(TriArgs T) {
 #ifdef TNML_EIGH_PROF
     if (wid == pw && lane == 0 && T.dbg) for (int i = 0; i < 6; ++i) T.dbg[i] = prof[i];
 #endif
-    {
+    if (kexit >= 0) {
+        for (int i = kexit + 1 + tid; i < n; i += 512) { T.D[i] = 0.; if (i < n - 1) { T.E[i] = 0.; T.tau[i] = 0.; } }
+        if (tid == 0 && T.nref) T.nref[0] = (double)(kexit + 1);
+    } else {
         const int kl = n - 1;
         double xl;
         switch (kl >> 6) { case 0: xl = x[0]; break; case 1: xl = x[1]; break; case 2: xl = x[2]; break; default: xl = x[3]; break; }
         const double dl = lane_bcast(xl, kl & 63);
-        if (tid == 7 * 64) T.D[kl] = dl;                              // wave 7 is live to the end
+        if (tid == 7 * 64) { T.D[kl] = dl; if (T.nref) T.nref[0] = (double)(n - 1); }   // wave 7 is live to the end
     }
 }
 
@@ -623,12 +670,13 @@ __global__ __launch_bounds__(512) void k_sytrd_v3(TriArgs T) {
 // reflectors are fetched 8 at a time so that the L2 latency of V is paid once per 8 dependent updates.
 #define BT_PF 8
 __global__ __launch_bounds__(64) void k_backtransform(const double* __restrict__ V, int ldv, const double* __restrict__ tau, int n,
-                                                     const double* __restrict__ Z, int ldz, double* __restrict__ U, int ldu) {
+                                                     const double* __restrict__ Z, int ldz, double* __restrict__ U, int ldu, const double* __restrict__ nrefp) {
     const int c = blockIdx.x, lane = threadIdx.x;
     double z[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) { const int i = lane + 64 * e; z[e] = i < n ? (Z ? Z[i + (size_t)ldz * c] : (i == c ? 1. : 0.)) : 0.; }   // Z == nullptr: the identity (forms H_0 ... H_{n-2} itself)
-    for (int k0 = n - 2; k0 >= 0; k0 -= BT_PF) {
+    const int nr = nrefp ? (int)nrefp[0] : n - 1;                      // reflectors 0 .. nr-1 exist (k_sytrd_v3 may stop early)
+    for (int k0 = nr - 1; k0 >= 0; k0 -= BT_PF) {
         double v[BT_PF][4], t[BT_PF];
 #pragma unroll
         for (int q = 0; q < BT_PF; ++q) {
@@ -746,10 +794,19 @@ __global__ __launch_bounds__(64) void k_backtransform_wy(const double* __restric
     for (int e = 0; e < 4; ++e) { const int i = lane + 64 * e; if (i < n) U[i + (size_t)ldu * c] = z[e]; }
 }
 
-// A (n x n symmetric, device) -> D, E, tau, V on the context's stream.  n <= TRI_MAXN.
-int eigh_tridiagonalize(tnml_ctx* c, const double* A, int n, double* D, double* E, double* tau, double* V) {
+static bool bt_wy_enabled() {
+    static const int wy = getenv("TNML_BT_WY") ? atoi(getenv("TNML_BT_WY")) : 0;   // measured slower than the one-reflector-at-a-time kernel (profiles/r02_ab_bt_wy.txt), off
+    return wy != 0;
+}
+// A (n x n symmetric, device) -> D, E, tau, V on the context's stream.  n <= TRI_MAXN.  `tau` has room for n doubles: tau[n-1]
+// receives the number of reflectors formed, which eigh_backtransform reads back on the device.  psd_tol > 0 promises a positive
+// semidefinite A (a Gram matrix) and lets k_sytrd_v3 stop once the trailing block's trace is <= psd_tol * trace(A).
+int eigh_tridiagonalize(tnml_ctx* c, const double* A, int n, double* D, double* E, double* tau, double* V, double psd_tol) {
     if (n > TRI_MAXN) return tnml_fail(c, "eigh_tridiagonalize: n=%d exceeds %d", n, TRI_MAXN);
-    TriArgs t{A, n, n, D, E, tau, V, n, nullptr};
+    static const double tol_env = getenv("TNML_SYTRD_TOL") ? atof(getenv("TNML_SYTRD_TOL")) : -1.;
+    if (tol_env >= 0.) psd_tol = psd_tol > 0. ? tol_env : 0.;
+    if (bt_wy_enabled()) psd_tol = 0.;                 // the compact-WY back transformation reads every reflector column
+    TriArgs t{A, n, n, D, E, tau, V, n, nullptr, tau + (n - 1), psd_tol};
     static const int ver = getenv("TNML_SYTRD") ? atoi(getenv("TNML_SYTRD")) : 3;
     if (ver == 3) {
         static const bool attr_set = (hipFuncSetAttribute(reinterpret_cast<const void*>(k_sytrd_v3), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -773,7 +830,7 @@ int eigh_tridiagonalize(tnml_ctx* c, const double* A, int n, double* D, double* 
     return 0;
 }
 int eigh_backtransform(tnml_ctx* c, const double* V, const double* tau, int n, const double* Z, int ldz, double* U, int ldu, int ncols, hipStream_t st) {
-    static const int wy = getenv("TNML_BT_WY") ? atoi(getenv("TNML_BT_WY")) : 0;   // measured slower than the one-reflector-at-a-time kernel (profiles/r02_ab_bt_wy.txt), off
+    const bool wy = bt_wy_enabled();
     if (wy && Z && c->sBT && n <= 256) {
         const int nblk = (n - 1 + BTW - 1) / BTW;
         hipLaunchKernelGGL(k_bt_tfactors, dim3(nblk), dim3(64), 0, st ? st : c->stream, V, n, tau, n, c->sBT);
@@ -781,7 +838,7 @@ int eigh_backtransform(tnml_ctx* c, const double* V, const double* tau, int n, c
         HIPCK(c, hipGetLastError());
         return 0;
     }
-    hipLaunchKernelGGL(k_backtransform, dim3(ncols), dim3(64), 0, st ? st : c->stream, V, n, tau, n, Z, ldz, U, ldu);
+    hipLaunchKernelGGL(k_backtransform, dim3(ncols), dim3(64), 0, st ? st : c->stream, V, n, tau, n, Z, ldz, U, ldu, tau + (n - 1));
     HIPCK(c, hipGetLastError());
     return 0;
 }

@@ -115,7 +115,7 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
     const double* evals = c->sD;                          // ascending eigenvalues of rho
     double* qh = nullptr;                                 // H_0 ... H_{n-2}, formed beside the tridiagonal eigenproblem
     if (tri) {
-        TCK(eigh_tridiagonalize(c, c->sG, n, c->sD, c->sE2, c->sTau, c->sV));
+        TCK(eigh_tridiagonalize(c, c->sG, n, c->sD, c->sE2, c->sTau, c->sV, 1e-15));   // sG is a Gram matrix: rank-adaptive exit at ~4 eps trace(G), the size of the error G = B^T B carries anyway
         // The reflectors are known as soon as the tridiagonalisation ends, the eigenvectors of T only ~200 us later: the product
         // H_0 ... H_{n-2} is formed on the second queue meanwhile (n independent columns, the same latency chain as the back
         // transformation of the eigenvectors), and the back transformation itself becomes one dgemm.
@@ -177,6 +177,10 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
     HIPCK(c, hipMemcpyAsync(h, evals, sizeof(double) * nev, hipMemcpyDeviceToHost, st));
     HIPCK(c, hipStreamSynchronize(st));
     if (own_eig) { hd[0] = h[n]; hd[1] = h[n + 1]; hd[2] = h[n + 2]; }
+    if (const char* pe = getenv("TNML_SVD_PRINT")) {                           // debugging aid: the spectrum of one call
+        static int calls = 0;
+        if (calls++ == atoi(pe)) { fprintf(stderr, "svd_spectrum n=%d:", n); for (int g = 0; g < n; ++g) fprintf(stderr, " %.3e", h[n - 1 - g]); fprintf(stderr, "\n"); }
+    }
     std::vector<double> p(n), sig(n);
     for (int g = 0; g < n; ++g) { double lam = h[n - 1 - g]; if (!(lam > 0.)) lam = 0.; p[g] = lam; sig[g] = std::sqrt(lam); }
     double te = 0.;

@@ -293,7 +293,7 @@ int launch_nudge(tnml_ctx* c, double* p);
 int launch_fingerprint(tnml_ctx* c, const double* x, size_t n, unsigned long long salt, unsigned long long* acc, bool reset);
 
 // ---- eigh.hip -----------------------------------------------------------------------------
-int eigh_tridiagonalize(tnml_ctx* c, const double* A, int n, double* D, double* E, double* tau, double* V);
+int eigh_tridiagonalize(tnml_ctx* c, const double* A, int n, double* D, double* E, double* tau, double* V, double psd_tol = 0.);   // tau: n doubles, tau[n-1] = number of reflectors
 int eigh_tridiag_eig(tnml_ctx* c, const double* D, const double* E, int n, double* W, int mk, double* Z, int ldz, double* scratch);
 int eigh_ns_matrix(tnml_ctx* c, const double* S, double* Cm, int m, double* dev);
 int eigh_chol_rinv(tnml_ctx* c, const double* S, int m, double* Rinv, double* flag);   // m <= 136
