@@ -1233,7 +1233,7 @@ __global__ __launch_bounds__(256) void k_chol_rinv_blocked(const double* __restr
             const int i = CQ_T * ti + r, j = CQ_T * tj + cc;
             a[r][cc] = (i < m && j < m && tj <= ti) ? S[i + (size_t)m * j] : (i == j ? 1. : 0.);
         }
-    {   // orthonormal already (max |S - I| < 1e-9): R = I, nothing to factor
+    {   // orthonormal already (max |S - I| < 5e-7): R = I, nothing to factor
         __shared__ double s_dev[4];
         double dv = 0.;
 #pragma unroll
@@ -1245,7 +1245,8 @@ __global__ __launch_bounds__(256) void k_chol_rinv_blocked(const double* __restr
         if ((tid & 63) == 0) s_dev[tid >> 6] = dv;
         __syncthreads();
         dv = fmax(fmax(s_dev[0], s_dev[1]), fmax(s_dev[2], s_dev[3]));
-        if (dv < 1e-9) {
+        if (tid == 0) flag[2] = dv;                                  // max |S - I| of the incoming basis (diagnostic)
+        if (dv < 5e-7) {                                             // the caller's Newton-Schulz step takes d to 3/4 d^2 < 2e-13
 #pragma unroll
             for (int r = 0; r < CQ_T; ++r)
 #pragma unroll

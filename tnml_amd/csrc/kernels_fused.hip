@@ -53,6 +53,8 @@ static __device__ __forceinline__ void tile_partials(double val, int lab, int co
     (void)s_part;
 }
 
+// physical tile of the t-th tile a workgroup visits: the traversal direction alternates between passes (FwdFusedArgs::rev)
+#define FF_PT(t) (A.rev ? A.ntiles - 1 - (t) : (t))
 #define FF_LDS_DOUBLES (FF_KT * FF_XS + FF_KT * FF_MS + FF_MO * FF_BM + 4 * TNML_NL * FF_BM)
 
 // the 12 GEMM waves of a workgroup: all tiles of this workgroup, then one drain round (barriers only)
@@ -103,11 +105,11 @@ static __device__ __forceinline__ void ff_gemm_role(const FwdFusedArgs& A, doubl
         }
     };
     int tile = blockIdx.x;
-    if (tile < A.ntiles) { load_phi(tile * FF_BM); load_chunk(tile * FF_BM, 0); }
+    if (tile < A.ntiles) { load_phi(FF_PT(tile) * FF_BM); load_chunk(FF_PT(tile) * FF_BM, 0); }
     for (; tile < A.ntiles + G; tile += G) {
         const bool has = tile < A.ntiles;
         if (!has) { __syncthreads(); __syncthreads(); continue; }     // drain round: the streaming waves run free between two barriers
-        const int n0 = tile * FF_BM;
+        const int n0 = FF_PT(tile) * FF_BM;
         const bool has_next = tile + G < A.ntiles;
         // the output-site feature of this lane's image, needed by the epilogue: fetched now, off the tile's critical path
         const double ph = A.phiO[(size_t)(g & 1) * NTp + n0 + wr * 16 + (lane & 15)];
@@ -133,7 +135,7 @@ static __device__ __forceinline__ void ff_gemm_role(const FwdFusedArgs& A, doubl
             __syncthreads();
         }
         // the first chunk of this workgroup's next tile: its loads fly during the epilogue and the tile barrier
-        if (has_next) { load_phi((tile + G) * FF_BM); load_chunk((tile + G) * FF_BM, 0); }
+        if (has_next) { load_phi(FF_PT(tile + G) * FF_BM); load_chunk(FF_PT(tile + G) * FF_BM, 0); }
         // lane (g = lane>>4, i = lane&15) holds rows g+4e of column tile c for image i; rows 2q, 2q+1 (site index t = 0,1 of
         // output link q) sit on lane groups g and g^1
 #pragma unroll
@@ -156,7 +158,8 @@ static __device__ __forceinline__ void ff_stream_role(const FwdFusedArgs& A, con
     for (int tile = blockIdx.x; tile < A.ntiles + G; tile += G) {
         const int stile = tile - G;
         const bool has = stile >= 0;
-        const int ns = (has ? stile : 0) * FF_BM + lane;
+        const int ptile = has ? FF_PT(stile) : 0;
+        const int ns = ptile * FF_BM + lane;
         double px[TNML_NL];
 #pragma unroll
         for (int l = 0; l < TNML_NL; ++l) px[l] = 0.;
@@ -233,7 +236,7 @@ static __device__ __forceinline__ void ff_stream_role(const FwdFusedArgs& A, con
                 }
                 cor = (lab >= 0 && arg == lab) ? 1 : 0;
             }
-            tile_partials(val, lab, cor, A.mode == LD_MODE_PAP, nullptr, A.partials + (size_t)stile * 12, lane);
+            tile_partials(val, lab, cor, A.mode == LD_MODE_PAP, nullptr, A.partials + (size_t)ptile * 12, lane);
         }
         // (the first barrier of the next round orders these reads of `red` and of Ub against the next round's writes)
     }

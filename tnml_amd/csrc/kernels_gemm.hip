@@ -589,6 +589,7 @@ struct Bgemm64KArgs {
     double* slab;
     int nsplit, imgs_per_split;
     int nt;                       // non-temporal loads of the Label-carrying environment (read once per launch)
+    int rev;                      // image ranges are handed out from the last to the first (same slabs, same sums: results identical)
 };
 
 // Software pipelined like k_fgemm64: the image chunk n+1 is fetched into registers while chunk n feeds
@@ -611,7 +612,8 @@ __global__ __launch_bounds__(64 * WR * WC) void k_bgemm64(Bgemm64KArgs K) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid / WC, wc = wid % WC;
     const int i0 = blockIdx.x * BMr, j0 = blockIdx.y * BNc;
-    const int split = blockIdx.z % K.nsplit, l = blockIdx.z / K.nsplit;
+    const int zs = blockIdx.z % K.nsplit, l = blockIdx.z / K.nsplit;
+    const int split = K.rev ? K.nsplit - 1 - zs : zs;
     const int NTp = A.NTp;
     const int nbeg = split * K.imgs_per_split;
     const int nend = min(nbeg + K.imgs_per_split, NTp);
@@ -1026,7 +1028,7 @@ static int bgemm64_go(tnml_ctx* c, const Bgemm64Args& a, double* G, int default_
     int per = ((chunks + nsplit - 1) / nsplit) * 32;
     nsplit = (a.NTp + per - 1) / per;
     static const int nt = getenv("TNML_BG_NT") ? atoi(getenv("TNML_BG_NT")) : 1;
-    Bgemm64KArgs K{a, (double*)c->slab, nsplit, per, nt};
+    Bgemm64KArgs K{a, (double*)c->slab, nsplit, per, nt, c->snake ? (c->stream_dir ^= 1) : 0};
     {
         ProfScope ps(c, KC_BGEMM);
         dim3 grid((a.Kp + BMr - 1) / BMr, (a.Np + BNc - 1) / BNc, nsplit * a.L);

@@ -153,7 +153,7 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
             // eigenvalues sit within a few 100 eps*|T| of each other: inverse iteration returns the right invariant subspace for
             // them but not orthogonal vectors (80 % of the bond updates of a sweep).  Any orthonormal basis of that subspace is
             // an equally valid set of singular vectors, so the basis ALWAYS goes through a Cholesky QR (Q1 = Q0 R^-1,
-            // Q0^T Q0 = R^T R; the kernel returns R = I straight away when Q0 is orthonormal to 1e-9) and one Newton-Schulz
+            // Q0^T Q0 = R^T R; the kernel returns R = I straight away when Q0 is orthonormal to 5e-7) and one Newton-Schulz
             // polish step whose input deviation is the check -- no host decision, no second synchronisation.
             TCK(eigh_chol_rinv(c, c->sS, mk, c->sCm, dv + 1));              // writes both flags
             RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, n, mk, mk, &one, Q0, n, c->sCm, mk, &zero, c->sG, n));   // the Gram matrix is consumed by now
@@ -166,12 +166,12 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
         direct_left = left && !labL && mk <= c->maxm;
         if (direct_left) Q = Sl.a;
         RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, n, mk, mk, &one, Qin, n, c->sCm, mk, &zero, Q, n));
-        if (!always_qr) HIPCK(c, hipMemsetAsync(dv + 1, 0, 2 * sizeof(double), st));
+        if (!always_qr) HIPCK(c, hipMemsetAsync(dv + 1, 0, 3 * sizeof(double), st));
     }
     // eigenvalues -> host: the truncation decision (ITensor truncate()) fixes the new bond dimension.  With more than
     // one rank the decision is made collective: every rank decides on rank 0's eigenvalues (and rank 0's orthogonality
     // check), so that a last-bit difference between replicas can never produce different bond dimensions.
-    const int nev = own_eig ? n + 3 : n;                 // the check values ride behind the eigenvalues: one broadcast, one copy
+    const int nev = own_eig ? n + 4 : n;                 // the check values ride behind the eigenvalues: one broadcast, one copy
     TCK(bcast_rank0(c, const_cast<double*>(evals), nev));
     double* h = c->h_scal;          // pinned, capacity >= 2*svd_n + 64
     HIPCK(c, hipMemcpyAsync(h, evals, sizeof(double) * nev, hipMemcpyDeviceToHost, st));
@@ -194,6 +194,7 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
     const SigmaRef d_sig{evals, n, 0}, d_isig{evals, n, 1}, no_scale{nullptr, 0, 0};   // sigma_g / 1/sigma_g of the kept columns, computed where they are used
 
     if (own_eig) {
+        if (const char* pe = getenv("TNML_SVD_PRINT")) if (atoi(pe) < 0) fprintf(stderr, "svd_check n=%d mk=%d dev=%.2e cholfail=%g factored=%g dev_in=%.2e\n", n, mk, hd[0], hd[1], hd[2], h[n + 3]);
         c->svd_last_dev0 = hd[0]; c->svd_last_dev1 = 0.75 * hd[0] * hd[0];      // Newton-Schulz: error -> 3/4 error^2
         bool ok = hd[0] < 1e-6 && (!always_qr || hd[1] == 0.);                   // the polish step leaves 3/4 d^2 < 1e-12
         if (always_qr && hd[2] != 0.) c->svd_cholqr += 1;

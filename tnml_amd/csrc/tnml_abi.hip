@@ -82,6 +82,7 @@ int tnml_set_option(tnml_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "overlap")) c->overlap = value;
     else if (!strcmp(name, "fused_fwd")) c->fused_fwd = value;
     else if (!strcmp(name, "bgemm_ps")) c->bgemm_ps = value;
+    else if (!strcmp(name, "snake")) c->snake = value;
     else if (!strcmp(name, "debug_nudge_rank")) c->debug_nudge_rank = value;
     else if (!strcmp(name, "fg64_cfg")) c->opt_fg64_cfg = value;
     else if (!strcmp(name, "ldot_cfg")) c->opt_ldot_cfg = value;
@@ -222,6 +223,7 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     if (const char* e = getenv("TNML_OVERLAP")) c->overlap = atoi(e);
     if (const char* e = getenv("TNML_FUSED_FWD")) c->fused_fwd = atoi(e);
     if (const char* e = getenv("TNML_BGEMM_PS")) c->bgemm_ps = atoi(e);
+    if (const char* e = getenv("TNML_SNAKE")) c->snake = atoi(e);
     if (rocblas_create_handle(&c->blas) != rocblas_status_success) return bail(tnml_fail(c, "rocblas_create_handle failed"));
     rocblas_set_stream(c->blas, c->stream);
     // replicas of W must stay bit-identical over the ranks: no atomics-based split-K inside rocBLAS
@@ -737,6 +739,7 @@ static int forward_pass(tnml_ctx* c, const double* vec, int mode, double* tail, 
             ff.EI = (const double*)p.EI; ff.mI = p.mI; ff.phiI = (const double*)p.phiI; ff.M = vec; ff.Kp = p.Kp; ff.Np = p.Np;
             ff.phiO = (const double*)p.phiO; ff.EL = (const double*)p.EX; ff.EL_lstride = ustride; ff.mO = p.mO; ff.NTp = c->NTp; ff.ntiles = c->NTp / 64;
             ff.label = c->label; ff.P = (double*)a.P; ff.dP = (double*)a.dP; ff.mode = mode; ff.partials = c->partials;
+            ff.rev = c->snake ? (c->stream_dir ^= 1) : 0;
             TCK(launch_fwd_fused(c, ff));
             return launch_labeldot_reduce(c, ff.ntiles, tail);
         }

@@ -85,6 +85,7 @@ struct tnml_ctx {
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     int overlap = 0;
     int fused_fwd = 1;
+    int snake = 0, stream_dir = 0;   // alternate the traversal direction of consecutive passes over the Label-carrying environment (MALL reuse); env TNML_SNAKE / option "snake"
     int bgemm_ps = 0;                // gradient GEMM with producer / consumer waves (kernels_fused.hip); env TNML_BGEMM_PS / option "bgemm_ps"               // forward pass as one persistent kernel (kernels_fused.hip); env TNML_FUSED_FWD / option "fused_fwd"             // env TNML_OVERLAP=0 / tnml_set_option "overlap"
     rocblas_handle blas = nullptr;
     ncclComm_t comm = nullptr;
@@ -268,6 +269,7 @@ struct FwdFusedArgs {
     double* P; double* dP;                            // [10][NTp], either may be null
     int mode;                                         // LD_MODE_*
     double* partials;                                 // [ntiles][12]
+    int rev;                                          // 1: tiles are visited from the last image to the first (results identical)
 };
 int launch_fwd_fused(tnml_ctx* c, const FwdFusedArgs& a);
 
