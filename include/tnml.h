@@ -229,6 +229,11 @@ int tnml_synchronize(tnml_ctx* ctx);
                       label dot of the previous tile, kernels_fused.hip): 1 = from 32 768 images per rank on (default),
                       0 = never, 2 = always (parity tests at small sizes), > 2 = always with that many workgroups at most
      "overlap"        two-queue forward pass (measured slower, default 0)
+     "sytrd_exit"     the split's tridiagonalisation stops once the trailing block of the Gram matrix is numerically zero
+                      (trace <= 1e-15 trace(G); default 1; 0 = all n-2 Householder steps)
+     "bgemm_ps"       producer / consumer form of the gradient GEMM (measured slower, default 0; 2 = force at any size)
+     "snake"          alternate passes over the Label-carrying environment run last-to-first (no measurable effect, default 0;
+                      results are bit-identical either way)
    fast_cg = reuse_p = 0 is the reference's literal evaluation order (fixedL.cc:374-421). */
 int tnml_set_option(tnml_ctx* ctx, const char* name, int value);
 /* health of the in-house eigensolver: number of fallbacks to rocSOLVER so far, number of splits whose kept basis

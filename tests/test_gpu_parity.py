@@ -465,6 +465,51 @@ def test_classify_after_training_agrees_with_quadcost_count():
     assert int(cnt.sum() - ninc.sum()) == rg[-1]["ncorrect"]
 
 
+@pytest.mark.parametrize("rank,noise", [(130, 0.0), (130, 1e-9), (60, 1e-13), (236, 0.0)])
+def test_rank_adaptive_exit_of_the_tridiagonalisation(rank, noise):
+    """the split's Householder chain stops when the trailing block of the Gram matrix is numerically zero (eigh.hip,
+    k_sytrd_v3 psd_tol): same singular values, truncation error, reconstruction and isometry as the full chain
+    (option sytrd_exit = 0) and as LAPACK, for the shape a sweep produces (rank m + a few of n = 2m), with a noise
+    floor above and below the threshold, and for a nearly full-rank tensor where the exit must not fire early"""
+    from tnml_amd import synth
+    from tnml_amd.fixedl import TrainStates
+    N, m, NT = 20, 120, 16
+    labels = synth.synthetic_labels(NT, seed=1)
+    ts = TrainStates(labels, N, m, pixels=synth.synthetic_images(N, labels, seed=1))
+    ts.set_mps(synth.random_mps(N, m, seed=2))
+    rng = np.random.default_rng(rank)
+    U0, _ = np.linalg.qr(rng.standard_normal((240, 240)))
+    V0, _ = np.linalg.qr(rng.standard_normal((240, 240)))
+    sv0 = np.zeros(240)
+    sv0[:rank] = np.exp(-0.03 * np.arange(rank))
+    sv0[rank:] = noise * rng.uniform(0.5, 1.0, 240 - rank)
+    M = (U0 * sv0) @ V0.T
+    B = M.reshape(120, 2, 2, 120, order="F")
+    s_ref = np.linalg.svd(M, compute_uv=False)
+    Ur, sr, Vr = np.linalg.svd(M)
+    best = (Ur[:, :120] * sr[:120]) @ Vr[:120]
+    te_ref = np.sum(s_ref[120:] ** 2) / np.sum(s_ref ** 2)
+    out = {}
+    for ex in (0, 1):
+        ts.set_option("sytrd_exit", ex)
+        for ha in (1, 2):
+            mg, te, sv = ts.svd_split(B, 8, ha, 0.0, 120, 60)        # cutoff 0: maxm decides
+            assert mg == 120
+            np.testing.assert_allclose(sv, s_ref, rtol=1e-7, atol=1.5e-7 * s_ref[0])
+            assert abs(te - te_ref) < 1e-12 + 1e-6 * te_ref
+            newB = ts.bond_tensor(8).reshape(240, 240, order="F")
+            assert np.abs(newB - best).max() < 2e-7 * sr[0]           # ties at the cut (sr[119] ~ sr[120]) leave this much freedom
+            assert abs(np.linalg.norm(newB - M) - np.linalg.norm(best - M)) < 1e-9 * sr[0]   # ... but the truncation is optimal
+            A = ts.get_site(8 if ha == 1 else 9)
+            Q = A.reshape(240, 120, order="F") if ha == 1 else A.reshape(120, 240, order="F").T
+            np.testing.assert_allclose(Q.T @ Q, np.eye(120), atol=1e-10)
+            out[(ex, ha)] = (te, sv)
+    for ha in (1, 2):
+        np.testing.assert_allclose(out[(1, ha)][1], out[(0, ha)][1], rtol=1e-9, atol=1.5e-7 * s_ref[0])
+    ts.set_option("sytrd_exit", 1)
+    assert ts.svd_stats()["fallbacks"] == 0
+
+
 @pytest.mark.parametrize("rank", [30, 119])
 def test_svd_split_rank_deficient_cluster(rank):
     """a bond tensor of numerical rank < minm: the kept basis contains a cluster of numerically zero eigenvalues.

@@ -115,7 +115,7 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
     const double* evals = c->sD;                          // ascending eigenvalues of rho
     double* qh = nullptr;                                 // H_0 ... H_{n-2}, formed beside the tridiagonal eigenproblem
     if (tri) {
-        TCK(eigh_tridiagonalize(c, c->sG, n, c->sD, c->sE2, c->sTau, c->sV, 1e-15));   // sG is a Gram matrix: rank-adaptive exit at ~4 eps trace(G), the size of the error G = B^T B carries anyway
+        TCK(eigh_tridiagonalize(c, c->sG, n, c->sD, c->sE2, c->sTau, c->sV, c->sytrd_exit ? 1e-15 : 0.));   // sG is a Gram matrix: rank-adaptive exit at ~4 eps trace(G), the size of the error G = B^T B carries anyway
         // The reflectors are known as soon as the tridiagonalisation ends, the eigenvectors of T only ~200 us later: the product
         // H_0 ... H_{n-2} is formed on the second queue meanwhile (n independent columns, the same latency chain as the back
         // transformation of the eigenvectors), and the back transformation itself becomes one dgemm.

@@ -83,6 +83,7 @@ int tnml_set_option(tnml_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "fused_fwd")) c->fused_fwd = value;
     else if (!strcmp(name, "bgemm_ps")) c->bgemm_ps = value;
     else if (!strcmp(name, "snake")) c->snake = value;
+    else if (!strcmp(name, "sytrd_exit")) c->sytrd_exit = value;
     else if (!strcmp(name, "debug_nudge_rank")) c->debug_nudge_rank = value;
     else if (!strcmp(name, "fg64_cfg")) c->opt_fg64_cfg = value;
     else if (!strcmp(name, "ldot_cfg")) c->opt_ldot_cfg = value;

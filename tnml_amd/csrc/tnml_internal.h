@@ -85,6 +85,7 @@ struct tnml_ctx {
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     int overlap = 0;
     int fused_fwd = 1;
+    int sytrd_exit = 1;              // rank-adaptive exit of the tridiagonalisation of the split's Gram matrix (eigh.hip); option "sytrd_exit", env TNML_SYTRD_TOL=0 disables
     int snake = 0, stream_dir = 0;   // alternate the traversal direction of consecutive passes over the Label-carrying environment (MALL reuse); env TNML_SNAKE / option "snake"
     int bgemm_ps = 0;                // gradient GEMM with producer / consumer waves (kernels_fused.hip); env TNML_BGEMM_PS / option "bgemm_ps"               // forward pass as one persistent kernel (kernels_fused.hip); env TNML_FUSED_FWD / option "fused_fwd"             // env TNML_OVERLAP=0 / tnml_set_option "overlap"
     rocblas_handle blas = nullptr;
