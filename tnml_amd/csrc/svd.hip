@@ -194,7 +194,11 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
     const SigmaRef d_sig{evals, n, 0}, d_isig{evals, n, 1}, no_scale{nullptr, 0, 0};   // sigma_g / 1/sigma_g of the kept columns, computed where they are used
 
     if (own_eig) {
-        if (const char* pe = getenv("TNML_SVD_PRINT")) if (atoi(pe) < 0) fprintf(stderr, "svd_check n=%d mk=%d dev=%.2e cholfail=%g factored=%g dev_in=%.2e\n", n, mk, hd[0], hd[1], hd[2], h[n + 3]);
+        if (const char* pe = getenv("TNML_SVD_PRINT")) if (atoi(pe) < 0) {
+            double nref = -1.;
+            (void)hipMemcpy(&nref, c->sTau + (n - 1), sizeof(double), hipMemcpyDeviceToHost);
+            fprintf(stderr, "svd_check n=%d mk=%d dev=%.2e cholfail=%g factored=%g dev_in=%.2e reflectors=%g\n", n, mk, hd[0], hd[1], hd[2], h[n + 3], nref);
+        }
         c->svd_last_dev0 = hd[0]; c->svd_last_dev1 = 0.75 * hd[0] * hd[0];      // Newton-Schulz: error -> 3/4 error^2
         bool ok = hd[0] < 1e-6 && (!always_qr || hd[1] == 0.);                   // the polish step leaves 3/4 d^2 < 1e-12
         if (always_qr && hd[2] != 0.) c->svd_cholqr += 1;
