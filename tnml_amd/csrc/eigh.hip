@@ -1217,7 +1217,7 @@ __global__ __launch_bounds__(1024) void k_chol_rinv(const double* __restrict__ S
 // ==========================================================================================
 #define CQ_T 8
 #define CQ_NT 16
-__global__ __launch_bounds__(256) void k_chol_rinv_blocked(const double* __restrict__ S, int m, double* __restrict__ Rinv, double* __restrict__ flag) {
+__global__ __launch_bounds__(256) void k_chol_rinv_blocked(const double* __restrict__ S, int m, double* __restrict__ Rinv, double* __restrict__ flag, int all_panels) {
     __shared__ __attribute__((aligned(16))) double s_li[CQ_T * CQ_T];            // L_pp^-1, row major, zeros above the diagonal
     __shared__ __attribute__((aligned(16))) double Pl[CQ_NT * CQ_T * CQ_T];      // L_ip rows: [row][k]
     __shared__ __attribute__((aligned(16))) double Px[CQ_T * CQ_NT * CQ_T];      // X_p* : [k][column]
@@ -1233,18 +1233,27 @@ __global__ __launch_bounds__(256) void k_chol_rinv_blocked(const double* __restr
             const int i = CQ_T * ti + r, j = CQ_T * tj + cc;
             a[r][cc] = (i < m && j < m && tj <= ti) ? S[i + (size_t)m * j] : (i == j ? 1. : 0.);
         }
+    int np = nt;                                                     // panels that have to be factored
     {   // orthonormal already (max |S - I| < 5e-7): R = I, nothing to factor
         __shared__ double s_dev[4];
+        __shared__ int s_np[4];
         double dv = 0.;
 #pragma unroll
         for (int r = 0; r < CQ_T; ++r)
 #pragma unroll
             for (int cc = 0; cc < CQ_T; ++cc) dv = fmax(dv, fabs(a[r][cc] - ((CQ_T * ti + r == CQ_T * tj + cc) ? 1. : 0.)));
+        // The kept basis is ordered "largest eigenvalue first": the vectors of the unreduced block of T come first, the unit vectors
+        // of the rows the tridiagonalisation dropped (k_sytrd_v3's rank-adaptive exit) follow, and those are orthonormal and orthogonal to
+        // everything else to round-off.  S = [S_main e; e^T I + e'] then, and only the leading panels need factoring: the rest of
+        // R^-1 is the identity (the deviation left in is < 5e-7, which the caller's polish step squares away).
+        int lp = (tj <= ti && !(dv < 5e-7)) ? ti + 1 : 0;           // NaN counts as non-trivial
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) dv = fmax(dv, __shfl_xor(dv, o));
-        if ((tid & 63) == 0) s_dev[tid >> 6] = dv;
+        for (int o = 32; o >= 1; o >>= 1) { dv = fmax(dv, __shfl_xor(dv, o)); const int t = __shfl_xor(lp, o); lp = t > lp ? t : lp; }
+        if ((tid & 63) == 0) { s_dev[tid >> 6] = dv; s_np[tid >> 6] = lp; }
         __syncthreads();
         dv = fmax(fmax(s_dev[0], s_dev[1]), fmax(s_dev[2], s_dev[3]));
+        np = max(max(s_np[0], s_np[1]), max(s_np[2], s_np[3]));
+        if (np > nt || all_panels) np = nt;
         if (tid == 0) flag[2] = dv;                                  // max |S - I| of the incoming basis (diagnostic)
         if (dv < 5e-7) {                                             // the caller's Newton-Schulz step takes d to 3/4 d^2 < 2e-13
 #pragma unroll
@@ -1258,7 +1267,13 @@ __global__ __launch_bounds__(256) void k_chol_rinv_blocked(const double* __restr
             return;
         }
     }
-    for (int p = 0; p < nt; ++p) {
+    if (ti >= np && tj <= ti) {                                      // rows that need no factoring: R^-1 = I there
+#pragma unroll
+        for (int r = 0; r < CQ_T; ++r)
+#pragma unroll
+            for (int cc = 0; cc < CQ_T; ++cc) a[r][cc] = (ti == tj && r == cc) ? 1. : 0.;
+    }
+    for (int p = 0; p < np; ++p) {
         if (ti == p && tj == p) {
             // (1) Cholesky of the diagonal tile (lower triangle) ...
             double dinv[CQ_T];
@@ -1415,7 +1430,8 @@ int eigh_chol_rinv(tnml_ctx* c, const double* S, int m, double* Rinv, double* fl
     if (m > CHOL_MAXM) return tnml_fail(c, "eigh_chol_rinv: m=%d exceeds %d", m, CHOL_MAXM);
     static const int old_kernel = getenv("TNML_CHOL_OLD") ? atoi(getenv("TNML_CHOL_OLD")) : 0;
     if (m <= CQ_T * CQ_NT && !old_kernel) {
-        hipLaunchKernelGGL(k_chol_rinv_blocked, dim3(1), dim3(256), 0, c->stream, S, m, Rinv, flag);
+        static const int all_panels = getenv("TNML_CHOL_ALL_PANELS") ? atoi(getenv("TNML_CHOL_ALL_PANELS")) : 0;   // A/B: factor every panel
+        hipLaunchKernelGGL(k_chol_rinv_blocked, dim3(1), dim3(256), 0, c->stream, S, m, Rinv, flag, all_panels);
         HIPCK(c, hipGetLastError());
         return 0;
     }
