@@ -355,7 +355,10 @@ def main():
         step()
     # timed region: HIP events only around the roofline kernel (two event records per launch cost host
     # time; timing all ~70 launches of a bond update would lower the very throughput being measured)
-    ts.profile(os.environ.get("TNML_BENCH_NOPROF", "0") != "1", only="fgemm_fwd,fwd_fused")
+    # (the split is one event pair per bond update around the whole of svd_split: it costs nothing and, unlike the other classes, its time
+    # depends on WHICH bonds are timed -- the rank-adaptive tridiagonalisation forms ~131 reflectors on bonds whose neighbours are still
+    # random-init and 14-27 later in a long window -- so it is taken inside the timed region, not on the breakdown steps after it)
+    ts.profile(os.environ.get("TNML_BENCH_NOPROF", "0") != "1", only="fgemm_fwd,fwd_fused,svd")
     ts.profile_reset()
     sync()
     t0 = time.perf_counter()
@@ -446,6 +449,9 @@ def main():
         peak = F64_MFMA_PEAK_TF if args.dtype != "f32" else F32_MFMA_PEAK_TF
         ms_per_step = 1e3 * elapsed / args.steps
         kms = {k: v[1] / nbreak for k, v in prof_all.items() if v[0]}
+        svd_after = kms.get("svd", 0.0)
+        if prof.get("svd", (0, 0.0))[0]:
+            kms["svd"] = prof["svd"][1] / prof["svd"][0]           # the split of the TIMED bond updates
         # whole-step MFMA fraction.  executed: the GEMM launches a bond update really issues (5 forward + 4 gradient with the two
         # shortcuts on) + its shiftE; algorithmic: SURVEY.md 8(d), (3P+1) passes of 2 NT (2m)^2 + 2 NT 2m 10, the shift, 22 (2m)^3
         nf_step = (prof_all.get("fgemm_fwd", (0, 0))[0] + prof_all.get("fwd_fused", (0, 0))[0]) / max(nbreak, 1)
@@ -501,6 +507,7 @@ def main():
             "kernel_ms_per_step": kms,
             "gradient_phase_ms": sum(kms.get(k, 0.0) for k in grad_classes),
             "svd_ms": kms.get("svd", 0.0),
+            "svd_ms_on_the_breakdown_steps": svd_after,
             "roofline_hbm": hbm_roofline(prof_all, img_ld, timed, args, world),
             "algebraic_shortcuts": [
                 "fast CG: B*t.v is linear in B, so P <- P + a (p*t.v) replaces Npass-1 forward GEMMs per bond (TNML_FAST_CG=0 disables)",
