@@ -229,6 +229,8 @@ int tnml_synchronize(tnml_ctx* ctx);
                       label dot of the previous tile, kernels_fused.hip): 1 = from 32 768 images per rank on (default),
                       0 = never, 2 = always (parity tests at small sizes), > 2 = always with that many workgroups at most
      "overlap"        two-queue forward pass (measured slower, default 0)
+     "cg_method"      TNML_MODE_SINGLE only: 0 = conj (single.h:162-288, default), 1 = fast_conj (single.h:290-398: one image sum
+                      per CG step, residual by recurrence, the reference's regulariser term as written, no cost in the trace)
      "sytrd_exit"     the split's tridiagonalisation stops once the trailing block of the Gram matrix is numerically zero
                       (trace <= 1e-15 trace(G); default 1; 0 = all n-2 Householder steps)
      "bgemm_ps"       producer / consumer form of the gradient GEMM (measured slower, default 0; 2 = force at any size)

@@ -321,6 +321,36 @@ class NpSingle:
             p = r + beta * p
         return B, trace
 
+    def fast_cgrad(self, B, npass, lam, cconv):                              # single.h:290-398
+        """one contraction with the images per step: p.v gives pAp and A p; residual by recurrence, with the reference's
+        'nr = nr - lambda*B' (:379) as written"""
+        B = B.copy()
+        r = self.gradient(B) - lam * B
+        trace = dict(skipped=False, cost=[], rnorm=[], alpha=[])
+        if np.linalg.norm(r) < cconv:
+            trace["skipped"] = True
+            return B, trace
+        p = r.copy()
+        for ps in range(1, npass + 1):
+            pv = self.forward(p)
+            pAp = float(np.sum(pv ** 2) + lam * np.sum(p * p))
+            a = float(np.sum(r * r)) / pAp
+            trace["alpha"].append(a)
+            B = B + a * p
+            if ps == npass:
+                break
+            Ap = np.einsum('n,nastr->astr', pv, self.v)
+            nr = r - a * Ap
+            if lam != 0.:
+                nr = nr - lam * B
+            beta = (np.linalg.norm(nr) / np.linalg.norm(r)) ** 2
+            r = nr
+            trace["rnorm"].append(float(np.linalg.norm(r)))
+            if np.linalg.norm(r) < cconv:
+                break
+            p = r + beta * p
+        return B, trace
+
     def svd_split(self, B, b, ha, cutoff, maxm, minm):                       # single.h:636-646
         mL, _, _, mR = B.shape
         M = B.reshape(2 * mL, 2 * mR, order="F") if False else np.einsum('astr->astr', B).reshape(mL * 2, 2 * mR)

@@ -265,6 +265,8 @@ def _slib():
         L.sorc_quadcost.restype = C.c_double
         L.sorc_quadcost.argtypes = [vp, dp, C.c_double, dp]
         L.sorc_cgrad.argtypes = [vp, dp, C.c_int, C.c_double, C.c_double, C.POINTER(CgTrace)]
+        L.sorc_fast_cgrad.argtypes = [vp, dp, C.c_int, C.c_double, C.c_double, C.POINTER(CgTrace)]
+        L.sorc_set_method.argtypes = [vp, C.c_int]
         L.sorc_svd_split.argtypes = [vp, dp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, dp, ip, dp, ip]
         L.sorc_mldmrg.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int,
                                   C.POINTER(SingleBondReport)]
@@ -377,6 +379,20 @@ class SingleOracle:
         return buf.reshape(B.shape, order="F"), dict(skipped=bool(skipped), npass_done=n, converged=bool(tr.converged), cost=list(tr.cost[:max(n - 1, 0)] if not tr.converged else tr.cost[:n]),
                                                      rnorm=list(tr.rnorm[:max(n - 1, 0)] if not tr.converged else tr.rnorm[:n]), pAp=list(tr.pAp[:n]), alpha=list(tr.alpha[:n]))
 
+    def fast_cgrad(self, B, npass, lam, cconv):
+        """single.h:290-398 (method = fast_conj): no cost in the trace"""
+        B = np.asarray(B)
+        buf = _f(B).copy()
+        tr = CgTrace()
+        skipped = self._ck(self._L.sorc_fast_cgrad(self._h, _dp(buf), npass, lam, cconv, C.byref(tr)))
+        n = tr.npass_done
+        return buf.reshape(B.shape, order="F"), dict(skipped=bool(skipped), npass_done=n, converged=bool(tr.converged), cost=[],
+                                                     rnorm=list(tr.rnorm[:max(n - 1, 0)] if not tr.converged else tr.rnorm[:n]), pAp=list(tr.pAp[:n]), alpha=list(tr.alpha[:n]))
+
+    def set_method(self, method):
+        """optimiser of mldmrg: "conj" (cgrad) or "fast_conj" (fast_cgrad), single.h:598-599"""
+        self._ck(self._L.sorc_set_method(self._h, {"conj": 0, "fast_conj": 1}[method]))
+
     def svd_split(self, B, b, ha, cutoff, maxm, minm):
         te, m, nsv = C.c_double(), C.c_int(), C.c_int()
         sv = np.zeros(4 * max(self.bond_shape(b)[0], self.bond_shape(b)[3]))
@@ -393,7 +409,7 @@ class SingleOracle:
             out.append(dict(sweep=r.sweep, half=r.half, c=r.c, origm=r.origm, newm=r.newm, truncerr=r.truncerr,
                             cost_old=r.cost_old, cost_cg=r.cost_cg, reg_cost=r.reg_cost, cost=r.cost_after_svd,
                             norm_oB=r.norm_oB, norm_newB=r.norm_newB, cg_skipped=bool(r.cg_skipped),
-                            cg_cost=list(r.cg.cost[:max(k - 1, 0)]), cg_alpha=list(r.cg.alpha[:k])))
+                            cg_cost=list(r.cg.cost[:max(k - 1, 0)]), cg_alpha=list(r.cg.alpha[:k]), cg_rnorm=list(r.cg.rnorm[:max(k - 1, 0)])))
         return out
 
     def output(self, i):

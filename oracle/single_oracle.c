@@ -1,6 +1,6 @@
 /* single_oracle.c -- CPU restatement of the per-label variant of the reference:
  *   /root/reference/single.cc   main: features (71-84), initial projections (181-199), precalc (204-216)
- *   /root/reference/single.h    TState (19-25), quadcost (82-112), cgrad (162-288), mldmrg (523-728)
+ *   /root/reference/single.h    TState (19-25), quadcost (82-112), cgrad (162-288), fast_cgrad (290-398), mldmrg (523-728)
  *   /root/reference/paralleldo.h static chunking, fork-join
  * TEST INFRASTRUCTURE ONLY (see single_oracle.h).  PARITY UNPINNED (no reference tests, ITensor absent).
  *
@@ -33,6 +33,7 @@ struct sorc {
     int currb;
     double* v; size_t vsz; int vmL, vmR;
     int sw, b, ha;
+    int method;     /* 0 = conj (cgrad), 1 = fast_conj (fast_cgrad): single.h:598-599 */
 };
 
 static int sfail(const char* msg) { fprintf(stderr, "single_oracle: %s\n", msg); return -1; }
@@ -290,6 +291,62 @@ done:
     free(r); free(p); free(nr); free(reals);
     return ret;
 }
+/* fast_cgrad, single.h:290-398: ONE pass over the images per CG step -- p*t.v gives |p.v|^2 for pAp (:359) and, weighted back
+ * onto t.v, the tensor A p (:360) -- and the residual follows the recurrence nr = r - a*Ap (:378) instead of being recomputed.
+ * Reproduced as written, including ":379 nr = nr - lambda*B" (the full -lambda*B is subtracted again at every pass; the exact
+ * recurrence would subtract a*lambda*p) and the absence of a cost print.  Trace: pAp, alpha, |r|; cost stays 0. */
+typedef struct { const sorc* o; const double* p; double* tensors; double* reals; } sfast_task;
+static void sfast_fn(void* q, SBound b) {
+    sfast_task* t = (sfast_task*)q; const sorc* o = t->o;
+    double* T = t->tensors + b.n * o->vsz;
+    for (size_t i = b.begin; i < b.end; ++i) {
+        const double* v = o->v + i * o->vsz;
+        double pvr = sdot(t->p, v, o->vsz);                /* pv.real() :358 */
+        t->reals[b.n] += pvr * pvr;                        /* :359 */
+        for (size_t k = 0; k < o->vsz; ++k) T[k] += pvr * v[k];   /* :360 */
+    }
+}
+int sorc_fast_cgrad(const sorc* o, double* B, int npass, double lambda, double cconv, orc_cg_trace* tr) {
+    if (!o->v) return sfail("setBond not called");
+    if (npass > 64) return sfail("npass > 64");
+    size_t n = o->vsz;
+    double* r = (double*)malloc(sizeof(double) * n); double* p = (double*)malloc(sizeof(double) * n); double* Ap = (double*)malloc(sizeof(double) * n);
+    double* tensors = (double*)malloc(sizeof(double) * n * (size_t)o->nthread);
+    double* reals = (double*)malloc(sizeof(double) * (size_t)o->nthread);
+    if (tr) memset(tr, 0, sizeof *tr);
+    int ret = 0;
+    seval_gradient(o, B, r, NULL);                                         /* :311-325 */
+    if (lambda != 0.) for (size_t k = 0; k < n; ++k) r[k] = r[k] - lambda * B[k];   /* :326 */
+    if (sqrt(ssq(r, n)) < cconv) { ret = 1; goto done; }                   /* :328-332 "not optimizing" */
+    memcpy(p, r, sizeof(double) * n);                                      /* :334 */
+    for (int pass = 1; pass <= npass; ++pass) {                            /* :335 */
+        memset(tensors, 0, sizeof(double) * n * (size_t)o->nthread);       /* :345-346 */
+        for (int k = 0; k < o->nthread; ++k) reals[k] = 0.;
+        sfast_task t = { o, p, tensors, reals };
+        sparallel_do(o->nthread, (size_t)o->NT, sfast_fn, &t);             /* :347-363 */
+        double pAp = 0.; for (int k = 0; k < o->nthread; ++k) pAp += reals[k];   /* :364 */
+        pAp += lambda * ssq(p, n);                                         /* :365 */
+        double a = ssq(r, n) / pAp;                                        /* :367 */
+        for (size_t k = 0; k < n; ++k) B[k] = B[k] + a * p[k];             /* :368 */
+        if (tr) { tr->npass_done = pass; tr->pAp[pass - 1] = pAp; tr->alpha[pass - 1] = a; }
+        if (pass == npass) break;                                          /* :371-375 */
+        memset(Ap, 0, sizeof(double) * n);
+        for (int th = 0; th < o->nthread; ++th) for (size_t k = 0; k < n; ++k) Ap[k] += tensors[(size_t)th * n + k];   /* :377 stdx::accumulate */
+        double rn_old = sqrt(ssq(r, n));
+        for (size_t k = 0; k < n; ++k) r[k] = r[k] - a * Ap[k];            /* :378 nr = r - a*Ap */
+        if (lambda != 0.) for (size_t k = 0; k < n; ++k) r[k] = r[k] - lambda * B[k];   /* :379 (as written) */
+        double rn = sqrt(ssq(r, n));
+        double q = rn / rn_old;
+        double beta = q * q;                                               /* :381 */
+        if (tr) tr->rnorm[pass - 1] = rn;                                  /* :382 r = nr */
+        if (rn < cconv) { if (tr) tr->converged = 1; break; }              /* :385-389 */
+        for (size_t k = 0; k < n; ++k) p[k] = r[k] + beta * p[k];          /* :395 */
+    }
+done:
+    free(r); free(p); free(Ap); free(tensors); free(reals);
+    return ret;
+}
+int sorc_set_method(sorc* o, int method) { if (method < 0 || method > 1) return sfail("method must be 0 (conj) or 1 (fast_conj)"); o->method = method; return 0; }
 /* svd(B,U,S,V,svd_args) with U on the indices of W.A(c); W.A(c) = U, W.A(c+dc) = S*V  (single.h:636-646) */
 int sorc_svd_split(sorc* o, const double* B, int b, int ha, double cutoff, int maxm, int minm,
                    double* truncerr, int* newm, double* sv_out, int* nsv) {
@@ -333,7 +390,7 @@ int sorc_svd_split(sorc* o, const double* B, int b, int ha, double cutoff, int m
     return 0;
 }
 int sorc_mldmrg(sorc* o, int nsweep, int maxm, int minm, double cutoff, int npass, double lambda,
-                double cconv, int max_bonds, sorc_bond_report* reports) {     /* single.h:523-728, Method = conj, noise = 0 */
+                double cconv, int max_bonds, sorc_bond_report* reports) {     /* single.h:523-728, Method = conj | fast_conj (sorc_set_method), noise = 0 */
     int done = 0;
     while (o->sw <= nsweep) {
         while (o->ha <= 2) {
@@ -350,7 +407,8 @@ int sorc_mldmrg(sorc* o, int nsweep, int maxm, int minm, double cutoff, int npas
             rp->norm_oB = sqrt(ssq(oB, n));                                    /* :572 */
             memcpy(B, oB, sizeof(double) * n);
             if (sorc_set_bond(o, b)) return -1;                                /* :579-596 */
-            int rc = sorc_cgrad(o, B, npass, lambda, cconv, &rp->cg);          /* :598 */
+            int rc = o->method == 1 ? sorc_fast_cgrad(o, B, npass, lambda, cconv, &rp->cg)   /* :599 */
+                                    : sorc_cgrad(o, B, npass, lambda, cconv, &rp->cg);       /* :598 */
             if (rc < 0) return -1;
             rp->cg_skipped = rc;
             rp->cost_old = sorc_quadcost(o, oB, lambda, NULL);                 /* :621 */

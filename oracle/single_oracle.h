@@ -54,6 +54,10 @@ int sorc_gradient(const sorc* o, const double* B, double* G);           /* sum_n
 double sorc_quadcost(const sorc* o, const double* B, double lambda, double* reg_cost);   /* single.h:82-112 */
 /* single.h:162-288; returns 1 if it did not optimise (|r| < cconv at entry), 0 otherwise, <0 on error */
 int sorc_cgrad(const sorc* o, double* B, int npass, double lambda, double cconv, orc_cg_trace* trace);
+/* fast_cgrad (single.h:290-398): one pass over the images per CG step, residual by recurrence; same return values as sorc_cgrad */
+int sorc_fast_cgrad(const sorc* o, double* B, int npass, double lambda, double cconv, orc_cg_trace* trace);
+/* optimiser used by sorc_mldmrg: 0 = conj (default), 1 = fast_conj (single.h:598-599) */
+int sorc_set_method(sorc* o, int method);
 int sorc_svd_split(sorc* o, const double* B, int b, int ha, double cutoff, int maxm, int minm,
                    double* truncerr, int* newm, double* sv, int* nsv);   /* single.h:636-646 (noise = 0) */
 int sorc_mldmrg(sorc* o, int nsweep, int maxm, int minm, double cutoff, int npass, double lambda,

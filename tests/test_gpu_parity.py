@@ -625,6 +625,50 @@ def test_single_forward_gradient_cost_cgrad(b, dtype):
     assert tsk["skipped"] and tsk["npass_done"] == 0 and np.array_equal(Bs, B0)
 
 
+@pytest.mark.parametrize("lam", [0.0, 1e-3])
+@pytest.mark.parametrize("b", [1, 6, 11])
+def test_single_fast_conj_matches_the_oracle(b, lam):
+    """method = fast_conj of the per-label variant (single.h:290-398; tnml_set_option cg_method = 1): one image sum per CG
+    step, residual by recurrence, the reference's regulariser term as written -- against oracle/single_oracle.c"""
+    ts, o = _single_pair()
+    for bb in range(1, b):
+        ts.shiftE(bb, True); o.shiftE(bb, True)
+    ts.setBond(b); o.set_bond(b)
+    B0 = o.bond_tensor(b)
+    ts.set_option("cg_method", 1)
+    Bg, tg = ts.cgrad(B0, 4, lam, 1e-10)
+    Bo, to = o.fast_cgrad(B0, 4, lam, 1e-10)
+    assert not tg["skipped"] and tg["npass_done"] == 4
+    np.testing.assert_allclose(tg["alpha"], to["alpha"], rtol=1e-7)
+    np.testing.assert_allclose(tg["rnorm"], to["rnorm"], rtol=1e-6)
+    assert _relmax(Bg, Bo) < 1e-6
+    if lam > 0.:                                            # ... and it is NOT the conj optimiser once the regulariser enters
+        _, tc = o.cgrad(B0, 4, lam, 1e-10)
+        assert abs(tg["alpha"][1] / tc["alpha"][1] - 1) > 1e-9
+    Bs, tsk = ts.cgrad(B0, 4, lam, 1e30)                    # entry check (single.h:328-332)
+    assert tsk["skipped"] and np.array_equal(Bs, B0)
+    ts.set_option("cg_method", 0)
+    Bc, tcg = ts.cgrad(B0, 4, lam, 1e-10)
+    _, toc = o.cgrad(B0, 4, lam, 1e-10)
+    np.testing.assert_allclose(tcg["alpha"], toc["alpha"], rtol=1e-7)    # the option switches back cleanly
+
+
+def test_single_fast_conj_sweep_matches_the_oracle():
+    ts, o = _single_pair(N=10, NT=80, m=3, target=7, maxm=5)
+    from tnml_amd.fixedl import mldmrg
+    ts.set_option("cg_method", 1)
+    o.set_method("fast_conj")
+    rg = mldmrg(ts, 2, 5, 2, 1e-10, 3, 1e-3, 1e-10)
+    ro = o.mldmrg(2, 5, 2, 1e-10, 3, 1e-3, 1e-10)
+    assert len(rg) == len(ro) == 2 * 2 * 9
+    for a, b in zip(rg, ro):
+        assert (a["c"], a["half"], a["origm"], a["newm"]) == (b["c"], b["half"], b["origm"], b["newm"])
+        assert a["cost_old"] == pytest.approx(b["cost_old"], rel=1e-7)
+        assert a["cost_cg"] == pytest.approx(b["cost_cg"], rel=1e-7)
+        assert a["cost"] == pytest.approx(b["cost"], rel=1e-7)
+    assert ro[-1]["cost"] < ro[0]["cost_old"]
+
+
 @pytest.mark.parametrize("normal", [True, False])
 def test_single_full_sweeps_and_decision_function(normal):
     ts, o = _single_pair(N=10, NT=80, m=3, target=7, normal=normal, maxm=5)
@@ -698,6 +742,33 @@ def test_single_and_separate_fulltest_cli(tmp_path):
             assert all(abs(a - r["newm"]) <= 1 for a, r in zip(newm, ro))
             m0 = re.search(r"Before DMRG, Cost = ([0-9.eE+-]+)", run.stdout)
             assert m0 and float(m0.group(1)) == pytest.approx(ro[0]["cost_old"] / per_label, rel=1e-6)   # divides by the Ntrain key (single.cc:218)
+    # method = fast_conj through the command line (single.cc:44, single.h:599): its own log format (pass and |r| on one line,
+    # no cost per pass) and the oracle's fast_cgrad trajectory
+    wd = tmp_path / "Lfast"
+    wd.mkdir()
+    inp = wd / "input"
+    inp.write_text("input\n{\n%slabel = 3\nNtrain = %d\nNsweep = 1\ncutoff = 1E-10\nmaxm = 5\nminm = 2\nninitial = 3\n"
+                   "lambda = 1E-3\nNpass = 3\nseed = 4\nnthread = 2\nmethod = fast_conj\n}\n" % (keys, per_label))
+    run = subprocess.run([os.path.join(root, "tnml_amd", "single"), str(inp)], capture_output=True, text=True, cwd=wd, timeout=300)
+    assert run.returncode == 0, run.stdout[-1500:] + run.stderr[-1500:]
+    o = pyoracle.SingleOracle(phi, lab[order], 3, hostlib.read_mps(str(tmp_path / "W0ref3")))
+    o.init()
+    o.set_method("fast_conj")
+    ro = o.mldmrg(1, 5, 2, 1e-10, 3, 1e-3, 1e-10)
+    c_cg = [float(b) for _, b in re.findall(r"Cost = ([0-9.eE+-]+) --> ([0-9.eE+-]+)", run.stdout)]
+    c_svd = [float(x) for x in re.findall(r"--> After SVD, Cost = ([0-9.eE+-]+) \(", run.stdout)]
+    assert len(c_svd) == len(ro) == 2 * (N - 1)
+    # the as-written regulariser term (:379) makes the iteration erratic (the cost goes UP on some bonds), so round-off
+    # differences grow faster than with conj: tight on the first bonds, loose on the whole sweep
+    np.testing.assert_allclose(c_cg[:12], [r["cost_cg"] / float(len(lab)) for r in ro][:12], rtol=2e-5, atol=2e-10)
+    np.testing.assert_allclose(c_svd[:12], [r["cost"] / float(len(lab)) for r in ro][:12], rtol=2e-5, atol=2e-10)
+    np.testing.assert_allclose(c_cg, [r["cost_cg"] / float(len(lab)) for r in ro], rtol=3e-2)
+    np.testing.assert_allclose(c_svd, [r["cost"] / float(len(lab)) for r in ro], rtol=3e-2)
+    assert re.search(r"^  Conj grad pass 1   \|r\| = [0-9.]+E[+-][0-9]+$", run.stdout, re.M) and not re.search(r"^  1 C = ", run.stdout, re.M)
+    bad = wd / "input_bad"
+    bad.write_text(inp.read_text().replace("fast_conj", "pinv"))
+    run = subprocess.run([os.path.join(root, "tnml_amd", "single"), str(bad)], capture_output=True, text=True, cwd=wd, timeout=300)
+    assert run.returncode != 0 and "not built here" in run.stdout
     # evaluator on the ten weight files
     (tmp_path / "sites").write_bytes((tmp_path / "L0" / "sites").read_bytes())
     tin = tmp_path / "input_test"

@@ -93,3 +93,58 @@ def test_cgrad_not_optimizing_branch():
     B = o.bond_tensor(1)
     B2, tr = o.cgrad(B, 4, 1e-3, 1e30)
     assert tr["skipped"] and np.array_equal(B2, B)
+
+
+@pytest.mark.parametrize("nthread", [1, 3])
+def test_fast_cgrad_matches_numpy_and_is_cgrad_without_the_regulariser(nthread):
+    """method = fast_conj (single.h:290-398): the C restatement against the numpy one; with lambda = 0 the residual
+    recurrence is exact, so fast_cgrad and cgrad agree to rounding; with lambda > 0 the reference's
+    'nr = nr - lambda*B' (:379) makes them differ from the second pass on -- reproduced, not repaired"""
+    pixels, labels, phi, W = problem()
+    phi = phi.copy(); phi[..., 1] *= 300.0
+    o = pyoracle.SingleOracle(phi, labels, 3, W, nthread=nthread)
+    n = npr.NpSingle(phi, labels, 3, W)
+    o.init(); n.init()
+    for b in (1, 5):
+        if b > 1:
+            for bb in range(1, b):
+                o.shiftE(bb, True); n.shiftE(bb, True)
+        o.set_bond(b); n.set_bond(b)
+        B = o.bond_tensor(b) + 0.1 * np.random.default_rng(b).standard_normal(o.bond_tensor(b).shape)
+        for lam in (0.0, 1e-3):
+            Bo, to = o.fast_cgrad(B, 4, lam, 1e-10)
+            Bn, tn = n.fast_cgrad(B, 4, lam, 1e-10)
+            np.testing.assert_allclose(to["alpha"], tn["alpha"], rtol=1e-8)
+            np.testing.assert_allclose(to["rnorm"], tn["rnorm"], rtol=1e-7)
+            np.testing.assert_allclose(Bo, Bn, rtol=1e-7, atol=1e-9)
+            assert to["cost"] == [] and len(to["rnorm"]) == 3
+            Bc, tc = o.cgrad(B, 4, lam, 1e-10)
+            np.testing.assert_allclose(to["alpha"][0], tc["alpha"][0], rtol=1e-12)      # the first step is the same computation
+            if lam == 0.0:
+                np.testing.assert_allclose(to["alpha"], tc["alpha"], rtol=1e-7)
+                np.testing.assert_allclose(to["rnorm"], tc["rnorm"], rtol=1e-6)
+                np.testing.assert_allclose(Bo, Bc, rtol=1e-6, atol=1e-8)
+            else:
+                assert abs(to["alpha"][1] / tc["alpha"][1] - 1) > 1e-9               # the as-written regulariser term shows
+        o.init(); n.init()
+
+
+def test_fast_conj_sweep_and_entry_check():
+    pixels, labels, phi, W = problem(N=8, NT=60, m=3)
+    phi = phi.copy(); phi[..., 1] *= 300.0
+    o = pyoracle.SingleOracle(phi, labels, 1, W, nthread=2)
+    o.init()
+    o.set_method("fast_conj")
+    ro = o.mldmrg(1, 4, 2, 1e-10, 3, 0.0, 1e-10)
+    o2 = pyoracle.SingleOracle(phi, labels, 1, W, nthread=2)
+    o2.init()
+    rc = o2.mldmrg(1, 4, 2, 1e-10, 3, 0.0, 1e-10)
+    assert len(ro) == len(rc) == 14
+    assert ro[0]["cg_alpha"] == pytest.approx(rc[0]["cg_alpha"], rel=1e-7)              # lambda = 0: the same optimiser
+    assert ro[0]["cost_cg"] == pytest.approx(rc[0]["cost_cg"], rel=1e-8)
+    assert all(r["cg_cost"] == [0.0] * len(r["cg_cost"]) for r in ro)                   # fast_cgrad prints no cost
+    assert ro[-1]["cost"] < ro[0]["cost_old"]
+    B = o.bond_tensor(1)
+    o.set_bond(1)
+    B2, tr = o.fast_cgrad(B, 4, 1e-3, 1e30)
+    assert tr["skipped"] and np.array_equal(B2, B)

@@ -251,6 +251,17 @@ __global__ __launch_bounds__(VB) void k_cg_resid2(const double* __restrict__ G, 
         scal[SC_CONV] = (double)conv;                      // host copy
     }
 }
+// method = fast_conj (single.h:290-398): the image sum of this pass is A p = sum_n (p.v_n) v_n, and the residual follows the
+// recurrence nr = r - a*Ap (:378); writing G <- r - a*Ap lets k_cg_resid1/2 finish the pass exactly as the reference writes it
+// (":379 nr = nr - lambda*B").  No cost is evaluated on this path (the reference prints none): the cost partials are cleared.
+__global__ __launch_bounds__(VB) void k_cg_fast_resid0(double* __restrict__ G, const double* __restrict__ R, size_t n, const double* __restrict__ scal,
+                                                      double* __restrict__ tail, int pass) {
+    if (scal[SC_CONVP + ((pass - 1) & 1)] != 0.) return;
+    const double a = scal[SC_ALPHA];
+    size_t lo, hi; slice(n, &lo, &hi);
+    for (size_t i = lo + threadIdx.x; i < hi; i += VB) G[i] = R[i] - a * G[i];
+    if (blockIdx.x == 0 && threadIdx.x < TNML_NL) tail[SC_COST0 + threadIdx.x] = 0.;
+}
 __global__ __launch_bounds__(VB) void k_norm2(const double* __restrict__ part, int nb, double* __restrict__ out, int nout) {
     __shared__ double sh[VB / 64];
     double a, b; sum_partials(part, nb, &a, &b, sh);
@@ -293,6 +304,12 @@ int launch_cg_resid(tnml_ctx* c, size_t n, double lambda, double cconv, int pass
     hipLaunchKernelGGL(k_cg_resid1, dim3(nb), dim3(VB), 0, c->stream, c->vG, c->vB, n, lambda, c->vpart);
     hipLaunchKernelGGL(k_cg_resid2, dim3(nb), dim3(VB), 0, c->stream, c->vG, c->vB, c->vR, c->vP, n, lambda, cconv, c->vG + n, c->vpart, nb, c->scal, in, out, c->cgtrace, pass, c->vpart + 512);
     c->rr_slot ^= 1;
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
+int launch_cg_fast_resid0(tnml_ctx* c, size_t n, int pass) {
+    ProfScope ps(c, KC_VEC);
+    hipLaunchKernelGGL(k_cg_fast_resid0, dim3(vec_blocks(n)), dim3(VB), 0, c->stream, c->vG, c->vR, n, c->scal, c->vG + n, pass);
     HIPCK(c, hipGetLastError());
     return 0;
 }

@@ -84,6 +84,7 @@ int tnml_set_option(tnml_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "bgemm_ps")) c->bgemm_ps = value;
     else if (!strcmp(name, "snake")) c->snake = value;
     else if (!strcmp(name, "sytrd_exit")) c->sytrd_exit = value;
+    else if (!strcmp(name, "cg_method")) { if (value < 0 || value > 1 || (value == 1 && !c->single())) return tnml_fail(c, "cg_method: 0 (conj) or, in TNML_MODE_SINGLE, 1 (fast_conj)"); c->cg_method = value; }
     else if (!strcmp(name, "debug_nudge_rank")) c->debug_nudge_rank = value;
     else if (!strcmp(name, "fg64_cfg")) c->opt_fg64_cfg = value;
     else if (!strcmp(name, "ldot_cfg")) c->opt_ldot_cfg = value;
@@ -774,10 +775,12 @@ static int forward_pass(tnml_ctx* c, const double* vec, int mode, double* tail, 
     return launch_labeldot(c, a, tail);
 }
 // G = sum_n dP_n*dag(t.v) over all ranks for the bond tensor in vB; cost partials ride in the tail
-static int grad_eval(tnml_ctx* c, bool from_P_update = false, bool outputs_current = false) {
+static int grad_eval(tnml_ctx* c, bool from_P_update = false, bool outputs_current = false, bool weights_pp = false) {
     const BondPlan& p = c->plan;
     const size_t n = p.msize();
-    if (outputs_current)    { if (!c->tail_zeroed) HIPCK(c, hipMemsetAsync(c->vG + n, 0, sizeof(double) * TNML_NSCAL_AR, c->stream)); }   // P/dP already hold B*t.v and the residuals (the pack kernel of tnml_bond_update has cleared the tail)
+    // weights_pp (fast_conj, per-label variant only): the image sum A p = sum_n (p.v_n) v_n, weights p.v_n as left in Pp by the pAp pass
+    if (weights_pp) { if (p.kind != 2) return tnml_fail(c, "grad_eval: weights_pp needs the per-label variant"); }
+    else if (outputs_current)    { if (!c->tail_zeroed) HIPCK(c, hipMemsetAsync(c->vG + n, 0, sizeof(double) * TNML_NSCAL_AR, c->stream)); }   // P/dP already hold B*t.v and the residuals (the pack kernel of tnml_bond_update has cleared the tail)
     else if (from_P_update) TCK(launch_pupdate(c, c->scal + SC_ALPHA, c->vG + n));          // P += a (p*t.v): no GEMM
     else                    TCK(forward_pass(c, c->vB, LD_MODE_COST, c->vG + n, c->fast_cg)); // keeps P when fast CG is on
     const bool fuse = c->f64() && c->fuse_z && p.kind != 2;
@@ -787,7 +790,7 @@ static int grad_eval(tnml_ctx* c, bool from_P_update = false, bool outputs_curre
         g.EL = nullptr; g.EL_lstride = 0; g.dPz = nullptr; g.env64 = c->env64();
         g.EI = p.EI; g.mI = p.mI; g.phiI = p.phiI; g.phiO = p.phiO; g.mO = p.mO;
         g.Kp = p.Kp; g.Np = p.Np; g.NTp = c->NTp; g.L = p.LB;
-        if (p.kind == 2) { g.Zq64 = nullptr; g.Zq32 = p.EX; g.w = (const double*)c->dP; g.w_lstride = c->NTp; }
+        if (p.kind == 2) { g.Zq64 = nullptr; g.Zq32 = p.EX; g.w = (const double*)(weights_pp ? c->Pp : c->dP); g.w_lstride = c->NTp; }
         else if (fuse)   { g.Zq64 = nullptr; g.Zq32 = nullptr; g.w = nullptr; g.w_lstride = 0; g.EL = p.EX; g.EL_lstride = (size_t)p.mO * c->NTp; g.dPz = (const double*)c->dP; }
         else             { g.Zq64 = (const double*)c->Zp; g.Zq32 = nullptr; g.w = nullptr; g.w_lstride = 0; }
         TCK(launch_bgemm64(c, g, c->vG));
@@ -795,7 +798,7 @@ static int grad_eval(tnml_ctx* c, bool from_P_update = false, bool outputs_curre
         BgemmArgs g;
         g.EI = (const float*)p.EI; g.mI = p.mI; g.phiI = (const float*)p.phiI; g.phiO = (const float*)p.phiO; g.mO = p.mO;
         g.Kp = p.Kp; g.Np = p.Np; g.NTp = c->NTp; g.L = p.LB;
-        if (p.kind == 2) { g.Zq = (const float*)p.EX; g.w = (const float*)c->dP; g.w_lstride = c->NTp; }
+        if (p.kind == 2) { g.Zq = (const float*)p.EX; g.w = (const float*)(weights_pp ? c->Pp : c->dP); g.w_lstride = c->NTp; }
         else             { g.Zq = (const float*)c->Zp; g.w = nullptr; g.w_lstride = 0; }
         TCK(launch_bgemm(c, g, c->vG));
     }
@@ -817,15 +820,19 @@ static int read_scal(tnml_ctx* c, const double* dev, int count, double* host_out
 static int cgrad_device(tnml_ctx* c, int npass, double lambda, double cconv, bool outputs_current = false) {
     if (npass < 1 || npass > TNML_MAX_PASS) return tnml_fail(c, "cgrad: Npass must be in 1..%d", TNML_MAX_PASS);
     const size_t n = c->plan.msize();
+    const bool fastc = c->single() && c->cg_method == 1;   // method = fast_conj of the per-label variant (single.h:290-398)
     TCK(grad_eval(c, false, outputs_current));           // :374-385
     TCK(launch_cg_init(c, n, lambda, c->single() ? cconv : -1.));   // :386-388 (single.h:200-208 with the entry check)
     for (int pass = 1; pass <= npass; ++pass) {          // :389
         c->cg_pass = pass;
-        TCK(forward_pass(c, c->vP, LD_MODE_PAP, c->vG + n, c->fast_cg));   // :394-401 (keeps p*t.v for the fast update)
+        TCK(forward_pass(c, c->vP, LD_MODE_PAP, c->vG + n, c->fast_cg || fastc));   // :394-401 (keeps p*t.v for the fast update)
         TCK(allreduce(c, c->vG + n, TNML_NSCAL_AR));                  // :402
         TCK(launch_cg_step(c, n, lambda, pass));         // :403-407
         if (pass == npass) break;                        // :409
-        TCK(grad_eval(c, c->fast_cg));                   // :412-421
+        if (fastc) {                                     // single.h:347-379: A p from the p.v of this pass, residual by recurrence
+            TCK(grad_eval(c, false, false, true));
+            TCK(launch_cg_fast_resid0(c, n, pass));
+        } else TCK(grad_eval(c, c->fast_cg));            // :412-421
         TCK(launch_cg_resid(c, n, lambda, cconv, pass)); // :422-428, :432-436, :442
     }
     return 0;

@@ -85,6 +85,7 @@ struct tnml_ctx {
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     int overlap = 0;
     int fused_fwd = 1;
+    int cg_method = 0;               // per-label variant: 0 = conj (single.h:162-288), 1 = fast_conj (single.h:290-398); option "cg_method"
     int sytrd_exit = 1;              // rank-adaptive exit of the tridiagonalisation of the split's Gram matrix (eigh.hip); option "sytrd_exit", env TNML_SYTRD_TOL=0 disables
     int snake = 0, stream_dir = 0;   // alternate the traversal direction of consecutive passes over the Label-carrying environment (MALL reuse); env TNML_SNAKE / option "snake"
     int bgemm_ps = 0;                // gradient GEMM with producer / consumer waves (kernels_fused.hip); env TNML_BGEMM_PS / option "bgemm_ps"               // forward pass as one persistent kernel (kernels_fused.hip); env TNML_FUSED_FWD / option "fused_fwd"             // env TNML_OVERLAP=0 / tnml_set_option "overlap"
@@ -287,7 +288,8 @@ int launch_bond_form(tnml_ctx* c, const SiteT& A1, const SiteT& A2, double* B); 
 // CG vector algebra on device scalars (single-block kernels)
 int launch_cg_init(tnml_ctx* c, size_t n, double lambda, double cconv0);   // cconv0 < 0: no entry check          // r = G - lambda B ; p = r ; RR = |r|^2
 int launch_cg_step(tnml_ctx* c, size_t n, double lambda, int pass);          // pAp, alpha, B += alpha p
-int launch_cg_resid(tnml_ctx* c, size_t n, double lambda, double cconv, int pass);   // nr, beta, r, cost, conv, p
+int launch_cg_resid(tnml_ctx* c, size_t n, double lambda, double cconv, int pass);
+int launch_cg_fast_resid0(tnml_ctx* c, size_t n, int pass);      // fast_conj: G <- r - a*G before launch_cg_resid   // nr, beta, r, cost, conv, p
 int launch_sqnorm(tnml_ctx* c, const double* x, size_t n, double* out);    // out[0] = |x|^2
 int launch_diffnorm(tnml_ctx* c, const double* x, const double* y, size_t n, double* out2);  // out2[0]=|x|^2, out2[1]=|x-y|^2
 int launch_fill_f32(tnml_ctx* c, float* p, float v, size_t n);

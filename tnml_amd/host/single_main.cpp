@@ -4,7 +4,7 @@
 // Keeps the reference's surface (single.cc:6-244 and the mldmrg of single.h:523-728): input keys, the files `sites`
 // and `W<label>` in the working directory, the `WRITE_WF` hook, the idx-ubyte training set under `datadir`, the
 // image order (labels taken round-robin, single.cc:156-181) and the log lines.  One tnml_bond_update per bond.
-// Not built: method = fast_conj | exact | pinv and the `noise` density-matrix term (single.h:290-517,648-672); they
+// Built: method = conj | fast_conj.  Not built: method = exact | pinv and the `noise` density-matrix term (single.h:117-160,404-517,648-672); they
 // stop with a message.  Extensions (never read by the reference): `seed`, `device`, `precision`, `imglen`,
 // `feature_scale` as in the fixedL driver.
 #include <array>
@@ -69,8 +69,9 @@ int main(int argc, const char* argv[]) {
         if (precision == "mixed") dtype = TNML_F64_E32; else if (precision == "f32") dtype = TNML_F32;
         else if (precision != "f64" && precision != "strict") { std::printf("precision must be f64, mixed or f32\n"); return 1; }
         if (L < 0 || L > 9) { std::printf("label must be in 0..9\n"); return 1; }
-        if (method == "fast_conj" || method == "exact" || method == "pinv") { std::printf("method \"%s\" is not built here (only conj)\n", method.c_str()); return 1; }
-        if (method != "conj") { std::printf("method type \"%s\" not recognized\n", method.c_str()); return 1; }   // single.h:611
+        if (method == "exact" || method == "pinv") { std::printf("method \"%s\" is not built here (conj and fast_conj are)\n", method.c_str()); return 1; }
+        if (method != "conj" && method != "fast_conj") { std::printf("method type \"%s\" not recognized\n", method.c_str()); return 1; }   // single.h:611
+        const bool fast_conj = method == "fast_conj";                                  // single.h:599
         if (noise >= 1E-14) { std::printf("noise > 0 (density-matrix split, single.h:648-672) is not built here\n"); return 1; }
 
         char wname[32]; std::snprintf(wname, sizeof wname, "W%d", L);                  // :53
@@ -138,6 +139,7 @@ int main(int argc, const char* argv[]) {
         }
         tnml_ctx* ctx = nullptr;
         if (tnml_create(&ctx, &cfg) != 0) die(nullptr, "tnml_create");
+        if (fast_conj) CK(ctx, tnml_set_option(ctx, "cg_method", 1));
         CK(ctx, tnml_set_data_phi(ctx, phi.data(), labels.data()));
         phi.clear(); phi.shrink_to_fit();
         for (int j = 1; j <= N; ++j) CK(ctx, tnml_set_site(ctx, j, W.A[j].ml, W.A[j].mr, 0, W.A[j].a.data()));
@@ -162,7 +164,14 @@ int main(int argc, const char* argv[]) {
                 std::printf("Sweep %ld Half %d Bond %d\n", sw, ha, r.c);                // :566
                 std::printf("norm(oB) = %.12g\n", r.norm_oB);                           // :572
                 if (r.cg.converged == 2) std::printf("  |r| < %.1E, not optimizing\n", cconv);   // :204 (|r| itself stays on the device)
-                for (int p = 0; p < r.cg.npass_done; ++p) {
+                for (int p = 0; fast_conj && p < r.cg.npass_done; ++p) {                // fast_cgrad prints pass and |r| on one line, no cost (single.h:337,373,387-393)
+                    std::printf("  Conj grad pass %d ", p + 1);
+                    const bool has_r = r.cg.converged ? true : p + 1 < r.cg.npass_done || r.cg.npass_done < Npass;
+                    if (!(has_r && p + 1 < Npass)) std::printf("\n");
+                    else if (r.cg.converged == 1 && p + 1 == r.cg.npass_done) std::printf("  |r| = %.1E < %.1E, breaking\n", r.cg.rnorm[p], cconv);
+                    else std::printf("  |r| = %.1E\n", r.cg.rnorm[p]);
+                }
+                for (int p = 0; !fast_conj && p < r.cg.npass_done; ++p) {
                     std::printf("  Conj grad pass %d\n", p + 1);                        // :211
                     const bool has_cost = r.cg.converged ? true : p + 1 < r.cg.npass_done || r.cg.npass_done < Npass;
                     if (has_cost && (p + 1 < Npass)) {
