@@ -226,7 +226,7 @@ int tnml_synchronize(tnml_ctx* ctx);
      "fg64_cfg", "ldot_cfg"  force a tile configuration of the feature GEMM / the label dot that is otherwise chosen by the
                       image count (2 / 1 = the large-image-count forms bench.py times; parity tests run them at small sizes)
      "fused_fwd"      the forward pass of a Label-on-environment bond at m = 120 as one persistent kernel (feature GEMM +
-                      label dot of the previous tile, kernels_fused.hip): 1 = from 32 768 images per rank on (default),
+                      label dot of the previous tile, kernels_fused.hip): 1 = from 14 336 images per rank on (default),
                       0 = never, 2 = always (parity tests at small sizes), > 2 = always with that many workgroups at most
      "overlap"        two-queue forward pass (measured slower, default 0)
      "cg_method"      TNML_MODE_SINGLE only: 0 = conj (single.h:162-288, default), 1 = fast_conj (single.h:290-398: one image sum

@@ -736,7 +736,7 @@ static int forward_pass(tnml_ctx* c, const double* vec, int mode, double* tail, 
         // 256 CUs).  Every image still goes through exactly the same arithmetic in the same order, and the cost partials are
         // reduced over all blocks in the fixed order afterwards: bit-identical to the single-queue form.
         if (c->fused_fwd && c->env64() && !c->single() && p.kind != 2 && p.Kp == 240 && p.Np == 240 && p.mI == 120 && p.mO == 120 &&
-            (c->fused_fwd >= 2 || c->NTp / 64 >= 2 * 256)) {
+            (c->fused_fwd >= 2 || c->NTp / 64 >= 224)) {
             FwdFusedArgs ff;
             ff.EI = (const double*)p.EI; ff.mI = p.mI; ff.phiI = (const double*)p.phiI; ff.M = vec; ff.Kp = p.Kp; ff.Np = p.Np;
             ff.phiO = (const double*)p.phiO; ff.EL = (const double*)p.EX; ff.EL_lstride = ustride; ff.mO = p.mO; ff.NTp = c->NTp; ff.ntiles = c->NTp / 64;
