@@ -83,12 +83,12 @@ struct tnml_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // second queue: the HBM-bound label dot of one image half runs beside the MFMA-bound feature GEMM of the other
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
-    int overlap = 0;
-    int fused_fwd = 1;
+    int overlap = 0;                 // two-queue forward pass (measured slower); env TNML_OVERLAP / option "overlap"
+    int fused_fwd = 1;               // forward pass as one persistent kernel (kernels_fused.hip): 1 = from 14 336 images per rank on, 0 never, 2 always; env TNML_FUSED_FWD / option "fused_fwd"
     int cg_method = 0;               // per-label variant: 0 = conj (single.h:162-288), 1 = fast_conj (single.h:290-398); option "cg_method"
     int sytrd_exit = 1;              // rank-adaptive exit of the tridiagonalisation of the split's Gram matrix (eigh.hip); option "sytrd_exit", env TNML_SYTRD_TOL=0 disables
     int snake = 0, stream_dir = 0;   // alternate the traversal direction of consecutive passes over the Label-carrying environment (MALL reuse); env TNML_SNAKE / option "snake"
-    int bgemm_ps = 0;                // gradient GEMM with producer / consumer waves (kernels_fused.hip); env TNML_BGEMM_PS / option "bgemm_ps"               // forward pass as one persistent kernel (kernels_fused.hip); env TNML_FUSED_FWD / option "fused_fwd"             // env TNML_OVERLAP=0 / tnml_set_option "overlap"
+    int bgemm_ps = 0;                // gradient GEMM with producer / consumer waves (kernels_fused.hip, measured slower); env TNML_BGEMM_PS / option "bgemm_ps"
     rocblas_handle blas = nullptr;
     ncclComm_t comm = nullptr;
     struct LocalComm* local = nullptr;   // in-process communicator of ranks sharing one device (local_comm.hip)
