@@ -1015,53 +1015,60 @@ __global__ __launch_bounds__(64) void k_tridiag_invit(TeigArgs T) {
     const double lam = T.mu[row];
     const double tiny = 2.2e-16 * tnorm + 1e-300;
 #define IX(k) ((k) * IV_L + lane)
-    // LAPACK dlagtf: (T - lam I) = P L U with partial pivoting; the rows are generated on the fly
+    // LAPACK dlagtf: (T - lam I) = P L U with partial pivoting; the rows are generated on the fly.
+    // Where the time of this kernel goes (tools/probe/probe_invit.hip, 131-row block): factorisation 45 us, reciprocal pivots 21 us,
+    // two sweeps 47 us of 131 -- the factorisation is one dependent chain per row, and in its straightforward form it holds two
+    // IEEE divisions on divergent branches (the lanes of a wave pivot differently).  Here the pivot choice is a select, the one
+    // multiplier of a row comes from v_rcp_f64 + two Newton steps, and the reciprocal pivot the solves need is formed in the same
+    // iteration, off the chain (no second pass over the block).
+    auto frcp = [](double x) {
+        if (!(fabs(x) > 1e-290 && fabs(x) < 1e290)) return 1. / x;    // out of the fast path's range: IEEE division
+        double y = __builtin_amdgcn_rcp(x);
+        double e = fma(-x, y, 1.0); y = fma(y, e, y);
+        e = fma(-x, y, 1.0); y = fma(y, e, y);
+        return y;
+    };
+    auto rpiv = [&](double pk) { if (fabs(pk) < tiny) pk = pk < 0. ? -tiny : tiny; return frcp(pk); };   // tiny pivots perturbed (dlagts job = -1 in spirit): the solves only multiply
     unsigned long long pv0 = 0, pv1 = 0, pv2 = 0, pv3 = 0;   // interchange flags, n <= 256 (named: no dynamic register indexing)
     double ak = s_d[lo] - lam, bk = s_e[lo];
     double scale1 = fabs(ak) + fabs(bk);
     for (int k = lo; k < hi - 1; ++k) {
         const double ck = s_e[k];                       // sub-diagonal entry of row k+1
-        double ak1 = s_d[k + 1] - lam;
+        const double ak1 = s_d[k + 1] - lam;
         const double bk1 = k < hi - 2 ? s_e[k + 1] : 0.;
         const double scale2 = fabs(ck) + fabs(ak1) + fabs(bk1);
-        double nak, nbk;                                // row k+1 after elimination
-        if (ck == 0.) {
-            a[IX(k)] = ak; b[IX(k)] = bk; c[IX(k)] = 0.; d2[IX(k)] = 0.;
-            nak = ak1; nbk = bk1;
-        } else {
-            // dlagtf's test |c_k|/scale2 <= |a_k|/scale1, cross-multiplied (no divisions)
-            if (fabs(ck) * scale1 <= fabs(ak) * scale2) {     // no interchange
-                const double mult = ck / ak;
-                a[IX(k)] = ak; b[IX(k)] = bk; c[IX(k)] = mult; d2[IX(k)] = 0.;
-                nak = ak1 - mult * bk; nbk = bk1;
-            } else {                                    // interchange rows k, k+1
-                const double mult = ak / ck;
-                a[IX(k)] = ck; b[IX(k)] = ak1; c[IX(k)] = mult; d2[IX(k)] = bk1;
-                nak = bk - mult * ak1; nbk = -mult * bk1;
-                const unsigned long long bit = 1ull << (k & 63); const int wq = k >> 6;
-                pv0 |= wq == 0 ? bit : 0ull; pv1 |= wq == 1 ? bit : 0ull; pv2 |= wq == 2 ? bit : 0ull; pv3 |= wq == 3 ? bit : 0ull;
-            }
-        }
+        // dlagtf's test |c_k|/scale2 <= |a_k|/scale1, cross-multiplied (no divisions); c_k = 0: nothing to eliminate
+        const bool zero = ck == 0.;
+        const bool sw = !zero && !(fabs(ck) * scale1 <= fabs(ak) * scale2);       // interchange rows k, k+1
+        const double num = sw ? ak : ck, den = sw ? ck : ak;
+        const double mult = zero ? 0. : num * frcp(den);
+        const double piv = sw ? ck : ak;
+        b[IX(k)] = sw ? ak1 : bk; c[IX(k)] = mult; d2[IX(k)] = sw ? bk1 : 0.;
+        const double nak = (sw ? bk : ak1) - mult * (sw ? ak1 : bk);
+        const double nbk = sw ? -mult * bk1 : bk1;
+        const unsigned long long bit = sw ? 1ull << (k & 63) : 0ull; const int wq = k >> 6;
+        pv0 |= wq == 0 ? bit : 0ull; pv1 |= wq == 1 ? bit : 0ull; pv2 |= wq == 2 ? bit : 0ull; pv3 |= wq == 3 ? bit : 0ull;
+        a[IX(k)] = rpiv(piv);                           // reciprocal pivot
         scale1 = scale2;
         ak = nak; bk = nbk;
     }
-    a[IX(hi - 1)] = ak; b[IX(hi - 1)] = 0.; d2[IX(hi - 1)] = 0.;
+    a[IX(hi - 1)] = rpiv(ak); b[IX(hi - 1)] = 0.; d2[IX(hi - 1)] = 0.;
     d2[IX(hi - 2)] = 0.;
-    // reciprocal pivots, tiny ones perturbed (dlagts job = -1 in spirit): the solves below only multiply
-    for (int k = lo; k < hi; ++k) { double pk = a[IX(k)]; if (fabs(pk) < tiny) pk = pk < 0. ? -tiny : tiny; a[IX(k)] = 1. / pk; }
     // start vector: deterministic pseudo-random entries in (-1, 1), different for every vector
     unsigned int seed = 12345u + 7919u * (unsigned)g;
     for (int k = lo; k < hi; ++k) { seed = seed * 1664525u + 1013904223u; x[IX(k)] = ((seed >> 8) * (1.0 / 8388608.0)) - 1.0; }
+    double xscale = 1.;                                     // max-norm scaling of the iterate, applied when the next pass reads it
     for (int iter = 0; iter < 2; ++iter) {                 // the shift is exact to round-off: two sweeps suffice
-        // forward: apply (P L)^-1
-        double xk = x[IX(lo)];
+        // forward: apply (P L)^-1 (the interchange is a select: the lanes of a wave pivot differently)
+        double xk = x[IX(lo)] * xscale;
         for (int k = lo; k < hi - 1; ++k) {
             const int wq = k >> 6;
             const unsigned long long word = wq == 0 ? pv0 : wq == 1 ? pv1 : wq == 2 ? pv2 : pv3;
             const bool sw = (word >> (k & 63)) & 1;
-            const double xk1 = x[IX(k + 1)], m = c[IX(k)];
-            if (!sw) { x[IX(k)] = xk; xk = xk1 - m * xk; }
-            else     { x[IX(k)] = xk1; xk = xk - m * xk1; }
+            const double xk1 = x[IX(k + 1)] * xscale, m = c[IX(k)];
+            const double keep = sw ? xk1 : xk, go = sw ? xk : xk1;
+            x[IX(k)] = keep;
+            xk = go - m * keep;
         }
         x[IX(hi - 1)] = xk;
         // back substitution
@@ -1072,13 +1079,12 @@ __global__ __launch_bounds__(64) void k_tridiag_invit(TeigArgs T) {
             xn2 = xn1; xn1 = t;
             vmax = fmax(vmax, fabs(t));
         }
-        const double inv = vmax > 0. ? 1. / vmax : 1.;          // max-norm scaling keeps the iterates in range
-        for (int k = lo; k < hi; ++k) x[IX(k)] *= inv;
+        xscale = vmax > 0. ? 1. / vmax : 1.;               // keeps the iterates in range
     }
     double nrm2 = 0.;
-    for (int k = lo; k < hi; ++k) { const double v = x[IX(k)]; nrm2 = fma(v, v, nrm2); }
+    for (int k = lo; k < hi; ++k) { const double v = x[IX(k)] * xscale; nrm2 = fma(v, v, nrm2); }
     const double inv = nrm2 > 0. ? 1. / sqrt(nrm2) : 0.;
-    for (int k = lo; k < hi; ++k) zc[k] = x[IX(k)] * inv;
+    for (int k = lo; k < hi; ++k) zc[k] = (x[IX(k)] * xscale) * inv;
 #undef IX
 }
 
