@@ -1103,22 +1103,27 @@ int eigh_tridiag_eig(tnml_ctx* c, const double* D, const double* E, int n, doubl
 }
 
 // C = 1.5 I - 0.5 S (Newton-Schulz polish of a nearly orthonormal basis), dev[0] = max |S - I|
-__global__ __launch_bounds__(256) void k_ns_matrix(const double* __restrict__ S, double* __restrict__ Cm, int m, double* __restrict__ dev) {
-    __shared__ double sh[256];
+// (one workgroup of 1024 lanes, a column per group of lanes: 14 independent loads per lane at m = 120 instead of a 57-deep chain)
+__global__ __launch_bounds__(1024) void k_ns_matrix(const double* __restrict__ S, double* __restrict__ Cm, int m, double* __restrict__ dev) {
+    __shared__ double sh[16];
     double mx = 0.;
-    for (int idx = threadIdx.x; idx < m * m; idx += 256) {
-        const int i = idx % m, j = idx / m;
-        const double s = S[idx], id = (i == j) ? 1. : 0.;
-        mx = fmax(mx, fabs(s - id));
-        Cm[idx] = 1.5 * id - 0.5 * s;
-    }
-    sh[threadIdx.x] = mx;
+    const int i = threadIdx.x & 127, j0 = threadIdx.x >> 7;               // row, first column (m <= 128: one lane per row; larger m: rows strided)
+    for (int ii = i; ii < m; ii += 128)
+#pragma unroll 4
+        for (int j = j0; j < m; j += 8) {
+            const size_t idx = ii + (size_t)m * j;
+            const double s = S[idx], id = (ii == j) ? 1. : 0.;
+            mx = fmax(mx, fabs(s - id));
+            Cm[idx] = 1.5 * id - 0.5 * s;
+        }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + s]); __syncthreads(); }
-    if (threadIdx.x == 0) dev[0] = sh[0];
+    if (threadIdx.x == 0) { double t = sh[0]; for (int w = 1; w < 16; ++w) t = fmax(t, sh[w]); dev[0] = t; }
 }
 int eigh_ns_matrix(tnml_ctx* c, const double* S, double* Cm, int m, double* dev) {
-    hipLaunchKernelGGL(k_ns_matrix, dim3(1), dim3(256), 0, c->stream, S, Cm, m, dev);
+    hipLaunchKernelGGL(k_ns_matrix, dim3(1), dim3(1024), 0, c->stream, S, Cm, m, dev);
     HIPCK(c, hipGetLastError());
     return 0;
 }
