@@ -100,7 +100,7 @@ int launch_bond_form(tnml_ctx* c, const SiteT& A1, const SiteT& A2, double* B) {
     if (k >= 16 && (A1.L == 1 || A2.L == 1)) {
         const double one = 1.0, zero = 0.0;
         rocblas_status st;
-        if (A1.L == 1) st = rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, nl, nr * A2.L, k, &one, A1.a, nl, A2.a, k, &zero, B, nl);
+        if (A1.L == 1) st = dgemm_strips(c->blas, rocblas_operation_none, rocblas_operation_none, nl, nr * A2.L, k, A1.a, nl, A2.a, k, B, nl, 2);
         else           st = rocblas_dgemm_strided_batched(c->blas, rocblas_operation_none, rocblas_operation_none, nl, nr, k, &one, A1.a, nl, (rocblas_stride)nl * k,
                                                          A2.a, k, 0, &zero, B, nl, (rocblas_stride)nl * nr, A1.L);
         if (st != rocblas_status_success) return tnml_fail(c, "bond_form: rocblas dgemm failed (%d)", (int)st);

@@ -103,8 +103,8 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
     }
     const bool left = (nl < nr) || (nl == nr && ha == 1);
     const double one = 1.0, zero = 0.0;
-    if (left) RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_transpose, nl, nl, nr, &one, M, nl, M, nl, &zero, c->sG, nl));
-    else      RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, nr, nr, nl, &one, M, nl, M, nl, &zero, c->sG, nr));
+    if (left) RBCK(c, dgemm_strips(c->blas, rocblas_operation_none, rocblas_operation_transpose, nl, nl, nr, M, nl, M, nl, c->sG, nl, 4));
+    else      RBCK(c, dgemm_strips(c->blas, rocblas_operation_transpose, rocblas_operation_none, nr, nr, nl, M, nl, M, nl, c->sG, nr, 4));
     // eigen-decomposition of rho: in-house one-workgroup tridiagonalisation + rocSOLVER dstedc + in-house back
     // transformation (TNML_SVD_SYEVD, n <= 240), or stock rocSOLVER dsyevd (TNML_SVD_ROCSOLVER / larger n)
     // backend: 0 = in-house tridiagonalisation + in-house bisection/inverse iteration (verified, with
@@ -264,7 +264,7 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
     double* Aright = Sr.a;                 // right factor (m x nr), ld = m  == A_{b+1}[g][t][be](,[l])
     if (left) {
         // Q = U_m
-        RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, m, nr, nl, &one, Q, nl, M, nl, &zero, Aright, m));   // U^T M = S V^T
+        RBCK(c, dgemm_strips(c->blas, rocblas_operation_transpose, rocblas_operation_none, m, nr, nl, Q, nl, M, nl, Aright, m, 2));   // U^T M = S V^T
         if (Q != Aleft) HIPCK(c, hipMemcpyAsync(Aleft, Q, sizeof(double) * (size_t)nl * m, hipMemcpyDeviceToDevice, st));
         if (ha == 2) {   // orthonormal factor goes right: V^T = S^-1 U^T M ; left gets U S
             hipLaunchKernelGGL(k_scale_rows, dim3(nblk((size_t)m * nr)), dim3(256), 0, st, Aright, m, (size_t)nr, d_isig);

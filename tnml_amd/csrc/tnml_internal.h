@@ -281,6 +281,17 @@ struct PackDesc {       // M[l][2x+s][TO==2 ? 2y+t : y] <-> T[off + x*sx + s*ss 
     long sx, ss, sy, st, sl;
     int Kp, Np;
 };
+// C = op(A) op(B) (alpha 1, beta 0) issued as a strided batch over `strips` column strips of C: at the few-hundred-square sizes of
+// the split rocBLAS picks 128 x 64 macro tiles and runs on 2-8 workgroups; the strips give it more, smaller ones
+// (tools/probe/probe_gemm_strips.hip: Gram 240^3 16.2 -> 10.0 us with 4 strips, U^T M 16.5 -> 10.0 and A_b A_{b+1} 10.0 -> 6.3 with 2).
+static inline rocblas_status dgemm_strips(rocblas_handle h, rocblas_operation ta, rocblas_operation tb, int M, int N, int K,
+                                          const double* A, int lda, const double* B, int ldb, double* C, int ldc, int strips) {
+    const double one = 1.0, zero = 0.0;
+    if (strips <= 1 || N % strips || N / strips < 16) return rocblas_dgemm(h, ta, tb, M, N, K, &one, A, lda, B, ldb, &zero, C, ldc);
+    const int ns = N / strips;
+    const rocblas_stride sb = tb == rocblas_operation_none ? (rocblas_stride)ns * ldb : (rocblas_stride)ns;
+    return rocblas_dgemm_strided_batched(h, ta, tb, M, ns, K, &one, A, lda, 0, B, ldb, sb, &zero, C, ldc, (rocblas_stride)ns * ldc, strips);
+}
 int launch_pack(tnml_ctx* c, const PackDesc& d, const double* T, double* Md, float* Mf, double* zero = nullptr, int nzero = 0);   // either output may be null; zero[0..nzero) is cleared on the way
 int launch_unpack(tnml_ctx* c, const PackDesc& d, const double* Md, double* T);
 int launch_cvt(tnml_ctx* c, const double* src, float* dst, size_t n);
