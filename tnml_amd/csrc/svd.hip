@@ -103,8 +103,9 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
     }
     const bool left = (nl < nr) || (nl == nr && ha == 1);
     const double one = 1.0, zero = 0.0;
-    if (left) RBCK(c, dgemm_strips(c->blas, rocblas_operation_none, rocblas_operation_transpose, nl, nl, nr, M, nl, M, nl, c->sG, nl, 4));
-    else      RBCK(c, dgemm_strips(c->blas, rocblas_operation_transpose, rocblas_operation_none, nr, nr, nl, M, nl, M, nl, c->sG, nr, 4));
+    const int gstrips = (left ? nr : nl) >= 1024 ? 8 : 4;     // the Label-on-B bonds reduce over 2400: 133 us as one call, 17 us as 8 strips
+    if (left) RBCK(c, dgemm_strips(c->blas, rocblas_operation_none, rocblas_operation_transpose, nl, nl, nr, M, nl, M, nl, c->sG, nl, gstrips));
+    else      RBCK(c, dgemm_strips(c->blas, rocblas_operation_transpose, rocblas_operation_none, nr, nr, nl, M, nl, M, nl, c->sG, nr, gstrips));
     // eigen-decomposition of rho: in-house one-workgroup tridiagonalisation + rocSOLVER dstedc + in-house back
     // transformation (TNML_SVD_SYEVD, n <= 240), or stock rocSOLVER dsyevd (TNML_SVD_ROCSOLVER / larger n)
     // backend: 0 = in-house tridiagonalisation + in-house bisection/inverse iteration (verified, with
@@ -272,7 +273,7 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
         }
     } else {
         // Q = V_m
-        RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, nl, m, nr, &one, M, nl, Q, nr, &zero, Aleft, nl));        // M V = U S
+        RBCK(c, dgemm_strips(c->blas, rocblas_operation_none, rocblas_operation_none, nl, m, nr, M, nl, Q, nr, Aleft, nl, 2));        // M V = U S
         if (ha == 2) {
             hipLaunchKernelGGL(k_transpose_scale, dim3(nblk((size_t)nr * m)), dim3(256), 0, st, Q, Aright, nr, m, no_scale);
         } else {         // orthonormal factor goes left: U = M V S^-1 ; right gets S V^T

@@ -28,6 +28,8 @@ int main() {
         {"G = M^T M     (TN 240 x 240 x 240)", rocblas_operation_transpose, rocblas_operation_none, 240, 240, 240, 240, 240, 240},
         {"SV = U^T M    (TN 120 x 240 x 240)", rocblas_operation_transpose, rocblas_operation_none, 120, 240, 240, 240, 240, 120},
         {"B = A1 A2     (NN 240 x 240 x 120)", rocblas_operation_none, rocblas_operation_none, 240, 240, 120, 240, 120, 240},
+        {"U S = M V     (NN 240 x 120 x 240)", rocblas_operation_none, rocblas_operation_none, 240, 120, 240, 240, 240, 240},
+        {"Gram, K=2400  (NT 240 x 240 x 2400)", rocblas_operation_none, rocblas_operation_transpose, 240, 240, 2400, 240, 240, 240},
     };
     for (const Case& c : cases) {
         printf("%s:", c.name);
