@@ -172,6 +172,12 @@ int tnml_quadcost(tnml_ctx* ctx, const double* B, double lambda, double* cost,
 /* cgrad (fixedL.cc:349-445): B is updated in place */
 int tnml_cgrad(tnml_ctx* ctx, double* B, int npass, double lambda, double cconv, tnml_cg_trace* trace);
 
+/* exact (single.h:117-160; TNML_MODE_SINGLE, TNML_F64, one rank): B = y Phi^+ through the SVD of the D x NT design matrix of the
+   v_n (D = 4 mL mR <= 4096; its rows come from D forward passes of unit tensors, the SVD is a one-sided Jacobi on the host so
+   that small singular values stay accurate), with the reference's filtered inverse s/(s^2 + lambda) for s > pcut.
+   B (ITensor layout, D doubles) is output only.  Meant for small problems, like the reference's (single.h:114). */
+int tnml_exact(tnml_ctx* ctx, double* B, double lambda, double pcut);
+
 /* ---- svd(B, W.Aref(c), S, W.Aref(c+dc)); W.Aref(c+dc) *= S  (fixedL.cc:519-521) ---------- */
 /* ha = 1: c = b (sweeping right), ha = 2: c = b+1 (sweeping left).  Updates the W replica.
    sv (nullable, capacity >= min(rows,cols)) receives all singular values, descending. */
@@ -230,7 +236,8 @@ int tnml_synchronize(tnml_ctx* ctx);
                       0 = never, 2 = always (parity tests at small sizes), > 2 = always with that many workgroups at most
      "overlap"        two-queue forward pass (measured slower, default 0)
      "cg_method"      TNML_MODE_SINGLE only: 0 = conj (single.h:162-288, default), 1 = fast_conj (single.h:290-398: one image sum
-                      per CG step, residual by recurrence, the reference's regulariser term as written, no cost in the trace)
+                      per CG step, residual by recurrence, the reference's regulariser term as written, no cost in the trace),
+                      2 = exact (single.h:117-160, see tnml_exact; "pcut" through tnml_set_option_real)
      "sytrd_exit"     the split's tridiagonalisation stops once the trailing block of the Gram matrix is numerically zero
                       (trace <= 1e-15 trace(G); default 1; 0 = all n-2 Householder steps)
      "bgemm_ps"       producer / consumer form of the gradient GEMM (measured slower, default 0; 2 = force at any size)
@@ -238,6 +245,8 @@ int tnml_synchronize(tnml_ctx* ctx);
                       results are bit-identical either way)
    fast_cg = reuse_p = 0 is the reference's literal evaluation order (fixedL.cc:374-421). */
 int tnml_set_option(tnml_ctx* ctx, const char* name, int value);
+/* real-valued options: "pcut" (PCut of the exact solver inside tnml_bond_update, single.cc:50, default 1E-8) */
+int tnml_set_option_real(tnml_ctx* ctx, const char* name, double value);
 /* health of the in-house eigensolver: number of fallbacks to rocSOLVER so far, number of splits whose kept basis
    held an eigenvalue cluster and was re-orthonormalised by Cholesky QR, and max|Q^T Q - I| of the kept basis
    before the first / second Newton-Schulz polish step of the last split */

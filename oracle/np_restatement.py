@@ -321,6 +321,14 @@ class NpSingle:
             p = r + beta * p
         return B, trace
 
+    def exact(self, lam, pcut=1e-8):                                         # single.h:117-160
+        """B = y Phi^+ with the filtered inverse s/(s^2 + lambda) above pcut (numpy.linalg.svd of the NT x D matrix of the v_n)"""
+        shp = self.v.shape[1:]
+        Phi = self.v.reshape(self.v.shape[0], -1)                            # [n][D], C order of (a, s, t, r)
+        U, sv, Vt = np.linalg.svd(Phi, full_matrices=False)
+        f = np.where(sv > pcut, sv / (sv * sv + lam), 0.0)
+        return ((self.y @ U) * f @ Vt).reshape(shp)
+
     def fast_cgrad(self, B, npass, lam, cconv):                              # single.h:290-398
         """one contraction with the images per step: p.v gives pAp and A p; residual by recurrence, with the reference's
         'nr = nr - lambda*B' (:379) as written"""

@@ -267,6 +267,8 @@ def _slib():
         L.sorc_cgrad.argtypes = [vp, dp, C.c_int, C.c_double, C.c_double, C.POINTER(CgTrace)]
         L.sorc_fast_cgrad.argtypes = [vp, dp, C.c_int, C.c_double, C.c_double, C.POINTER(CgTrace)]
         L.sorc_set_method.argtypes = [vp, C.c_int]
+        L.sorc_set_pcut.argtypes = [vp, C.c_double]
+        L.sorc_exact.argtypes = [vp, dp, C.c_double, C.c_double]
         L.sorc_svd_split.argtypes = [vp, dp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, dp, ip, dp, ip]
         L.sorc_mldmrg.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int,
                                   C.POINTER(SingleBondReport)]
@@ -389,9 +391,16 @@ class SingleOracle:
         return buf.reshape(B.shape, order="F"), dict(skipped=bool(skipped), npass_done=n, converged=bool(tr.converged), cost=[],
                                                      rnorm=list(tr.rnorm[:max(n - 1, 0)] if not tr.converged else tr.rnorm[:n]), pAp=list(tr.pAp[:n]), alpha=list(tr.alpha[:n]))
 
-    def set_method(self, method):
-        """optimiser of mldmrg: "conj" (cgrad) or "fast_conj" (fast_cgrad), single.h:598-599"""
-        self._ck(self._L.sorc_set_method(self._h, {"conj": 0, "fast_conj": 1}[method]))
+    def exact(self, b, lam, pcut=1e-8):
+        """single.h:117-160 (method = exact) for the bond set by set_bond(b): returns the solved bond tensor"""
+        buf = np.zeros(int(np.prod(self.bond_shape(b))))
+        self._ck(self._L.sorc_exact(self._h, _dp(buf), lam, pcut))
+        return buf.reshape(self.bond_shape(b), order="F")
+
+    def set_method(self, method, pcut=1e-8):
+        """optimiser of mldmrg: "conj" (cgrad), "fast_conj" (fast_cgrad) or "exact", single.h:598-600"""
+        self._ck(self._L.sorc_set_method(self._h, {"conj": 0, "fast_conj": 1, "exact": 2}[method]))
+        self._ck(self._L.sorc_set_pcut(self._h, pcut))
 
     def svd_split(self, B, b, ha, cutoff, maxm, minm):
         te, m, nsv = C.c_double(), C.c_int(), C.c_int()

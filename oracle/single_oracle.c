@@ -1,6 +1,6 @@
 /* single_oracle.c -- CPU restatement of the per-label variant of the reference:
  *   /root/reference/single.cc   main: features (71-84), initial projections (181-199), precalc (204-216)
- *   /root/reference/single.h    TState (19-25), quadcost (82-112), cgrad (162-288), fast_cgrad (290-398), mldmrg (523-728)
+ *   /root/reference/single.h    TState (19-25), quadcost (82-112), exact (117-160), cgrad (162-288), fast_cgrad (290-398), mldmrg (523-728)
  *   /root/reference/paralleldo.h static chunking, fork-join
  * TEST INFRASTRUCTURE ONLY (see single_oracle.h).  PARITY UNPINNED (no reference tests, ITensor absent).
  *
@@ -33,7 +33,8 @@ struct sorc {
     int currb;
     double* v; size_t vsz; int vmL, vmR;
     int sw, b, ha;
-    int method;     /* 0 = conj (cgrad), 1 = fast_conj (fast_cgrad): single.h:598-599 */
+    int method;     /* 0 = conj (cgrad), 1 = fast_conj (fast_cgrad), 2 = exact: single.h:598-600 */
+    double pcut;    /* PCut of the exact solver (single.cc: pcut key, default 1E-8) */
 };
 
 static int sfail(const char* msg) { fprintf(stderr, "single_oracle: %s\n", msg); return -1; }
@@ -72,7 +73,7 @@ sorc* sorc_create(int N, int NT, const double* phi, const int* labels, int targe
     memcpy(o->labels, labels, sizeof(int) * (size_t)NT);
     o->W = (ssite_t*)calloc((size_t)N + 2, sizeof(ssite_t));
     o->E = (senv_t*)calloc((size_t)N + 2, sizeof(senv_t));
-    o->currb = -1; o->sw = 1; o->b = 1; o->ha = 1;
+    o->currb = -1; o->sw = 1; o->b = 1; o->ha = 1; o->pcut = 1E-8;
     return o;
 }
 void sorc_destroy(sorc* o) {
@@ -346,7 +347,32 @@ done:
     free(r); free(p); free(Ap); free(tensors); free(reals);
     return ret;
 }
-int sorc_set_method(sorc* o, int method) { if (method < 0 || method > 1) return sfail("method must be 0 (conj) or 1 (fast_conj)"); o->method = method; return 0; }
+/* exact, single.h:117-160: B = y Phi^+ with Phi = [v_1 ... v_NT] (D x NT, D = 4 mL mR), through the thin SVD of Phi and the
+ * filtered inverse s -> s/(s^2 + lambda) for s > pcut, 0 otherwise (:145-153).  "Only works for rather small number of training
+ * samples" (:114).  The incoming B is ignored.  [ITensor-recall] svd(Phi,U,S,V) with default arguments does not truncate. */
+int sorc_exact(const sorc* o, double* B, double lambda, double pcut) {
+    if (!o->v) return sfail("setBond not called");
+    const int D = (int)o->vsz, NT = o->NT;
+    const int k = D < NT ? D : NT;
+    double* Phi = (double*)malloc(sizeof(double) * (size_t)D * NT);           /* column n = v_n (:137) */
+    for (int n = 0; n < NT; ++n) memcpy(Phi + (size_t)D * n, o->v + (size_t)n * o->vsz, sizeof(double) * (size_t)D);
+    double* U = (double*)malloc(sizeof(double) * (size_t)D * k); double* sv = (double*)malloc(sizeof(double) * (size_t)k);
+    double* Vt = (double*)malloc(sizeof(double) * (size_t)k * NT);
+    orc_thin_svd(D, NT, Phi, U, sv, Vt);                                     /* Phi = U diag(s) Vt; ITensor's U carries the image index: roles swapped, same product */
+    memset(B, 0, sizeof(double) * (size_t)D);
+    for (int g = 0; g < k; ++g) {
+        const double s1 = sv[g];
+        const double f = s1 > pcut ? s1 / (s1 * s1 + lambda) : 0.;           /* pseudoInv :145-153 */
+        if (f == 0.) continue;
+        double yv = 0.;
+        for (int n = 0; n < NT; ++n) yv += sy(o, n) * Vt[g + (size_t)k * n];  /* yL * U */
+        for (int i = 0; i < D; ++i) B[i] += yv * f * U[i + (size_t)D * g];    /* ... * Sinv * V (:158-159) */
+    }
+    free(Phi); free(U); free(sv); free(Vt);
+    return 0;
+}
+int sorc_set_pcut(sorc* o, double pcut) { o->pcut = pcut; return 0; }
+int sorc_set_method(sorc* o, int method) { if (method < 0 || method > 2) return sfail("method must be 0 (conj), 1 (fast_conj) or 2 (exact)"); o->method = method; return 0; }
 /* svd(B,U,S,V,svd_args) with U on the indices of W.A(c); W.A(c) = U, W.A(c+dc) = S*V  (single.h:636-646) */
 int sorc_svd_split(sorc* o, const double* B, int b, int ha, double cutoff, int maxm, int minm,
                    double* truncerr, int* newm, double* sv_out, int* nsv) {
@@ -407,7 +433,8 @@ int sorc_mldmrg(sorc* o, int nsweep, int maxm, int minm, double cutoff, int npas
             rp->norm_oB = sqrt(ssq(oB, n));                                    /* :572 */
             memcpy(B, oB, sizeof(double) * n);
             if (sorc_set_bond(o, b)) return -1;                                /* :579-596 */
-            int rc = o->method == 1 ? sorc_fast_cgrad(o, B, npass, lambda, cconv, &rp->cg)   /* :599 */
+            int rc = o->method == 2 ? sorc_exact(o, B, lambda, o->pcut)                      /* :600 */
+                   : o->method == 1 ? sorc_fast_cgrad(o, B, npass, lambda, cconv, &rp->cg)   /* :599 */
                                     : sorc_cgrad(o, B, npass, lambda, cconv, &rp->cg);       /* :598 */
             if (rc < 0) return -1;
             rp->cg_skipped = rc;

@@ -56,8 +56,11 @@ double sorc_quadcost(const sorc* o, const double* B, double lambda, double* reg_
 int sorc_cgrad(const sorc* o, double* B, int npass, double lambda, double cconv, orc_cg_trace* trace);
 /* fast_cgrad (single.h:290-398): one pass over the images per CG step, residual by recurrence; same return values as sorc_cgrad */
 int sorc_fast_cgrad(const sorc* o, double* B, int npass, double lambda, double cconv, orc_cg_trace* trace);
-/* optimiser used by sorc_mldmrg: 0 = conj (default), 1 = fast_conj (single.h:598-599) */
+/* exact (single.h:117-160): B = y Phi^+ through the thin SVD of the D x NT matrix of the v_n, filtered inverse s/(s^2+lambda) above pcut */
+int sorc_exact(const sorc* o, double* B, double lambda, double pcut);
+/* optimiser used by sorc_mldmrg: 0 = conj (default), 1 = fast_conj, 2 = exact (single.h:598-600); pcut of the exact solver (default 1E-8) */
 int sorc_set_method(sorc* o, int method);
+int sorc_set_pcut(sorc* o, double pcut);
 int sorc_svd_split(sorc* o, const double* B, int b, int ha, double cutoff, int maxm, int minm,
                    double* truncerr, int* newm, double* sv, int* nsv);   /* single.h:636-646 (noise = 0) */
 int sorc_mldmrg(sorc* o, int nsweep, int maxm, int minm, double cutoff, int npass, double lambda,

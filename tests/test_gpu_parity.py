@@ -653,6 +653,46 @@ def test_single_fast_conj_matches_the_oracle(b, lam):
     np.testing.assert_allclose(tcg["alpha"], toc["alpha"], rtol=1e-7)    # the option switches back cleanly
 
 
+@pytest.mark.parametrize("lam", [1e-3, 0.0])
+def test_single_exact_solver_matches_the_oracle(lam):
+    """method = exact of the per-label variant (single.h:117-160; tnml_exact): the dense least-squares solution through
+    the D x D normal matrix (columns from the forward / weighted-gradient kernels, rocSOLVER dsyevd, filtered inverse on
+    the host) against the oracle's SVD of the design matrix; with lambda > 0 the regularised residual vanishes"""
+    ts, o = _single_pair(N=10, NT=90, m=3, boost=300.0)
+    for b in (1, 4):
+        for bb in range(1 if b == 1 else 1, b):
+            ts.shiftE(bb, True); o.shiftE(bb, True)
+        ts.setBond(b); o.set_bond(b)
+        import numpy.linalg as la
+        B0 = o.bond_tensor(b)
+        pcut = 1e-8 if lam > 0 else 1e-3                     # lambda = 0 needs a cut well above the Gram route's sqrt(eps) floor
+        Bo = o.exact(b, lam, pcut)
+        Bg = ts.exact(b, lam, pcut)
+        assert _relmax(Bg, Bo) < (1e-6 if lam > 0 else 1e-4), (b, lam, _relmax(Bg, Bo))
+        if lam > 0:
+            r = ts.gradient(Bg) - lam * Bg
+            assert np.abs(r).max() < 1e-7 * np.abs(ts.gradient(np.zeros_like(Bg))).max()
+            assert ts.quadcost(Bg, lam)[0] <= o.cgrad(B0, 8, lam, 1e-12)[1]["cost"][-1] * (1 + 1e-9)
+        break_out = b
+        # walk on for the next bond from fresh environments
+        ts.init(); o.init()
+
+
+def test_single_exact_method_in_the_sweep():
+    ts, o = _single_pair(N=8, NT=60, m=3, target=1, maxm=4)
+    from tnml_amd.fixedl import mldmrg
+    ts.set_option("cg_method", 2)
+    ts.set_option_real("pcut", 1e-8)
+    o.set_method("exact", pcut=1e-8)
+    rg = mldmrg(ts, 1, 4, 2, 1e-10, 3, 1e-3, 1e-10)
+    ro = o.mldmrg(1, 4, 2, 1e-10, 3, 1e-3, 1e-10)
+    assert len(rg) == len(ro) == 14
+    for a, b in zip(rg, ro):
+        assert (a["c"], a["half"], a["origm"], a["newm"]) == (b["c"], b["half"], b["origm"], b["newm"])
+        assert a["cost_cg"] == pytest.approx(b["cost_cg"], rel=1e-6)
+        assert a["cost"] == pytest.approx(b["cost"], rel=1e-6)
+
+
 def test_single_fast_conj_sweep_matches_the_oracle():
     ts, o = _single_pair(N=10, NT=80, m=3, target=7, maxm=5)
     from tnml_amd.fixedl import mldmrg
@@ -765,6 +805,21 @@ def test_single_and_separate_fulltest_cli(tmp_path):
     np.testing.assert_allclose(c_cg, [r["cost_cg"] / float(len(lab)) for r in ro], rtol=3e-2)
     np.testing.assert_allclose(c_svd, [r["cost"] / float(len(lab)) for r in ro], rtol=3e-2)
     assert re.search(r"^  Conj grad pass 1   \|r\| = [0-9.]+E[+-][0-9]+$", run.stdout, re.M) and not re.search(r"^  1 C = ", run.stdout, re.M)
+    # method = exact through the command line (single.h:600): the dense solver at these toy sizes, against the oracle
+    wde = tmp_path / "Lexact"                               # a fresh directory: the driver continues from an existing W<label>
+    wde.mkdir()
+    ex = wde / "input_exact"
+    ex.write_text(inp.read_text().replace("method = fast_conj", "method = exact\npcut = 1E-8"))
+    run = subprocess.run([os.path.join(root, "tnml_amd", "single"), str(ex)], capture_output=True, text=True, cwd=wde, timeout=300)
+    assert run.returncode == 0, run.stdout[-1500:] + run.stderr[-1500:]
+    o = pyoracle.SingleOracle(phi, lab[order], 3, hostlib.read_mps(str(tmp_path / "W0ref3")))
+    o.init()
+    o.set_method("exact", pcut=1e-8)
+    ro = o.mldmrg(1, 5, 2, 1e-10, 3, 1e-3, 1e-10)
+    c_cg = [float(b) for _, b in re.findall(r"Cost = ([0-9.eE+-]+) --> ([0-9.eE+-]+)", run.stdout)]
+    assert len(c_cg) == len(ro)
+    np.testing.assert_allclose(c_cg[:10], [r["cost_cg"] / float(len(lab)) for r in ro][:10], rtol=1e-4, atol=1e-9)
+    assert "Conj grad pass" not in run.stdout
     bad = wd / "input_bad"
     bad.write_text(inp.read_text().replace("fast_conj", "pinv"))
     run = subprocess.run([os.path.join(root, "tnml_amd", "single"), str(bad)], capture_output=True, text=True, cwd=wd, timeout=300)

@@ -148,3 +148,42 @@ def test_fast_conj_sweep_and_entry_check():
     o.set_bond(1)
     B2, tr = o.fast_cgrad(B, 4, 1e-3, 1e30)
     assert tr["skipped"] and np.array_equal(B2, B)
+
+
+@pytest.mark.parametrize("lam", [1e-3, 0.0])
+def test_exact_solver_matches_numpy_and_solves_the_normal_equations(lam):
+    """method = exact (single.h:117-160): B = y Phi^+ with the filtered inverse s/(s^2 + lambda) above pcut -- C restatement
+    (own Jacobi SVD) against numpy.linalg.svd, and the defining property: the regularised residual vanishes"""
+    pixels, labels, phi, W = problem(N=10, NT=90, m=3)
+    phi = phi.copy(); phi[..., 1] *= 300.0
+    o = pyoracle.SingleOracle(phi, labels, 3, W, nthread=2)
+    n = npr.NpSingle(phi, labels, 3, W)
+    o.init(); n.init()
+    for b in (1, 4):
+        if b > 1:
+            for bb in range(1, b):
+                o.shiftE(bb, True); n.shiftE(bb, True)
+        o.set_bond(b); n.set_bond(b)
+        D = int(np.prod(o.bond_shape(b)))
+        sv = np.linalg.svd(n.v.reshape(n.v.shape[0], -1), compute_uv=False)
+        pcut = 0.5 * (sv[min(D, len(sv)) - 1] + 0.0) if lam > 0 else 1e-6 * sv[0]    # lambda = 0 needs the cut (rank-deficient Phi)
+        Bo = o.exact(b, lam, pcut)
+        Bn = n.exact(lam, pcut)
+        np.testing.assert_allclose(Bo, Bn, rtol=1e-7, atol=1e-9 * np.abs(Bn).max())
+        if lam > 0:
+            r = o.gradient(Bo) - lam * Bo
+            assert np.abs(r).max() < 1e-8 * np.abs(o.gradient(np.zeros_like(Bo))).max()
+            assert o.quadcost(Bo, lam)[0] <= o.cgrad(o.bond_tensor(b), 6, lam, 1e-12)[1]["cost"][-1] * (1 + 1e-9)   # no CG does better
+        o.init(); n.init()
+
+
+def test_exact_method_in_the_sweep():
+    pixels, labels, phi, W = problem(N=8, NT=60, m=3)
+    phi = phi.copy(); phi[..., 1] *= 300.0
+    o = pyoracle.SingleOracle(phi, labels, 1, W, nthread=2)
+    o.init()
+    o.set_method("exact", pcut=1e-8)
+    ro = o.mldmrg(1, 4, 2, 1e-10, 3, 1e-3, 1e-10)
+    assert len(ro) == 14 and all(r["cg_alpha"] == [] for r in ro)
+    assert all(r["cost_cg"] <= r["cost_old"] * (1 + 1e-9) for r in ro)     # the exact minimiser never does worse than the incoming tensor
+    assert ro[-1]["cost"] < 0.5 * ro[0]["cost_old"]

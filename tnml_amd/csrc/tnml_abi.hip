@@ -84,7 +84,7 @@ int tnml_set_option(tnml_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "bgemm_ps")) c->bgemm_ps = value;
     else if (!strcmp(name, "snake")) c->snake = value;
     else if (!strcmp(name, "sytrd_exit")) c->sytrd_exit = value;
-    else if (!strcmp(name, "cg_method")) { if (value < 0 || value > 1 || (value == 1 && !c->single())) return tnml_fail(c, "cg_method: 0 (conj) or, in TNML_MODE_SINGLE, 1 (fast_conj)"); c->cg_method = value; }
+    else if (!strcmp(name, "cg_method")) { if (value < 0 || value > 2 || (value >= 1 && !c->single())) return tnml_fail(c, "cg_method: 0 (conj) or, in TNML_MODE_SINGLE, 1 (fast_conj) / 2 (exact)"); c->cg_method = value; }
     else if (!strcmp(name, "debug_nudge_rank")) c->debug_nudge_rank = value;
     else if (!strcmp(name, "fg64_cfg")) c->opt_fg64_cfg = value;
     else if (!strcmp(name, "ldot_cfg")) c->opt_ldot_cfg = value;
@@ -890,6 +890,93 @@ static int quadcost_device(tnml_ctx* c, double lambda, double* cost, double* lab
     return 0;
 }
 
+// One-sided Jacobi (Hestenes) SVD of a tall column-major matrix A (R x C, R >= C), in place on the host: on return column j of A
+// is u_j s_j, V (C x C) holds the right singular vectors, s the singular values (unsorted).  Small singular values keep their
+// relative accuracy, which the pcut test of the exact solver needs (a Gram matrix loses everything below sqrt(eps) s_max).
+static void hestenes_svd(int R, int C, double* A, double* sv, double* V) {
+    for (int j = 0; j < C; ++j) for (int i = 0; i < C; ++i) V[i + (size_t)C * j] = i == j ? 1. : 0.;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        bool rotated = false;
+        for (int p = 0; p < C - 1; ++p)
+            for (int q = p + 1; q < C; ++q) {
+                double* ap = A + (size_t)R * p; double* aq = A + (size_t)R * q;
+                double alpha = 0., beta = 0., gamma = 0.;
+                for (int i = 0; i < R; ++i) { alpha += ap[i] * ap[i]; beta += aq[i] * aq[i]; gamma += ap[i] * aq[i]; }
+                if (!(std::fabs(gamma) > 1e-15 * std::sqrt(alpha * beta))) continue;
+                rotated = true;
+                const double zeta = (beta - alpha) / (2. * gamma);
+                const double t = (zeta >= 0. ? 1. : -1.) / (std::fabs(zeta) + std::sqrt(1. + zeta * zeta));
+                const double cs = 1. / std::sqrt(1. + t * t), sn = cs * t;
+                for (int i = 0; i < R; ++i) { const double x = ap[i], y = aq[i]; ap[i] = cs * x - sn * y; aq[i] = sn * x + cs * y; }
+                double* vp = V + (size_t)C * p; double* vq = V + (size_t)C * q;
+                for (int i = 0; i < C; ++i) { const double x = vp[i], y = vq[i]; vp[i] = cs * x - sn * y; vq[i] = sn * x + cs * y; }
+            }
+        if (!rotated) break;
+    }
+    for (int j = 0; j < C; ++j) { double t = 0.; const double* a = A + (size_t)R * j; for (int i = 0; i < R; ++i) t += a[i] * a[i]; sv[j] = std::sqrt(t); }
+}
+// exact (single.h:117-160, per-label variant): B = y Phi^+ with the filtered inverse s/(s^2 + lambda) above pcut, Phi = [v_1 ... v_NT]
+// (D x NT, D = 4 mL mR).  "Only works for rather small number of training samples" (single.h:114).  The dense per-image tensors
+// are not formed on the device here either: row j of Phi is the output vector of ONE forward pass of the unit tensor e_j
+// (p.v_n = v_n[j], the pAp pass of the CG).  The D x NT matrix then goes to the host, whose one-sided Jacobi SVD keeps the small
+// singular values accurate enough for the reference's `s > pcut` test (pcut = 1E-8 by default).  Result in vB (M-layout) and tB
+// (ITensor layout).  One rank only: the images of other ranks would have to be gathered.
+static int exact_device(tnml_ctx* c, double lambda, double pcut) {
+    if (!c->single()) return tnml_fail(c, "exact: only the per-label variant (TNML_MODE_SINGLE) has this solver");
+    if (c->cfg.dtype != TNML_F64) return tnml_fail(c, "exact: TNML_F64 contexts only");
+    if (c->cfg.nranks > 1) return tnml_fail(c, "exact: one rank only (the design matrix of all images is needed in one place)");
+    const BondPlan p = c->plan;
+    const PackDesc pd = bond_pack_desc(p);
+    const size_t n = p.msize();
+    const int D = p.mL * 4 * p.mR, NT = c->NT;
+    if (D > 4096 || (double)D * NT > 4e8) return tnml_fail(c, "exact: %d unknowns x %d images -- the dense solver is meant for small problems", D, NT);
+    std::vector<double> Pt((size_t)NT * D);                             // Phi^T, column j = row j of Phi
+    std::vector<int> lab((size_t)NT);
+    HIPCK(c, hipMemcpyAsync(lab.data(), c->label, sizeof(int) * (size_t)NT, hipMemcpyDeviceToHost, c->stream));
+    for (int j = 0; j < D; ++j) {
+        HIPCK(c, hipMemsetAsync(c->tB2, 0, sizeof(double) * D, c->stream));
+        TCK(launch_fill_f64(c, c->tB2 + j, 1.0, 1));
+        TCK(launch_pack(c, pd, c->tB2, c->vP, nullptr));
+        TCK(forward_pass(c, c->vP, LD_MODE_PAP, c->vG + n, true));      // Pp[n] = v_n . e_j
+        HIPCK(c, hipMemcpyAsync(Pt.data() + (size_t)NT * j, c->Pp, sizeof(double) * (size_t)NT, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    std::vector<double> hB((size_t)D, 0.);
+    const int tgt = c->target();
+    if (NT >= D) {                                                      // Phi^T = U S V^T: columns u_j s_j (images), V in tensor space
+        std::vector<double> V((size_t)D * D), sv((size_t)D);
+        hestenes_svd(NT, D, Pt.data(), sv.data(), V.data());
+        for (int j = 0; j < D; ++j) {
+            const double s1 = sv[j];
+            if (!(s1 > pcut)) continue;                                 // pseudoInv, single.h:145-153
+            double yu = 0.;
+            const double* u = Pt.data() + (size_t)NT * j;
+            for (int i = 0; i < NT; ++i) if (lab[i] == tgt) yu += u[i];  // y . (u_j s_j)
+            const double f = yu / (s1 * s1 + lambda);                   // (y.u_j) s/(s^2+lambda) = (y.u_j s_j)/(s^2+lambda)
+            const double* v = V.data() + (size_t)D * j;
+            for (int k = 0; k < D; ++k) hB[k] += f * v[k];
+        }
+    } else {                                                            // more unknowns than images: Phi = V' S U'^T on the D x NT matrix
+        std::vector<double> Ph((size_t)D * NT), U((size_t)NT * NT), sv((size_t)NT);
+        for (int j = 0; j < D; ++j) for (int i = 0; i < NT; ++i) Ph[j + (size_t)D * i] = Pt[i + (size_t)NT * j];
+        hestenes_svd(D, NT, Ph.data(), sv.data(), U.data());
+        for (int j = 0; j < NT; ++j) {
+            const double s1 = sv[j];
+            if (!(s1 > pcut)) continue;
+            double yu = 0.;
+            const double* u = U.data() + (size_t)NT * j;
+            for (int i = 0; i < NT; ++i) if (lab[i] == tgt) yu += u[i];
+            const double f = yu / (s1 * s1 + lambda);                   // (y.u'_j) s/(s^2+lambda) v'_j with v'_j = column / s
+            const double* vs = Ph.data() + (size_t)D * j;
+            for (int k = 0; k < D; ++k) hB[k] += f * vs[k];
+        }
+    }
+    HIPCK(c, hipMemcpyAsync(c->tB, hB.data(), sizeof(double) * D, hipMemcpyHostToDevice, c->stream));
+    TCK(launch_pack(c, pd, c->tB, c->vB, nullptr));
+    HIPCK(c, hipStreamSynchronize(c->stream));                          // hB is a local
+    return 0;
+}
+
 static int upload_bond(tnml_ctx* c, const double* B) {     // host ITensor layout -> tB, vB
     if (c->currb < 1) return tnml_fail(c, "setBond has not been called");
     const BondPlan& p = c->plan;
@@ -933,6 +1020,17 @@ int tnml_quadcost(tnml_ctx* c, const double* B, double lambda, double* cost, dou
     c->p_valid = false;
     TCK(upload_bond(c, B));
     return quadcost_device(c, lambda, cost, label_cost, reg_cost, ncorrect, false);
+}
+int tnml_exact(tnml_ctx* c, double* B, double lambda, double pcut) {   // single.h:117-160 on the bond chosen by tnml_set_bond
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    if (c->currb < 1) return tnml_fail(c, "tnml_exact: setBond has not been called");
+    c->p_valid = false;
+    TCK(exact_device(c, lambda, pcut));
+    return download_bond(c, c->vB, B);
+}
+int tnml_set_option_real(tnml_ctx* c, const char* name, double value) {
+    if (!strcmp(name, "pcut")) { if (!(value >= 0.)) return tnml_fail(c, "pcut must be >= 0"); c->pcut = value; return 0; }
+    return tnml_fail(c, "tnml_set_option_real: unknown option %s", name);
 }
 int tnml_cgrad(tnml_ctx* c, double* B, int npass, double lambda, double cconv, tnml_cg_trace* trace) {
     HIPCK(c, hipSetDevice(c->cfg.device));
@@ -986,13 +1084,16 @@ int tnml_bond_update_begin(tnml_ctx* c, int b, int ha, const tnml_sweep_params* 
         rep->norm_oB = c->last_bnorm;
         outputs_current = c->reuse_p;                                 // that was the forward pass of the first gradient
     }
-    TCK(cgrad_device(c, sp->npass, sp->lambda, sp->cconv, outputs_current));   // :504
+    const bool exact = c->single() && c->cg_method == 2;              // method = exact (single.h:600)
+    if (exact) TCK(exact_device(c, sp->lambda, c->pcut));
+    else TCK(cgrad_device(c, sp->npass, sp->lambda, sp->cconv, outputs_current));   // :504
     c->tail_zeroed = false;
     if (sp->report_costs) TCK(quadcost_device(c, sp->lambda_cost, &rep->cost_cg, nullptr, &rep->reg_cost_cg, nullptr, false));   // single.h:622,626
     TCK(launch_unpack(c, pd, c->vB, c->tB));
     TCK(cgrad_trace_enqueue(c));                                      // lands with the split's own synchronisation (eigenvalues)
     TCK(svd_split_device(c, c->tB, b, ha, sp->cutoff, sp->maxm, sp->minm, &rep->truncerr, &rep->newm, nullptr, nullptr));   // :519-522
     cgrad_trace_parse(c, sp->npass, &rep->cg);
+    if (exact) memset(&rep->cg, 0, sizeof rep->cg);               // no CG ran
     if (c->debug_nudge_rank == c->cfg.rank) TCK(launch_nudge(c, c->W[b].a));
     TCK(launch_bond_form(c, c->W[b], c->W[b + 1], c->tB2));           // :527
     TCK(launch_pack(c, pd, c->tB2, c->vB, nullptr));

@@ -85,7 +85,8 @@ struct tnml_ctx {
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     int overlap = 0;                 // two-queue forward pass (measured slower); env TNML_OVERLAP / option "overlap"
     int fused_fwd = 1;               // forward pass as one persistent kernel (kernels_fused.hip): 1 = from 14 336 images per rank on, 0 never, 2 always; env TNML_FUSED_FWD / option "fused_fwd"
-    int cg_method = 0;               // per-label variant: 0 = conj (single.h:162-288), 1 = fast_conj (single.h:290-398); option "cg_method"
+    int cg_method = 0;               // per-label variant: 0 = conj (single.h:162-288), 1 = fast_conj (single.h:290-398), 2 = exact (single.h:117-160); option "cg_method"
+    double pcut = 1e-8;              // PCut of the exact solver (single.cc:50); tnml_set_option_real "pcut"
     int sytrd_exit = 1;              // rank-adaptive exit of the tridiagonalisation of the split's Gram matrix (eigh.hip); option "sytrd_exit", env TNML_SYTRD_TOL=0 disables
     int snake = 0, stream_dir = 0;   // alternate the traversal direction of consecutive passes over the Label-carrying environment (MALL reuse); env TNML_SNAKE / option "snake"
     int bgemm_ps = 0;                // gradient GEMM with producer / consumer waves (kernels_fused.hip, measured slower); env TNML_BGEMM_PS / option "bgemm_ps"

@@ -205,6 +205,16 @@ class TrainStates:
         self._ck(self._L.tnml_cgrad(self._h, _lib.dptr(buf), npass, lam, cconv, C.byref(tr)))
         return buf.reshape(B.shape, order="F"), _trace_dict(tr)
 
+    def exact(self, b, lam, pcut=1e-8):
+        """single.h:117-160 on the bond chosen by setBond(b) (per-label variant): the solved bond tensor"""
+        shape = self.bond_tensor(b).shape
+        buf = np.zeros(int(np.prod(shape)))
+        self._ck(self._L.tnml_exact(self._h, _lib.dptr(buf), lam, pcut))
+        return buf.reshape(shape, order="F")
+
+    def set_option_real(self, name, value):
+        self._ck(self._L.tnml_set_option_real(self._h, name.encode(), float(value)))
+
     def svd_split(self, B, b, ha, cutoff, maxm, minm):
         te, m, nsv = C.c_double(), C.c_int(), C.c_int()
         sv = np.empty(4 * self.maxm + 8)

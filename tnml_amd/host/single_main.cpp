@@ -4,7 +4,7 @@
 // Keeps the reference's surface (single.cc:6-244 and the mldmrg of single.h:523-728): input keys, the files `sites`
 // and `W<label>` in the working directory, the `WRITE_WF` hook, the idx-ubyte training set under `datadir`, the
 // image order (labels taken round-robin, single.cc:156-181) and the log lines.  One tnml_bond_update per bond.
-// Built: method = conj | fast_conj.  Not built: method = exact | pinv and the `noise` density-matrix term (single.h:117-160,404-517,648-672); they
+// Built: method = conj | fast_conj | exact.  Not built: method = pinv (random start, single.h:404-517) and the `noise` density-matrix term (single.h:648-672); they
 // stop with a message.  Extensions (never read by the reference): `seed`, `device`, `precision`, `imglen`,
 // `feature_scale` as in the fixedL driver.
 #include <array>
@@ -59,7 +59,7 @@ int main(int argc, const char* argv[]) {
         (void)input.getReal("alpha", 1.0); (void)input.getReal("clip", 1.0);
         const long Npass = input.getInt("Npass", 4);
         const double cconv = input.getReal("cconv", 1E-10);
-        (void)input.getInt("Ntarget", 10); (void)input.getReal("pcut", 1E-8); (void)input.getYesNo("precalc", true);
+        (void)input.getInt("Ntarget", 10); const double pcut = input.getReal("pcut", 1E-8); (void)input.getYesNo("precalc", true);
         const uint64_t seed = (uint64_t)input.getInt("seed", 1);
         const int device = (int)input.getInt("device", 0);
         const std::string precision = input.getString("precision", "f64");
@@ -69,9 +69,10 @@ int main(int argc, const char* argv[]) {
         if (precision == "mixed") dtype = TNML_F64_E32; else if (precision == "f32") dtype = TNML_F32;
         else if (precision != "f64" && precision != "strict") { std::printf("precision must be f64, mixed or f32\n"); return 1; }
         if (L < 0 || L > 9) { std::printf("label must be in 0..9\n"); return 1; }
-        if (method == "exact" || method == "pinv") { std::printf("method \"%s\" is not built here (conj and fast_conj are)\n", method.c_str()); return 1; }
-        if (method != "conj" && method != "fast_conj") { std::printf("method type \"%s\" not recognized\n", method.c_str()); return 1; }   // single.h:611
+        if (method == "pinv") { std::printf("method \"%s\" is not built here (conj, fast_conj and exact are)\n", method.c_str()); return 1; }
+        if (method != "conj" && method != "fast_conj" && method != "exact") { std::printf("method type \"%s\" not recognized\n", method.c_str()); return 1; }   // single.h:611
         const bool fast_conj = method == "fast_conj";                                  // single.h:599
+        const bool exact = method == "exact";                                          // single.h:600
         if (noise >= 1E-14) { std::printf("noise > 0 (density-matrix split, single.h:648-672) is not built here\n"); return 1; }
 
         char wname[32]; std::snprintf(wname, sizeof wname, "W%d", L);                  // :53
@@ -140,6 +141,7 @@ int main(int argc, const char* argv[]) {
         tnml_ctx* ctx = nullptr;
         if (tnml_create(&ctx, &cfg) != 0) die(nullptr, "tnml_create");
         if (fast_conj) CK(ctx, tnml_set_option(ctx, "cg_method", 1));
+        if (exact) { CK(ctx, tnml_set_option(ctx, "cg_method", 2)); CK(ctx, tnml_set_option_real(ctx, "pcut", pcut)); }
         CK(ctx, tnml_set_data_phi(ctx, phi.data(), labels.data()));
         phi.clear(); phi.shrink_to_fit();
         for (int j = 1; j <= N; ++j) CK(ctx, tnml_set_site(ctx, j, W.A[j].ml, W.A[j].mr, 0, W.A[j].a.data()));
