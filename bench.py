@@ -293,7 +293,7 @@ def main():
     if world > 1:
         comm_ranks = ts.replica_check()                          # ncclCommCount == world and bit-identical W replicas
         assert comm_ranks == world, (comm_ranks, world)
-        ts.set_option("check_replicas", 2)                       # a last-bit replica difference is repaired (rank 0 re-broadcast) and counted, not fatal
+        pass                                                     # replica check: mode 1 (folded into the packed all-reduce; a mismatch is an error)
     t_init = time.time()
     ts.init()
     ts.synchronize()

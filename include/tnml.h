@@ -45,8 +45,13 @@ typedef struct tnml_ctx tnml_ctx;
                  the reference to ~1e-6, but the rounding of the environments (1e-7) is amplified by the CG, so a
                  sweep follows the fp64 trajectory only loosely (DESIGN.md "fp32 environments").
    TNML_F32      v_mfma_f32_16x16x4_f32, exact-fp32 arithmetic -- 2x the MFMA rate, for the tolerance study only:
-                 the reference's CG is not reproducible in fp32 (DESIGN.md "why fp64 MFMA"). */
-enum { TNML_F32 = 0, TNML_F64_E32 = 1, TNML_F64 = 2 };
+                 the reference's CG is not reproducible in fp32 (DESIGN.md "why fp64 MFMA").
+   TNML_BF16     as TNML_F32 (fp32 storage, fp32 CG/label dot/gradient GEMM) with the forward feature GEMM of B*t.v on
+                 v_mfma_f32_16x16x32_bf16: operands rounded to bf16 while staging, fp32 accumulation (BASELINE config 5's
+                 "bf16 MFMA bond contraction"; report-don't-gate)
+   TNML_BF16X3   the same with every operand split hi + lo (x = bf16(x) + bf16(x - bf16(x))) and three bf16 MFMAs per product
+                 (hi*hi + hi*lo + lo*hi): ~16 mantissa bits */
+enum { TNML_F32 = 0, TNML_F64_E32 = 1, TNML_F64 = 2, TNML_BF16 = 3, TNML_BF16X3 = 4 };
 /* eigensolver of the Gram matrix inside tnml_svd_split (n = smaller side of the matricised bond tensor):
    TNML_SVD_SYEVD      in-house: one-workgroup tridiagonalisation, bisection + inverse iteration, back
                        transform, Newton-Schulz polish; verified per call, falls back to rocSOLVER dstedc
@@ -71,7 +76,7 @@ typedef struct {
     int NT_local;        /* training images owned by this rank */
     int64_t NT_total;    /* training images over all ranks (costs are reported un-normalised) */
     int maxm;            /* largest bond dimension that will occur (workspace sizing) */
-    int dtype;           /* TNML_F64 (default choice), TNML_F64_E32 or TNML_F32 */
+    int dtype;           /* TNML_F64 (default choice), TNML_F64_E32, TNML_F32, TNML_BF16 or TNML_BF16X3 */
     int svd_backend;     /* TNML_SVD_* */
     int mode;            /* TNML_MODE_FIXEDL (0, default) or TNML_MODE_SINGLE */
     int target_label;    /* TNML_MODE_SINGLE: the selected label L (single.cc:19); the target is y_n = [l_n == L] */
@@ -138,6 +143,9 @@ int tnml_comm_init_local(tnml_ctx** ctxs, int n);
    rewrites after every split (TNML_CHECK_REPLICAS=0 disables that).  nranks_in_comm (nullable) receives the communicator size. */
 int tnml_replica_check(tnml_ctx* ctx, int* nranks_in_comm);
 int64_t tnml_replica_repairs(tnml_ctx* ctx);           /* re-broadcasts so far in check_replicas mode 2 */
+/* collectives this rank has entered so far: sum all-reduces (the payload: gradient / A p + scalars) and broadcasts (rank 0's
+   eigenvalues in the split) */
+int tnml_collective_stats(tnml_ctx* ctx, int64_t* allreduces, int64_t* broadcasts);
 
 /* ---- training set: TState ctor fixedL.cc:28-47 + feature map :637-642 -------------------- */
 /* raw bytes [NT_local][N] with the reference's feature map phi = [1, byte/(255*255*4)] */
@@ -167,6 +175,8 @@ int tnml_forward(tnml_ctx* ctx, const double* B, double* P);
 /* sum_n dP_n*dag(t.v) over ALL ranks (fixedL.cc:375-385): G has the layout of B */
 int tnml_gradient(tnml_ctx* ctx, const double* B, double* G);
 /* quadcost (fixedL.cc:280-344): *cost = sum_l C_l + lambda|B|^2, un-normalised, over all ranks */
+/* <p|A|p> = sum_n |p*t.v_n|^2 + lambda |p|^2 of a direction p (the pAp pass of cgrad, fixedL.cc:394-403); collective */
+int tnml_pAp(tnml_ctx* ctx, const double* p, double lambda, double* pAp);
 int tnml_quadcost(tnml_ctx* ctx, const double* B, double lambda, double* cost,
                   double label_cost[TNML_NL], double* reg_cost, int64_t* ncorrect);
 /* cgrad (fixedL.cc:349-445): B is updated in place */
@@ -227,22 +237,30 @@ int tnml_synchronize(tnml_ctx* ctx);
      "fast_cg"        P <- P + a (p*t.v) instead of re-running the forward GEMM inside cgrad (single.h:290-398 idea)
      "reuse_p"        the after-SVD quadcost of one bond update provides the first residuals of the next
      "fuse_z"         the gradient GEMM builds Z = sum_l EL[l] dP[l] itself
-     "check_replicas" multi-rank: fingerprint check of the rewritten site tensors after every split (1: a mismatch is an
-                      error; 2: rank 0's two site tensors are re-broadcast, the sweep continues, tnml_replica_repairs counts)
+     "merged_cg"      one all-reduce per CG pass instead of two: the image sum of a pass is A p = sum_n (p.v_n) v_n, formed from the
+                      pAp pass's own outputs, and travels with sum |p.v_n|^2; the residual follows r <- r - a (A p + lambda p)
+                      (the structure of the reference's own fast_cgrad, single.h:347-379); needs fast_cg.  1 (default): on ranks that
+                      have a communicator -- where it halves the collectives; a single rank keeps the reference's literal residual
+                      (the recurrence moves the 4th step size of an ill-conditioned Label-on-B bond by 1e-3, the cost by 1e-10);
+                      2: always; 0: never
+     "defer_tail"     multi-rank: the cost partials of the "after SVD" quadcost and the replica fingerprint ride in the first
+                      all-reduce of the NEXT bond update (tnml_bond_update_end issues one small all-reduce when nothing followed);
+                      with both on a bond update enters 5 payload all-reduces instead of 9 + 1 (default 1)
+     "check_replicas" multi-rank: fingerprint check of the two site tensors a split rewrote (1, default: folded into the packed
+                      sum all-reduce as exact integer pieces, a mismatch is an error when the report is handed out; 2: checked at
+                      once inside the bond update, before anything consumes the tensors -- one extra 8-double all-reduce and a
+                      host synchronisation -- and on a mismatch rank 0's two tensors are re-broadcast, the sweep continues,
+                      tnml_replica_repairs counts; 0: off)
      "fg64_cfg", "ldot_cfg"  force a tile configuration of the feature GEMM / the label dot that is otherwise chosen by the
                       image count (2 / 1 = the large-image-count forms bench.py times; parity tests run them at small sizes)
      "fused_fwd"      the forward pass of a Label-on-environment bond at m = 120 as one persistent kernel (feature GEMM +
                       label dot of the previous tile, kernels_fused.hip): 1 = from 14 336 images per rank on (default),
                       0 = never, 2 = always (parity tests at small sizes), > 2 = always with that many workgroups at most
-     "overlap"        two-queue forward pass (measured slower, default 0)
      "cg_method"      TNML_MODE_SINGLE only: 0 = conj (single.h:162-288, default), 1 = fast_conj (single.h:290-398: one image sum
                       per CG step, residual by recurrence, the reference's regulariser term as written, no cost in the trace),
                       2 = exact (single.h:117-160, see tnml_exact; "pcut" through tnml_set_option_real)
      "sytrd_exit"     the split's tridiagonalisation stops once the trailing block of the Gram matrix is numerically zero
                       (trace <= 1e-15 trace(G); default 1; 0 = all n-2 Householder steps)
-     "bgemm_ps"       producer / consumer form of the gradient GEMM (measured slower, default 0; 2 = force at any size)
-     "snake"          alternate passes over the Label-carrying environment run last-to-first (no measurable effect, default 0;
-                      results are bit-identical either way)
    fast_cg = reuse_p = 0 is the reference's literal evaluation order (fixedL.cc:374-421). */
 int tnml_set_option(tnml_ctx* ctx, const char* name, int value);
 /* real-valued options: "pcut" (PCut of the exact solver inside tnml_bond_update, single.cc:50, default 1E-8) */

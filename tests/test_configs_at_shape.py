@@ -232,8 +232,7 @@ def test_c3_kernel_instantiations_of_the_benchmark_match_the_oracle():
 @pytest.mark.gpu
 @pytest.mark.parametrize("NT", [300, 1100])
 def test_fused_forward_kernel_matches_the_oracle(NT):
-    """k_bgemm_ps (gradient GEMM with producer / consumer waves; option "bgemm_ps") and
-    k_fwd_fused (feature GEMM + label dot of the previous tile in one persistent workgroup; option "fused_fwd") forced at
+    """k_fwd_fused (feature GEMM + label dot of the previous tile in one persistent workgroup; option "fused_fwd") forced at
     an oracle-sized image count: 300 images = 8 tiles on 8 workgroups (one tile + the drain round each), 1100 images = 20 tiles
     on 20 workgroups; with a grid cap of 4 workgroups (fused_fwd = 4) every workgroup runs several rounds.  Forward map,
     gradient, cost / #correct, the CG (its pAp passes use the |P|^2 mode) and a bond update, for both bond kinds it serves."""
@@ -244,7 +243,6 @@ def test_fused_forward_kernel_matches_the_oracle(NT):
     pixels, labels, phi, W = make_problem(N, NT, m, 7, pixel_boost=200.0)
     ts = TrainStates(labels, N, m, phi=phi)
     ts.set_option("fused_fwd", 4 if NT > 1000 else 2)
-    ts.set_option("bgemm_ps", 2)                                      # and the producer / consumer gradient GEMM (k_bgemm_ps)
     ts.set_mps(W)
     ts.init()
     o = pyoracle.Oracle(phi, labels, W, nthread=min(8, os.cpu_count() or 1))

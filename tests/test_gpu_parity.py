@@ -96,6 +96,35 @@ def test_cgrad_matches_oracle(b, lam, dtype):
     assert all(x >= y * (1 - 1e-6) for x, y in zip(tg["cost"], tg["cost"][1:]))      # CG monotone
 
 
+@pytest.mark.parametrize("b,lam", [(1, 0.0), (3, 1e-3), (6, 1e-3), (9, 1e-3)])
+def test_merged_cg_passes_match_the_oracle(b, lam):
+    """option merged_cg = 2: the CG with ONE image sum per pass -- A p = sum_n (p.v_n) v_n formed from the pAp pass's outputs,
+    residual r <- r - a (A p + lambda p), cost partials of a pass reported with the next one (what a multi-rank run uses to
+    halve its all-reduces) -- against the oracle's literal cgrad (fixedL.cc:349-445) on every bond kind"""
+    ts, o = _pair()
+    ts.set_option("merged_cg", 2)
+    _walk(ts, o, b)
+    B0 = o.bond_tensor(b)
+    Bg, tg = ts.cgrad(B0, 4, lam, 1e-10)
+    Bo, to = o.cgrad(B0, 4, lam, 1e-10)
+    assert tg["npass_done"] == to["npass_done"] == 4
+    np.testing.assert_allclose(tg["cost"], to["cost"], rtol=TOL["f64"]["cgc"])
+    np.testing.assert_allclose(tg["pAp"], to["pAp"], rtol=TOL["f64"]["cga"])
+    np.testing.assert_allclose(tg["alpha"], to["alpha"], rtol=TOL["f64"]["cga"])
+    np.testing.assert_allclose(tg["rnorm"], to["rnorm"], rtol=TOL["f64"]["cga"])
+    assert _relmax(Bg, Bo) < TOL["f64"]["cga"]
+
+
+@pytest.mark.parametrize("b", [2, 6, 9])
+def test_pAp_entry_point(b):
+    """tnml_pAp: sum_n |p*t.v_n|^2 + lambda |p|^2 (fixedL.cc:394-403) for a random direction, against the oracle's forward map"""
+    ts, o = _pair()
+    _walk(ts, o, b)
+    p = np.random.default_rng(b).standard_normal(o.bond_shape(b))
+    ref = float(np.sum(o.forward(p) ** 2) + 1e-3 * np.sum(p ** 2))
+    assert ts.pAp(p, 1e-3) == pytest.approx(ref, rel=1e-11)
+
+
 @pytest.mark.parametrize("b,ha", [(1, 1), (3, 1), (3, 2), (5, 1), (5, 2), (6, 1), (6, 2), (8, 2), (11, 2)])
 def test_svd_split_matches_oracle(b, ha):
     ts, o = _pair(N=12, NT=60, m=6)
@@ -1045,14 +1074,6 @@ def test_properties_at_the_full_baseline_size():
     G = ts.gradient(B1)
     assert _relmax(ts.gradient(B1), G) == 0.0                                  # deterministic reductions: bit-identical
     C, lc, cr, nc = ts.quadcost(B1, 1e-3)
-    # the two-queue forward pass (label dot of one image half beside the feature GEMM of the other) against the one-queue
-    # form: same arithmetic per image, same reduction order -> identical bits
-    ts.set_option("overlap", 0)
-    P1s, Gs1 = ts.forward(B1), ts.gradient(B1)
-    Cs = ts.quadcost(B1, 1e-3)
-    ts.set_option("overlap", 1)
-    assert np.array_equal(P1s, P1) and np.array_equal(Gs1, G)
-    assert Cs[0] == C and np.array_equal(Cs[1], lc) and Cs[3] == nc
     ts.shiftE(b0, True)
     ts.setBond(b0 + 1)
     C2, lc2, cr2, nc2 = ts.quadcost(ts.bond_tensor(b0 + 1), 1e-3)
@@ -1068,10 +1089,10 @@ def test_properties_at_the_full_baseline_size():
 
 
 @pytest.mark.parametrize("m,NT", [(150, 48), (300, 24)])
-def test_bond_dimension_above_120_uses_the_rocsolver_path(m, NT):
-    """maxm > 120 (BASELINE config 5 goes to 300): Gram side n = 2m > 240, beyond the in-house tridiagonalisation;
-    the split falls to rocSOLVER dsyevd and the generic GEMM tiles.  One bond update at m = 150 and at m = 300
-    (config 5's bond dimension) against the oracle."""
+def test_bond_dimension_above_120_splits_on_the_workgroup_cluster(m, NT):
+    """maxm > 120 (BASELINE config 5 goes to 300): Gram side n = 2m > 240, beyond the one-workgroup tridiagonalisation;
+    the split runs on the multi-workgroup kernel (eigh_mc.hip) with the Cholesky QR on rocSOLVER dpotrf, the GEMMs on the
+    generic tiles.  One bond update at m = 150 and at m = 300 (config 5's bond dimension) against the oracle."""
     ts, o = _pair(N=24, NT=NT, m=m, maxm=m)
     _walk(ts, o, 10)                                           # bond 10 of 24: m x m, Label on the right environment (c0 = 12)
     B = o.bond_tensor(10)
@@ -1084,35 +1105,3 @@ def test_bond_dimension_above_120_uses_the_rocsolver_path(m, NT):
     assert mg == mo
     np.testing.assert_allclose(svg[:mg], svo[:mo], rtol=1e-7, atol=1e-8 * svo[0])
     assert _relmax(ts.bond_tensor(10), o.bond_tensor(10)) < 1e-8
-
-
-def test_lds_dma_gradient_gemm_variant_matches_the_default(tmp_path):
-    """k_bgemm64_dma (TNML_BGF_CFG=5: image stream staged by global_load_lds instead of registers) against the default
-    register-staged kernel on the same state: 4096 images at m = 120, so that every workgroup runs prologue, steady
-    state and drain of the two-stage DMA ring (the knob is read once per process -> two subprocesses)."""
-    import subprocess
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script = (
-        "import sys, numpy as np\n"
-        "sys.path.insert(0, %r)\n"
-        "from tnml_amd import synth\n"
-        "from tnml_amd.fixedl import TrainStates\n"
-        "N, NT, m = 20, 4096, 120\n"
-        "labels = synth.synthetic_labels(NT)\n"
-        "pixels = synth.synthetic_images(N, labels)\n"
-        "W = synth.random_mps(N, m, seed=5)\n"
-        "ts = TrainStates(labels, N, m, pixels=pixels)\n"
-        "ts.set_mps(W); ts.init()\n"
-        "for bb in range(1, 8): ts.shiftE(bb, True)\n"
-        "ts.setBond(8)\n"
-        "B = ts.bond_tensor(8) + 0.05 * np.random.default_rng(1).standard_normal((120, 2, 2, 120))\n"
-        "np.save(sys.argv[1], ts.gradient(B))\n" % root)
-    outs = []
-    for cfg in ("0", "5"):
-        out = tmp_path / ("g%s.npy" % cfg)
-        run = subprocess.run([sys.executable, "-c", script, str(out)], capture_output=True, text=True, timeout=300,
-                             env=dict(os.environ, TNML_BGF_CFG=cfg))
-        assert run.returncode == 0, run.stderr[-1500:]
-        outs.append(np.load(out))
-    assert outs[0].shape == (120, 2, 2, 120)
-    assert _relmax(outs[1], outs[0]) < 1e-12

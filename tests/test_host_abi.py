@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     src = open(os.path.join(ROOT, "include", "tnml.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(tnml_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(tnml_[A-Za-z0-9_]+)\s*\(", src)))
 
 
 def test_library_exports_every_declared_symbol():

@@ -176,3 +176,42 @@ def test_a_diverging_replica_is_detected_and_can_be_repaired():
     assert repaired[0]["repairs"] == repaired[1]["repairs"] == 2 * (N - 1)
     assert repaired[0]["cost"] == repaired[1]["cost"]
     np.testing.assert_allclose(repaired[0]["cost"], clean[0]["cost"], rtol=1e-9)
+
+
+def test_a_pipelined_bond_update_enters_five_payload_allreduces():
+    """SURVEY.md 8(e) counts 2 Npass + 1 = 9 all-reduces per bond update for the literal cgrad (fixedL.cc:385,402,421 per pass, :333
+    after the split); round 2 added a fingerprint max-reduce.  With the merged CG (A p rides with sum |p.v_n|^2) and the after-SVD
+    cost partials + fingerprint pieces carried into the next bond update's first all-reduce, a pipelined sweep enters
+    1 + (Npass - 1) + 1 = 5 sum all-reduces per bond update (+ the broadcast of rank 0's eigenvalues), and the costs are those of
+    the unmerged, undeferred run to round-off."""
+    from tnml_amd.fixedl import mldmrg
+    N, NT, m, npass = 12, 150, 6, 4
+    pixels, labels, phi, W = make_problem(N, NT, m, 3, pixel_boost=200.0)
+    args = (1, m, m // 2, 1e-10, npass, 1e-3, 1e-10)
+
+    def body(merged, defer, pipelined):
+        def run(ts, r):
+            ts.set_option("merged_cg", merged)
+            ts.set_option("defer_tail", defer)
+            ts.init()
+            a0, b0 = ts.collective_stats()
+            reps = mldmrg(ts, *args, pipelined=pipelined)
+            a1, b1 = ts.collective_stats()
+            ts.replica_check()
+            return dict(cost=[x["cost"] for x in reps], nc=[x["ncorrect"] for x in reps], newm=[x["newm"] for x in reps],
+                        allreduces=a1 - a0, bcasts=b1 - b0, cg=[x["cg"]["cost"][:npass - 1] for x in reps])
+        return run
+    nb = 2 * (N - 1)
+    new = _run_ranks(2, labels, phi, W, N, m, body(1, 1, True))
+    old = _run_ranks(2, labels, phi, W, N, m, body(0, 0, False))
+    assert new[0]["cost"] == new[1]["cost"]
+    assert new[0]["allreduces"] == (npass + 1) * nb + 1, new[0]["allreduces"]     # 5 per bond update + the flush of the last report
+    assert old[0]["allreduces"] == (2 * npass + 1) * nb, old[0]["allreduces"]     # 9 per bond update (the fingerprint no longer has its own)
+    assert new[0]["bcasts"] == old[0]["bcasts"] == nb
+    assert new[0]["newm"] == old[0]["newm"] and new[0]["nc"] == old[0]["nc"]
+    # same algebra, different rounding: identical to 1e-9 while the two runs are still on the same trajectory (a free-running sweep
+    # amplifies any rounding difference -- the oracle with 1 and with 8 threads does the same, DESIGN.md section 2), close after
+    np.testing.assert_allclose(new[0]["cost"][:8], old[0]["cost"][:8], rtol=1e-9)
+    np.testing.assert_allclose(new[0]["cost"], old[0]["cost"], rtol=1e-3)
+    for a, b in zip(new[0]["cg"][:8], old[0]["cg"][:8]):                          # the per-pass costs the reference prints (:429)
+        np.testing.assert_allclose(a, b, rtol=1e-9)

@@ -1,26 +1,16 @@
-// eigh.hip -- single-kernel Householder tridiagonalisation + back-transformation for the bond-tensor
-// split (n <= 240, fp64).
+// eigh.hip -- eigen-decomposition stages of the bond-tensor split (fixedL.cc:519-521), fp64, n <= 240 in one workgroup
+// (larger n: eigh_mc.hip): Householder tridiagonalisation with the matrix resident in registers, the tridiagonal
+// eigenproblem (bisection + inverse iteration), back transformation, Cholesky QR and Newton-Schulz helpers.
 //
 // Why: the SVD of fixedL.cc:519-521 sits on the critical path of every bond update and rocSOLVER's
 // dsyevd spends 4.0 of its 5.6 ms at n=240 in ~1700 tiny sytrd kernels (profiles/r01_bench_c3_kernel_stats.csv:
 // hemvn, sytd2, dot, syr2, latrd, larfg, set_tau).  The reduction is inherently sequential in n, so it is
-// done here by ONE workgroup with the matrix resident in registers (lower-triangular 16x16 blocks, 4 lanes
-// per block, 64 doubles per lane): per Householder step one LDS round for the column, a symmetric
-// matrix-vector product reduced through LDS in a fixed order, and the rank-2 update -- five barriers per
-// step, no kernel boundary; the Householder scalars are recomputed by every wave instead of broadcast.  The tridiagonal eigenproblem stays on rocSOLVER (dstedc); the back
-// transformation U = H_0 H_1 ... Z is one wave per kept column.
+// done here by ONE workgroup with the matrix resident in registers.  Two earlier generations of that kernel (16 x 16 blocks
+// with four lanes each; 8 x 8 blocks with the column in LDS) were measured against k_sytrd_v3 in rounds 1-2
+// (profiles/r02_probe_eigh.txt: 1.20 / 0.70 / 0.62 ms for all 238 steps at n = 240) and are gone.
 #include "tnml_internal.h"
 
-#define TB 16            // block edge
-#define TU 4             // lanes per block (each owns 4 columns of the block)
 #define TRI_MAXN 240
-#define TRI_MAXNB (TRI_MAXN / TB)
-
-#ifdef TNML_EIGH_PROF
-#define TP(i) do { if (tid == 0) { long long t_ = clock64(); prof[i] += t_ - tlast; tlast = t_; } } while (0)
-#else
-#define TP(i) do {} while (0)
-#endif
 
 struct TriArgs {
     const double* A; int n; int lda;     // symmetric input (both triangles valid)
@@ -31,188 +21,6 @@ struct TriArgs {
     double psd_tol;                      // k_sytrd_v3, positive semidefinite input only: stop once trace(trailing block) <= psd_tol * trace(A); 0 = never
 };
 
-__global__ __launch_bounds__(512) void k_sytrd_onewg(TriArgs T) {
-    __shared__ double s_v[TRI_MAXN + TB], s_w[TRI_MAXN + TB], s_x[TRI_MAXN + TB];
-    __shared__ double s_red[16];
-    __shared__ double S1[TB * (TRI_MAXNB * (TRI_MAXNB + 1) / 2)];            // [R][C][16], quad-reduced
-    __shared__ double S2[TB * (TRI_MAXNB * (TRI_MAXNB - 1) / 2) + TB];      // [C][R-C-1][16]
-    const int n = T.n;
-    const int nb = (n + TB - 1) / TB;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int nthr_blocks = nb * (nb + 1) / 2;
-    const int bi = tid >> 2, u = tid & 3;
-    const bool owner = bi < nthr_blocks;
-    // blocks are enumerated column-block major (C = 0 first) so that the blocks left of the active
-    // window -- a prefix of this order -- retire whole waves as the reduction proceeds
-    int R = 0, C = 0;
-    if (owner) { int cc = 0; while ((cc + 1) * nb - (cc + 1) * cc / 2 <= bi) ++cc; C = cc; R = cc + (bi - (cc * nb - cc * (cc - 1) / 2)); }
-    const int off1 = TB * (R * (R + 1) / 2);                      // S1 base of row-block R: [R][C][16]
-    const int off2 = TB * (C * nb - C * (C + 1) / 2);            // S2 base of column-block C: sum_{c<C}(nb-1-c)
-    const int i0 = TB * R, j0 = TB * C + TU * u;
-    const int nwaves = (blockDim.x + 63) / 64;
-
-    double a[TB][TU];
-#pragma unroll
-    for (int r = 0; r < TB; ++r)
-#pragma unroll
-        for (int jj = 0; jj < TU; ++jj) {
-            const int i = i0 + r, j = j0 + jj;
-            a[r][jj] = (owner && i < n && j < n) ? T.A[i + (size_t)T.lda * j] : 0.;
-        }
-    for (int i = tid; i < TRI_MAXN + TB; i += blockDim.x) { s_v[i] = 0.; s_w[i] = 0.; s_x[i] = 0.; }
-    __syncthreads();
-
-#ifdef TNML_EIGH_PROF
-    long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tlast = clock64(); const long long w0 = wall_clock64();
-#endif
-    for (int k = 0; k < n - 1; ++k) {
-        const int kb = (k + 1) / TB;                 // first block (row or column) that still holds rows/cols > k
-        const int kc = k / TB, ku = (k % TB) / TU, kj = k % TU;
-        // 1. column k of the current matrix -> LDS; the diagonal entry is d_k
-        if (owner && C == kc && u == ku) {
-#pragma unroll
-            for (int r = 0; r < TB; ++r) {
-                double x = 0.;
-#pragma unroll
-                for (int jj = 0; jj < TU; ++jj) if (jj == kj) x = a[r][jj];
-                s_x[i0 + r] = x;
-            }
-        }
-        __syncthreads();
-        TP(0);
-        // 2. Householder vector (LAPACK dlarfg), computed redundantly by every wave: no barrier, no
-        //    serial section.  v = [0..0, 1, x[k+2:]*scale]
-        double sig = 0.;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {                  // n <= 256: four independent LDS reads
-            const int i = k + 2 + lane + 64 * e;
-            const double x = i < n ? s_x[i] : 0.;
-            sig = fma(x, x, sig);
-        }
-        sig = wave_sum(sig);
-        const double alpha = s_x[k + 1];
-        double tau = 0., beta = alpha, scale = 0.;
-        if (sig > 0.) {
-            const double nrm = sqrt(fma(alpha, alpha, sig));
-            beta = alpha >= 0. ? -nrm : nrm;
-            const double dlt = alpha - beta;           // one reciprocal serves tau and scale
-            const double inv = 1. / (beta * dlt);
-            tau = -dlt * dlt * inv;                    // (beta - alpha)/beta
-            scale = beta * inv;                        // 1/(alpha - beta)
-        }
-        auto vval = [&](int i) -> double { return i == k + 1 ? 1. : ((i > k + 1 && i < n) ? s_x[i] * scale : 0.); };
-        if (tid < nb * TB) {
-            const double v = vval(tid);
-            s_v[tid] = v;                              // read only after the next barrier (step 4)
-            if (tid < n) T.V[tid + (size_t)T.ldv * k] = v;
-        }
-        if (tid == 0) { T.D[k] = s_x[k]; T.E[k] = beta; T.tau[k] = tau; }
-        TP(1);
-        if (tau != 0.) {                               // uniform: every lane computed the same tau
-            // 3. y = A v : every lane multiplies its 16x4 sub-tile both ways
-            const bool active = owner && C >= kb;
-            double vI[TB], vJ[TU];
-            if (active) {
-#pragma unroll
-                for (int r = 0; r < TB; ++r) vI[r] = vval(i0 + r);
-#pragma unroll
-                for (int jj = 0; jj < TU; ++jj) vJ[jj] = vval(j0 + jj);
-#pragma unroll
-                for (int r = 0; r < TB; ++r) {
-                    double c1 = 0.;
-#pragma unroll
-                    for (int jj = 0; jj < TU; ++jj) c1 = fma(a[r][jj], vJ[jj], c1);
-                    c1 += dpp_quad<0xB1>(c1);          // lane ^ 1
-                    c1 += dpp_quad<0x4E>(c1);          // lane ^ 2
-                    if ((r & 3) == u) S1[off1 + C * TB + r] = c1;
-                }
-                if (R != C) {
-#pragma unroll
-                    for (int jj = 0; jj < TU; ++jj) {
-                        double c2 = 0.;
-#pragma unroll
-                        for (int r = 0; r < TB; ++r) c2 = fma(a[r][jj], vI[r], c2);
-                        S2[off2 + (R - C - 1) * TB + TU * u + jj] = c2;
-                    }
-                }
-            }
-            __syncthreads();
-            TP(2);
-            // 4. reduce y (fixed order), p = tau*y, K = -tau/2 p.v, w = p + K v
-            double pi = 0., part = 0.;
-            if (tid > k && tid < n) {
-                const int Ri = tid / TB, r = tid % TB;
-                double y0 = 0., y1 = 0., y2 = 0., y3 = 0.;
-                const int o1 = TB * (Ri * (Ri + 1) / 2) + r;
-                int s = kb;
-                for (; s + 3 <= Ri; s += 4) { y0 += S1[o1 + s * TB]; y1 += S1[o1 + (s + 1) * TB]; y2 += S1[o1 + (s + 2) * TB]; y3 += S1[o1 + (s + 3) * TB]; }
-                for (; s <= Ri; ++s) y0 += S1[o1 + s * TB];
-                const int o2 = TB * (Ri * nb - Ri * (Ri + 1) / 2) + r - (Ri + 1) * TB;
-                int Rp = Ri + 1;
-                for (; Rp + 3 < nb; Rp += 4) { y0 += S2[o2 + Rp * TB]; y1 += S2[o2 + (Rp + 1) * TB]; y2 += S2[o2 + (Rp + 2) * TB]; y3 += S2[o2 + (Rp + 3) * TB]; }
-                for (; Rp < nb; ++Rp) y1 += S2[o2 + Rp * TB];
-                pi = tau * ((y0 + y1) + (y2 + y3));
-                part = pi * s_v[tid];
-            }
-            part = wave_sum(part);
-            if (lane == 0) s_red[tid >> 6] = part;
-            TP(3);
-            __syncthreads();
-            double ksum = 0.;
-            for (int w = 0; w < nwaves; ++w) ksum += s_red[w];      // same order in every lane
-            const double K = -0.5 * tau * ksum;
-            if (tid < nb * TB) s_w[tid] = (tid > k && tid < n) ? fma(K, s_v[tid], pi) : 0.;
-            __syncthreads();
-            TP(4);
-            // 5. A <- A - v w^T - w v^T on the trailing blocks
-            if (active) {
-                double wJ[TU];
-#pragma unroll
-                for (int jj = 0; jj < TU; ++jj) wJ[jj] = s_w[j0 + jj];
-#pragma unroll
-                for (int r = 0; r < TB; ++r) {
-                    const double wr = s_w[i0 + r];
-#pragma unroll
-                    for (int jj = 0; jj < TU; ++jj) a[r][jj] = fma(-vI[r], wJ[jj], fma(-wr, vJ[jj], a[r][jj]));
-                }
-            }
-        }
-        else __syncthreads();     // no reflector (zero column): still fence this iteration's s_x reads
-        TP(5);
-        // every LDS read above is separated from the next write of the same array by one of the three
-        // barriers inside the branch (s_v[tid] is only ever touched by lane tid)
-    }
-#ifdef TNML_EIGH_PROF
-    if (tid == 0 && T.dbg) { for (int i = 0; i < 6; ++i) T.dbg[i] = prof[i]; T.dbg[6] = wall_clock64() - w0; }
-#endif
-    if (tid == 0 && T.nref) T.nref[0] = (double)(n - 1);
-    // last diagonal entry
-    const int kl = n - 1;
-    if (owner && C == kl / TB && R == C && u == (kl % TB) / TU) {
-        const int r = kl % TB, kj = kl % TU;
-        double x = 0.;
-#pragma unroll
-        for (int rr = 0; rr < TB; ++rr)
-#pragma unroll
-            for (int jj = 0; jj < TU; ++jj) if (rr == r && jj == kj) x = a[rr][jj];
-        T.D[kl] = x;
-    }
-}
-
-// ==========================================================================================
-// k_sytrd_v2 -- the same reduction with 8x8 blocks, ONE lane per block (64 doubles in registers), two barriers
-// per Householder step instead of four, and no cross-lane traffic in the matrix-vector product:
-//   A  (every wave, redundantly) Householder scalars and v from the current column in LDS;
-//   B  per block: row sums a*vJ and (off-diagonal blocks) column sums a^T*vI to LDS, the block's share of
-//      v^T A v through a wave reduction; the owners of column k+1 stage it (pre-update) for the look-ahead;
-//   -- barrier --
-//   C  thread i sums the partials of row i in a fixed order, w_i = tau*y_i - tau^2/2 (v^T A v) v_i;
-//   -- barrier --
-//   D  rank-2 update of the registers; every wave then forms the NEXT column x' = x_old - v w_{k+1} - w
-//      itself (v_{k+1} = 1), so step k+1 starts without another barrier.
-// Blocks are enumerated column-block major so that waves retire as the active window shrinks.  Parity
-// double-buffering of x, x_old and v keeps a fast wave's look-ahead writes away from a slow wave's reads.
-// ==========================================================================================
 #define T8 8
 #define T8_MAXNB (TRI_MAXN / T8)
 static __device__ __forceinline__ void wave_lds_fence() {
@@ -220,179 +28,20 @@ static __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__global__ __launch_bounds__(512) void k_sytrd_v2(TriArgs T) {
-    __shared__ double s_x[2][256], s_xo[2][256], s_v[2][256], s_w[256];
-    __shared__ double s_red[8];
-    __shared__ double S1[T8 * (T8_MAXNB * (T8_MAXNB + 1) / 2)];          // [R][C][8] row partials
-    __shared__ double S2[T8 * (T8_MAXNB * (T8_MAXNB - 1) / 2) + T8];     // [C][R-C-1][8] column partials
-    const int n = T.n, nb = (n + T8 - 1) / T8;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int nblocks = nb * (nb + 1) / 2;
-    const bool owner = tid < nblocks;
-    int R = 0, C = 0;
-    if (owner) { int cc = 0; while ((cc + 1) * nb - (cc + 1) * cc / 2 <= tid) ++cc; C = cc; R = cc + (tid - (cc * nb - cc * (cc - 1) / 2)); }
-    const int i0 = T8 * R, j0 = T8 * C;
-    const int off1 = T8 * (R * (R + 1) / 2 + C);
-    const int off2 = T8 * (C * nb - C * (C + 1) / 2 + (R - C - 1));
-    double a[T8][T8];
-#pragma unroll
-    for (int r = 0; r < T8; ++r)
-#pragma unroll
-        for (int cc = 0; cc < T8; ++cc) {
-            const int i = i0 + r, j = j0 + cc;
-            a[r][cc] = (owner && i < n && j < n) ? T.A[i + (size_t)T.lda * j] : 0.;
-        }
-    if (tid < 256) {
-        s_x[0][tid] = tid < n ? T.A[tid] : 0.; s_x[1][tid] = 0.;
-        s_xo[0][tid] = 0.; s_xo[1][tid] = 0.; s_v[0][tid] = 0.; s_v[1][tid] = 0.; s_w[tid] = 0.;
-    }
-    __syncthreads();
-#ifdef TNML_EIGH_PROF
-    long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tlast = clock64();
-#endif
-    for (int k = 0; k < n - 1; ++k) {
-        const int par = k & 1;
-        const int kb = (k + 1) / T8;                  // first block row/column holding an index > k
-        // ---- A: Householder scalars (LAPACK dlarfg) and v, redundantly per wave
-        double sig = 0.;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { const int i = k + 2 + lane + 64 * e; const double x = i < n ? s_x[par][i] : 0.; sig = fma(x, x, sig); }
-        sig = wave_sum(sig);
-        const double alpha = s_x[par][k + 1];
-        double tau = 0., beta = alpha, scale = 0.;
-        if (sig > 0.) {
-            const double nrm = sqrt(fma(alpha, alpha, sig));
-            beta = alpha >= 0. ? -nrm : nrm;
-            const double dlt = alpha - beta;
-            const double inv = 1. / (beta * dlt);
-            tau = -dlt * dlt * inv;
-            scale = beta * inv;
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int i = lane + 64 * e;
-            const double v = i == k + 1 ? 1. : ((i > k + 1 && i < n) ? s_x[par][i] * scale : 0.);
-            s_v[par][i] = v;                          // identical values from every wave
-            if (wid == 0 && i < n) T.V[i + (size_t)T.ldv * k] = v;
-        }
-        if (tid == 0) { T.D[k] = s_x[par][k]; T.E[k] = beta; T.tau[k] = tau; }
-        wave_lds_fence();
-        TP(0);
-        const bool active = owner && C >= kb;
-        // the owners of column k+1 stage it as it is before this step's update
-        if (owner && C == kb) {                       // (k + 1) / 8 == kb; the column index is uniform: a scalar switch, no selects
-#define T8_STAGE(J) { _Pragma("unroll") for (int r = 0; r < T8; ++r) s_xo[par][i0 + r] = a[r][J]; } break
-            switch ((k + 1) & 7) {
-                case 0: T8_STAGE(0); case 1: T8_STAGE(1); case 2: T8_STAGE(2); case 3: T8_STAGE(3);
-                case 4: T8_STAGE(4); case 5: T8_STAGE(5); case 6: T8_STAGE(6); default: T8_STAGE(7);
-            }
-#undef T8_STAGE
-        }
-        if (tau != 0.) {                              // uniform: every wave computed the same tau
-            double vI[T8], vJ[T8];
-            double q = 0.;
-            if (active) {
-#pragma unroll
-                for (int r = 0; r < T8; ++r) vI[r] = s_v[par][i0 + r];
-#pragma unroll
-                for (int cc = 0; cc < T8; ++cc) vJ[cc] = s_v[par][j0 + cc];
-#pragma unroll
-                for (int r = 0; r < T8; ++r) {
-                    double c1 = 0.;
-#pragma unroll
-                    for (int cc = 0; cc < T8; ++cc) c1 = fma(a[r][cc], vJ[cc], c1);
-                    S1[off1 + r] = c1;
-                    q = fma(vI[r], c1, q);
-                }
-                if (R != C) {
-#pragma unroll
-                    for (int cc = 0; cc < T8; ++cc) {
-                        double c2 = 0.;
-#pragma unroll
-                        for (int r = 0; r < T8; ++r) c2 = fma(a[r][cc], vI[r], c2);
-                        S2[off2 + cc] = c2;
-                    }
-                    q *= 2.;
-                }
-            }
-            q = wave_sum(q);
-            if (lane == 0) s_red[wid] = q;
-            TP(1);
-            __syncthreads();
-            TP(2);
-            // ---- C: y_i in a fixed order, w_i
-            double vAv = 0.;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) vAv += s_red[w];
-            const double K = -0.5 * tau * tau * vAv;
-            if (tid < 256) {
-                double wi = 0.;
-                if (tid > k && tid < n) {
-                    const int Ri = tid / T8, r = tid % T8;
-                    double y0 = 0., y1 = 0., y2 = 0., y3 = 0.;
-                    const int o1 = T8 * (Ri * (Ri + 1) / 2) + r;
-                    int cb = kb;
-                    for (; cb + 3 <= Ri; cb += 4) { y0 += S1[o1 + cb * T8]; y1 += S1[o1 + (cb + 1) * T8]; y2 += S1[o1 + (cb + 2) * T8]; y3 += S1[o1 + (cb + 3) * T8]; }
-                    for (; cb <= Ri; ++cb) y0 += S1[o1 + cb * T8];
-                    const int o2 = T8 * (Ri * nb - Ri * (Ri + 1) / 2) + r;
-                    int q2 = 0; const int nq = nb - 1 - Ri;
-                    for (; q2 + 3 < nq; q2 += 4) { y0 += S2[o2 + q2 * T8]; y1 += S2[o2 + (q2 + 1) * T8]; y2 += S2[o2 + (q2 + 2) * T8]; y3 += S2[o2 + (q2 + 3) * T8]; }
-                    for (; q2 < nq; ++q2) y1 += S2[o2 + q2 * T8];
-                    wi = fma(K, s_v[par][tid], tau * ((y0 + y1) + (y2 + y3)));
-                }
-                s_w[tid] = wi;
-            }
-            TP(3);
-            __syncthreads();
-            TP(4);
-            // ---- D: A <- A - v w^T - w v^T
-            if (active) {
-                double wJ[T8];
-#pragma unroll
-                for (int cc = 0; cc < T8; ++cc) wJ[cc] = s_w[j0 + cc];
-#pragma unroll
-                for (int r = 0; r < T8; ++r) {
-                    const double wr = s_w[i0 + r];
-#pragma unroll
-                    for (int cc = 0; cc < T8; ++cc) a[r][cc] = fma(-vI[r], wJ[cc], fma(-wr, vJ[cc], a[r][cc]));
-                }
-            }
-            // look-ahead: column k+1 of the updated matrix
-            const double wk1 = s_w[k + 1];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int i = lane + 64 * e;
-                const double xn = (i >= k + 1 && i < n) ? (s_xo[par][i] - s_v[par][i] * wk1) - s_w[i] : 0.;
-                s_x[par ^ 1][i] = xn;
-            }
-            TP(5);
-        } else {                                      // no reflector: the matrix is unchanged
-            __syncthreads();
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const int i = lane + 64 * e; s_x[par ^ 1][i] = (i >= k + 1 && i < n) ? s_xo[par][i] : 0.; }
-            __syncthreads();
-        }
-        wave_lds_fence();
-    }
-#ifdef TNML_EIGH_PROF
-    if (tid == 0 && T.dbg) for (int i = 0; i < 6; ++i) T.dbg[i] = prof[i];
-#endif
-    if (tid == 0) { T.D[n - 1] = s_x[(n - 1) & 1][n - 1]; if (T.nref) T.nref[0] = (double)(n - 1); }
-}
 
 // ==========================================================================================
-// k_sytrd_v3 -- k_sytrd_v2's block ownership (8x8 blocks of the lower triangle, one lane per block, column-block major so
-// that waves retire) with the serial part of a Householder step cut down (profiles/r02_probe_eigh.txt):
+// k_sytrd_v3 -- 8x8 blocks of the lower triangle, one lane per block (64 doubles), enumerated column-block major so that waves
+// retire as the active window shrinks; the serial part of a Householder step cut down (profiles/r02_probe_eigh.txt):
 //   * the current column lives in REGISTERS of every wave (rows lane + 64 e): the look-ahead column formed at the end of
 //     step k is the input of step k+1 without an LDS round trip, alpha comes from a readlane;
 //   * Householder scalars from v_rsq_f64 / v_rcp_f64 with explicit Newton steps (one dependent chain of ~25 fp64 ops
 //     instead of the ~45 of IEEE sqrt + division), tau = 1 + |alpha|/norm;
 //   * the partial sums of y = A v go to a table Y[c][i] (c = block column that produced the partial, i = row; row stride
 //     242 doubles): every block writes its 8 row sums and its 8 column sums as 16-byte stores that are bank-conflict
-//     free across the lanes of a wave (v2's [block][8] layout made them 4-way conflicted), and the partials of a row are
+//     free across the lanes of a wave (a [block][8] layout is 4-way conflicted), and the partials of a row are
 //     a strided run that TWO lanes per row read with all loads in flight before the first add;
 //   * the global stores of v are taken by a different wave every step.
-// Two barriers per step as before; same Householder convention as the other two kernels (LAPACK dlarfg).
+// Two barriers per step; Householder convention of LAPACK dlarfg.
 // ==========================================================================================
 #define V3_LD 242
 #define V3_SMEM_DOUBLES (T8_MAXNB * V3_LD + 240 + 240 + 2 * 240 + 32)
@@ -666,179 +315,66 @@ __global__ __launch_bounds__(512) void k_sytrd_v3(TriArgs T) {
     }
 }
 
-// U[:, c] = H_0 H_1 ... H_{n-2} Z[:, c]; one wave per column, 4 rows per lane (n <= 256).  The
-// reflectors are fetched 8 at a time so that the L2 latency of V is paid once per 8 dependent updates.
-#define BT_PF 8
+// U[:, c] = H_0 H_1 ... H_{n-2} Z[:, c]; one wave per column, NE rows per lane (n <= 64 NE).  The
+// reflectors are fetched PF at a time so that the L2 latency of V is paid once per PF dependent updates.
+template <int NE, int PF>
 __global__ __launch_bounds__(64) void k_backtransform(const double* __restrict__ V, int ldv, const double* __restrict__ tau, int n,
                                                      const double* __restrict__ Z, int ldz, double* __restrict__ U, int ldu, const double* __restrict__ nrefp) {
     const int c = blockIdx.x, lane = threadIdx.x;
-    double z[4];
+    double z[NE];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { const int i = lane + 64 * e; z[e] = i < n ? (Z ? Z[i + (size_t)ldz * c] : (i == c ? 1. : 0.)) : 0.; }   // Z == nullptr: the identity (forms H_0 ... H_{n-2} itself)
-    const int nr = nrefp ? (int)nrefp[0] : n - 1;                      // reflectors 0 .. nr-1 exist (k_sytrd_v3 may stop early)
-    for (int k0 = nr - 1; k0 >= 0; k0 -= BT_PF) {
-        double v[BT_PF][4], t[BT_PF];
+    for (int e = 0; e < NE; ++e) { const int i = lane + 64 * e; z[e] = i < n ? (Z ? Z[i + (size_t)ldz * c] : (i == c ? 1. : 0.)) : 0.; }   // Z == nullptr: the identity (forms H_0 ... H_{n-2} itself)
+    const int nr = nrefp ? (int)nrefp[0] : n - 1;                      // reflectors 0 .. nr-1 exist (the tridiagonalisation may stop early)
+    for (int k0 = nr - 1; k0 >= 0; k0 -= PF) {
+        double v[PF][NE], t[PF];
 #pragma unroll
-        for (int q = 0; q < BT_PF; ++q) {
+        for (int q = 0; q < PF; ++q) {
             const int k = k0 - q;
             t[q] = k >= 0 ? tau[k] : 0.;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const int i = lane + 64 * e; v[q][e] = (k >= 0 && i < n && i > k) ? V[i + (size_t)ldv * k] : 0.; }
+            for (int e = 0; e < NE; ++e) { const int i = lane + 64 * e; v[q][e] = (k >= 0 && i < n && i > k) ? V[i + (size_t)ldv * k] : 0.; }
         }
 #pragma unroll
-        for (int q = 0; q < BT_PF; ++q) {
+        for (int q = 0; q < PF; ++q) {
             double dot = 0.;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dot = fma(v[q][e], z[e], dot);
+            for (int e = 0; e < NE; ++e) dot = fma(v[q][e], z[e], dot);
             dot = wave_sum(dot);                    // DPP reduction: six ds_bpermute round trips per reflector were 40 % of this kernel
             const double f = t[q] * dot;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) z[e] -= f * v[q][e];
+            for (int e = 0; e < NE; ++e) z[e] -= f * v[q][e];
         }
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { const int i = lane + 64 * e; if (i < n) U[i + (size_t)ldu * c] = z[e]; }
+    for (int e = 0; e < NE; ++e) { const int i = lane + 64 * e; if (i < n) U[i + (size_t)ldu * c] = z[e]; }
 }
 
-// ------------------------------------------------------------------------------------------
-// Blocked back transformation.  Eight consecutive reflectors are applied as one compact-WY block,
-//   H_a H_{a+1} ... H_{a+7} = I - V T V^T      (V = [v_a .. v_{a+7}], T upper triangular, LAPACK dlarft 'F','C'),
-// so that a column needs 8 INDEPENDENT dot products per block (their wave reductions interleave) instead of 8 dependent
-// dot -> reduce -> update rounds: the one-wave-per-column kernel above is a latency chain of n-1 wave reductions.
-// k_bt_tfactors: one wave per block forms T from the Gram matrix of the block's vectors and tau.
-// ------------------------------------------------------------------------------------------
-#define BTW 8
-__global__ __launch_bounds__(64) void k_bt_tfactors(const double* __restrict__ V, int ldv, const double* __restrict__ tau, int n, double* __restrict__ Tf) {
-    const int blk = blockIdx.x, lane = threadIdx.x, a = blk * BTW;
-    double v[BTW][4], t[BTW];
-#pragma unroll
-    for (int q = 0; q < BTW; ++q) {
-        const int k = a + q;
-        t[q] = k < n - 1 ? tau[k] : 0.;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { const int i = lane + 64 * e; v[q][e] = (k < n - 1 && i < n && i > k) ? V[i + (size_t)ldv * k] : 0.; }
-    }
-    double g[BTW][BTW];                                   // g[i][j] = v_i . v_j, i < j
-#pragma unroll
-    for (int i = 0; i < BTW; ++i)
-#pragma unroll
-        for (int j = i + 1; j < BTW; ++j) {
-            double d = 0.;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) d = fma(v[i][e], v[j][e], d);
-            g[i][j] = wave_sum(d);
-        }
-    // T(0:j-1, j) = -tau_j T(0:j-1, 0:j-1) (V(:, 0:j-1)^T v_j),  T(j,j) = tau_j      -- every lane, identical values
-    double T[BTW][BTW];
-#pragma unroll
-    for (int i = 0; i < BTW; ++i)
-#pragma unroll
-        for (int j = 0; j < BTW; ++j) T[i][j] = 0.;
-#pragma unroll
-    for (int j = 0; j < BTW; ++j) {
-#pragma unroll
-        for (int i = 0; i < j; ++i) {
-            double acc = 0.;
-#pragma unroll
-            for (int k = i; k < j; ++k) acc = fma(T[i][k], g[k][j], acc);
-            T[i][j] = -t[j] * acc;
-        }
-        T[j][j] = t[j];
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < BTW; ++i)
-#pragma unroll
-            for (int j = 0; j < BTW; ++j) Tf[(size_t)blk * BTW * BTW + i * BTW + j] = T[i][j];
-    }
-}
-__global__ __launch_bounds__(64) void k_backtransform_wy(const double* __restrict__ V, int ldv, const double* __restrict__ Tf, int n,
-                                                        const double* __restrict__ Z, int ldz, double* __restrict__ U, int ldu) {
-    const int c = blockIdx.x, lane = threadIdx.x;
-    double z[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { const int i = lane + 64 * e; z[e] = i < n ? Z[i + (size_t)ldz * c] : 0.; }
-    const int nblk = (n - 1 + BTW - 1) / BTW;
-    for (int blk = nblk - 1; blk >= 0; --blk) {
-        const int a = blk * BTW;
-        double v[BTW][4], w[BTW];
-#pragma unroll
-        for (int q = 0; q < BTW; ++q) {
-            const int k = a + q;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const int i = lane + 64 * e; v[q][e] = (k < n - 1 && i < n && i > k) ? V[i + (size_t)ldv * k] : 0.; }
-        }
-        const double* Tb = Tf + (size_t)blk * BTW * BTW;
-        double T[BTW][BTW];
-#pragma unroll
-        for (int i = 0; i < BTW; ++i)
-#pragma unroll
-            for (int j = i; j < BTW; ++j) T[i][j] = Tb[i * BTW + j];          // the same address in every lane: a broadcast load
-#pragma unroll
-        for (int q = 0; q < BTW; ++q) {
-            double d = 0.;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) d = fma(v[q][e], z[e], d);
-            w[q] = wave_sum(d);                                               // eight independent reductions
-        }
-#pragma unroll
-        for (int i = 0; i < BTW; ++i) {                                       // y = T w, then z -= V y
-            double y = 0.;
-#pragma unroll
-            for (int j = i; j < BTW; ++j) y = fma(T[i][j], w[j], y);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) z[e] = fma(-y, v[i][e], z[e]);
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { const int i = lane + 64 * e; if (i < n) U[i + (size_t)ldu * c] = z[e]; }
-}
-
-static bool bt_wy_enabled() {
-    static const int wy = getenv("TNML_BT_WY") ? atoi(getenv("TNML_BT_WY")) : 0;   // measured slower than the one-reflector-at-a-time kernel (profiles/r02_ab_bt_wy.txt), off
-    return wy != 0;
-}
 // A (n x n symmetric, device) -> D, E, tau, V on the context's stream.  n <= TRI_MAXN.  `tau` has room for n doubles: tau[n-1]
 // receives the number of reflectors formed, which eigh_backtransform reads back on the device.  psd_tol > 0 promises a positive
 // semidefinite A (a Gram matrix) and lets k_sytrd_v3 stop once the trailing block's trace is <= psd_tol * trace(A).
 int eigh_tridiagonalize(tnml_ctx* c, const double* A, int n, double* D, double* E, double* tau, double* V, double psd_tol) {
-    if (n > TRI_MAXN) return tnml_fail(c, "eigh_tridiagonalize: n=%d exceeds %d", n, TRI_MAXN);
     static const double tol_env = getenv("TNML_SYTRD_TOL") ? atof(getenv("TNML_SYTRD_TOL")) : -1.;
     if (tol_env >= 0.) psd_tol = psd_tol > 0. ? tol_env : 0.;
-    if (bt_wy_enabled()) psd_tol = 0.;                 // the compact-WY back transformation reads every reflector column
+    if (n > TRI_MAXN) {                                // the multi-workgroup kernel (eigh_mc.hip)
+        if (!c->mc_xbuf) return tnml_fail(c, "eigh_tridiagonalize: n=%d needs the multi-workgroup exchange buffer (context created with maxm <= %d)", n, TRI_MAXN / 2);
+        return eigh_mc_tridiagonalize(c, c->stream, A, n, D, E, tau, V, psd_tol, c->mc_xbuf, &c->mc_epoch);
+    }
     TriArgs t{A, n, n, D, E, tau, V, n, nullptr, tau + (n - 1), psd_tol};
-    static const int ver = getenv("TNML_SYTRD") ? atoi(getenv("TNML_SYTRD")) : 3;
-    if (ver == 3) {
-        static const bool attr_set = (hipFuncSetAttribute(reinterpret_cast<const void*>(k_sytrd_v3), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                          (int)(V3_SMEM_DOUBLES * sizeof(double))) == hipSuccess);
-        if (!attr_set) return tnml_fail(c, "eigh_tridiagonalize: cannot reserve %zu bytes of LDS", V3_SMEM_DOUBLES * sizeof(double));
-        hipLaunchKernelGGL(k_sytrd_v3, dim3(1), dim3(512), V3_SMEM_DOUBLES * sizeof(double), c->stream, t);
-        HIPCK(c, hipGetLastError());
-        return 0;
+    if (!c->attr_sytrd) {                              // function attributes are per device: remembered per context, not per process
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_sytrd_v3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(V3_SMEM_DOUBLES * sizeof(double))) != hipSuccess)
+            return tnml_fail(c, "eigh_tridiagonalize: cannot reserve %zu bytes of LDS", V3_SMEM_DOUBLES * sizeof(double));
+        c->attr_sytrd = true;
     }
-    if (ver == 2) {
-        hipLaunchKernelGGL(k_sytrd_v2, dim3(1), dim3(512), 0, c->stream, t);
-        HIPCK(c, hipGetLastError());
-        return 0;
-    }
-    const int nb = (n + TB - 1) / TB;
-    int threads = TU * nb * (nb + 1) / 2;
-    if (threads < nb * TB) threads = nb * TB;
-    threads = (threads + 63) / 64 * 64;
-    hipLaunchKernelGGL(k_sytrd_onewg, dim3(1), dim3(threads), 0, c->stream, t);
+    hipLaunchKernelGGL(k_sytrd_v3, dim3(1), dim3(512), V3_SMEM_DOUBLES * sizeof(double), c->stream, t);
     HIPCK(c, hipGetLastError());
     return 0;
 }
 int eigh_backtransform(tnml_ctx* c, const double* V, const double* tau, int n, const double* Z, int ldz, double* U, int ldu, int ncols, hipStream_t st) {
-    const bool wy = bt_wy_enabled();
-    if (wy && Z && c->sBT && n <= 256) {
-        const int nblk = (n - 1 + BTW - 1) / BTW;
-        hipLaunchKernelGGL(k_bt_tfactors, dim3(nblk), dim3(64), 0, st ? st : c->stream, V, n, tau, n, c->sBT);
-        hipLaunchKernelGGL(k_backtransform_wy, dim3(ncols), dim3(64), 0, st ? st : c->stream, V, n, (const double*)c->sBT, n, Z, ldz, U, ldu);
-        HIPCK(c, hipGetLastError());
-        return 0;
-    }
-    hipLaunchKernelGGL(k_backtransform, dim3(ncols), dim3(64), 0, st ? st : c->stream, V, n, tau, n, Z, ldz, U, ldu, tau + (n - 1));
+    if (!st) st = c->stream;
+    if (n <= 256)      hipLaunchKernelGGL((k_backtransform<4, 8>), dim3(ncols), dim3(64), 0, st, V, n, tau, n, Z, ldz, U, ldu, tau + (n - 1));
+    else if (n <= 384) hipLaunchKernelGGL((k_backtransform<6, 6>), dim3(ncols), dim3(64), 0, st, V, n, tau, n, Z, ldz, U, ldu, tau + (n - 1));
+    else if (n <= 640) hipLaunchKernelGGL((k_backtransform<10, 4>), dim3(ncols), dim3(64), 0, st, V, n, tau, n, Z, ldz, U, ldu, tau + (n - 1));
+    else return tnml_fail(c, "eigh_backtransform: n=%d exceeds 640", n);
     HIPCK(c, hipGetLastError());
     return 0;
 }
@@ -868,15 +404,16 @@ struct TeigArgs {
 // there.  Eigenvectors of different blocks have disjoint supports -- exactly orthogonal -- and inverse iteration
 // inside a block works at the block's own scale.  (Without the split the tail is one big cluster at the
 // resolution of inverse iteration, and its vectors come out far from orthogonal.)
-__global__ __launch_bounds__(256) void k_tridiag_split(TeigArgs T) {
-    __shared__ double s_red[256];
-    __shared__ int s_cut[257];
+#define TEIG_MAXN 640
+__global__ __launch_bounds__(1024) void k_tridiag_split(TeigArgs T) {
+    __shared__ double s_red[1024];
+    __shared__ int s_cut[1025];
     const int n = T.n, i = threadIdx.x;
     double rs = 0.;
     if (i < n) rs = fabs(T.D[i]) + (i > 0 ? fabs(T.E[i - 1]) : 0.) + (i < n - 1 ? fabs(T.E[i]) : 0.);
     s_red[i] = rs;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if (i < s) s_red[i] = fmax(s_red[i], s_red[i + s]); __syncthreads(); }
+    for (int s = 512; s > 0; s >>= 1) { if (i < s) s_red[i] = fmax(s_red[i], s_red[i + s]); __syncthreads(); }
     const double thr = 2.220446049250313e-16 * s_red[0];
     if (i < n) {
         const bool cut = (i == n - 1) || !(fabs(T.E[i]) > thr);      // block ends after row i
@@ -927,7 +464,7 @@ static __device__ __forceinline__ int sturm_count(const double2* s_de, int lo, i
 // rounds to fp64 resolution instead of 53 bisections).  The recurrence is a pure latency chain, so width is
 // free: one wave per row on as many CUs.
 __global__ __launch_bounds__(64) void k_tridiag_eigvals(TeigArgs T) {
-    __shared__ double2 s_de[256];
+    __shared__ double2 s_de[TEIG_MAXN];
     __shared__ double s_bounds[4];
     const int lane = threadIdx.x;
     const int i = blockIdx.x;
@@ -974,8 +511,8 @@ __global__ __launch_bounds__(64) void k_tridiag_eigvals(TeigArgs T) {
 }
 
 // global order: row i owns the g-th largest eigenvalue, g = #{j : mu_j > mu_i or (mu_j == mu_i and j < i)}
-__global__ __launch_bounds__(256) void k_tridiag_rank(TeigArgs T) {
-    __shared__ double s_mu[256];
+__global__ __launch_bounds__(1024) void k_tridiag_rank(TeigArgs T) {
+    __shared__ double s_mu[1024];
     const int n = T.n, i = threadIdx.x;
     s_mu[i] = i < n ? T.mu[i] : 0.;
     __syncthreads();
@@ -989,17 +526,21 @@ __global__ __launch_bounds__(256) void k_tridiag_rank(TeigArgs T) {
 
 // eigenvectors of the mk largest eigenvalues by inverse iteration inside the owning block; 16 vectors per
 // workgroup, their LU factors and iterates live in LDS as [array][k][lane]
-#define IV_L 16
+// IV_L: vectors per workgroup (16 up to n = 256; 8 / 4 for the larger blocks of eigh_mc.hip, whose LU factors would not fit otherwise);
+// BIG: the interchange flags live in LDS bytes instead of four 64-bit registers
+template <int IV_L, bool BIG>
 __global__ __launch_bounds__(64) void k_tridiag_invit(TeigArgs T) {
     extern __shared__ __attribute__((aligned(16))) double iv_lds[];
     const int n = T.n, lane = threadIdx.x;
+    const int ns = (n + 63) & ~63;
     double* s_d = iv_lds;                 // [n]
-    double* s_e = s_d + 256;              // [n]
-    double* a = s_e + 256;                // U diagonal            [k][IV_L]
+    double* s_e = s_d + ns;               // [n]
+    double* a = s_e + ns;                 // U diagonal            [k][IV_L]
     double* b = a + (size_t)n * IV_L;     // U first superdiagonal
     double* c = b + (size_t)n * IV_L;     // L multipliers
     double* d2 = c + (size_t)n * IV_L;    // U second superdiagonal
     double* x = d2 + (size_t)n * IV_L;    // iterate
+    unsigned char* pvb = reinterpret_cast<unsigned char*>(x + (size_t)n * IV_L);   // BIG: interchange flags [k][IV_L]
     for (int k = lane; k < n; k += 64) { s_d[k] = T.D[k]; s_e[k] = k < n - 1 ? T.Es[k] : 0.; }
     __syncthreads();
     const int g = blockIdx.x * IV_L + lane;           // g-th largest eigenvalue
@@ -1046,8 +587,11 @@ __global__ __launch_bounds__(64) void k_tridiag_invit(TeigArgs T) {
         b[IX(k)] = sw ? ak1 : bk; c[IX(k)] = mult; d2[IX(k)] = sw ? bk1 : 0.;
         const double nak = (sw ? bk : ak1) - mult * (sw ? ak1 : bk);
         const double nbk = sw ? -mult * bk1 : bk1;
-        const unsigned long long bit = sw ? 1ull << (k & 63) : 0ull; const int wq = k >> 6;
-        pv0 |= wq == 0 ? bit : 0ull; pv1 |= wq == 1 ? bit : 0ull; pv2 |= wq == 2 ? bit : 0ull; pv3 |= wq == 3 ? bit : 0ull;
+        if (BIG) pvb[IX(k)] = sw ? 1 : 0;
+        else {
+            const unsigned long long bit = sw ? 1ull << (k & 63) : 0ull; const int wq = k >> 6;
+            pv0 |= wq == 0 ? bit : 0ull; pv1 |= wq == 1 ? bit : 0ull; pv2 |= wq == 2 ? bit : 0ull; pv3 |= wq == 3 ? bit : 0ull;
+        }
         a[IX(k)] = rpiv(piv);                           // reciprocal pivot
         scale1 = scale2;
         ak = nak; bk = nbk;
@@ -1062,9 +606,13 @@ __global__ __launch_bounds__(64) void k_tridiag_invit(TeigArgs T) {
         // forward: apply (P L)^-1 (the interchange is a select: the lanes of a wave pivot differently)
         double xk = x[IX(lo)] * xscale;
         for (int k = lo; k < hi - 1; ++k) {
-            const int wq = k >> 6;
-            const unsigned long long word = wq == 0 ? pv0 : wq == 1 ? pv1 : wq == 2 ? pv2 : pv3;
-            const bool sw = (word >> (k & 63)) & 1;
+            bool sw;
+            if (BIG) sw = pvb[IX(k)] != 0;
+            else {
+                const int wq = k >> 6;
+                const unsigned long long word = wq == 0 ? pv0 : wq == 1 ? pv1 : wq == 2 ? pv2 : pv3;
+                sw = (word >> (k & 63)) & 1;
+            }
             const double xk1 = x[IX(k + 1)] * xscale, m = c[IX(k)];
             const double keep = sw ? xk1 : xk, go = sw ? xk : xk1;
             x[IX(k)] = keep;
@@ -1088,16 +636,28 @@ __global__ __launch_bounds__(64) void k_tridiag_invit(TeigArgs T) {
 #undef IX
 }
 
+// scratch: TEIG_SCRATCH_DOUBLES doubles
 int eigh_tridiag_eig(tnml_ctx* c, const double* D, const double* E, int n, double* W, int mk, double* Z, int ldz, double* scratch) {
-    if (n > 256 || mk > 256) return tnml_fail(c, "eigh_tridiag_eig: n=%d mk=%d exceed 256", n, mk);
-    TeigArgs t{D, E, n, W, mk, Z, ldz, scratch, scratch + 256, (int*)(scratch + 512), (int*)(scratch + 512) + 256, (int*)(scratch + 512) + 512};
-    hipLaunchKernelGGL(k_tridiag_split, dim3(1), dim3(256), 0, c->stream, t);
+    if (n > TEIG_MAXN || mk > n) return tnml_fail(c, "eigh_tridiag_eig: n=%d mk=%d exceed %d", n, mk, TEIG_MAXN);
+    int* is = (int*)(scratch + 2 * TEIG_MAXN);
+    TeigArgs t{D, E, n, W, mk, Z, ldz, scratch, scratch + TEIG_MAXN, is, is + TEIG_MAXN, is + 2 * TEIG_MAXN};
+    hipLaunchKernelGGL(k_tridiag_split, dim3(1), dim3(1024), 0, c->stream, t);
     hipLaunchKernelGGL(k_tridiag_eigvals, dim3(n), dim3(64), 0, c->stream, t);
-    hipLaunchKernelGGL(k_tridiag_rank, dim3(1), dim3(256), 0, c->stream, t);
-    const size_t lds = sizeof(double) * (512 + (size_t)5 * n * IV_L);
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_tridiag_invit, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
-    hipLaunchKernelGGL(k_tridiag_invit, dim3((mk + IV_L - 1) / IV_L), dim3(64), lds, c->stream, t);
+    hipLaunchKernelGGL(k_tridiag_rank, dim3(1), dim3(1024), 0, c->stream, t);
+    const int ns = (n + 63) & ~63;
+    const int ivl = n <= 256 ? 16 : (n <= 448 ? 8 : 4);
+    const size_t lds = sizeof(double) * (2 * (size_t)ns + (size_t)5 * n * ivl) + (n > 256 ? (size_t)n * ivl : 0);
+    if (lds > 160 * 1024) return tnml_fail(c, "eigh_tridiag_eig: %zu bytes of LDS for n=%d", lds, n);
+    if (!c->attr_invit) {
+        (void)hipFuncSetAttribute((const void*)k_tridiag_invit<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_tridiag_invit<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_tridiag_invit<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        c->attr_invit = true;
+    }
+    const dim3 grid((mk + ivl - 1) / ivl);
+    if (ivl == 16)     hipLaunchKernelGGL((k_tridiag_invit<16, false>), grid, dim3(64), lds, c->stream, t);
+    else if (ivl == 8) hipLaunchKernelGGL((k_tridiag_invit<8, true>), grid, dim3(64), lds, c->stream, t);
+    else               hipLaunchKernelGGL((k_tridiag_invit<4, true>), grid, dim3(64), lds, c->stream, t);
     HIPCK(c, hipGetLastError());
     return 0;
 }
@@ -1129,94 +689,14 @@ int eigh_ns_matrix(tnml_ctx* c, const double* S, double* Cm, int m, double* dev)
 }
 
 // ==========================================================================================
-// Cholesky QR of a basis whose Gram matrix S = Q^T Q is given (m x m, m <= 136): S = L L^T in LDS, then
-// Rinv = L^-T written dense (upper triangular), so that Q Rinv is orthonormal.  Used when inverse iteration
-// returned an eigenvalue CLUSTER: its vectors (random starts) span the right invariant subspace but are
-// not orthogonal to each other; any orthonormal basis of that subspace is an equally valid set of
-// eigenvectors, and well separated vectors are left alone to round-off (their rows of L are ~ e_i).
-// flag[0] = 1 when a pivot is not safely positive (dependent vectors) -- the caller then falls back.
+// Cholesky QR of a basis whose Gram matrix S = Q^T Q is given (m x m): S = L L^T, then Rinv = L^-T written dense
+// (upper triangular), so that Q Rinv is orthonormal.  Used because inverse iteration returns, for an eigenvalue
+// CLUSTER, vectors (random starts) that span the right invariant subspace but are not orthogonal to each other; any
+// orthonormal basis of that subspace is an equally valid set of eigenvectors, and well separated vectors are left alone
+// to round-off (their rows of L are ~ e_i).  flag[0] = 1 when a pivot is not safely positive (dependent vectors) --
+// the caller then falls back.  (A column-by-column LDS kernel did this in 204 us at m = 120, profiles/r02_ab_chol_panels.txt.)
 // ==========================================================================================
-#define CHOL_MAXM 136
-__global__ __launch_bounds__(1024) void k_chol_rinv(const double* __restrict__ S, int m, double* __restrict__ Rinv, double* __restrict__ flag) {
-    extern __shared__ __attribute__((aligned(16))) double ch_lds[];
-    const int ld = m | 1;                                  // odd leading dimension
-    double* A = ch_lds;                                    // [ld * m]: X = L^-1 (transposed) above the diagonal after the factorisation
-    double* col = A + (size_t)ld * m;                      // [2][CHOL_MAXM] scaled pivot column, double buffered
-    double* dinv = col + 2 * CHOL_MAXM;                    // [m] 1 / L_jj
-    __shared__ int s_fail;
-    const int tid = threadIdx.x;
-    if (tid == 0) s_fail = 0;
-    // lower-triangular elements e = tid, tid + 1024, ... (column major packed) live in registers: at most 10 per lane
-    constexpr int EPT = (CHOL_MAXM * (CHOL_MAXM + 1) / 2 + 1023) / 1024;
-    const int ntri = m * (m + 1) / 2;
-    double a[EPT]; int ei[EPT], ej[EPT];
-#pragma unroll
-    for (int q = 0; q < EPT; ++q) {
-        const int e = tid + 1024 * q;
-        int j = 0, i = 0;
-        if (e < ntri) {                                    // column j holds m - j elements: offset(j) = j*m - j(j-1)/2
-            j = (int)((2. * m + 1. - sqrt((2. * m + 1.) * (2. * m + 1.) - 8. * e)) * 0.5);
-            while (j > 0 && j * m - j * (j - 1) / 2 > e) --j;
-            while ((j + 1) * m - (j + 1) * j / 2 <= e) ++j;
-            i = j + (e - (j * m - j * (j - 1) / 2));
-        }
-        ei[q] = e < ntri ? i : -1; ej[q] = j;
-        a[q] = e < ntri ? S[i + (size_t)m * j] : 0.;
-    }
-    for (int idx = tid; idx < ld * m; idx += 1024) A[idx] = 0.;
-    __syncthreads();
-    // right-looking Cholesky: the owner of (k,k) publishes the pivot, the owners of column k publish L[:,k], everyone updates
-    for (int k = 0; k < m; ++k) {
-        double* ck = col + (k & 1) * CHOL_MAXM;
-#pragma unroll
-        for (int q = 0; q < EPT; ++q) if (ei[q] == k && ej[q] == k) { if (!(a[q] > 1e-13)) s_fail = 1; dinv[k] = rsqrt(a[q] > 1e-13 ? a[q] : 1.); }
-        __syncthreads();
-        const double inv = dinv[k];
-#pragma unroll
-        for (int q = 0; q < EPT; ++q) if (ej[q] == k && ei[q] >= k) { a[q] *= inv; ck[ei[q]] = a[q]; }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < EPT; ++q) if (ej[q] > k && ei[q] >= 0) a[q] = fma(-ck[ei[q]], ck[ej[q]], a[q]);
-    }
-    __syncthreads();
-    if (s_fail) { if (tid == 0) flag[0] = 1.; return; }
-    // L -> LDS (below and on the diagonal); dinv holds 1/L_jj
-#pragma unroll
-    for (int q = 0; q < EPT; ++q) if (ei[q] >= 0) A[ei[q] + (size_t)ld * ej[q]] = a[q];
-    __syncthreads();
-    // X = L^-1, column j by a group of 8 (4 when m > 128) lanes of one wave: x_j = 1/L_jj,
-    // x_i = -(sum_{j<=k<i} L[i][k] x_k) / L_ii with the sum split over the group and combined by DPP; x_k is kept
-    // at A[j + ld*k] (k > j, the unused upper triangle) and read back by the same wave (in-order LDS).
-    {
-        const int lpc = m <= 128 ? 8 : 4;
-        const int j = tid / lpc, sub = tid % lpc;
-        const int jw = (tid & ~63) / lpc;                              // first column of this wave: common loop start
-        const bool col_ok = j < m;
-        for (int i = jw + 1; i < m; ++i) {
-            double acc = 0.;
-            if (col_ok && i > j) {
-                for (int k = j + sub; k < i; k += lpc) {
-                    const double xk = k == j ? dinv[j] : A[j + (size_t)ld * k];
-                    acc = fma(A[i + (size_t)ld * k], xk, acc);
-                }
-            }
-            acc += dpp_quad<0xB1>(acc);                                   // lane ^ 1
-            acc += dpp_quad<0x4E>(acc);                                   // lane ^ 2
-            if (lpc == 8) acc += dpp_quad<0x141>(acc);                    // row_half_mirror: the other quad of the 8
-            if (col_ok && i > j && sub == 0) A[j + (size_t)ld * i] = -acc * dinv[i];
-            wave_lds_fence();
-        }
-    }
-    __syncthreads();
-    // Rinv = X^T: Rinv[k][i] = X[i][k] for i > k, 1/L_kk on the diagonal, 0 below
-    for (int idx = tid; idx < m * m; idx += 1024) {
-        const int k = idx % m, i = idx / m;
-        Rinv[idx] = k < i ? A[k + (size_t)ld * i] : (k == i ? dinv[k] : 0.);
-    }
-    if (tid == 0) flag[0] = 0.;
-}
-// ==========================================================================================
-// k_chol_rinv_blocked -- the same result (S = L L^T, Rinv = L^-T) for m <= 128 by a blocked right-looking Cholesky on
+// k_chol_rinv_blocked -- S = L L^T, Rinv = L^-T for m <= 128 by a blocked right-looking Cholesky on
 // 8 x 8 register tiles, one lane per tile of the lower triangle (16 x 16 lanes), with the inverse accumulated alongside:
 // W starts as the identity and takes the same eliminations as the trailing matrix, so that the row block p of
 // X = L^-1 is final right after panel p (X_p* = L_pp^-1 W_p*) and no separate triangular inversion pass is needed.
@@ -1224,7 +704,7 @@ __global__ __launch_bounds__(1024) void k_chol_rinv(const double* __restrict__ S
 // Per panel p: (1) lane (p,p) factors its tile and inverts the 8 x 8 triangle; (2) the lanes of column p form
 // L_ip = A_ip L_pp^-T, the lanes of row p form X_pj = L_pp^-1 W_pj, both published in LDS; (3) every lane below row
 // block p updates its tile with one 8 x 8 x 8 product.  Two barriers per panel, 16 panels: ~45 us at m = 120 against
-// 204 us for the column-by-column kernel above (whose two barriers per COLUMN and separate inversion dominate).
+// 204 us for a column-by-column kernel (two barriers per COLUMN and a separate inversion pass).
 // ==========================================================================================
 #define CQ_T 8
 #define CQ_NT 16
@@ -1438,18 +918,8 @@ __global__ __launch_bounds__(256) void k_chol_rinv_blocked(const double* __restr
     if (tid == 0) { flag[0] = 0.; flag[1] = 1.; }          // flag[1]: a factorisation was needed
 }
 int eigh_chol_rinv(tnml_ctx* c, const double* S, int m, double* Rinv, double* flag) {
-    if (m > CHOL_MAXM) return tnml_fail(c, "eigh_chol_rinv: m=%d exceeds %d", m, CHOL_MAXM);
-    static const int old_kernel = getenv("TNML_CHOL_OLD") ? atoi(getenv("TNML_CHOL_OLD")) : 0;
-    if (m <= CQ_T * CQ_NT && !old_kernel) {
-        static const int all_panels = getenv("TNML_CHOL_ALL_PANELS") ? atoi(getenv("TNML_CHOL_ALL_PANELS")) : 0;   // A/B: factor every panel
-        hipLaunchKernelGGL(k_chol_rinv_blocked, dim3(1), dim3(256), 0, c->stream, S, m, Rinv, flag, all_panels);
-        HIPCK(c, hipGetLastError());
-        return 0;
-    }
-    const size_t lds = sizeof(double) * ((size_t)(m | 1) * m + 3 * CHOL_MAXM);
-    static size_t attr_lds = 0;                          // the kernel also has a few bytes of static LDS: ask for what is needed
-    if (lds > attr_lds) { HIPCK(c, hipFuncSetAttribute((const void*)k_chol_rinv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_lds = lds; }
-    hipLaunchKernelGGL(k_chol_rinv, dim3(1), dim3(1024), lds, c->stream, S, m, Rinv, flag);
+    if (m > CQ_T * CQ_NT) return tnml_fail(c, "eigh_chol_rinv: m=%d exceeds %d", m, CQ_T * CQ_NT);
+    hipLaunchKernelGGL(k_chol_rinv_blocked, dim3(1), dim3(256), 0, c->stream, S, m, Rinv, flag, 0);
     HIPCK(c, hipGetLastError());
     return 0;
 }

@@ -53,8 +53,7 @@ static __device__ __forceinline__ void tile_partials(double val, int lab, int co
     (void)s_part;
 }
 
-// physical tile of the t-th tile a workgroup visits: the traversal direction alternates between passes (FwdFusedArgs::rev)
-#define FF_PT(t) (A.rev ? A.ntiles - 1 - (t) : (t))
+#define FF_PT(t) (t)
 #define FF_LDS_DOUBLES (FF_KT * FF_XS + FF_KT * FF_MS + FF_MO * FF_BM + 4 * TNML_NL * FF_BM)
 
 // the 12 GEMM waves of a workgroup: all tiles of this workgroup, then one drain round (barriers only)
@@ -256,212 +255,19 @@ __global__ __launch_bounds__(1024) void k_fwd_fused(FwdFusedArgs A) {
 int launch_fwd_fused(tnml_ctx* c, const FwdFusedArgs& a) {
     if (a.NTp % FF_BM || a.Np != FF_BN || a.Kp != 240 || a.mO != FF_MO || a.mI != 120) return tnml_fail(c, "fwd_fused: shape not supported");
     if (a.ntiles > c->partial_cap) return tnml_fail(c, "fwd_fused: partial buffer too small");
-    int ncu = 256;
-    {
-        static int cached = 0;
-        if (!cached) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, c->cfg.device) == hipSuccess) cached = pr.multiProcessorCount; else cached = 256; }
-        ncu = cached;
-    }
+    if (!c->cu_count) { hipDeviceProp_t pr; c->cu_count = hipGetDeviceProperties(&pr, c->cfg.device) == hipSuccess ? pr.multiProcessorCount : 256; }
+    int ncu = c->cu_count;
     if (c->fused_fwd > 2 && c->fused_fwd < ncu) ncu = c->fused_fwd;      // test knob: fewer workgroups -> several rounds each
     const int grid = a.ntiles < ncu ? a.ntiles : ncu;
     const size_t lds = sizeof(double) * FF_LDS_DOUBLES;
-    static const bool attr_set = (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess);
-    if (!attr_set) return tnml_fail(c, "fwd_fused: cannot reserve %zu bytes of LDS", lds);
+    if (!c->attr_fused) {                                                // per device: remembered in the context
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return tnml_fail(c, "fwd_fused: cannot reserve %zu bytes of LDS", lds);
+        c->attr_fused = true;
+    }
     {
         ProfScope ps(c, KC_FWD_FUSED);
         hipLaunchKernelGGL(k_fwd_fused, dim3(grid), dim3(1024), lds, c->stream, a);
-    }
-    HIPCK(c, hipGetLastError());
-    return 0;
-}
-
-// ==========================================================================================
-// k_bgemm_ps -- the gradient GEMM dP*dag(t.v) (fixedL.cc:379,418; kernels_gemm.hip k_bgemm64 with the fused Z build) with the
-// two halves of its work on different waves of the workgroup:
-//     waves 12..15 (producers): stream the image chunk -- 120 rows of the Label-free environment, 10 x 32 rows of the
-//                  Label-carrying one, the dP and feature tiles -- and build the operand tiles in LDS,
-//                  X[(a,s)][n] = EI[a][n] phiI[s][n],   Y[(q,t)][n] = phiO[t][n] sum_l EL[l][q][n] dP[l][n];
-//     waves 0..11  (consumers, 3 x 4, five 16-row tiles each): G_tile += X Y^T on v_mfma_f64_16x16x4_f64 from the OTHER buffer.
-// In k_bgemm64 every wave does both, one after the other: while a chunk is widened into LDS nothing is in flight and the
-// matrix pipe idles (51 % busy, 4.8 TB/s).  Here the chunk of 16 images is double buffered (one barrier per chunk), the
-// producers have their loads in flight while the consumers multiply, and the dP / feature tiles travel three chunks deep
-// through LDS so that no producer ever waits for another.  240 x 64 output tile per workgroup, split-K over image ranges into
-// fp64 slabs as before (k_slab_reduce64 sums them in a fixed order -> deterministic).
-// ==========================================================================================
-#define PS_KT 16
-#define PS_ST (PS_KT + 2)
-#define PS_BM 240
-#define PS_BN 64
-#define PS_AS (PS_BM * PS_ST)
-#define PS_BS (PS_BN * PS_ST)
-#define PS_LDS_DOUBLES (2 * PS_AS + 2 * PS_BS + 3 * TNML_NL * PS_KT + 3 * 4 * PS_KT)
-
-struct BgemmPsArgs {
-    const double* EI; const double* phiI; const double* EL; size_t EL_lstride; const double* phiO; const double* dP;
-    int NTp, Np; double* slab; int nsplit, imgs_per_split, nt;
-};
-
-static __device__ __forceinline__ void ps_consumer(const BgemmPsArgs& K, const double* As, const double* Bs, int lane, int wid, int nch, int j0, int split) {
-    const int wr = wid >> 2, wc = wid & 3;
-    f64x4 acc[5];
-#pragma unroll
-    for (int r = 0; r < 5; ++r) acc[r] = f64x4{0., 0., 0., 0.};
-    __syncthreads();                                         // P1
-    __syncthreads();                                         // P2: chunk 0 is in buffer 0
-    for (int c = 0; c < nch; ++c) {
-        const double* Ab = As + (c & 1) * PS_AS;
-        const double* Bb = Bs + (c & 1) * PS_BS;
-#pragma unroll
-        for (int kk = 0; kk < PS_KT; kk += 8) {
-            // lane group g owns images kk+2g, kk+2g+1; MFMA step e uses element e of every group
-            const int ko = kk + 2 * (lane >> 4);
-            double2 a[5];
-#pragma unroll
-            for (int r = 0; r < 5; ++r) a[r] = ld2(&Ab[((wr * 5 + r) * 16 + (lane & 15)) * PS_ST + ko]);
-            const double2 b = ld2(&Bb[(wc * 16 + (lane & 15)) * PS_ST + ko]);
-#pragma unroll
-            for (int r = 0; r < 5; ++r) {
-                acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r].x, b.x, acc[r], 0, 0, 0);
-                acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r].y, b.y, acc[r], 0, 0, 0);
-            }
-        }
-        __syncthreads();
-    }
-    double* slab = K.slab + (size_t)split * 240 * K.Np;
-    const int j = j0 + wc * 16 + (lane & 15);
-#pragma unroll
-    for (int r = 0; r < 5; ++r)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int i = (wr * 5 + r) * 16 + (lane >> 4) + 4 * e;            // f64 C map: row = g + 4*reg
-            if (j < K.Np) slab[(size_t)i * K.Np + j] = acc[r][e];             // the fourth column tile covers 192..255 of 240 columns
-        }
-}
-
-static __device__ __forceinline__ void ps_producer(const BgemmPsArgs& K, double* As, double* Bs, double* dPs, double* phs, int pt, int nch, int nbeg, int j0) {
-    const int NTp = K.NTp;
-    // this lane's tasks: two 4-image pieces of Label-free environment rows, one (row, image pair) of the Label-carrying side
-    const int xa0 = pt >> 2, xa1 = (pt + 256) >> 2, xc = pt & 3;            // rows pt/4 and 64 + pt/4 (the second only below 120)
-    const bool x1 = xa1 < 120;
-    const int zq = pt >> 3, zc = pt & 7;
-    const bool zok = j0 / 2 + zq < K.Np / 2;                 // the fourth column tile has only 24 of its 32 rows
-    const double* e0p = K.EI + (size_t)xa0 * NTp + xc * 4;
-    const double* e1p = K.EI + (size_t)(x1 ? xa1 : 0) * NTp + xc * 4;
-    const double* elp = K.EL + (size_t)(zok ? j0 / 2 + zq : 0) * NTp + zc * 2;
-    double2 xr0a, xr0b, xr1a, xr1b, el[TNML_NL];
-    double tl = 0.;                                          // this lane's entry of the dP / feature tile in flight
-    auto tile_load = [&](int n) -> double {                  // [dP 10][16] then [phiI 0, phiI 1, phiO 0, phiO 1][16]
-        if (pt < TNML_NL * PS_KT) return K.dP[(size_t)(pt / PS_KT) * NTp + n + (pt % PS_KT)];
-        if (pt < (TNML_NL + 4) * PS_KT) { const int w = (pt - TNML_NL * PS_KT) / PS_KT; return (w < 2 ? K.phiI : K.phiO)[(size_t)(w & 1) * NTp + n + (pt % PS_KT)]; }
-        return 0.;
-    };
-    auto tile_store = [&](int slot, double v) {
-        if (pt < TNML_NL * PS_KT) dPs[slot * TNML_NL * PS_KT + pt] = v;
-        else if (pt < (TNML_NL + 4) * PS_KT) phs[slot * 4 * PS_KT + (pt - TNML_NL * PS_KT)] = v;
-    };
-    // The three parts of a chunk (the Label-carrying rows -- three quarters of the bytes --, then the two Label-free pieces) are
-    // consumed and re-issued ONE AT A TIME: right after a part has been widened into LDS its registers take the same part of
-    // the next chunk, so every load has a whole iteration to arrive (build-all-then-load-all left them only the barrier wait).
-    auto load_z = [&](int n) {
-#pragma unroll
-        for (int l = 0; l < TNML_NL; ++l) {
-            const double* ep = elp + (size_t)l * K.EL_lstride + n;
-            if (K.nt) { typedef double d2v __attribute__((ext_vector_type(2))); const d2v t = __builtin_nontemporal_load(reinterpret_cast<const d2v*>(ep)); el[l] = make_double2(t.x, t.y); }
-            else el[l] = ld2(ep);
-        }
-    };
-    auto load_x0 = [&](int n) { xr0a = ld2(e0p + n); xr0b = ld2(e0p + n + 2); };
-    auto load_x1 = [&](int n) { if (x1) { xr1a = ld2(e1p + n); xr1b = ld2(e1p + n + 2); } };
-    auto build_z = [&](int buf, int slot) {
-        double* Bb = Bs + buf * PS_BS;
-        const double* dp = dPs + slot * TNML_NL * PS_KT;
-        const double* ph = phs + slot * 4 * PS_KT;
-        double z0 = 0., z1 = 0.;
-#pragma unroll
-        for (int l = 0; l < TNML_NL; ++l) {                  // Z = sum_l EL[l] dP[l], l = 0, 1, ... as k_bgemm64
-            const double2 d = ld2(&dp[l * PS_KT + zc * 2]);
-            z0 = fma(el[l].x, d.x, z0);
-            z1 = fma(el[l].y, d.y, z1);
-        }
-        if (!zok) { z0 = 0.; z1 = 0.; }
-        const double2 f0 = ld2(&ph[2 * PS_KT + zc * 2]), f1 = ld2(&ph[3 * PS_KT + zc * 2]);
-        *reinterpret_cast<double2*>(&Bb[(2 * zq) * PS_ST + zc * 2]) = make_double2(z0 * f0.x, z1 * f0.y);
-        *reinterpret_cast<double2*>(&Bb[(2 * zq + 1) * PS_ST + zc * 2]) = make_double2(z0 * f1.x, z1 * f1.y);
-    };
-    auto build_x = [&](int buf, int slot, int xa, const double2& ra, const double2& rb) {
-        double* Ab = As + buf * PS_AS;
-        const double* ph = phs + slot * 4 * PS_KT;
-        const double2 p0a = ld2(&ph[xc * 4]), p0b = ld2(&ph[xc * 4 + 2]), p1a = ld2(&ph[PS_KT + xc * 4]), p1b = ld2(&ph[PS_KT + xc * 4 + 2]);
-        double* r0 = &Ab[(2 * xa) * PS_ST + xc * 4];
-        double* r1 = &Ab[(2 * xa + 1) * PS_ST + xc * 4];
-        *reinterpret_cast<double2*>(r0) = make_double2(ra.x * p0a.x, ra.y * p0a.y);
-        *reinterpret_cast<double2*>(r0 + 2) = make_double2(rb.x * p0b.x, rb.y * p0b.y);
-        *reinterpret_cast<double2*>(r1) = make_double2(ra.x * p1a.x, ra.y * p1a.y);
-        *reinterpret_cast<double2*>(r1 + 2) = make_double2(rb.x * p1b.x, rb.y * p1b.y);
-    };
-    // builds chunk `ch` into buffer `buf` from the registers and re-issues each part for chunk `ch + 1` (if it exists)
-    auto build_and_refill = [&](int ch, int buf, int slot) {
-        const int nn = nbeg + (ch + 1) * PS_KT;
-        const bool more = ch + 1 < nch;
-        build_z(buf, slot);                 if (more) load_z(nn);
-        build_x(buf, slot, xa0, xr0a, xr0b); if (more) load_x0(nn);
-        if (x1) build_x(buf, slot, xa1, xr1a, xr1b);
-        if (more) load_x1(nn);
-    };
-    // P1: the dP / feature tiles of chunks 0 and 1 into slots 0 and 1, the stream of chunk 0 under way
-    if (nch > 0) { load_z(nbeg); load_x0(nbeg); load_x1(nbeg); tile_store(0, tile_load(nbeg)); }
-    if (nch > 1) tile_store(1, tile_load(nbeg + PS_KT));
-    __syncthreads();                                         // P1
-    if (nch > 0) build_and_refill(0, 0, 0);
-    if (nch > 2) tl = tile_load(nbeg + 2 * PS_KT);
-    __syncthreads();                                         // P2
-    for (int c = 0; c < nch; ++c) {
-        if (c + 1 < nch) build_and_refill(c + 1, (c + 1) & 1, (c + 1) % 3);   // the buffer the consumers read one chunk ago; tile slot written one chunk ago
-        if (c + 2 < nch) tile_store((c + 2) % 3, tl);        // read by build() in the next iteration, after the barrier
-        if (c + 3 < nch) tl = tile_load(nbeg + (c + 3) * PS_KT);
-        __syncthreads();
-    }
-}
-
-__global__ __launch_bounds__(1024) void k_bgemm_ps(BgemmPsArgs K) {
-    extern __shared__ __attribute__((aligned(16))) double ps_lds[];
-    double* As = ps_lds;                                    // [2][240][18]
-    double* Bs = As + 2 * PS_AS;                            // [2][64][18]
-    double* dPs = Bs + 2 * PS_BS;                           // [3][10][16]
-    double* phs = dPs + 3 * TNML_NL * PS_KT;                // [3][4][16]
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int j0 = blockIdx.y * PS_BN, split = blockIdx.z;
-    const int nbeg = split * K.imgs_per_split;
-    const int nend = min(nbeg + K.imgs_per_split, K.NTp);
-    const int nch = nend > nbeg ? (nend - nbeg) / PS_KT : 0;
-    if (wid < 12) ps_consumer(K, As, Bs, lane, wid, nch, j0, split);
-    else          ps_producer(K, As, Bs, dPs, phs, tid - 768, nch, nbeg, j0);
-}
-
-int launch_bgemm_ps(tnml_ctx* c, const Bgemm64Args& a, double* G) {
-    if (!(a.EL && a.dPz && a.env64 && a.Kp == 240 && a.Np == 240 && a.L == 1 && a.mI == 120 && a.mO == 120 && !a.w)) return tnml_fail(c, "bgemm_ps: shape not supported");
-    const int tiles = 4;
-    int nsplit = (256 + tiles - 1) / tiles;
-    const int chunks = a.NTp / 32;
-    if (nsplit > chunks) nsplit = chunks;
-    if (nsplit < 1) nsplit = 1;
-    const size_t n = (size_t)a.Kp * a.Np;
-    const size_t cap = c->slab_bytes / sizeof(double);
-    while (nsplit > 1 && (size_t)nsplit * n > cap) --nsplit;
-    const int per = ((chunks + nsplit - 1) / nsplit) * 32;
-    nsplit = (a.NTp + per - 1) / per;
-    static const int nt = getenv("TNML_BG_NT") ? atoi(getenv("TNML_BG_NT")) : 1;
-    BgemmPsArgs K{(const double*)a.EI, (const double*)a.phiI, (const double*)a.EL, a.EL_lstride, (const double*)a.phiO, a.dPz, a.NTp, a.Np, (double*)c->slab, nsplit, per, nt};
-    const size_t lds = sizeof(double) * PS_LDS_DOUBLES;
-    static const bool attr_set = (hipFuncSetAttribute(reinterpret_cast<const void*>(k_bgemm_ps), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess);
-    if (!attr_set) return tnml_fail(c, "bgemm_ps: cannot reserve %zu bytes of LDS", lds);
-    {
-        ProfScope ps(c, KC_BGEMM);
-        hipLaunchKernelGGL(k_bgemm_ps, dim3(1, 4, nsplit), dim3(1024), lds, c->stream, K);
-    }
-    {
-        ProfScope ps(c, KC_SLABRED);
-        launch_slab_reduce64(c, (const double*)c->slab, G, n, nsplit);
     }
     HIPCK(c, hipGetLastError());
     return 0;

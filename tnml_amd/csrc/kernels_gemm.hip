@@ -115,9 +115,150 @@ static void fgemm_go(tnml_ctx* c, const FgemmArgs& a) {
     else        hipLaunchKernelGGL((k_fgemm<RT, CT, WR, WC, 1>), grid, block, 0, c->stream, a);
 }
 
+// ------------------------------------------------------------------------------------------
+// k_fgemm_bf16 -- the forward feature GEMM on the bf16 matrix pipe (TNML_BF16 / TNML_BF16X3; BASELINE config 5's "bf16 MFMA
+// bond contraction", a tolerance study): same tiling, same epilogue and the same C-fragment map as k_fgemm
+// (v_mfma_f32_16x16x32_bf16: col = lane & 15, row = 4 (lane >> 4) + reg), fp32 storage, fp32 accumulation.  The operands are
+// rounded to bf16 (round to nearest even) while they are staged: X_n = EI_n (x) phiI_n is formed in fp32 and then rounded, so
+// is every element of the bond matrix.  An A / B fragment is 8 consecutive reduction indices of one row / column
+// (k = 8 (lane >> 4) + 0..7), so the LDS tiles are [row][k] with k contiguous (80-byte rows: the four lane groups of a
+// 16-byte fragment read land on distinct banks).  SPLIT: every operand x = hi + lo with hi = bf16(x), lo = bf16(x - hi) and
+// three MFMAs per product, hi*hi + hi*lo + lo*hi (the lo*lo term is below fp32 round-off): ~16 mantissa bits.
+// ------------------------------------------------------------------------------------------
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+static __device__ __forceinline__ unsigned short f2bf(float x) {
+    const unsigned u = __float_as_uint(x);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+static __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+template <int RT, int CT, int WR, int WC, int TO, int SPLIT>
+__global__ __launch_bounds__(64 * WR * WC) void k_fgemm_bf16(FgemmArgs A) {
+    constexpr int T = 64 * WR * WC, BM = 16 * RT * WR, BN = 16 * CT * WC, KT = 32, KS = KT + 8;     // KS: row stride in bf16 elements
+    constexpr int NP = SPLIT ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) unsigned short lds[NP * (BM + BN) * KS];
+    unsigned short* Xs = lds;                               // [NP][BM][KS]
+    unsigned short* Ms = lds + NP * BM * KS;                // [NP][BN][KS]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid / WC, wc = wid % WC;
+    const int n0 = blockIdx.x * BM, j0 = blockIdx.y * BN, l = blockIdx.z;
+    const float* E = A.EI + (size_t)l * A.EI_lstride;
+    const float* M = A.M + (size_t)l * A.M_lstride;
+    const int NTp = A.NTp;
+
+    f32x4 acc[RT][CT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = 0; k0 < A.Kp; k0 += KT) {
+        // stage X: KT/2 environment rows, each expanded to its two site-index rows, transposed to [image][k]
+        for (int idx = tid; idx < (KT / 2) * (BM / 4); idx += T) {
+            const int ar = idx / (BM / 4), c4 = idx % (BM / 4);
+            const int a = k0 / 2 + ar, n = n0 + c4 * 4;
+            float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a < A.mI) e = *reinterpret_cast<const float4*>(E + (size_t)a * NTp + n);
+            const float4 p0 = *reinterpret_cast<const float4*>(A.phiI + n);
+            const float4 p1 = *reinterpret_cast<const float4*>(A.phiI + NTp + n);
+            const float x0[4] = {e.x * p0.x, e.y * p0.y, e.z * p0.z, e.w * p0.w};
+            const float x1[4] = {e.x * p1.x, e.y * p1.y, e.z * p1.z, e.w * p1.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = c4 * 4 + q;
+                const unsigned short h0 = f2bf(x0[q]), h1 = f2bf(x1[q]);
+                *reinterpret_cast<unsigned*>(&Xs[row * KS + 2 * ar]) = (unsigned)h0 | ((unsigned)h1 << 16);
+                if (SPLIT) {
+                    const unsigned short l0 = f2bf(x0[q] - bf2f(h0)), l1 = f2bf(x1[q] - bf2f(h1));
+                    *reinterpret_cast<unsigned*>(&Xs[BM * KS + row * KS + 2 * ar]) = (unsigned)l0 | ((unsigned)l1 << 16);
+                }
+            }
+        }
+        // stage M: KT rows of the (zero padded) bond matrix, transposed to [column][k]
+        for (int idx = tid; idx < KT * (BN / 4); idx += T) {
+            const int r = idx / (BN / 4), c4 = idx % (BN / 4);
+            const int j = j0 + c4 * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < A.Np) v = *reinterpret_cast<const float4*>(M + (size_t)(k0 + r) * A.Np + j);
+            const float mv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned short h = f2bf(mv[q]);
+                Ms[(c4 * 4 + q) * KS + r] = h;
+                if (SPLIT) Ms[BN * KS + (c4 * 4 + q) * KS + r] = f2bf(mv[q] - bf2f(h));
+            }
+        }
+        __syncthreads();
+        {
+            const int ko = 8 * (lane >> 4);
+            bf16x8 ah[RT], bh[CT], al[SPLIT ? RT : 1], bl[SPLIT ? CT : 1];
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                ah[r] = *reinterpret_cast<const bf16x8*>(&Xs[((wr * RT + r) * 16 + (lane & 15)) * KS + ko]);
+                if (SPLIT) al[r] = *reinterpret_cast<const bf16x8*>(&Xs[BM * KS + ((wr * RT + r) * 16 + (lane & 15)) * KS + ko]);
+            }
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                bh[c] = *reinterpret_cast<const bf16x8*>(&Ms[((wc * CT + c) * 16 + (lane & 15)) * KS + ko]);
+                if (SPLIT) bl[c] = *reinterpret_cast<const bf16x8*>(&Ms[BN * KS + ((wc * CT + c) * 16 + (lane & 15)) * KS + ko]);
+            }
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    if (SPLIT) {                                   // small terms first
+                        acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[r], bh[c], acc[r][c], 0, 0, 0);
+                        acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[r], bl[c], acc[r][c], 0, 0, 0);
+                    }
+                    acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[r], bh[c], acc[r][c], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C fragment = 4 consecutive images (rows) x 1 column per lane (as k_fgemm)
+    float* out = A.out + (size_t)l * A.out_lstride;
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        const int n = n0 + (wr * RT + r) * 16 + (lane >> 4) * 4;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const int j = j0 + (wc * CT + c) * 16 + (lane & 15);
+            if (TO == 2) {
+                const int t = j & 1, q = j >> 1;
+                const float4 ph = *reinterpret_cast<const float4*>(A.phiO + (size_t)t * NTp + n);
+                float4 v = make_float4(acc[r][c][0] * ph.x, acc[r][c][1] * ph.y, acc[r][c][2] * ph.z, acc[r][c][3] * ph.w);
+                v.x += __shfl_xor(v.x, 1); v.y += __shfl_xor(v.y, 1);
+                v.z += __shfl_xor(v.z, 1); v.w += __shfl_xor(v.w, 1);
+                if (t == 0 && q < A.mO) *reinterpret_cast<float4*>(out + (size_t)q * NTp + n) = v;
+            } else {
+                if (j < A.mO)
+                    *reinterpret_cast<float4*>(out + (size_t)j * NTp + n) = make_float4(acc[r][c][0], acc[r][c][1], acc[r][c][2], acc[r][c][3]);
+            }
+        }
+    }
+}
+
+template <int RT, int CT, int WR, int WC>
+static void fgemm_bf16_go(tnml_ctx* c, const FgemmArgs& a, int split) {
+    constexpr int BM = 16 * RT * WR, BN = 16 * CT * WC;
+    dim3 grid(a.NTp / BM, (a.Np + BN - 1) / BN, a.L);
+    dim3 block(64 * WR * WC);
+    if (split) hipLaunchKernelGGL((k_fgemm_bf16<RT, CT, WR, WC, 2, 1>), grid, block, 0, c->stream, a);
+    else       hipLaunchKernelGGL((k_fgemm_bf16<RT, CT, WR, WC, 2, 0>), grid, block, 0, c->stream, a);
+}
+
 int launch_fgemm(tnml_ctx* c, const FgemmArgs& a) {
     ProfScope ps(c, a.phiO ? KC_FGEMM_FWD : KC_FGEMM_SHIFT);
     if (a.NTp % TNML_NTPAD) return tnml_fail(c, "fgemm: NTp not padded");
+    if (c->bf16() && a.phiO) {                              // forward pass on the bf16 matrix pipe (the reduction runs in chunks of 32: Kp is a multiple of 16, the
+        if (a.Kp % 32) return tnml_fail(c, "fgemm (bf16): the padded reduction dimension %d is not a multiple of 32", a.Kp);   // bond plan pads to 32 in these modes)
+        if (a.Np > 64) fgemm_bf16_go<4, 4, 2, 2>(c, a, c->bf16() == 2);   // 128 x 128
+        else           fgemm_bf16_go<4, 2, 2, 2>(c, a, c->bf16() == 2);   // 128 x 64
+        HIPCK(c, hipGetLastError());
+        return 0;
+    }
     if (a.Np == 240)      fgemm_go<4, 5, 2, 3>(c, a);      // m = 120: exactly 15 column tiles, no padding waste
     else if (a.Np > 64)   fgemm_go<4, 4, 2, 2>(c, a);      // 128 x 128 tiles
     else if (a.Np > 32)   fgemm_go<4, 2, 2, 2>(c, a);      // 128 x 64
@@ -589,7 +730,6 @@ struct Bgemm64KArgs {
     double* slab;
     int nsplit, imgs_per_split;
     int nt;                       // non-temporal loads of the Label-carrying environment (read once per launch)
-    int rev;                      // image ranges are handed out from the last to the first (same slabs, same sums: results identical)
 };
 
 // Software pipelined like k_fgemm64: the image chunk n+1 is fetched into registers while chunk n feeds
@@ -613,7 +753,7 @@ __global__ __launch_bounds__(64 * WR * WC) void k_bgemm64(Bgemm64KArgs K) {
     const int wr = wid / WC, wc = wid % WC;
     const int i0 = blockIdx.x * BMr, j0 = blockIdx.y * BNc;
     const int zs = blockIdx.z % K.nsplit, l = blockIdx.z / K.nsplit;
-    const int split = K.rev ? K.nsplit - 1 - zs : zs;
+    const int split = zs;
     const int NTp = A.NTp;
     const int nbeg = split * K.imgs_per_split;
     const int nend = min(nbeg + K.imgs_per_split, NTp);
@@ -821,196 +961,6 @@ __global__ void k_slab_reduce64(const double* __restrict__ slab, double* __restr
     G[i] = s;
 }
 
-// ------------------------------------------------------------------------------------------
-// k_bgemm64_dma (TNML_BGF_CFG=5, not the default): the fused gradient GEMM (240 x 64 tile, 12 waves, fp64
-// environments) with the image stream staged by LDS-DMA (global_load_lds_dwordx4) instead of registers.
-// Measured equal to the register-staged kernel (181 us per launch at C3): the stream is NOT what limits this
-// GEMM -- its traversal alone moves 5.9-6.0 TB/s (tools/probe/probe_pieces.hip) -- the serialisation of the
-// widen phase and the MFMA phase inside the one workgroup a CU holds is.  A variant that widened in registers in the
-// shadow of the MFMAs (wave-uniform roles, both streams in one basic block) was slower (208 us): hipcc's interleaving
-// puts LDS waits into the MFMA chain.  Kept as the starting point of a producer/consumer wave split.  The register-staged kernel above
-// holds one 32-image chunk (112 KB per CU) in VGPRs and has nothing in flight while that chunk is widened into
-// the operand tiles; here two 16-image raw stages (2 x 57 KB) live in LDS, the DMA of chunk c+2 is issued
-// before the MFMA phase of chunk c, and a counted s_waitcnt vmcnt(N) lets it stay in flight across the
-// barriers (hipcc does not track the asm DMA, so every wait on it is explicit).
-//   LDS (doubles): As[240][18] | Bs[64][18] | 2 x { EL[10][32][16] | EI[120][16] | dP[10][16] | phi[4][16] }
-//   = 160 000 B.  A DMA instruction moves 64 lanes x 16 B = 8 rows of 16 images; a stage is 58 instructions
-//   dealt round-robin to the 12 waves (waves 0..9: 5, waves 10, 11: 4).  Rows beyond the bond dimension are
-//   clamped to the last valid row: they only feed output columns that are never stored.
-static __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-#define BGD_KT 16
-#define BGD_ST (BGD_KT + 2)
-#define BGD_OPS ((240 + 64) * BGD_ST)                    // doubles: operand tiles
-#define BGD_EL 0
-#define BGD_EI (10 * 32 * BGD_KT)
-#define BGD_DP (BGD_EI + 120 * BGD_KT)
-#define BGD_PH (BGD_DP + 10 * BGD_KT)
-#define BGD_STAGE (BGD_PH + 4 * BGD_KT)                  // doubles per raw stage
-__global__ __launch_bounds__(768) void k_bgemm64_dma(Bgemm64KArgs K) {
-    constexpr int KT = BGD_KT, ST = BGD_ST, RT = 5, WC = 4;
-    __shared__ __attribute__((aligned(16))) double lds[BGD_OPS + 2 * BGD_STAGE];
-    double* As = lds;
-    double* Bs = lds + 240 * ST;
-    const Bgemm64Args& A = K.a;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wid / WC, wc = wid % WC;
-    const int j0 = blockIdx.y * 64;
-    const int split = blockIdx.z;
-    const int NTp = A.NTp;
-    const int nbeg = split * K.imgs_per_split;
-    const int nend = min(nbeg + K.imgs_per_split, NTp);
-    const int nchunk = (nend - nbeg) / KT;
-    const double* EIp = static_cast<const double*>(A.EI);
-    const double* ELp = static_cast<const double*>(A.EL);
-    const double* phiI = static_cast<const double*>(A.phiI);
-    const double* phiO = static_cast<const double*>(A.phiO);
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) double*)lds;     // LDS byte address of lds[0]
-
-    // this lane's source pointer (at image nbeg) and the wave's LDS offset (doubles, within a stage) of its 5 DMA slots
-    const double* src[5];
-    unsigned dst[5];
-    const int row8 = lane >> 3, c2 = (lane & 7) * 2;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const int k = wid + 12 * i;
-        const double* p = EIp;
-        unsigned d = 0;
-        if (k < 40) {                                            // EL rows r = l * 32 + q
-            const int r = 8 * k + row8, l = r >> 5, q = min(j0 / 2 + (r & 31), A.mO - 1);
-            p = ELp + (size_t)l * A.EL_lstride + (size_t)q * NTp + c2;
-            d = BGD_EL + 8 * k * KT;
-        } else if (k < 55) {                                     // EI rows
-            const int a = min(8 * (k - 40) + row8, A.mI - 1);
-            p = EIp + (size_t)a * NTp + c2;
-            d = BGD_EI + 8 * (k - 40) * KT;
-        } else if (k < 57) {                                     // dP rows (10)
-            const int l = min(8 * (k - 55) + row8, TNML_NL - 1);
-            p = A.dPz + (size_t)l * NTp + c2;
-            d = BGD_DP + 8 * (k - 55) * KT;
-        } else {                                                 // feature rows: phiI s=0,1, phiO t=0,1
-            const int r = row8 & 3;
-            p = (r < 2 ? phiI : phiO) + (size_t)(r & 1) * NTp + c2;
-            d = BGD_PH;
-        }
-        src[i] = p + nbeg;
-        dst[i] = d;
-    }
-    const int nslot = wid < 10 ? 5 : 4;                          // slots 58, 59 do not exist
-    auto issue = [&](int c) {                                    // chunk c -> raw stage c & 1
-        const unsigned base = lds0 + (unsigned)(BGD_OPS + (c & 1) * BGD_STAGE) * 8u;
-        const size_t adv = (size_t)c * KT;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            if (i < nslot) {
-                const int k = wid + 12 * i;
-                const bool on = k < 55 || (k == 55) || (k == 56 && lane < 16) || (k == 57 && lane < 32);
-                if (on) glds16(src[i] + adv, __builtin_amdgcn_readfirstlane(base + dst[i] * 8u));
-            }
-        }
-    };
-
-    f64x4 acc[RT];
-#pragma unroll
-    for (int r = 0; r < RT; ++r) acc[r] = f64x4{0., 0., 0., 0.};
-
-    if (nchunk > 0) issue(0);
-    if (nchunk > 1) issue(1);
-    for (int c = 0; c < nchunk; ++c) {
-        // chunk c has landed for this wave's own DMA instructions once at most the newer stage is outstanding
-        if (c + 1 < nchunk) {
-            if (wid < 10) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            else          asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();                                         // ... and for everybody's; MFMA phase of chunk c-1 is over
-        const double* raw = lds + BGD_OPS + (c & 1) * BGD_STAGE;
-        const double* phs = raw + BGD_PH;
-        if (tid < 256) {                                         // B operand: Z[q][n] = sum_l EL[l][q][n] dP[l][n], times the output feature
-            const int qr = tid >> 3, cc = (tid & 7) * 2;
-            double z0 = 0., z1 = 0.;
-#pragma unroll
-            for (int l = 0; l < TNML_NL; ++l) {
-                const double2 e = *reinterpret_cast<const double2*>(&raw[BGD_EL + (l * 32 + qr) * KT + cc]);
-                const double2 d = *reinterpret_cast<const double2*>(&raw[BGD_DP + l * KT + cc]);
-                z0 = fma(e.x, d.x, z0);
-                z1 = fma(e.y, d.y, z1);
-            }
-            const double2 f0 = *reinterpret_cast<const double2*>(&phs[2 * KT + cc]);
-            const double2 f1 = *reinterpret_cast<const double2*>(&phs[3 * KT + cc]);
-            *reinterpret_cast<double2*>(&Bs[(2 * qr) * ST + cc]) = make_double2(z0 * f0.x, z1 * f0.y);
-            *reinterpret_cast<double2*>(&Bs[(2 * qr + 1) * ST + cc]) = make_double2(z0 * f1.x, z1 * f1.y);
-        } else if (tid < 256 + 480) {                            // A operand: X[2a+s][n] = E[a][n] phi_s[n]
-            const int t = tid - 256, ar = t >> 2, c4 = (t & 3) * 4;
-            const double2 e0 = *reinterpret_cast<const double2*>(&raw[BGD_EI + ar * KT + c4]);
-            const double2 e1 = *reinterpret_cast<const double2*>(&raw[BGD_EI + ar * KT + c4 + 2]);
-            const double2 p0a = *reinterpret_cast<const double2*>(&phs[c4]), p0b = *reinterpret_cast<const double2*>(&phs[c4 + 2]);
-            const double2 p1a = *reinterpret_cast<const double2*>(&phs[KT + c4]), p1b = *reinterpret_cast<const double2*>(&phs[KT + c4 + 2]);
-            double* x0 = &As[(2 * ar) * ST + c4];
-            double* x1 = &As[(2 * ar + 1) * ST + c4];
-            *reinterpret_cast<double2*>(x0) = make_double2(e0.x * p0a.x, e0.y * p0a.y);
-            *reinterpret_cast<double2*>(x0 + 2) = make_double2(e1.x * p0b.x, e1.y * p0b.y);
-            *reinterpret_cast<double2*>(x1) = make_double2(e0.x * p1a.x, e0.y * p1a.y);
-            *reinterpret_cast<double2*>(x1 + 2) = make_double2(e1.x * p1b.x, e1.y * p1b.y);
-        }
-        __syncthreads();                                         // operand tiles complete; raw stage c & 1 is free again
-        if (c + 2 < nchunk) issue(c + 2);
-#pragma unroll
-        for (int kk = 0; kk < KT; kk += 8) {
-            double2 a[RT];
-            const int ko = kk + 2 * (lane >> 4);
-#pragma unroll
-            for (int r = 0; r < RT; ++r) a[r] = *reinterpret_cast<const double2*>(&As[((wr * RT + r) * 16 + (lane & 15)) * ST + ko]);
-            const double2 b = *reinterpret_cast<const double2*>(&Bs[(wc * 16 + (lane & 15)) * ST + ko]);
-#pragma unroll
-            for (int r = 0; r < RT; ++r) {
-                acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r].x, b.x, acc[r], 0, 0, 0);
-                acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r].y, b.y, acc[r], 0, 0, 0);
-            }
-        }
-    }
-
-    double* slab = K.slab + (size_t)split * A.Kp * A.Np;
-#pragma unroll
-    for (int r = 0; r < RT; ++r) {
-        const int j = j0 + wc * 16 + (lane & 15);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int i = (wr * RT + r) * 16 + (lane >> 4) + 4 * e;              // f64 C map: row = g + 4*reg
-            if (i < A.Kp && j < A.Np) slab[(size_t)i * A.Np + j] = acc[r][e];
-        }
-    }
-}
-
-static int bgemm64_dma_go(tnml_ctx* c, const Bgemm64Args& a, double* G) {
-    const int tiles = 4;                                         // 240 x 240 output, 240 x 64 tiles
-    int nsplit = 256 / tiles;
-    const int chunks = a.NTp / 32;
-    if (nsplit > chunks) nsplit = chunks;
-    const size_t n = (size_t)a.Kp * a.Np;
-    const size_t cap = c->slab_bytes / sizeof(double);
-    while (nsplit > 1 && (size_t)nsplit * n > cap) --nsplit;
-    if ((size_t)nsplit * n > cap) return tnml_fail(c, "bgemm64: slab workspace too small");
-    const int per = ((chunks + nsplit - 1) / nsplit) * 32;
-    nsplit = (a.NTp + per - 1) / per;
-    Bgemm64KArgs K{a, (double*)c->slab, nsplit, per, 1};
-    {
-        ProfScope ps(c, KC_BGEMM);
-        hipLaunchKernelGGL(k_bgemm64_dma, dim3(1, 4, nsplit), dim3(768), 0, c->stream, K);
-    }
-    {
-        ProfScope ps(c, KC_SLABRED);
-        hipLaunchKernelGGL(k_slab_reduce64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const double*)c->slab, G, n, nsplit);
-    }
-    HIPCK(c, hipGetLastError());
-    return 0;
-}
-
 template <int RT, int CT, int WR, int WC, int FUSE = 0>
 static int bgemm64_go(tnml_ctx* c, const Bgemm64Args& a, double* G, int default_wgs = 768) {
     constexpr int BMr = 16 * RT * WR, BNc = 16 * CT * WC;
@@ -1028,7 +978,7 @@ static int bgemm64_go(tnml_ctx* c, const Bgemm64Args& a, double* G, int default_
     int per = ((chunks + nsplit - 1) / nsplit) * 32;
     nsplit = (a.NTp + per - 1) / per;
     static const int nt = getenv("TNML_BG_NT") ? atoi(getenv("TNML_BG_NT")) : 1;
-    Bgemm64KArgs K{a, (double*)c->slab, nsplit, per, nt, c->snake ? (c->stream_dir ^= 1) : 0};
+    Bgemm64KArgs K{a, (double*)c->slab, nsplit, per, nt};
     {
         ProfScope ps(c, KC_BGEMM);
         dim3 grid((a.Kp + BMr - 1) / BMr, (a.Np + BNc - 1) / BNc, nsplit * a.L);
@@ -1049,15 +999,11 @@ void launch_slab_reduce64(tnml_ctx* c, const double* slab, double* G, size_t n, 
 
 int launch_bgemm64(tnml_ctx* c, const Bgemm64Args& a, double* G) {
     static const int cfg = getenv("TNML_BG64_CFG") ? atoi(getenv("TNML_BG64_CFG")) : 0;
-    // producer / consumer form (kernels_fused.hip) for the shape of BASELINE config 3 when the images fill the chip
-    if (c->bgemm_ps && a.EL && a.dPz && a.env64 && !a.w && a.Kp == 240 && a.Np == 240 && a.L == 1 && a.mI == 120 && a.mO == 120 &&
-        (c->bgemm_ps >= 2 || a.NTp >= 128 * 192)) return launch_bgemm_ps(c, a, G);
     if (a.EL) {                                             // fused Z build: >= 320 lanes per workgroup
         static const int fcfg = getenv("TNML_BGF_CFG") ? atoi(getenv("TNML_BGF_CFG")) : 0;
         if (a.Kp % 240 == 0 && a.Np % 240 == 0) {
             if (fcfg == 1) return bgemm64_go<5, 1, 3, 5, 1>(c, a, G, 255 * a.L);   // 240 x 80, 15 waves (128-VGPR cap: spills)
             if (fcfg == 2) return bgemm64_go<5, 1, 3, 3, 1>(c, a, G, 255 * a.L);   // 240 x 48, 9 waves
-            if (fcfg == 5 && a.env64 && a.Kp == 240 && a.Np == 240 && a.L == 1 && a.mI == 120) return bgemm64_dma_go(c, a, G);   // LDS-DMA staging
             return bgemm64_go<5, 1, 3, 4, 1>(c, a, G, 256 * a.L);                  // 240 x 64, 12 waves: 187 us vs 153+90 unfused
         }
         if (a.Kp % 80 == 0 && a.Np % 80 == 0) return bgemm64_go<1, 5, 5, 1, 1>(c, a, G);               // 80 x 80, 5 waves

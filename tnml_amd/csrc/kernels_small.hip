@@ -182,7 +182,14 @@ __global__ __launch_bounds__(VB) void k_norm1(const double* __restrict__ x, cons
 // pAp = sum_n|p v_n|^2 + lambda|p|^2 (:402-403); a = |r|^2/pAp (:405); B = B + a p (:406)
 __global__ __launch_bounds__(VB) void k_cg_step2(double* __restrict__ B, const double* __restrict__ Pv, size_t n, double lambda,
                                                 const double* __restrict__ tail, const double* __restrict__ part, int nb,
-                                                double* __restrict__ scal, int rr_in, double* __restrict__ trace, int pass) {
+                                                double* __restrict__ scal, int rr_in, double* __restrict__ trace, int pass, int merged) {
+    // merged CG: the cost partials of the PREVIOUS pass's update (fixedL.cc:419,427-428) came with this pass's all-reduce
+    if (merged && pass > 1 && blockIdx.x == 0 && threadIdx.x == 0 && scal[SC_CONVP + (pass & 1)] == 0.) {   // (slot of pass - 2: not converged before the previous pass)
+        double cs = 0.;
+        for (int l = 0; l < TNML_NL; ++l) cs += tail[SC_COST0 + l];
+        const double cst = cs + lambda * scal[SC_BNORM2];
+        scal[SC_COST] = cst; trace[4 * (pass - 2) + 2] = cst;
+    }
     if (scal[SC_CONVP + ((pass - 1) & 1)] != 0.) return;   // |r| < cconv was hit in an earlier pass (fixedL.cc:432-436)
     __shared__ double sh[VB / 64];
     // |p|^2: p = r in pass 1 (fixedL.cc:388), afterwards the partial sums left by k_cg_resid2 when it formed p = r + beta p
@@ -198,14 +205,17 @@ __global__ __launch_bounds__(VB) void k_cg_step2(double* __restrict__ B, const d
     }
 }
 // partial |nr|^2 with nr = G - lambda B, and |B|^2
+// merged (R, Pv given): G holds A p = sum_n (p.v_n) v_n and nr = r - a (A p + lambda p) with a = scal[SC_ALPHA] (single.h:378-379 structure)
 __global__ __launch_bounds__(VB) void k_cg_resid1(const double* __restrict__ G, const double* __restrict__ B, size_t n, double lambda,
-                                                 double* __restrict__ part) {
+                                                 double* __restrict__ part, const double* __restrict__ R, const double* __restrict__ Pv, const double* __restrict__ scal) {
     __shared__ double sh[VB];
     size_t lo, hi; slice(n, &lo, &hi);
     double an = 0., ab = 0.;
+    const double a = R ? scal[SC_ALPHA] : 0.;
     for (size_t i = lo + threadIdx.x; i < hi; i += VB) {
-        double nr = G[i];
-        if (lambda != 0.) nr = nr - lambda * B[i];
+        double nr;
+        if (R) { double t = G[i]; if (lambda != 0.) t = t + lambda * Pv[i]; nr = R[i] - a * t; }
+        else { nr = G[i]; if (lambda != 0.) nr = nr - lambda * B[i]; }
         an += nr * nr; ab += B[i] * B[i];
     }
     const double s0 = block_sum(an, sh);
@@ -218,7 +228,7 @@ __global__ __launch_bounds__(VB) void k_cg_resid2(const double* __restrict__ G, 
                                                  double* __restrict__ Pv, size_t n, double lambda, double cconv,
                                                  const double* __restrict__ tail, const double* __restrict__ part, int nb,
                                                  double* __restrict__ scal, int rr_in, int rr_out,
-                                                 double* __restrict__ trace, int pass, double* __restrict__ part_p) {
+                                                 double* __restrict__ trace, int pass, double* __restrict__ part_p, int merged) {
     const double was = scal[SC_CONVP + ((pass - 1) & 1)];
     if (was != 0.) {                                       // already converged: hand the flag on to the next pass's slot
         if (blockIdx.x == 0 && threadIdx.x == 0) scal[SC_CONVP + (pass & 1)] = was;
@@ -232,21 +242,26 @@ __global__ __launch_bounds__(VB) void k_cg_resid2(const double* __restrict__ G, 
     const int conv = rn < cconv;
     size_t lo, hi; slice(n, &lo, &hi);
     double pacc = 0.;
+    const double a = merged ? scal[SC_ALPHA] : 0.;
     for (size_t i = lo + threadIdx.x; i < hi; i += VB) {
-        double nr = G[i];
-        if (lambda != 0.) nr = nr - lambda * B[i];
+        double nr;
+        if (merged) { double t = G[i]; if (lambda != 0.) t = t + lambda * Pv[i]; nr = R[i] - a * t; }
+        else { nr = G[i]; if (lambda != 0.) nr = nr - lambda * B[i]; }
         R[i] = nr;
         if (!conv) { const double pv = nr + beta * Pv[i]; Pv[i] = pv; pacc += pv * pv; }
     }
     const double ps = block_sum(pacc, sh);                 // partial |p|^2 of the next pass (k_cg_step2 sums them in block order)
     if (threadIdx.x == 0) { part_p[2 * blockIdx.x] = ps; part_p[2 * blockIdx.x + 1] = 0.; }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        double cs = 0.;
-        for (int l = 0; l < TNML_NL; ++l) cs += tail[SC_COST0 + l];
-        scal[SC_COST] = cs + lambda * bn2;
+        if (!merged) {                                    // (merged: this pass's cost partials are summed over the ranks by the next all-reduce)
+            double cs = 0.;
+            for (int l = 0; l < TNML_NL; ++l) cs += tail[SC_COST0 + l];
+            scal[SC_COST] = cs + lambda * bn2;
+            trace[4 * (pass - 1) + 2] = cs + lambda * bn2;
+        }
         scal[SC_BNORM2] = bn2; scal[SC_BETA] = beta; scal[SC_RNORM] = rn;
         scal[rr_out] = nn;
-        trace[4 * (pass - 1) + 2] = cs + lambda * bn2; trace[4 * (pass - 1) + 3] = rn;
+        trace[4 * (pass - 1) + 3] = rn;
         scal[SC_CONVP + (pass & 1)] = (double)conv;        // read by the kernels of the next pass; this pass's readers use the other slot
         scal[SC_CONV] = (double)conv;                      // host copy
     }
@@ -290,26 +305,26 @@ int launch_cg_init(tnml_ctx* c, size_t n, double lambda, double cconv0) {
     HIPCK(c, hipGetLastError());
     return 0;
 }
-int launch_cg_step(tnml_ctx* c, size_t n, double lambda, int pass) {
+int launch_cg_step(tnml_ctx* c, size_t n, double lambda, int pass, bool merged) {
     ProfScope ps(c, KC_VEC);
     const int nb = vec_blocks(n);
-    hipLaunchKernelGGL(k_cg_step2, dim3(nb), dim3(VB), 0, c->stream, c->vB, c->vP, n, lambda, c->vG + n, c->vpart + 512, nb, c->scal, SC_RR + c->rr_slot, c->cgtrace, pass);
+    hipLaunchKernelGGL(k_cg_step2, dim3(nb), dim3(VB), 0, c->stream, c->vB, c->vP, n, lambda, c->tail, c->vpart + 512, nb, c->scal, SC_RR + c->rr_slot, c->cgtrace, pass, merged ? 1 : 0);
     HIPCK(c, hipGetLastError());
     return 0;
 }
-int launch_cg_resid(tnml_ctx* c, size_t n, double lambda, double cconv, int pass) {
+int launch_cg_resid(tnml_ctx* c, size_t n, double lambda, double cconv, int pass, bool merged) {
     ProfScope ps(c, KC_VEC);
     const int nb = vec_blocks(n);
     const int in = SC_RR + c->rr_slot, out = SC_RR + (c->rr_slot ^ 1);
-    hipLaunchKernelGGL(k_cg_resid1, dim3(nb), dim3(VB), 0, c->stream, c->vG, c->vB, n, lambda, c->vpart);
-    hipLaunchKernelGGL(k_cg_resid2, dim3(nb), dim3(VB), 0, c->stream, c->vG, c->vB, c->vR, c->vP, n, lambda, cconv, c->vG + n, c->vpart, nb, c->scal, in, out, c->cgtrace, pass, c->vpart + 512);
+    hipLaunchKernelGGL(k_cg_resid1, dim3(nb), dim3(VB), 0, c->stream, c->vG, c->vB, n, lambda, c->vpart, merged ? (const double*)c->vR : (const double*)nullptr, (const double*)c->vP, (const double*)c->scal);
+    hipLaunchKernelGGL(k_cg_resid2, dim3(nb), dim3(VB), 0, c->stream, c->vG, c->vB, c->vR, c->vP, n, lambda, cconv, c->tail, c->vpart, nb, c->scal, in, out, c->cgtrace, pass, c->vpart + 512, merged ? 1 : 0);
     c->rr_slot ^= 1;
     HIPCK(c, hipGetLastError());
     return 0;
 }
 int launch_cg_fast_resid0(tnml_ctx* c, size_t n, int pass) {
     ProfScope ps(c, KC_VEC);
-    hipLaunchKernelGGL(k_cg_fast_resid0, dim3(vec_blocks(n)), dim3(VB), 0, c->stream, c->vG, c->vR, n, c->scal, c->vG + n, pass);
+    hipLaunchKernelGGL(k_cg_fast_resid0, dim3(vec_blocks(n)), dim3(VB), 0, c->stream, c->vG, c->vR, n, c->scal, c->tail, pass);
     HIPCK(c, hipGetLastError());
     return 0;
 }
@@ -351,6 +366,19 @@ __global__ __launch_bounds__(1024) void k_fingerprint(const double* __restrict__
 }
 int launch_fingerprint(tnml_ctx* c, const double* x, size_t n, unsigned long long salt, unsigned long long* acc, bool reset) {
     hipLaunchKernelGGL(k_fingerprint, dim3(1), dim3(1024), 0, c->stream, x, n, salt | 1ull, acc, reset ? 1 : 0);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
+
+// The 64-bit fingerprint h as four 16-bit pieces p_i and their squares: a SUM all-reduce over R ranks gives S_i = sum p_i and Q_i = sum p_i^2
+// exactly (S_i <= R 65535, Q_i <= R 2^32: integers far below 2^53), and all ranks hold the same h iff R Q_i == S_i^2 for every piece
+// (Cauchy-Schwarz with equality) -- so the check rides in the packed sum all-reduce instead of a max-reduce of its own.
+__global__ void k_fingerprint_pieces(const unsigned long long* __restrict__ acc, double* __restrict__ out8) {
+    const int i = threadIdx.x;
+    if (i < 4) { const double p = (double)((acc[0] >> (16 * i)) & 0xffffull); out8[i] = p; out8[4 + i] = p * p; }
+}
+int launch_fingerprint_pieces(tnml_ctx* c, const unsigned long long* acc, double* out8) {
+    hipLaunchKernelGGL(k_fingerprint_pieces, dim3(1), dim3(64), 0, c->stream, acc, out8);
     HIPCK(c, hipGetLastError());
     return 0;
 }

@@ -167,10 +167,11 @@ __global__ __launch_bounds__(64 * NW) void k_labeldot(LdotArgs A, double* __rest
     sum_wave_partials(s_part, LDI / 64, partials + (size_t)blk * 12, tid);
 }
 
-__global__ __launch_bounds__(768) void k_reduce_partials(const double* __restrict__ partials, int nblk, double* __restrict__ out) {
+__global__ __launch_bounds__(768) void k_reduce_partials(const double* __restrict__ partials, int nblk, double* __restrict__ out, int only_sum) {
     // 12 waves, wave t sums column t: lane i takes rows i, i+64, ... in order, then a fixed shuffle
     // tree -> deterministic for a given nblk
     const int t = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (only_sum && t != 11) return;                       // the pAp pass: cost partials of the previous update stay where they are
     double s = 0.;
     for (int b = lane; b < nblk; b += 64) s += partials[(size_t)b * 12 + t];
 #pragma unroll
@@ -210,16 +211,16 @@ int launch_labeldot_blocks(tnml_ctx* c, const LdotArgs& a_in, int blk_off, int n
     HIPCK(c, hipGetLastError());
     return 0;
 }
-int launch_labeldot_reduce(tnml_ctx* c, int nblk_total, double* scal_out) {
+int launch_labeldot_reduce(tnml_ctx* c, int nblk_total, double* scal_out, int only_sum) {
     ProfScope ps(c, KC_PUPDATE);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(768), 0, c->stream, c->partials, nblk_total, scal_out);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(768), 0, c->stream, c->partials, nblk_total, scal_out, only_sum);
     HIPCK(c, hipGetLastError());
     return 0;
 }
 int launch_labeldot(tnml_ctx* c, const LdotArgs& a, double* scal_out) {
     const int nblk = a.NTp / (labeldot_streaming(c, a.NTp) ? 128 : 64);
     TCK(launch_labeldot_blocks(c, a, 0, nblk, c->stream, KC_LABELDOT, 0));
-    return launch_labeldot_reduce(c, nblk, scal_out);
+    return launch_labeldot_reduce(c, nblk, scal_out, a.mode == LD_MODE_PAP ? 1 : 0);
 }
 
 template <typename T, typename TE>
@@ -293,7 +294,7 @@ int launch_pupdate(tnml_ctx* c, const double* alpha_dev, double* scal_out) {
     const int nblk = c->NTp / LD_IMGS;
     if (c->f64()) hipLaunchKernelGGL(k_pupdate<double>, dim3(nblk), dim3(LD_IMGS), 0, c->stream, (double*)c->P, (const double*)c->Pp, (double*)c->dP, c->label, c->NTp, alpha_dev, c->scal + SC_CONVP + ((c->cg_pass - 1) & 1), c->partials, c->nl(), c->target());
     else          hipLaunchKernelGGL(k_pupdate<float>, dim3(nblk), dim3(LD_IMGS), 0, c->stream, (float*)c->P, (const float*)c->Pp, (float*)c->dP, c->label, c->NTp, alpha_dev, c->scal + SC_CONVP + ((c->cg_pass - 1) & 1), c->partials, c->nl(), c->target());
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(768), 0, c->stream, c->partials, nblk, scal_out);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(768), 0, c->stream, c->partials, nblk, scal_out, 0);
     HIPCK(c, hipGetLastError());
     return 0;
 }

@@ -3,8 +3,8 @@
 // RCCL refuses two ranks on the same GPU, so on a one-GPU box the multi-rank logic of the library (image shards,
 // packed [G | cost | ncorrect | pAp] all-reduce, collective truncation decision, replica fingerprints) could only ever
 // run with a 1-rank communicator.  This communicator gives every rank of one process its own context and stream on the
-// same device and implements the three collectives the library uses -- sum all-reduce of fp64, broadcast from rank 0,
-// max all-reduce of uint64 -- through a staging buffer in device memory, ordered by HIP events between the ranks'
+// same device and implements the two collectives the library uses -- sum all-reduce of fp64, broadcast from rank 0 --
+// through a staging buffer in device memory, ordered by HIP events between the ranks'
 // streams and a host barrier between their threads (one host thread per rank, as in the C++ fixedL driver).  The sum
 // runs over the ranks in rank order on every rank: bit-identical results everywhere, like a ring all-reduce.
 //
@@ -41,13 +41,6 @@ __global__ void k_lc_sum(const double* __restrict__ st, int n, size_t cap, size_
         out[i] = s;
     }
 }
-__global__ void k_lc_maxu64(const double* __restrict__ st, int n, size_t cap, size_t count, double* __restrict__ out) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
-        unsigned long long s = (unsigned long long)__double_as_longlong(st[i]);
-        for (int r = 1; r < n; ++r) { const unsigned long long v = (unsigned long long)__double_as_longlong(st[(size_t)r * cap + i]); s = v > s ? v : s; }
-        out[i] = __longlong_as_double((long long)s);
-    }
-}
 __global__ void k_lc_copy(const double* __restrict__ st, size_t count, double* __restrict__ out) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) out[i] = st[i];
 }
@@ -61,7 +54,7 @@ int tnml_comm_init_local(tnml_ctx** ctxs, int n) {
         if (c->cfg.nranks != n || c->cfg.rank != r) return tnml_fail(c, "tnml_comm_init_local: context %d was created as rank %d of %d", r, c->cfg.rank, c->cfg.nranks);
         if (c->cfg.device != ctxs[0]->cfg.device) return tnml_fail(c, "tnml_comm_init_local: ranks on different devices use RCCL (tnml_comm_init)");
         if (c->comm || c->local) return tnml_fail(c, "tnml_comm_init_local: context already has a communicator");
-        if (c->mcap + TNML_NSCAL_AR > cap) cap = c->mcap + TNML_NSCAL_AR;
+        if (c->mcap + TNML_TAILN > cap) cap = c->mcap + TNML_TAILN;
         if (c->mcap != ctxs[0]->mcap) return tnml_fail(c, "tnml_comm_init_local: contexts must share maxm");
     }
     LocalComm* lc = new LocalComm();
@@ -95,7 +88,7 @@ void local_comm_release(tnml_ctx* c) {
 }
 int local_comm_size(const tnml_ctx* c) { return c->local ? c->local->n : 0; }
 
-// op: 0 = sum of doubles, 1 = copy of rank 0's values, 2 = max of the 64-bit patterns as unsigned integers
+// op: 0 = sum of doubles, 1 = copy of rank 0's values
 int local_comm_exchange(tnml_ctx* c, double* buf, size_t count, int op) {
     LocalComm* lc = c->local;
     if (count > lc->cap) return tnml_fail(c, "local communicator: %zu elements exceed the staging capacity %zu", count, lc->cap);
@@ -110,8 +103,7 @@ int local_comm_exchange(tnml_ctx* c, double* buf, size_t count, int op) {
     for (int j = 0; j < n; ++j) if (j != r) HIPCK(c, hipStreamWaitEvent(st, lc->written[p][j], 0));
     const int nb = (int)((count + 255) / 256 > 1024 ? 1024 : (count + 255) / 256);
     if (op == 0)      hipLaunchKernelGGL(k_lc_sum, dim3(nb), dim3(256), 0, st, (const double*)lc->staging[p], n, lc->cap, count, buf);
-    else if (op == 1) hipLaunchKernelGGL(k_lc_copy, dim3(nb), dim3(256), 0, st, (const double*)lc->staging[p], count, buf);
-    else              hipLaunchKernelGGL(k_lc_maxu64, dim3(nb), dim3(256), 0, st, (const double*)lc->staging[p], n, lc->cap, count, buf);
+    else              hipLaunchKernelGGL(k_lc_copy, dim3(nb), dim3(256), 0, st, (const double*)lc->staging[p], count, buf);
     HIPCK(c, hipGetLastError());
     HIPCK(c, hipEventRecord(lc->read_done[p][r], st));
     lc->barrier();                                        // ... and its `read_done` event, before anyone re-uses the parity

@@ -4,7 +4,7 @@
 // M M^T; this back-end does the same on the device in fp64:
 //   M (nl x nr): rows = (a,s[,l]) indices of site b, columns = (t,beta[,l]) indices of site b+1
 //   rho = M M^T or M^T M on the smaller side  (rocBLAS dgemm)
-//   rho = Q diag(lambda) Q^T                  (eigh.hip tridiagonalisation + rocSOLVER dstedc; stock
+//   rho = Q diag(lambda) Q^T                  (in-house eigensolver, eigh.hip / eigh_mc.hip; stock
 //                                              rocSOLVER dsyevd measured 5.9 ms at n=240, dgesvdj 29 ms,
 //                                              dgesvd 153 ms -- profiles/r01_probe_*)
 //   sigma = sqrt(lambda), truncation rule on the host (tnml_truncate), kept factors by dgemm:
@@ -79,6 +79,11 @@ __global__ void k_scale_cols(double* __restrict__ X, size_t rows, int m, SigmaRe
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) X[idx] *= sigma_of(colscale, (int)(idx / rows));
 }
 
+// rocsolver_dpotrf's info -> flags of the Cholesky QR: flag[0] = the factorisation failed (a pivot was not positive), flag[1] = a factorisation ran
+__global__ void k_potrf_flags(const int* __restrict__ info, double* __restrict__ flag) {
+    if (threadIdx.x == 0) { flag[0] = info[0] != 0 ? 1. : 0.; flag[1] = 1.; }
+}
+
 #define RBCK(c, expr) do { rocblas_status s_ = (expr); if (s_ != rocblas_status_success) return tnml_fail((c), "%s failed: rocblas status %d (%s:%d)", #expr, (int)s_, __FILE__, __LINE__); } while (0)
 
 int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cutoff, int maxm, int minm,
@@ -106,28 +111,17 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
     const int gstrips = (left ? nr : nl) >= 1024 ? 8 : 4;     // the Label-on-B bonds reduce over 2400: 133 us as one call, 17 us as 8 strips
     if (left) RBCK(c, dgemm_strips(c->blas, rocblas_operation_none, rocblas_operation_transpose, nl, nl, nr, M, nl, M, nl, c->sG, nl, gstrips));
     else      RBCK(c, dgemm_strips(c->blas, rocblas_operation_transpose, rocblas_operation_none, nr, nr, nl, M, nl, M, nl, c->sG, nr, gstrips));
-    // eigen-decomposition of rho: in-house one-workgroup tridiagonalisation + rocSOLVER dstedc + in-house back
-    // transformation (TNML_SVD_SYEVD, n <= 240), or stock rocSOLVER dsyevd (TNML_SVD_ROCSOLVER / larger n)
-    // backend: 0 = in-house tridiagonalisation + in-house bisection/inverse iteration (verified, with
-    // fallback), 2 = in-house tridiagonalisation + rocSOLVER dstedc, 1 = stock rocSOLVER dsyevd
-    const bool tri = (c->cfg.svd_backend != TNML_SVD_ROCSOLVER) && n <= 240 && n >= 3;
+    // eigen-decomposition of rho.  backend 0 (default): in-house Householder tridiagonalisation (one workgroup up to n = 240,
+    // eigh.hip; a cluster of workgroups up to n = 640, eigh_mc.hip) + in-house bisection / inverse iteration + back
+    // transformation, verified, with rocSOLVER as the fallback; 2: in-house tridiagonalisation + rocSOLVER dstedc; 1: stock
+    // rocSOLVER dsyevd (5.9 ms at n = 240, 11.7 ms at n = 600: ~9 000 launches of 3-4 us, profiles/r03_prof_m300_before.txt)
+    const bool tri = (c->cfg.svd_backend != TNML_SVD_ROCSOLVER) && n >= 3 && (n <= 240 || (n <= eigh_mc_max_n() && c->mc_xbuf));
     bool own_eig = tri && c->cfg.svd_backend == TNML_SVD_SYEVD;
+    const bool mc = tri && n > 240;
     const int mk = maxm < n ? maxm : n;                   // the truncation never keeps more than maxm
     const double* evals = c->sD;                          // ascending eigenvalues of rho
-    double* qh = nullptr;                                 // H_0 ... H_{n-2}, formed beside the tridiagonal eigenproblem
     if (tri) {
         TCK(eigh_tridiagonalize(c, c->sG, n, c->sD, c->sE2, c->sTau, c->sV, c->sytrd_exit ? 1e-15 : 0.));   // sG is a Gram matrix: rank-adaptive exit at ~4 eps trace(G), the size of the error G = B^T B carries anyway
-        // The reflectors are known as soon as the tridiagonalisation ends, the eigenvectors of T only ~200 us later: the product
-        // H_0 ... H_{n-2} is formed on the second queue meanwhile (n independent columns, the same latency chain as the back
-        // transformation of the eigenvectors), and the back transformation itself becomes one dgemm.
-        static const int use_qh = getenv("TNML_SVD_QH") ? atoi(getenv("TNML_SVD_QH")) : 0;   // measured: no gain (profiles/r02_ab_svd_qh.txt), off
-        qh = use_qh && own_eig && (size_t)n * n + 2048 <= std::max<size_t>((size_t)5 * c->svd_n * c->maxm, 1024) ? c->sScr + 2048 : nullptr;
-        if (qh) {
-            HIPCK(c, hipEventRecord(c->ev_a, st));
-            HIPCK(c, hipStreamWaitEvent(c->stream2, c->ev_a, 0));
-            TCK(eigh_backtransform(c, c->sV, c->sTau, n, nullptr, n, qh, n, n, c->stream2));
-            HIPCK(c, hipEventRecord(c->ev_b, c->stream2));
-        }
         if (own_eig) { TCK(eigh_tridiag_eig(c, c->sD, c->sE2, n, c->sW, mk, c->sC, n, c->sScr)); evals = c->sW; }
         else RBCK(c, rocsolver_dstedc(c->blas, rocblas_evect_tridiagonal, n, c->sD, c->sE2, c->sC, n, c->sInfo));
     } else {
@@ -138,36 +132,36 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
     double* Lf = c->sF + (size_t)c->svd_n * c->maxm;     // left factor when a permutation is still needed
     double* Q0 = c->sQ1;
     double* hd = c->h_scal + 2 * c->svd_n + 32;
-    const bool always_qr = own_eig && mk <= 128;          // k_chol_rinv_blocked covers m <= 128
     double* dv = own_eig ? c->sW + n : c->sDev;           // [0] max|Q^T Q - I| into the polish step, [1] Cholesky failed, [2] a factorisation was needed
     if (own_eig) {
         // Z (already "largest first") -> U = H_0 H_1 ... Z for all mk candidate columns, queued BEFORE the eigenvalues go to
         // the host, so that the truncation decision costs no idle gap on the device; the kept columns are the first m.
-        if (qh) {
-            HIPCK(c, hipStreamWaitEvent(st, c->ev_b, 0));
-            RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, n, mk, n, &one, qh, n, c->sC, n, &zero, Q0, n));
-        } else TCK(eigh_backtransform(c, c->sV, c->sTau, n, c->sC, n, Q0, n, mk));
+        TCK(eigh_backtransform(c, c->sV, c->sTau, n, c->sC, n, Q0, n, mk));
         RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, mk, mk, n, &one, Q0, n, Q0, n, &zero, c->sS, mk));
-        const double* Qin = Q0;
-        if (always_qr) {
-            // The Gram matrix of a bond tensor spans 12+ decades (the common mode of the images dominates), so most of the kept
-            // eigenvalues sit within a few 100 eps*|T| of each other: inverse iteration returns the right invariant subspace for
-            // them but not orthogonal vectors (80 % of the bond updates of a sweep).  Any orthonormal basis of that subspace is
-            // an equally valid set of singular vectors, so the basis ALWAYS goes through a Cholesky QR (Q1 = Q0 R^-1,
-            // Q0^T Q0 = R^T R; the kernel returns R = I straight away when Q0 is orthonormal to 5e-7) and one Newton-Schulz
-            // polish step whose input deviation is the check -- no host decision, no second synchronisation.
+        // The Gram matrix of a bond tensor spans 12+ decades (the common mode of the images dominates), so most of the kept
+        // eigenvalues sit within a few 100 eps*|T| of each other: inverse iteration returns the right invariant subspace for
+        // them but not orthogonal vectors (80 % of the bond updates of a sweep).  Any orthonormal basis of that subspace is
+        // an equally valid set of singular vectors, so the basis ALWAYS goes through a Cholesky QR (Q1 = Q0 R^-1,
+        // Q0^T Q0 = R^T R) and one Newton-Schulz polish step whose input deviation is the check -- no host decision, no
+        // second synchronisation.
+        const double* Qin;
+        if (mk <= TNML_CHOL_MAXM) {                       // one-workgroup kernel; returns R = I straight away when Q0 is orthonormal to 5e-7
             TCK(eigh_chol_rinv(c, c->sS, mk, c->sCm, dv + 1));              // writes both flags
             RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, n, mk, mk, &one, Q0, n, c->sCm, mk, &zero, c->sG, n));   // the Gram matrix is consumed by now
-            RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, mk, mk, n, &one, c->sG, n, c->sG, n, &zero, c->sS, mk));
             Qin = c->sG;
+        } else {                                          // larger bases (maxm > 128): rocSOLVER dpotrf + rocBLAS dtrsm, in place
+            RBCK(c, rocsolver_dpotrf(c->blas, rocblas_fill_upper, mk, c->sS, mk, c->sInfo));
+            hipLaunchKernelGGL(k_potrf_flags, dim3(1), dim3(64), 0, st, (const int*)c->sInfo, dv + 1);
+            RBCK(c, rocblas_dtrsm(c->blas, rocblas_side_right, rocblas_fill_upper, rocblas_operation_none, rocblas_diagonal_non_unit, n, mk, &one, c->sS, mk, Q0, n));
+            Qin = Q0;
         }
+        RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, mk, mk, n, &one, Qin, n, Qin, n, &zero, c->sS, mk));
         // Newton-Schulz step Q <- Q (1.5 I - 0.5 Q^T Q); d = max|Q^T Q - I| before the step is checked on the host (after it: ~0.75 d^2)
         TCK(eigh_ns_matrix(c, c->sS, c->sCm, mk, dv));
         // the kept basis lands where it is needed: straight in the site tensor when that is its final place
         direct_left = left && !labL && mk <= c->maxm;
         if (direct_left) Q = Sl.a;
         RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, n, mk, mk, &one, Qin, n, c->sCm, mk, &zero, Q, n));
-        if (!always_qr) HIPCK(c, hipMemsetAsync(dv + 1, 0, 3 * sizeof(double), st));
     }
     // eigenvalues -> host: the truncation decision (ITensor truncate()) fixes the new bond dimension.  With more than
     // one rank the decision is made collective: every rank decides on rank 0's eigenvalues (and rank 0's orthogonality
@@ -176,7 +170,24 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
     TCK(bcast_rank0(c, const_cast<double*>(evals), nev));
     double* h = c->h_scal;          // pinned, capacity >= 2*svd_n + 64
     HIPCK(c, hipMemcpyAsync(h, evals, sizeof(double) * nev, hipMemcpyDeviceToHost, st));
+    unsigned long long* h_mc = reinterpret_cast<unsigned long long*>(h + n + 8);
+    *h_mc = 0;
+    if (mc) HIPCK(c, hipMemcpyAsync(h_mc, eigh_mc_status_ptr(c->mc_xbuf), 8, hipMemcpyDeviceToHost, st));
     HIPCK(c, hipStreamSynchronize(st));
+    bool stock = !tri;                                   // eigenvectors of rho itself in sG (dsyevd)
+    if (mc && *h_mc) {
+        // the workgroup cluster gave up waiting for a peer (a workgroup that never got a CU): nothing it wrote is used.  Redo this
+        // split with the stock solver: Gram matrix again (sG may have served as workspace), dsyevd, eigenvalues to the host.
+        c->svd_fallbacks += 1;
+        HIPCK(c, hipMemsetAsync(const_cast<void*>(static_cast<const void*>(static_cast<const char*>(eigh_mc_status_ptr(c->mc_xbuf)) - 8)), 0, 16, st));
+        if (left) RBCK(c, dgemm_strips(c->blas, rocblas_operation_none, rocblas_operation_transpose, nl, nl, nr, M, nl, M, nl, c->sG, nl, gstrips));
+        else      RBCK(c, dgemm_strips(c->blas, rocblas_operation_transpose, rocblas_operation_none, nr, nr, nl, M, nl, M, nl, c->sG, nr, gstrips));
+        RBCK(c, rocsolver_dsyevd(c->blas, rocblas_evect_original, rocblas_fill_upper, n, c->sG, n, c->sD, c->sE, c->sInfo));
+        evals = c->sD; own_eig = false; stock = true; Q = c->sF; direct_left = false;
+        TCK(bcast_rank0(c, const_cast<double*>(evals), n));
+        HIPCK(c, hipMemcpyAsync(h, evals, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+        HIPCK(c, hipStreamSynchronize(st));
+    }
     if (own_eig) { hd[0] = h[n]; hd[1] = h[n + 1]; hd[2] = h[n + 2]; }
     if (const char* pe = getenv("TNML_SVD_PRINT")) {                           // debugging aid: the spectrum of one call
         static int calls = 0;
@@ -201,8 +212,8 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
             fprintf(stderr, "svd_check n=%d mk=%d dev=%.2e cholfail=%g factored=%g dev_in=%.2e reflectors=%g\n", n, mk, hd[0], hd[1], hd[2], h[n + 3], nref);
         }
         c->svd_last_dev0 = hd[0]; c->svd_last_dev1 = 0.75 * hd[0] * hd[0];      // Newton-Schulz: error -> 3/4 error^2
-        bool ok = hd[0] < 1e-6 && (!always_qr || hd[1] == 0.);                   // the polish step leaves 3/4 d^2 < 1e-12
-        if (always_qr && hd[2] != 0.) c->svd_cholqr += 1;
+        const bool ok = hd[0] < 1e-6 && hd[1] == 0.;                             // the polish step leaves 3/4 d^2 < 1e-12
+        if (hd[2] != 0.) c->svd_cholqr += 1;
         if (!ok) if (const char* dump = getenv("TNML_SVD_DUMP")) {               // debugging aid: the offending tridiagonal problem
             static int dumped = 0;
             if (dumped < 4) {
@@ -216,49 +227,20 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
                 if (FILE* f = fopen(fn, "wb")) { fwrite(hb.data(), sizeof(double), hb.size(), f); fclose(f); }
             }
         }
-        if (!ok && hd[0] == hd[0] && !always_qr) {
-            // Close eigenvalues inside one unreduced block: inverse iteration gave independent but not quite
-            // orthogonal vectors of the right invariant subspace.  Mild cases (max|Q^T Q - I| < 0.3) are repaired by
-            // further Newton-Schulz steps (error -> 3/4 error^2, until it is below 1e-12); worse ones first go through a Cholesky QR
-            // (Q1 = Q0 R^-1 with Q0^T Q0 = R^T R).  The last step lands in Q and its input deviation is checked.
-            const bool need_chol = !(hd[0] < 0.3);
-            if (!need_chol || mk <= TNML_CHOL_MAXM) {
-                c->svd_cholqr += 1;
-                double* cur = Q0; double* other = c->sG;                        // the Gram matrix is consumed by now
-                HIPCK(c, hipMemsetAsync(c->sDev + 1, 0, sizeof(double), st));
-                if (need_chol) {
-                    TCK(eigh_chol_rinv(c, c->sS, mk, c->sCm, c->sDev + 1));
-                    RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, n, mk, mk, &one, cur, n, c->sCm, mk, &zero, other, n));
-                    std::swap(cur, other);
-                }
-                const int nit = need_chol ? 1 : (hd[0] < 1e-3 ? 1 : (hd[0] < 0.05 ? 3 : 4));   // d -> 3/4 d^2 per step; the last input must be < 1e-6
-                for (int it = 0; it <= nit; ++it) {
-                    double* dst = it == nit ? Q : other;
-                    RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, mk, mk, n, &one, cur, n, cur, n, &zero, c->sS, mk));
-                    TCK(eigh_ns_matrix(c, c->sS, c->sCm, mk, c->sDev));
-                    RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, n, mk, mk, &one, cur, n, c->sCm, mk, &zero, dst, n));
-                    if (it < nit) std::swap(cur, other);
-                }
-                TCK(bcast_rank0(c, c->sDev, 2));
-                HIPCK(c, hipMemcpyAsync(hd, c->sDev, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
-                HIPCK(c, hipStreamSynchronize(st));
-                ok = hd[1] == 0. && hd[0] < 1e-6;
-                c->svd_last_dev1 = 0.75 * hd[0] * hd[0];
-            }
-        }
         if (!ok) {
             // dependent vectors even after re-orthonormalisation: redo the tridiagonal stage with rocSOLVER's
             // divide and conquer (D, E, V, tau are still intact)
             c->svd_fallbacks += 1;
             own_eig = false;
+            Q = c->sF; direct_left = false;
             RBCK(c, rocsolver_dstedc(c->blas, rocblas_evect_tridiagonal, n, c->sD, c->sE2, c->sC, n, c->sInfo));
         }
     }
-    if (tri && !own_eig) {
+    if (tri && !own_eig && !stock) {
         // kept eigenvectors of the tridiagonal matrix (largest first), then U = H_0 H_1 ... Z
         hipLaunchKernelGGL(k_take_top, dim3(nblk((size_t)n * m)), dim3(256), 0, st, c->sC, c->sG, n, m, (const double*)nullptr);
         TCK(eigh_backtransform(c, c->sV, c->sTau, n, c->sG, n, Q, n, m));
-    } else if (!tri) {
+    } else if (stock) {
         hipLaunchKernelGGL(k_take_top, dim3(nblk((size_t)n * m)), dim3(256), 0, st, c->sG, Q, n, m, (const double*)nullptr);
     }
     double* Aleft = labL ? Lf : Sl.a;      // left factor target, (nl x m), ld = nl

@@ -34,7 +34,6 @@ void prof_end(tnml_ctx* c, int kc, hipEvent_t e0, hipStream_t st) {
 void prof_resolve(tnml_ctx* c) {
     if (c->prof_pending.empty()) return;
     (void)hipStreamSynchronize(c->stream);
-    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     for (auto& p : c->prof_pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) { c->prof_ms[p.kc] += ms; c->prof_launches[p.kc] += 1; }
@@ -78,11 +77,10 @@ int tnml_set_option(tnml_ctx* c, const char* name, int value) {
     if (!strcmp(name, "fast_cg")) c->fast_cg = value != 0;
     else if (!strcmp(name, "reuse_p")) { c->reuse_p = value != 0; c->p_valid = false; }
     else if (!strcmp(name, "fuse_z")) c->fuse_z = value != 0;
+    else if (!strcmp(name, "merged_cg")) c->merged_cg = value;
+    else if (!strcmp(name, "defer_tail")) { if (c->pend_count) return tnml_fail(c, "defer_tail: a bond update is in flight"); c->defer_tail = value != 0; }
     else if (!strcmp(name, "check_replicas")) { c->check_replicas = value != 0; c->check_replicas_mode = value; }
-    else if (!strcmp(name, "overlap")) c->overlap = value;
     else if (!strcmp(name, "fused_fwd")) c->fused_fwd = value;
-    else if (!strcmp(name, "bgemm_ps")) c->bgemm_ps = value;
-    else if (!strcmp(name, "snake")) c->snake = value;
     else if (!strcmp(name, "sytrd_exit")) c->sytrd_exit = value;
     else if (!strcmp(name, "cg_method")) { if (value < 0 || value > 2 || (value >= 1 && !c->single())) return tnml_fail(c, "cg_method: 0 (conj) or, in TNML_MODE_SINGLE, 1 (fast_conj) / 2 (exact)"); c->cg_method = value; }
     else if (!strcmp(name, "debug_nudge_rank")) c->debug_nudge_rank = value;
@@ -150,12 +148,13 @@ int64_t tnml_estimate_bytes(const tnml_config* cfg) {
     if (!cfg || cfg->N < 1 || cfg->NT_local < 1 || cfg->maxm < 1) return -1;
     const double NTp = (double)((cfg->NT_local + TNML_NTPAD - 1) / TNML_NTPAD * TNML_NTPAD);
     const double m = cfg->maxm, Kmax = ru16(2 * cfg->maxm), n = 2. * m;
-    const double esz = cfg->dtype != TNML_F32 ? 8 : 4, eesz = cfg->dtype == TNML_F64 ? 8 : 4;
+    const bool is64 = cfg->dtype == TNML_F64 || cfg->dtype == TNML_F64_E32;
+    const double esz = is64 ? 8 : 4, eesz = cfg->dtype == TNML_F64 ? 8 : 4;
     const bool single = cfg->mode == TNML_MODE_SINGLE;
     const double mcap = TNML_NL * Kmax * Kmax;
     double b = cfg->N * 2. * NTp * eesz + NTp * (4 + eesz);                                  // features, labels, ones
     b += (TNML_NL * m * NTp + 3. * TNML_NL * NTp + m * NTp) * esz;                          // U, P, dP, Pp, Zp
-    b += mcap * (4 + 6 * 8) + 128. * Kmax * Kmax * 4 * (cfg->dtype != TNML_F32 ? 2 : 1);    // Mf, vB vR vP vG tB tB2, split-K slabs
+    b += mcap * (4 + 6 * 8) + 128. * Kmax * Kmax * 4 * (is64 ? 2 : 1);    // Mf, vB vR vP [tail|G] tB tB2, split-K slabs
     b += 8. * (std::max(40. * m * m, TNML_NL * Kmax * (double)ru16(cfg->maxm)) + 3. * n * n + 7. * n * m + 2. * TNML_NL * m * m + 2. * m * m);   // split workspaces
     b += 8. * (cfg->N - 1 + TNML_NL) * 2. * m * m;                                            // W replica
     const double nslab = single ? (cfg->N / 10. + 2.) : (0.55 * cfg->N + 3.);
@@ -202,7 +201,7 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     *out = nullptr;
     if (cfg->N < 4) return tnml_fail(nullptr, "tnml_create: need N >= 4 sites");
     if (cfg->NT_local < 1 || cfg->maxm < 1) return tnml_fail(nullptr, "tnml_create: NT_local and maxm must be positive");
-    if (cfg->dtype != TNML_F32 && cfg->dtype != TNML_F64 && cfg->dtype != TNML_F64_E32) return tnml_fail(nullptr, "tnml_create: dtype must be TNML_F64, TNML_F64_E32 or TNML_F32");
+    if (cfg->dtype < TNML_F32 || cfg->dtype > TNML_BF16X3) return tnml_fail(nullptr, "tnml_create: dtype must be TNML_F64, TNML_F64_E32, TNML_F32, TNML_BF16 or TNML_BF16X3");
     if (cfg->nranks < 1 || cfg->rank < 0 || cfg->rank >= cfg->nranks) return tnml_fail(nullptr, "tnml_create: bad rank/nranks");
     if (cfg->mode != TNML_MODE_FIXEDL && cfg->mode != TNML_MODE_SINGLE) return tnml_fail(nullptr, "tnml_create: mode must be TNML_MODE_FIXEDL or TNML_MODE_SINGLE");
     if (cfg->mode == TNML_MODE_SINGLE && (cfg->target_label < 0 || cfg->target_label >= TNML_NL)) return tnml_fail(nullptr, "tnml_create: target_label must be in 0..9");
@@ -219,24 +218,18 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     int rc = 0;
     auto bail = [&](int r) { g_create_err = c->err; tnml_destroy(c); return r; };
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(tnml_fail(c, "hipStreamCreate failed"));
-    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) return bail(tnml_fail(c, "hipStreamCreate failed"));
-    if (hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) != hipSuccess)
-        return bail(tnml_fail(c, "hipEventCreate failed"));
-    if (const char* e = getenv("TNML_OVERLAP")) c->overlap = atoi(e);
     if (const char* e = getenv("TNML_FUSED_FWD")) c->fused_fwd = atoi(e);
-    if (const char* e = getenv("TNML_BGEMM_PS")) c->bgemm_ps = atoi(e);
-    if (const char* e = getenv("TNML_SNAKE")) c->snake = atoi(e);
     if (rocblas_create_handle(&c->blas) != rocblas_status_success) return bail(tnml_fail(c, "rocblas_create_handle failed"));
     rocblas_set_stream(c->blas, c->stream);
     // replicas of W must stay bit-identical over the ranks: no atomics-based split-K inside rocBLAS
     rocblas_set_atomics_mode(c->blas, rocblas_atomics_not_allowed);
     const size_t NTp = c->NTp;
-    const int Kmax = ru16(2 * c->maxm);
+    const int Kmax = c->bf16() ? (2 * c->maxm + 31) / 32 * 32 : ru16(2 * c->maxm);
     c->mcap = (size_t)TNML_NL * Kmax * Kmax;
     c->small_elems = (size_t)c->maxm * NTp;
     c->big_elems = (size_t)TNML_NL * c->maxm * NTp;
     c->svd_n = 2 * c->maxm;
-    c->slab_bytes = (size_t)128 * Kmax * Kmax * 4 * (cfg->dtype != TNML_F32 ? 2 : 1);
+    c->slab_bytes = (size_t)128 * Kmax * Kmax * 4 * ((cfg->dtype == TNML_F64 || cfg->dtype == TNML_F64_E32) ? 2 : 1);
     c->partial_cap = (int)(NTp / 64);
     c->W.resize(c->N + 2);
     c->env.resize(c->N + 2);
@@ -251,6 +244,8 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     if (const char* e = getenv("TNML_FAST_CG")) c->fast_cg = atoi(e) != 0;
     if (const char* e = getenv("TNML_FUSE_Z")) c->fuse_z = atoi(e) != 0;
     if (const char* e = getenv("TNML_REUSE_P")) c->reuse_p = atoi(e) != 0;
+    if (const char* e = getenv("TNML_MERGED_CG")) c->merged_cg = atoi(e);
+    if (const char* e = getenv("TNML_DEFER_TAIL")) c->defer_tail = atoi(e) != 0;
     if (const char* e = getenv("TNML_FG64_CFG")) c->opt_fg64_cfg = atoi(e);
     if (const char* e = getenv("TNML_LDOT_CFG")) c->opt_ldot_cfg = atoi(e);
     if ((rc = dmalloc(c, (char**)&c->Zp, c->small_elems * esz))) return bail(rc);
@@ -260,7 +255,9 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     if ((rc = dmalloc(c, &c->vB, c->mcap))) return bail(rc);
     if ((rc = dmalloc(c, &c->vR, c->mcap))) return bail(rc);
     if ((rc = dmalloc(c, &c->vP, c->mcap))) return bail(rc);
-    if ((rc = dmalloc(c, &c->vG, c->mcap + TNML_NSCAL_AR))) return bail(rc);
+    if ((rc = dmalloc(c, &c->arbuf, c->mcap + TNML_TAILN))) return bail(rc);
+    c->tail = c->arbuf; c->vG = c->arbuf + TNML_TAILN;
+    if ((rc = dmalloc(c, &c->locals, 32))) return bail(rc);
     if ((rc = dmalloc(c, &c->scal, SC_N + (size_t)4 * TNML_MAX_PASS))) return bail(rc);   // CG scalars, then the per-pass trace: one copy to the host
     c->cgtrace = c->scal + SC_N;
     if ((rc = dmalloc(c, &c->vpart, 1024))) return bail(rc);   // [256][2] phase-1 partials, then [256][2] for |p|^2 of the next pass
@@ -282,20 +279,26 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     if ((rc = dmalloc(c, &c->sV, (size_t)c->svd_n * c->svd_n))) return bail(rc);
     if ((rc = dmalloc(c, &c->sC, (size_t)c->svd_n * c->svd_n))) return bail(rc);
     if ((rc = dmalloc(c, &c->sW, (size_t)c->svd_n + 8))) return bail(rc);           // + room for the orthogonality check values behind the eigenvalues
-    if ((rc = dmalloc(c, &c->sScr, std::max<size_t>((size_t)5 * c->svd_n * c->maxm, 1024)))) return bail(rc);
+    if ((rc = dmalloc(c, &c->sScr, std::max<size_t>((size_t)5 * c->svd_n * c->maxm, TEIG_SCRATCH_DOUBLES)))) return bail(rc);
     if ((rc = dmalloc(c, &c->sS, (size_t)c->maxm * c->maxm))) return bail(rc);
     if ((rc = dmalloc(c, &c->sCm, (size_t)c->maxm * c->maxm))) return bail(rc);
     if ((rc = dmalloc(c, &c->sQ1, (size_t)c->svd_n * c->maxm))) return bail(rc);
     if ((rc = dmalloc(c, &c->sDev, 4))) return bail(rc);
-    if ((rc = dmalloc(c, &c->sBT, 32 * 64))) return bail(rc);
+    if (c->svd_n > 240) {                               // multi-workgroup tridiagonalisation (eigh_mc.hip)
+        if ((rc = dmalloc(c, (char**)&c->mc_xbuf, eigh_mc_xbuf_bytes()))) return bail(rc);
+        if (hipMemsetAsync(c->mc_xbuf, 0, eigh_mc_xbuf_bytes(), c->stream) != hipSuccess) return bail(tnml_fail(c, "memset failed"));
+    }
     if (const char* e = getenv("TNML_SVD_BACKEND")) c->cfg.svd_backend = atoi(e);
-    for (int k = 0; k < 2; ++k) if (hipEventCreateWithFlags(&c->pend[k].ev, hipEventDisableTiming) != hipSuccess) return bail(tnml_fail(c, "hipEventCreate failed"));
+    for (int k = 0; k < 2; ++k)
+        if (hipEventCreateWithFlags(&c->pend[k].ev, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->pend[k].ev2, hipEventDisableTiming) != hipSuccess)
+            return bail(tnml_fail(c, "hipEventCreate failed"));
     if (hipHostMalloc((void**)&c->h_scal, sizeof(double) * (2 * c->svd_n + 64 + SC_N + 4 * TNML_MAX_PASS + 2 * 64)) != hipSuccess) return bail(tnml_fail(c, "hipHostMalloc failed"));
     for (int j = 1; j <= c->N; ++j) {
         const size_t cap = (size_t)2 * c->maxm * c->maxm * (j == c->c0 ? TNML_NL : 1);
         if ((rc = dmalloc(c, &c->W[j].a, cap))) return bail(rc);
     }
-    if (hipMemsetAsync(c->vG, 0, sizeof(double) * (c->mcap + TNML_NSCAL_AR), c->stream) != hipSuccess) return bail(tnml_fail(c, "memset failed"));
+    if (hipMemsetAsync(c->arbuf, 0, sizeof(double) * (c->mcap + TNML_TAILN), c->stream) != hipSuccess) return bail(tnml_fail(c, "memset failed"));
+    if (hipMemsetAsync(c->locals, 0, sizeof(double) * 32, c->stream) != hipSuccess) return bail(tnml_fail(c, "memset failed"));
     if (hipMemsetAsync(c->scal, 0, sizeof(double) * SC_N, c->stream) != hipSuccess) return bail(tnml_fail(c, "memset failed"));
     if ((rc = c->env64() ? launch_fill_f64(c, (double*)c->ones, 1.0, NTp) : launch_fill_f32(c, (float*)c->ones, 1.0f, NTp))) return bail(rc);
     if (hipStreamSynchronize(c->stream) != hipSuccess) return bail(tnml_fail(c, "sync failed"));
@@ -309,19 +312,16 @@ int tnml_destroy(tnml_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) ncclCommDestroy(c->comm);
     local_comm_release(c);
-    for (int k = 0; k < 2; ++k) if (c->pend[k].ev) (void)hipEventDestroy(c->pend[k].ev);
+    for (int k = 0; k < 2; ++k) { if (c->pend[k].ev) (void)hipEventDestroy(c->pend[k].ev); if (c->pend[k].ev2) (void)hipEventDestroy(c->pend[k].ev2); }
     for (auto& p : c->prof_pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     for (auto e : c->prof_free) (void)hipEventDestroy(e);
     void* ptrs[] = {c->phi, c->label, c->ones, c->U, c->P, c->dP, c->Pp, c->Zp, c->Mf, c->slab, c->partials, c->vB, c->vR, c->vP,
-                    c->vG, c->scal, c->vpart, c->tB, c->tB2, c->sM, c->sG, c->sD, c->sE, c->sF, c->sInfo, c->sE2, c->sTau, c->sV, c->sC, c->sW, c->sScr, c->sS, c->sCm, c->sQ1, c->sDev, c->sBT, c->fprint};
+                    c->arbuf, c->locals, c->scal, c->vpart, c->tB, c->tB2, c->sM, c->sG, c->sD, c->sE, c->sF, c->sInfo, c->sE2, c->sTau, c->sV, c->sC, c->sW, c->sScr, c->sS, c->sCm, c->sQ1, c->sDev, c->mc_xbuf, c->fprint};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& s : c->W) if (s.a) (void)hipFree(s.a);
     for (auto& sl : c->slabs) if (sl.base) (void)hipFree(sl.base);
     if (c->h_scal) (void)hipHostFree(c->h_scal);
     if (c->blas) rocblas_destroy_handle(c->blas);
-    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
-    if (c->ev_a) (void)hipEventDestroy(c->ev_a);
-    if (c->ev_b) (void)hipEventDestroy(c->ev_b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -347,34 +347,59 @@ int tnml_comm_init(tnml_ctx* c, const void* id128) {
 }
 // sum over ranks of a fp64 device buffer, in stream order (replaces stdx::accumulate, fixedL.cc:385,402,421,427)
 static int allreduce(tnml_ctx* c, double* buf, size_t count) {
-    if (c->local) { ProfScope ps(c, KC_ALLREDUCE); return local_comm_exchange(c, buf, count, 0); }
+    if (c->local) { ProfScope ps(c, KC_ALLREDUCE); c->allreduce_calls += 1; return local_comm_exchange(c, buf, count, 0); }
     if (!c->comm) {
         if (c->cfg.nranks == 1) return 0;
         return tnml_fail(c, "nranks > 1 but tnml_comm_init was not called");
     }
     ProfScope ps(c, KC_ALLREDUCE);
+    c->allreduce_calls += 1;
     ncclResult_t r = ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, c->comm, c->stream);
     if (r != ncclSuccess) return tnml_fail(c, "ncclAllReduce failed: %s", ncclGetErrorString(r));
     return 0;
 }
+static double* pend_host(tnml_ctx* c, int slot) { return c->h_scal + 2 * c->svd_n + 64 + SC_N + 4 * TNML_MAX_PASS + 64 * slot; }
+// the carried slots of a finished bond update (after-SVD cost partials, fingerprint pieces) have just been summed over the ranks by an
+// all-reduce that covered them: hand them to the host report they belong to
+static int carry_deliver(tnml_ctx* c) {
+    if (c->carry_slot < 0) return 0;
+    const int slot = c->carry_slot;
+    c->carry_slot = -1;
+    HIPCK(c, hipMemcpyAsync(pend_host(c, slot) + TNML_CARRY, c->tail + TNML_CARRY, sizeof(double) * TNML_CARRYN, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipEventRecord(c->pend[slot].ev2, c->stream));
+    return 0;
+}
+// the packed buffer [tail | G] of the current bond (n = elements of G)
+static int allreduce_packed(tnml_ctx* c, size_t n) {
+    TCK(allreduce(c, c->arbuf, TNML_TAILN + n));
+    return carry_deliver(c);
+}
 int bcast_rank0(tnml_ctx* c, double* buf, size_t count) {
-    if (c->local) return local_comm_exchange(c, buf, count, 1);
+    if (c->local) { c->bcast_calls += 1; return local_comm_exchange(c, buf, count, 1); }
     if (!c->comm) return 0;
+    c->bcast_calls += 1;
     ncclResult_t r = ncclBroadcast(buf, buf, count, ncclDouble, 0, c->comm, c->stream);
     if (r != ncclSuccess) return tnml_fail(c, "ncclBroadcast failed: %s", ncclGetErrorString(r));
     return 0;
 }
+int tnml_collective_stats(tnml_ctx* c, int64_t* allreduces, int64_t* broadcasts) {
+    if (allreduces) *allreduces = c->allreduce_calls;
+    if (broadcasts) *broadcasts = c->bcast_calls;
+    return 0;
+}
 static int check_W(tnml_ctx* c);
-// fingerprints of the replicated site tensors j0..j1 -> fprint[0..1], max-all-reduced: [max h, ~min h]
-static int replica_fingerprint(tnml_ctx* c, int j0, int j1) {
+// fingerprint of the replicated site tensors j0..j1 as exact integer pieces -> out8 (device; see k_fingerprint_pieces)
+static int replica_fingerprint(tnml_ctx* c, int j0, int j1, double* out8) {
     for (int j = j0; j <= j1; ++j) {
         const SiteT& s = c->W[j];
         TCK(launch_fingerprint(c, s.a, (size_t)s.ml * 2 * s.mr * s.L, 0x9E3779B97F4A7C15ull * (unsigned long long)(2 * j + 1), c->fprint, j == j0));
     }
-    if (c->local) return local_comm_exchange(c, reinterpret_cast<double*>(c->fprint), 2, 2);
-    ncclResult_t r = ncclAllReduce(c->fprint, c->fprint, 2, ncclUint64, ncclMax, c->comm, c->stream);
-    if (r != ncclSuccess) return tnml_fail(c, "ncclAllReduce failed: %s", ncclGetErrorString(r));
-    return 0;
+    return launch_fingerprint_pieces(c, c->fprint, out8);
+}
+// sums S_i, Q_i of the fingerprint pieces over R ranks: every rank held the same fingerprint iff R Q_i == S_i^2 for all four pieces
+static bool fingerprint_agrees(const double* sums8, int nranks) {
+    for (int i = 0; i < 4; ++i) if ((double)nranks * sums8[4 + i] != sums8[i] * sums8[i]) return false;
+    return true;
 }
 int tnml_replica_check(tnml_ctx* c, int* nranks_in_comm) {
     HIPCK(c, hipSetDevice(c->cfg.device));
@@ -386,11 +411,13 @@ int tnml_replica_check(tnml_ctx* c, int* nranks_in_comm) {
     if (nranks_in_comm) *nranks_in_comm = cnt;
     if (cnt != c->cfg.nranks) return tnml_fail(c, "communicator has %d ranks, context was created for %d", cnt, c->cfg.nranks);
     TCK(check_W(c));
-    TCK(replica_fingerprint(c, 1, c->N));
-    unsigned long long h[2];
-    HIPCK(c, hipMemcpyAsync(h, c->fprint, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    if (c->pend_count) return tnml_fail(c, "tnml_replica_check: a bond update is in flight");
+    TCK(replica_fingerprint(c, 1, c->N, c->tail + TNML_FPSLOT));
+    TCK(allreduce(c, c->tail + TNML_FPSLOT, 8));
+    double h[8];
+    HIPCK(c, hipMemcpyAsync(h, c->tail + TNML_FPSLOT, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
-    if (h[0] != ~h[1]) return tnml_fail(c, "replicas of the weight MPS differ between ranks");
+    if (!fingerprint_agrees(h, c->cfg.nranks)) return tnml_fail(c, "replicas of the weight MPS differ between ranks");
     return 0;
 }
 
@@ -611,7 +638,7 @@ int tnml_classify(tnml_ctx* c, double* weights, int32_t* pred, int64_t count[TNM
     for (int j = 1; j < cs && !rc; ++j) { rc = shift_core(c, j, true, Lc, 1, lbuf[lcur], false, nullptr); Lc = lbuf[lcur]; lcur ^= 1; }
     // centre site: T[l][r][n] = sum_{a,s} L[a][n] phi_c[s][n] A_c[a,s,r,l], then W_n[l] = sum_r T[l][r][n] R[r][n]
     if (!rc) rc = shift_core(c, cs, true, Lc, 1, c->U, true, nullptr);
-    double* tail = c->vG + c->mcap;
+    double* tail = c->tail;
     if (!rc) {
         LdotArgs a;
         a.A = c->U; a.A_lstride = (size_t)c->W[cs].mr * c->NTp; a.Bv = R; a.a_is_env = 0;
@@ -692,6 +719,7 @@ int tnml_set_bond(tnml_ctx* c, int b) {
         return tnml_fail(c, "Couldn't find Label index at bond %d", b);       // fixedL.cc:291-296,362
     }
     p.Kp = ru16(2 * p.mI); p.Np = ru16(2 * p.mO);
+    if (c->bf16()) p.Kp = (2 * p.mI + 31) / 32 * 32;            // the bf16 MFMA reduces 32 indices at a time
     c->plan = p; c->currb = b;
     return 0;
 }
@@ -731,35 +759,15 @@ static int forward_pass(tnml_ctx* c, const double* vec, int mode, double* tail, 
         f.phiO = p.phiO;
         f.out = (double*)c->U; f.out_lstride = ustride; f.mO = p.mO;
         f.NTp = c->NTp; f.L = p.LB; f.env64 = c->env64();
-        // Two image halves on two queues: the feature GEMM is bound by the matrix pipe, the label dot by HBM, so the label
-        // dot of the first half runs beside the feature GEMM of the second (each half is one round of 128-image tiles on the
-        // 256 CUs).  Every image still goes through exactly the same arithmetic in the same order, and the cost partials are
-        // reduced over all blocks in the fixed order afterwards: bit-identical to the single-queue form.
+        // one persistent kernel for both halves of B*t.v where it pays (kernels_fused.hip)
         if (c->fused_fwd && c->env64() && !c->single() && p.kind != 2 && p.Kp == 240 && p.Np == 240 && p.mI == 120 && p.mO == 120 &&
             (c->fused_fwd >= 2 || c->NTp / 64 >= 224)) {
             FwdFusedArgs ff;
             ff.EI = (const double*)p.EI; ff.mI = p.mI; ff.phiI = (const double*)p.phiI; ff.M = vec; ff.Kp = p.Kp; ff.Np = p.Np;
             ff.phiO = (const double*)p.phiO; ff.EL = (const double*)p.EX; ff.EL_lstride = ustride; ff.mO = p.mO; ff.NTp = c->NTp; ff.ntiles = c->NTp / 64;
             ff.label = c->label; ff.P = (double*)a.P; ff.dP = (double*)a.dP; ff.mode = mode; ff.partials = c->partials;
-            ff.rev = c->snake ? (c->stream_dir ^= 1) : 0;
             TCK(launch_fwd_fused(c, ff));
-            return launch_labeldot_reduce(c, ff.ntiles, tail);
-        }
-        const int nblk = c->NTp / 128;
-        if (c->overlap && nblk >= 2 * 192 && p.Np == 240 && c->opt_fg64_cfg == 0 && labeldot_streaming(c, c->NTp)) {
-            const int b1 = (nblk + 1) / 2, b2 = nblk - b1;
-            f.n_off = 0; f.n_cnt = b1 * 128; f.kclass = KC_FGEMM_FWD;                 // alone on the machine: the roofline sample
-            TCK(launch_fgemm64(c, f));
-            HIPCK(c, hipEventRecord(c->ev_a, c->stream));
-            HIPCK(c, hipStreamWaitEvent(c->stream2, c->ev_a, 0));
-            const int lf = c->overlap == 2 ? 2 : (c->overlap == 3 && c->env64() ? 3 : 1), lm = lf == 2 ? 2 : 1;   // overlap = 2: 64-image label-dot blocks; 3: two rows in flight per wave
-            TCK(launch_labeldot_blocks(c, a, 0, b1 * lm, c->stream2, KC_LABELDOT_OVL, lf));
-            HIPCK(c, hipEventRecord(c->ev_b, c->stream2));
-            f.n_off = b1 * 128; f.n_cnt = b2 * 128; f.kclass = KC_FGEMM_FWD_OVL;
-            TCK(launch_fgemm64(c, f));
-            TCK(launch_labeldot_blocks(c, a, b1 * lm, b2 * lm, c->stream, KC_LABELDOT, lf));   // alone again: the HBM roofline sample
-            HIPCK(c, hipStreamWaitEvent(c->stream, c->ev_b, 0));
-            return launch_labeldot_reduce(c, nblk * lm, tail);
+            return launch_labeldot_reduce(c, ff.ntiles, tail, mode == LD_MODE_PAP ? 1 : 0);
         }
         TCK(launch_fgemm64(c, f));
     } else {
@@ -774,35 +782,37 @@ static int forward_pass(tnml_ctx* c, const double* vec, int mode, double* tail, 
     }
     return launch_labeldot(c, a, tail);
 }
-// G = sum_n dP_n*dag(t.v) over all ranks for the bond tensor in vB; cost partials ride in the tail
-static int grad_eval(tnml_ctx* c, bool from_P_update = false, bool outputs_current = false, bool weights_pp = false) {
+// G = sum_n dP_n*dag(t.v) over all ranks for the bond tensor in vB; cost partials ride in the tail.
+// weights_pp: the image sum A p = sum_n (p.v_n) v_n instead, weights p.v_n as left in Pp by the pAp pass (fast_conj of the per-label
+// variant, single.h:347-379, and the merged CG of every variant); the tail is left as it is
+static int grad_eval(tnml_ctx* c, bool from_P_update = false, bool outputs_current = false, bool weights_pp = false, bool reduce = true) {
     const BondPlan& p = c->plan;
     const size_t n = p.msize();
-    // weights_pp (fast_conj, per-label variant only): the image sum A p = sum_n (p.v_n) v_n, weights p.v_n as left in Pp by the pAp pass
-    if (weights_pp) { if (p.kind != 2) return tnml_fail(c, "grad_eval: weights_pp needs the per-label variant"); }
-    else if (outputs_current)    { if (!c->tail_zeroed) HIPCK(c, hipMemsetAsync(c->vG + n, 0, sizeof(double) * TNML_NSCAL_AR, c->stream)); }   // P/dP already hold B*t.v and the residuals (the pack kernel of tnml_bond_update has cleared the tail)
-    else if (from_P_update) TCK(launch_pupdate(c, c->scal + SC_ALPHA, c->vG + n));          // P += a (p*t.v): no GEMM
-    else                    TCK(forward_pass(c, c->vB, LD_MODE_COST, c->vG + n, c->fast_cg)); // keeps P when fast CG is on
+    if (weights_pp) {}
+    else if (outputs_current)    { if (!c->tail_zeroed) HIPCK(c, hipMemsetAsync(c->tail, 0, sizeof(double) * TNML_NSCAL_AR, c->stream)); }   // P/dP already hold B*t.v and the residuals (the pack kernel of tnml_bond_update has cleared the tail)
+    else if (from_P_update) TCK(launch_pupdate(c, c->scal + SC_ALPHA, c->tail));          // P += a (p*t.v): no GEMM
+    else                    TCK(forward_pass(c, c->vB, LD_MODE_COST, c->tail, c->fast_cg)); // keeps P when fast CG is on
+    const void* wsrc = weights_pp ? c->Pp : c->dP;           // the per-image weights of the sum
     const bool fuse = c->f64() && c->fuse_z && p.kind != 2;
-    if (p.kind != 2 && !fuse) TCK(launch_zprime(c, p.EX, (size_t)p.mO * c->NTp, c->dP, c->Zp, p.mO, c->NTp));
+    if (p.kind != 2 && !fuse) TCK(launch_zprime(c, p.EX, (size_t)p.mO * c->NTp, wsrc, c->Zp, p.mO, c->NTp));
     if (c->f64()) {
         Bgemm64Args g;
         g.EL = nullptr; g.EL_lstride = 0; g.dPz = nullptr; g.env64 = c->env64();
         g.EI = p.EI; g.mI = p.mI; g.phiI = p.phiI; g.phiO = p.phiO; g.mO = p.mO;
         g.Kp = p.Kp; g.Np = p.Np; g.NTp = c->NTp; g.L = p.LB;
-        if (p.kind == 2) { g.Zq64 = nullptr; g.Zq32 = p.EX; g.w = (const double*)(weights_pp ? c->Pp : c->dP); g.w_lstride = c->NTp; }
-        else if (fuse)   { g.Zq64 = nullptr; g.Zq32 = nullptr; g.w = nullptr; g.w_lstride = 0; g.EL = p.EX; g.EL_lstride = (size_t)p.mO * c->NTp; g.dPz = (const double*)c->dP; }
+        if (p.kind == 2) { g.Zq64 = nullptr; g.Zq32 = p.EX; g.w = (const double*)wsrc; g.w_lstride = c->NTp; }
+        else if (fuse)   { g.Zq64 = nullptr; g.Zq32 = nullptr; g.w = nullptr; g.w_lstride = 0; g.EL = p.EX; g.EL_lstride = (size_t)p.mO * c->NTp; g.dPz = (const double*)wsrc; }
         else             { g.Zq64 = (const double*)c->Zp; g.Zq32 = nullptr; g.w = nullptr; g.w_lstride = 0; }
         TCK(launch_bgemm64(c, g, c->vG));
     } else {
         BgemmArgs g;
         g.EI = (const float*)p.EI; g.mI = p.mI; g.phiI = (const float*)p.phiI; g.phiO = (const float*)p.phiO; g.mO = p.mO;
         g.Kp = p.Kp; g.Np = p.Np; g.NTp = c->NTp; g.L = p.LB;
-        if (p.kind == 2) { g.Zq = (const float*)p.EX; g.w = (const float*)(weights_pp ? c->Pp : c->dP); g.w_lstride = c->NTp; }
+        if (p.kind == 2) { g.Zq = (const float*)p.EX; g.w = (const float*)wsrc; g.w_lstride = c->NTp; }
         else             { g.Zq = (const float*)c->Zp; g.w = nullptr; g.w_lstride = 0; }
         TCK(launch_bgemm(c, g, c->vG));
     }
-    return allreduce(c, c->vG, n + TNML_NSCAL_AR);
+    return reduce ? allreduce_packed(c, n) : 0;
 }
 static int read_scal(tnml_ctx* c, const double* dev, int count, double* host_out) {
     double* h = c->h_scal + 2 * c->svd_n + 64;
@@ -821,19 +831,30 @@ static int cgrad_device(tnml_ctx* c, int npass, double lambda, double cconv, boo
     if (npass < 1 || npass > TNML_MAX_PASS) return tnml_fail(c, "cgrad: Npass must be in 1..%d", TNML_MAX_PASS);
     const size_t n = c->plan.msize();
     const bool fastc = c->single() && c->cg_method == 1;   // method = fast_conj of the per-label variant (single.h:290-398)
+    // Merged passes (one all-reduce per pass instead of two): with P <- P + a (p*t.v) already in use, the image sum of a pass can be
+    // A p = sum_n (p.v_n) v_n -- formed from the pAp pass's own outputs BEFORE alpha is known -- so that it travels with
+    // sum_n |p.v_n|^2; the residual then follows nr = r - a (A p + lambda p) instead of being re-summed from the new dP (the same
+    // algebra; rounding differs at 1e-16 |r| per pass).  The cost partials of a pass's update ride in the NEXT pass's all-reduce.
+    // It is used where it buys something -- when the sum over images is also a sum over ranks (merged_cg = 1) -- because the
+    // recurrence is not the reference's literal order: on the reference's own, badly conditioned feature map the fourth step size of
+    // a Label-on-B bond moves by 1e-3 (the cost by 1e-10); merged_cg = 2 forces it on a single rank (parity tests), 0 disables it.
+    const bool merged = c->fast_cg && !fastc && (c->merged_cg >= 2 || (c->merged_cg == 1 && (c->comm || c->local)));
     TCK(grad_eval(c, false, outputs_current));           // :374-385
     TCK(launch_cg_init(c, n, lambda, c->single() ? cconv : -1.));   // :386-388 (single.h:200-208 with the entry check)
     for (int pass = 1; pass <= npass; ++pass) {          // :389
         c->cg_pass = pass;
-        TCK(forward_pass(c, c->vP, LD_MODE_PAP, c->vG + n, c->fast_cg || fastc));   // :394-401 (keeps p*t.v for the fast update)
-        TCK(allreduce(c, c->vG + n, TNML_NSCAL_AR));                  // :402
-        TCK(launch_cg_step(c, n, lambda, pass));         // :403-407
+        TCK(forward_pass(c, c->vP, LD_MODE_PAP, c->tail, c->fast_cg || fastc));   // :394-401 (keeps p*t.v for the fast update)
+        if (merged && pass < npass) TCK(grad_eval(c, false, false, true));        // A p, all-reduced with the tail
+        else TCK(allreduce(c, c->tail, TNML_NSCAL_AR));                            // :402
+        TCK(launch_cg_step(c, n, lambda, pass, merged)); // :403-407
         if (pass == npass) break;                        // :409
-        if (fastc) {                                     // single.h:347-379: A p from the p.v of this pass, residual by recurrence
+        if (merged) {
+            TCK(launch_pupdate(c, c->scal + SC_ALPHA, c->tail));                  // P, dP and the cost partials of the new B (:414-420, without the GEMM)
+        } else if (fastc) {                              // single.h:347-379: A p from the p.v of this pass, residual by recurrence
             TCK(grad_eval(c, false, false, true));
             TCK(launch_cg_fast_resid0(c, n, pass));
         } else TCK(grad_eval(c, c->fast_cg));            // :412-421
-        TCK(launch_cg_resid(c, n, lambda, cconv, pass)); // :422-428, :432-436, :442
+        TCK(launch_cg_resid(c, n, lambda, cconv, pass, merged)); // :422-428, :432-436, :442
     }
     return 0;
 }
@@ -865,10 +886,9 @@ static int cgrad_fetch_trace(tnml_ctx* c, int npass, tnml_cg_trace* tr) {
 // launches only: cost partials, #correct and |B|^2 end up in the 13 doubles behind G (t[0..9] per-label costs, t[10] ncorrect, t[12] |B|^2)
 static int quadcost_launch(tnml_ctx* c, bool want_P) {
     const size_t n = c->plan.msize();
-    double* tail = c->vG + n;
-    TCK(forward_pass(c, c->vB, LD_MODE_COST, tail, want_P));
-    TCK(allreduce(c, tail, TNML_NSCAL_AR));
-    TCK(launch_sqnorm(c, c->vB, n, tail + 12));                 // |B|^2 rides behind the cost partials
+    TCK(forward_pass(c, c->vB, LD_MODE_COST, c->tail, want_P));
+    TCK(allreduce(c, c->tail, TNML_NSCAL_AR));
+    TCK(launch_sqnorm(c, c->vB, n, c->tail + 12));              // |B|^2 rides behind the cost partials (local: written after the reduction)
     return 0;
 }
 static void quadcost_parse(tnml_ctx* c, const double* t, double lambda, double* cost, double* label_cost, double* reg_cost, int64_t* ncorrect) {
@@ -885,7 +905,7 @@ static void quadcost_parse(tnml_ctx* c, const double* t, double lambda, double* 
 static int quadcost_device(tnml_ctx* c, double lambda, double* cost, double* label_cost, double* reg_cost, int64_t* ncorrect, bool want_P) {
     TCK(quadcost_launch(c, want_P));
     double t[13];
-    TCK(read_scal(c, c->vG + c->plan.msize(), 13, t));
+    TCK(read_scal(c, c->tail, 13, t));
     quadcost_parse(c, t, lambda, cost, label_cost, reg_cost, ncorrect);
     return 0;
 }
@@ -893,8 +913,9 @@ static int quadcost_device(tnml_ctx* c, double lambda, double* cost, double* lab
 // One-sided Jacobi (Hestenes) SVD of a tall column-major matrix A (R x C, R >= C), in place on the host: on return column j of A
 // is u_j s_j, V (C x C) holds the right singular vectors, s the singular values (unsorted).  Small singular values keep their
 // relative accuracy, which the pcut test of the exact solver needs (a Gram matrix loses everything below sqrt(eps) s_max).
-static void hestenes_svd(int R, int C, double* A, double* sv, double* V) {
+static bool hestenes_svd(int R, int C, double* A, double* sv, double* V) {      // false: 60 sweeps did not converge
     for (int j = 0; j < C; ++j) for (int i = 0; i < C; ++i) V[i + (size_t)C * j] = i == j ? 1. : 0.;
+    bool converged = false;
     for (int sweep = 0; sweep < 60; ++sweep) {
         bool rotated = false;
         for (int p = 0; p < C - 1; ++p)
@@ -911,9 +932,10 @@ static void hestenes_svd(int R, int C, double* A, double* sv, double* V) {
                 double* vp = V + (size_t)C * p; double* vq = V + (size_t)C * q;
                 for (int i = 0; i < C; ++i) { const double x = vp[i], y = vq[i]; vp[i] = cs * x - sn * y; vq[i] = sn * x + cs * y; }
             }
-        if (!rotated) break;
+        if (!rotated) { converged = true; break; }
     }
     for (int j = 0; j < C; ++j) { double t = 0.; const double* a = A + (size_t)R * j; for (int i = 0; i < R; ++i) t += a[i] * a[i]; sv[j] = std::sqrt(t); }
+    return converged;
 }
 // exact (single.h:117-160, per-label variant): B = y Phi^+ with the filtered inverse s/(s^2 + lambda) above pcut, Phi = [v_1 ... v_NT]
 // (D x NT, D = 4 mL mR).  "Only works for rather small number of training samples" (single.h:114).  The dense per-image tensors
@@ -929,7 +951,9 @@ static int exact_device(tnml_ctx* c, double lambda, double pcut) {
     const PackDesc pd = bond_pack_desc(p);
     const size_t n = p.msize();
     const int D = p.mL * 4 * p.mR, NT = c->NT;
-    if (D > 4096 || (double)D * NT > 4e8) return tnml_fail(c, "exact: %d unknowns x %d images -- the dense solver is meant for small problems", D, NT);
+    // the one-sided Jacobi below costs ~6 min(D, NT)^2 max(D, NT) flops per sweep on ONE host thread and needs up to a few dozen sweeps
+    if (D > 4096 || (double)D * NT > 4e8 || (double)std::min(D, NT) * std::min(D, NT) * std::max(D, NT) > 2e10)
+        return tnml_fail(c, "exact: %d unknowns x %d images -- the dense solver is meant for small problems (\"Only works for rather small number of training samples\", single.h:114)", D, NT);
     std::vector<double> Pt((size_t)NT * D);                             // Phi^T, column j = row j of Phi
     std::vector<int> lab((size_t)NT);
     HIPCK(c, hipMemcpyAsync(lab.data(), c->label, sizeof(int) * (size_t)NT, hipMemcpyDeviceToHost, c->stream));
@@ -937,7 +961,7 @@ static int exact_device(tnml_ctx* c, double lambda, double pcut) {
         HIPCK(c, hipMemsetAsync(c->tB2, 0, sizeof(double) * D, c->stream));
         TCK(launch_fill_f64(c, c->tB2 + j, 1.0, 1));
         TCK(launch_pack(c, pd, c->tB2, c->vP, nullptr));
-        TCK(forward_pass(c, c->vP, LD_MODE_PAP, c->vG + n, true));      // Pp[n] = v_n . e_j
+        TCK(forward_pass(c, c->vP, LD_MODE_PAP, c->tail, true));      // Pp[n] = v_n . e_j
         HIPCK(c, hipMemcpyAsync(Pt.data() + (size_t)NT * j, c->Pp, sizeof(double) * (size_t)NT, hipMemcpyDeviceToHost, c->stream));
     }
     HIPCK(c, hipStreamSynchronize(c->stream));
@@ -945,7 +969,7 @@ static int exact_device(tnml_ctx* c, double lambda, double pcut) {
     const int tgt = c->target();
     if (NT >= D) {                                                      // Phi^T = U S V^T: columns u_j s_j (images), V in tensor space
         std::vector<double> V((size_t)D * D), sv((size_t)D);
-        hestenes_svd(NT, D, Pt.data(), sv.data(), V.data());
+        if (!hestenes_svd(NT, D, Pt.data(), sv.data(), V.data())) return tnml_fail(c, "exact: the Jacobi SVD of the %d x %d design matrix did not converge in 60 sweeps", NT, D);
         for (int j = 0; j < D; ++j) {
             const double s1 = sv[j];
             if (!(s1 > pcut)) continue;                                 // pseudoInv, single.h:145-153
@@ -959,7 +983,7 @@ static int exact_device(tnml_ctx* c, double lambda, double pcut) {
     } else {                                                            // more unknowns than images: Phi = V' S U'^T on the D x NT matrix
         std::vector<double> Ph((size_t)D * NT), U((size_t)NT * NT), sv((size_t)NT);
         for (int j = 0; j < D; ++j) for (int i = 0; i < NT; ++i) Ph[j + (size_t)D * i] = Pt[i + (size_t)NT * j];
-        hestenes_svd(D, NT, Ph.data(), sv.data(), U.data());
+        if (!hestenes_svd(D, NT, Ph.data(), sv.data(), U.data())) return tnml_fail(c, "exact: the Jacobi SVD of the %d x %d design matrix did not converge in 60 sweeps", D, NT);
         for (int j = 0; j < NT; ++j) {
             const double s1 = sv[j];
             if (!(s1 > pcut)) continue;
@@ -997,7 +1021,7 @@ int tnml_forward(tnml_ctx* c, const double* B, double* P) {
     HIPCK(c, hipSetDevice(c->cfg.device));
     c->p_valid = false;
     TCK(upload_bond(c, B));
-    TCK(forward_pass(c, c->vB, LD_MODE_COST, c->vG + c->plan.msize(), true));
+    TCK(forward_pass(c, c->vB, LD_MODE_COST, c->tail, true));
     const size_t ne = (size_t)TNML_NL * c->NTp;
     std::vector<char> h(ne * c->esz());
     HIPCK(c, hipStreamSynchronize(c->stream));
@@ -1014,6 +1038,20 @@ int tnml_gradient(tnml_ctx* c, const double* B, double* G) {
     TCK(upload_bond(c, B));
     TCK(grad_eval(c));
     return download_bond(c, c->vG, G);
+}
+// sum_n |p.v_n|^2 + lambda |p|^2 for a direction p (fixedL.cc:394-403), collective
+int tnml_pAp(tnml_ctx* c, const double* p, double lambda, double* pAp) {
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    c->p_valid = false;
+    TCK(upload_bond(c, p));
+    const size_t n = c->plan.msize();
+    TCK(forward_pass(c, c->vB, LD_MODE_PAP, c->tail, false));
+    TCK(allreduce(c, c->tail, TNML_NSCAL_AR));
+    TCK(launch_sqnorm(c, c->vB, n, c->tail + 12));
+    double t[13];
+    TCK(read_scal(c, c->tail, 13, t));
+    if (pAp) *pAp = t[SC_PP] + lambda * t[12];
+    return 0;
 }
 int tnml_quadcost(tnml_ctx* c, const double* B, double lambda, double* cost, double label_cost[TNML_NL], double* reg_cost, int64_t* ncorrect) {
     HIPCK(c, hipSetDevice(c->cfg.device));
@@ -1075,9 +1113,9 @@ int tnml_bond_update_begin(tnml_ctx* c, int b, int ha, const tnml_sweep_params* 
     TCK(launch_bond_form(c, c->W[b], c->W[b + 1], c->tB));            // :494
     bool outputs_current = c->reuse_p && c->p_valid;                  // left by the previous bond update's quadcost
     c->p_valid = false;
-    // with carried outputs no label dot rewrites the [cost | ncorrect | pAp] tail behind G before the first all-reduce: the
+    // with carried outputs no label dot rewrites the [cost | ncorrect | pAp] head of the tail before the first all-reduce: the
     // pack kernel clears it on the way
-    TCK(launch_pack(c, pd, c->tB, c->vB, nullptr, outputs_current && !sp->report_costs ? c->vG + p.msize() : nullptr, TNML_NSCAL_AR));
+    TCK(launch_pack(c, pd, c->tB, c->vB, nullptr, outputs_current && !sp->report_costs ? c->tail : nullptr, TNML_NSCAL_AR));
     c->tail_zeroed = outputs_current && !sp->report_costs;
     if (sp->report_costs) {                                           // single.h:572,621: norm(oB), quadcost(oB)
         TCK(quadcost_device(c, sp->lambda_cost, &rep->cost_old, nullptr, nullptr, nullptr, true));
@@ -1089,23 +1127,47 @@ int tnml_bond_update_begin(tnml_ctx* c, int b, int ha, const tnml_sweep_params* 
     else TCK(cgrad_device(c, sp->npass, sp->lambda, sp->cconv, outputs_current));   // :504
     c->tail_zeroed = false;
     if (sp->report_costs) TCK(quadcost_device(c, sp->lambda_cost, &rep->cost_cg, nullptr, &rep->reg_cost_cg, nullptr, false));   // single.h:622,626
+    if (c->carry_slot >= 0) { TCK(allreduce(c, c->tail + TNML_CARRY, TNML_CARRYN)); TCK(carry_deliver(c)); }   // (only when no packed all-reduce ran above: the exact solver)
     TCK(launch_unpack(c, pd, c->vB, c->tB));
     TCK(cgrad_trace_enqueue(c));                                      // lands with the split's own synchronisation (eigenvalues)
     TCK(svd_split_device(c, c->tB, b, ha, sp->cutoff, sp->maxm, sp->minm, &rep->truncerr, &rep->newm, nullptr, nullptr));   // :519-522
     cgrad_trace_parse(c, sp->npass, &rep->cg);
     if (exact) memset(&rep->cg, 0, sizeof rep->cg);               // no CG ran
     if (c->debug_nudge_rank == c->cfg.rank) TCK(launch_nudge(c, c->W[b].a));
+    // replicas: the two site tensors the split just wrote must be bit-identical on every rank.  Their fingerprint goes into the
+    // carried slots of the tail as exact integer pieces (mode 1: summed with the next packed all-reduce, checked when the report
+    // is handed out -- no collective of its own).  Mode 2 checks at once, BEFORE anything consumes the tensors (bond tensor, P/dP,
+    // the shifted environment): on a mismatch rank 0's two tensors replace everybody's, counted.
+    pr.fp = (c->comm || c->local) && c->check_replicas;
+    if (pr.fp) {
+        TCK(replica_fingerprint(c, b, b + 1, c->tail + TNML_FPSLOT));
+        if (c->check_replicas_mode == 2) {
+            TCK(allreduce(c, c->tail + TNML_FPSLOT, 8));
+            double* hf = pend_host(c, slot) + 48;
+            HIPCK(c, hipMemcpyAsync(hf, c->tail + TNML_FPSLOT, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIPCK(c, hipStreamSynchronize(c->stream));
+            if (!fingerprint_agrees(hf, c->cfg.nranks)) {             // every rank sees the same sums: every rank takes this branch together
+                for (int j = b; j <= b + 1; ++j) { SiteT& sT = c->W[j]; TCK(bcast_rank0(c, sT.a, (size_t)sT.ml * 2 * sT.mr * sT.L)); }
+                c->replica_repairs += 1;
+            }
+            pr.fp = false;                                            // settled
+        }
+    }
     TCK(launch_bond_form(c, c->W[b], c->W[b + 1], c->tB2));           // :527
     TCK(launch_pack(c, pd, c->tB2, c->vB, nullptr));
-    TCK(quadcost_launch(c, true));                                    // :532; P and dP stay for the next bond update
-    TCK(launch_diffnorm(c, c->tB2, c->tB, ne, c->vG + c->plan.msize() + 13));   // :528,:530 -> slots 13, 14 behind the cost partials
-    // the end-of-bond scalars come back in one copy, queued before the environment shift: no idle gap for them
-    double* hq = c->h_scal + 2 * c->svd_n + 64 + SC_N + 4 * TNML_MAX_PASS + 64 * slot;
-    HIPCK(c, hipMemcpyAsync(hq, c->vG + c->plan.msize(), sizeof(double) * TNML_NSCAL_AR, hipMemcpyDeviceToHost, c->stream));
-    pr.fp = (c->comm || c->local) && c->check_replicas;
-    if (pr.fp) {                                                      // the two site tensors the split just wrote must be bit-identical on every rank
-        TCK(replica_fingerprint(c, b, b + 1));
-        HIPCK(c, hipMemcpyAsync(hq + 32, c->fprint, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    // :532 quadcost(newB); P and dP stay for the next bond update.  Its cost partials land in the CARRIED slots of the tail.
+    TCK(forward_pass(c, c->vB, LD_MODE_COST, c->tail + TNML_CARRY, true));
+    double* loc = c->locals + 16 * slot;                              // local scalars: slot 12 |newB|^2, 13/14 of :528,:530
+    TCK(launch_sqnorm(c, c->vB, c->plan.msize(), loc + 12));
+    TCK(launch_diffnorm(c, c->tB2, c->tB, ne, loc + 13));
+    double* hq = pend_host(c, slot);
+    HIPCK(c, hipMemcpyAsync(hq, loc, sizeof(double) * 16, hipMemcpyDeviceToHost, c->stream));
+    const bool multi = c->comm || c->local;
+    if (multi && c->defer_tail) c->carry_slot = slot;                 // summed by the next packed all-reduce (tnml_bond_update_end flushes otherwise)
+    else {
+        c->carry_slot = slot;
+        if (multi) TCK(allreduce(c, c->tail + TNML_CARRY, TNML_CARRYN));
+        TCK(carry_deliver(c));
     }
     HIPCK(c, hipEventRecord(pr.ev, c->stream));
     TCK(tnml_shift_env(c, b, ha == 1));                               // :540
@@ -1118,25 +1180,20 @@ int tnml_bond_update_end(tnml_ctx* c, tnml_bond_report* rep) {
     if (c->pend_count < 1) return tnml_fail(c, "tnml_bond_update_end: no bond update in flight");
     const int slot = c->pend_tail;
     PendingReport& pr = c->pend[slot];
-    HIPCK(c, hipEventSynchronize(pr.ev));
-    c->pend_tail ^= 1; c->pend_count -= 1;
-    const double* hq = c->h_scal + 2 * c->svd_n + 64 + SC_N + 4 * TNML_MAX_PASS + 64 * slot;
-    if (pr.fp) {
-        unsigned long long h[2]; memcpy(h, hq + 32, sizeof h);
-        if (h[0] != ~h[1]) {
-            // every rank sees the same [max, ~min] pair, so every rank takes this branch together
-            if (c->check_replicas_mode != 2)
-                return tnml_fail(c, "bond %d: replicas of W.A(%d), W.A(%d) differ between ranks after the split", pr.rep.bond, pr.rep.bond, pr.rep.bond + 1);
-            // repair mode: rank 0's two site tensors replace everybody's (a last-bit difference, e.g. from a library GEMM that
-            // chose another kernel on another device); counted and reported, the sweep goes on
-            for (int j = pr.rep.bond; j <= pr.rep.bond + 1; ++j) {
-                SiteT& sT = c->W[j];
-                TCK(bcast_rank0(c, sT.a, (size_t)sT.ml * 2 * sT.mr * sT.L));
-            }
-            c->replica_repairs += 1;
-        }
+    if (c->carry_slot == slot) {                                      // nothing followed that would have carried them: one small all-reduce
+        TCK(allreduce(c, c->tail + TNML_CARRY, TNML_CARRYN));
+        TCK(carry_deliver(c));
     }
-    quadcost_parse(c, hq, pr.lambda_cost, &pr.rep.cost_after_svd, pr.rep.label_cost, &pr.rep.reg_cost, &pr.rep.ncorrect);
+    HIPCK(c, hipEventSynchronize(pr.ev));
+    HIPCK(c, hipEventSynchronize(pr.ev2));
+    c->pend_tail ^= 1; c->pend_count -= 1;
+    double* hq = pend_host(c, slot);
+    if (pr.fp && !fingerprint_agrees(hq + TNML_FPSLOT, c->cfg.nranks))   // every rank sees the same sums
+        return tnml_fail(c, "bond %d: replicas of W.A(%d), W.A(%d) differ between ranks after the split", pr.rep.bond, pr.rep.bond, pr.rep.bond + 1);
+    double t[13];
+    for (int l = 0; l < 12; ++l) t[l] = hq[TNML_CARRY + l];
+    t[12] = hq[12];
+    quadcost_parse(c, t, pr.lambda_cost, &pr.rep.cost_after_svd, pr.rep.label_cost, &pr.rep.reg_cost, &pr.rep.ncorrect);
     pr.rep.norm_newB = std::sqrt(hq[13]); pr.rep.diff_B_newB = std::sqrt(hq[14]);
     if (rep) *rep = pr.rep;
     return 0;

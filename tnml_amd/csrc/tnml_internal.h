@@ -31,11 +31,11 @@
 
 enum KClass {
     KC_FGEMM_FWD = 0, KC_FGEMM_SHIFT, KC_LABELDOT, KC_ZPRIME, KC_BGEMM, KC_SLABRED, KC_PACK, KC_VEC,
-    KC_SMALLGEMM, KC_SVD, KC_ALLREDUCE, KC_PUPDATE, KC_FGEMM_FWD_OVL, KC_LABELDOT_OVL, KC_FWD_FUSED, KC_COUNT
+    KC_SMALLGEMM, KC_SVD, KC_ALLREDUCE, KC_PUPDATE, KC_FWD_FUSED, KC_COUNT
 };
 static const char* const kclass_names[KC_COUNT] = {
     "fgemm_fwd", "fgemm_shift", "labeldot", "zprime", "bgemm", "slab_reduce", "pack", "cg_vec",
-    "small_gemm", "svd", "allreduce", "p_update", "fgemm_fwd_overlapped", "labeldot_overlapped", "fwd_fused"};
+    "small_gemm", "svd", "allreduce", "p_update", "fwd_fused"};
 
 struct EnvSlot {
     void* ptr = nullptr;    // [L][m][NTp], fp32 or fp64 elements (tnml_ctx::env64)
@@ -61,7 +61,17 @@ struct SiteT {
 enum { SC_COST0 = 0, /* ..9 */ SC_NCORR = 10, SC_PP = 11, SC_RR = 12, /* 13: second |r|^2 slot */ SC_ALPHA = 14, SC_BETA = 15,
        SC_PNORM2 = 16, SC_BNORM2 = 17, SC_PAP = 18, SC_RNORM = 19, SC_COST = 20, SC_CONV = 21 /* host copy of the flag */, SC_CONV_NEXT = 22, SC_NPASS = 23, SC_CONVP = 24 /* ,25: the flag by pass parity */,
        SC_NORMS = 28 /* |newB|^2, |B-newB|^2 */, SC_N = 32 };
-#define TNML_NSCAL_AR 16   /* scalars that ride behind G in the all-reduce buffer */
+// The all-reduce buffer of a rank is [tail (TNML_TAILN) | G (Kp*Np*LB)]: the scalars ride IN FRONT of the gradient, at a fixed place.
+//   tail[0..9]  per-label cost partials, [10] #correct, [11] sum |p.v_n|^2 (the pAp pass), [12..14] local (not summed) scalars of
+//               tnml_quadcost: |B|^2, |newB|^2, |B - newB|^2 -- written AFTER the reduction
+//   tail[16..26] the same cost partials of the "after SVD" quadcost of a bond update, [32..39] the replica fingerprint of the two site
+//               tensors the split wrote, as exact integer pieces (see fingerprint_pieces): both are produced at the END of a bond
+//               update and ride in the FIRST all-reduce of the next one (or in one small all-reduce when nothing follows)
+#define TNML_NSCAL_AR 16   /* live CG scalars at the head of the tail */
+#define TNML_TAILN 48
+#define TNML_CARRY 16      /* first carried slot */
+#define TNML_FPSLOT 32     /* first fingerprint slot (8 doubles) */
+#define TNML_CARRYN 24     /* carried doubles: slots 16..39 */
 
 struct BondPlan {
     int b = -1;
@@ -75,21 +85,16 @@ struct BondPlan {
 };
 
 struct ProfPending { hipEvent_t e0, e1; int kc; };
-struct PendingReport { tnml_bond_report rep; double lambda_cost = 0.; hipEvent_t ev = nullptr; bool fp = false; };
+struct PendingReport { tnml_bond_report rep; double lambda_cost = 0.; hipEvent_t ev = nullptr, ev2 = nullptr; bool fp = false; };
 
 struct tnml_ctx {
     tnml_config cfg;
     int N = 0, NT = 0, NTp = 0, c0 = 0, maxm = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;   // second queue: the HBM-bound label dot of one image half runs beside the MFMA-bound feature GEMM of the other
-    hipEvent_t ev_a = nullptr, ev_b = nullptr;
-    int overlap = 0;                 // two-queue forward pass (measured slower); env TNML_OVERLAP / option "overlap"
     int fused_fwd = 1;               // forward pass as one persistent kernel (kernels_fused.hip): 1 = from 14 336 images per rank on, 0 never, 2 always; env TNML_FUSED_FWD / option "fused_fwd"
     int cg_method = 0;               // per-label variant: 0 = conj (single.h:162-288), 1 = fast_conj (single.h:290-398), 2 = exact (single.h:117-160); option "cg_method"
     double pcut = 1e-8;              // PCut of the exact solver (single.cc:50); tnml_set_option_real "pcut"
     int sytrd_exit = 1;              // rank-adaptive exit of the tridiagonalisation of the split's Gram matrix (eigh.hip); option "sytrd_exit", env TNML_SYTRD_TOL=0 disables
-    int snake = 0, stream_dir = 0;   // alternate the traversal direction of consecutive passes over the Label-carrying environment (MALL reuse); env TNML_SNAKE / option "snake"
-    int bgemm_ps = 0;                // gradient GEMM with producer / consumer waves (kernels_fused.hip, measured slower); env TNML_BGEMM_PS / option "bgemm_ps"
     rocblas_handle blas = nullptr;
     ncclComm_t comm = nullptr;
     struct LocalComm* local = nullptr;   // in-process communicator of ranks sharing one device (local_comm.hip)
@@ -124,7 +129,8 @@ struct tnml_ctx {
     float* Mf = nullptr;       // fp32 GEMM operand, M-layout, capacity 10*Kmax*Kmax (env shifts, F32 mode)
     void* slab = nullptr;      // split-K partial slabs
     size_t slab_bytes = 0;
-    bool f64() const { return cfg.dtype != TNML_F32; }                 // fp64 MFMA arithmetic
+    bool f64() const { return cfg.dtype == TNML_F64 || cfg.dtype == TNML_F64_E32; }   // fp64 MFMA arithmetic
+    int bf16() const { return cfg.dtype == TNML_BF16 ? 1 : (cfg.dtype == TNML_BF16X3 ? 2 : 0); }   // forward feature GEMM on the bf16 matrix pipe: 1 plain, 2 hi + lo split
     bool env64() const { return cfg.dtype == TNML_F64; }
     bool single() const { return cfg.mode == TNML_MODE_SINGLE; }
     int nl() const { return single() ? 1 : TNML_NL; }
@@ -133,7 +139,17 @@ struct tnml_ctx {
     size_t eesz() const { return env64() ? 8 : 4; }
     double* partials = nullptr;  // [nblk][16]
     int partial_cap = 0;
-    double *vB = nullptr, *vR = nullptr, *vP = nullptr, *vG = nullptr;   // CG vectors, M-layout fp64 (vG has TNML_NSCAL_AR tail)
+    double *vB = nullptr, *vR = nullptr, *vP = nullptr;   // CG vectors, M-layout fp64
+    double* arbuf = nullptr;   // the all-reduce buffer [tail | G]
+    double* tail = nullptr;    // = arbuf
+    double* vG = nullptr;      // = arbuf + TNML_TAILN: gradient / A p, M-layout
+    double* locals = nullptr;  // [2][16] device: the local scalars (|B|^2, |newB|^2, |B - newB|^2) of the bond updates in flight
+    int merged_cg = 1;         // (1: with a communicator, 2: always, 0: never) CG passes with ONE all-reduce each: A p = sum_n (p.v_n) v_n is formed from the pAp pass's outputs before alpha is
+                               // known and rides with sum |p.v_n|^2; the residual follows r <- r - alpha (A p + lambda p) (the structure of the
+                               // reference's own fast_cgrad, single.h:347-379).  Needs fast_cg.  env TNML_MERGED_CG / option "merged_cg"
+    bool defer_tail = true;    // multi-rank: the after-SVD cost partials and the replica fingerprint ride in the next bond update's first all-reduce
+    int carry_slot = -1;       // pending report whose carried slots have not been reduced yet
+    long allreduce_calls = 0, bcast_calls = 0;  // collectives entered: sum all-reduces (the payload) and broadcasts (rank 0's eigenvalues), for tests and the bench line
     double* scal = nullptr;    // device scalars [SC_N]
     double* cgtrace = nullptr; // device CG trace [TNML_MAX_PASS][4] = pAp, alpha, cost, |r|
     double* vpart = nullptr;   // per-workgroup partial sums of the CG vector kernels [256][2]
@@ -147,13 +163,17 @@ struct tnml_ctx {
     double *sM = nullptr, *sG = nullptr, *sD = nullptr, *sE = nullptr, *sF = nullptr;
     double *sE2 = nullptr, *sTau = nullptr, *sV = nullptr, *sC = nullptr;   // eigh.hip: subdiagonal, tau, reflectors, tridiagonal eigenvectors
     double *sW = nullptr, *sScr = nullptr, *sS = nullptr, *sCm = nullptr, *sQ1 = nullptr, *sDev = nullptr;   // own tridiagonal eigensolver + Newton-Schulz polish
-    double* sBT = nullptr;     // compact-WY T factors of the blocked back transformation: [32][8][8]
+    void* mc_xbuf = nullptr;   // exchange buffer of the multi-workgroup tridiagonalisation (eigh_mc.hip), contexts with maxm > 120 only
+    unsigned mc_epoch = 0;
+    bool attr_sytrd = false, attr_invit = false, attr_fused = false;   // per-device function attributes set (a process may drive several devices)
+    int cu_count = 0;
     double svd_last_dev0 = 0., svd_last_dev1 = 0.;   // max|Q^T Q - I| before the 1st / 2nd polish step of the last split
     long svd_fallbacks = 0, svd_cholqr = 0;
     double last_bnorm = 0.;         // |B| of the last quadcost
     int* sInfo = nullptr;
-    unsigned long long* fprint = nullptr;   // [2] device: fingerprint of replicated tensors and its complement
-    int check_replicas_mode = 1;            // 1: a mismatch is an error; 2: rank 0's site tensors are re-broadcast and the event is counted
+    unsigned long long* fprint = nullptr;   // [2] device: fingerprint of replicated tensors (and its complement)
+    int check_replicas_mode = 1;            // 1: a mismatch is an error (checked with the deferred tail: no extra collective); 2: checked at once, inside the bond update
+                                            //    and before the environment shift; on a mismatch rank 0's two site tensors are re-broadcast and the event is counted
     long replica_repairs = 0;
     int debug_nudge_rank = -1;              // test hook: this rank's copy of W.A(b) is moved by one ulp after every split
     bool check_replicas = true;             // multi-rank: compare the fingerprints of W[b], W[b+1] after every bond update (env TNML_CHECK_REPLICAS=0 disables)
@@ -233,7 +253,6 @@ struct Bgemm64Args {
     int env64;
 };
 int launch_bgemm64(tnml_ctx* c, const Bgemm64Args& a, double* G);
-int launch_bgemm_ps(tnml_ctx* c, const Bgemm64Args& a, double* G);      // kernels_fused.hip: producer / consumer waves
 void launch_slab_reduce64(tnml_ctx* c, const double* slab, double* G, size_t n, int nsplit);
 
 // ---- kernels_stream.hip -------------------------------------------------------------------
@@ -255,7 +274,7 @@ struct LdotArgs {
 int launch_labeldot(tnml_ctx* c, const LdotArgs& a, double* scal_out);
 // the two halves of launch_labeldot for a split launch: blocks [blk_off, blk_off + nblk) on `st`, then the reduction of ALL partials
 int launch_labeldot_blocks(tnml_ctx* c, const LdotArgs& a, int blk_off, int nblk, hipStream_t st, int kclass, int form = 0);   // form 1: 128-image blocks, 2: 64-image blocks, 0: by image count
-int launch_labeldot_reduce(tnml_ctx* c, int nblk_total, double* scal_out);
+int launch_labeldot_reduce(tnml_ctx* c, int nblk_total, double* scal_out, int only_sum = 0);   // only_sum: write slot 11 alone (the pAp pass must leave the cost partials in place)
 bool labeldot_streaming(const tnml_ctx* c, int NTp);   // the 128-images-per-workgroup form is in use
 int launch_pupdate(tnml_ctx* c, const double* alpha_dev, double* scal_out);     // uses c->nl(), c->target()
 int launch_zprime(tnml_ctx* c, const void* EL, size_t lstride, const void* dP, void* Z, int mq, int NTp);
@@ -272,7 +291,6 @@ struct FwdFusedArgs {
     double* P; double* dP;                            // [10][NTp], either may be null
     int mode;                                         // LD_MODE_*
     double* partials;                                 // [ntiles][12]
-    int rev;                                          // 1: tiles are visited from the last image to the first (results identical)
 };
 int launch_fwd_fused(tnml_ctx* c, const FwdFusedArgs& a);
 
@@ -299,8 +317,8 @@ int launch_cvt(tnml_ctx* c, const double* src, float* dst, size_t n);
 int launch_bond_form(tnml_ctx* c, const SiteT& A1, const SiteT& A2, double* B);            // B = A1*A2, ITensor layout
 // CG vector algebra on device scalars (single-block kernels)
 int launch_cg_init(tnml_ctx* c, size_t n, double lambda, double cconv0);   // cconv0 < 0: no entry check          // r = G - lambda B ; p = r ; RR = |r|^2
-int launch_cg_step(tnml_ctx* c, size_t n, double lambda, int pass);          // pAp, alpha, B += alpha p
-int launch_cg_resid(tnml_ctx* c, size_t n, double lambda, double cconv, int pass);
+int launch_cg_step(tnml_ctx* c, size_t n, double lambda, int pass, bool merged = false);          // pAp, alpha, B += alpha p (merged: also the cost of the previous pass)
+int launch_cg_resid(tnml_ctx* c, size_t n, double lambda, double cconv, int pass, bool merged = false);   // merged: G holds A p, residual by recurrence
 int launch_cg_fast_resid0(tnml_ctx* c, size_t n, int pass);      // fast_conj: G <- r - a*G before launch_cg_resid   // nr, beta, r, cost, conv, p
 int launch_sqnorm(tnml_ctx* c, const double* x, size_t n, double* out);    // out[0] = |x|^2
 int launch_diffnorm(tnml_ctx* c, const double* x, const double* y, size_t n, double* out2);  // out2[0]=|x|^2, out2[1]=|x-y|^2
@@ -308,19 +326,27 @@ int launch_fill_f32(tnml_ctx* c, float* p, float v, size_t n);
 int launch_fill_f64(tnml_ctx* c, double* p, double v, size_t n);
 int launch_nudge(tnml_ctx* c, double* p);
 int launch_fingerprint(tnml_ctx* c, const double* x, size_t n, unsigned long long salt, unsigned long long* acc, bool reset);
+int launch_fingerprint_pieces(tnml_ctx* c, const unsigned long long* acc, double* out8);   // 16-bit pieces p_i and p_i^2 of the 64-bit fingerprint: sums over ranks stay exact
 
 // ---- eigh.hip -----------------------------------------------------------------------------
 int eigh_tridiagonalize(tnml_ctx* c, const double* A, int n, double* D, double* E, double* tau, double* V, double psd_tol = 0.);   // tau: n doubles, tau[n-1] = number of reflectors
 int eigh_tridiag_eig(tnml_ctx* c, const double* D, const double* E, int n, double* W, int mk, double* Z, int ldz, double* scratch);
 int eigh_ns_matrix(tnml_ctx* c, const double* S, double* Cm, int m, double* dev);
-int eigh_chol_rinv(tnml_ctx* c, const double* S, int m, double* Rinv, double* flag);   // m <= 136
-#define TNML_CHOL_MAXM 136
+int eigh_chol_rinv(tnml_ctx* c, const double* S, int m, double* Rinv, double* flag);   // m <= 128
+#define TNML_CHOL_MAXM 128
+#define TEIG_SCRATCH_DOUBLES 4096        // eigh_tridiag_eig scratch
+// ---- eigh_mc.hip: tridiagonalisation on a cluster of workgroups, 240 < n <= 640
+size_t eigh_mc_xbuf_bytes();
+int eigh_mc_max_n();
+int eigh_mc_tridiagonalize(tnml_ctx* c, hipStream_t st, const double* A, int n, double* D, double* E, double* tau, double* V, double psd_tol,
+                           void* xbuf, unsigned* epoch, long long* dbg = nullptr, int nap_first = 0, int nap_retry = 0, int same_xcd = 0);
+const void* eigh_mc_status_ptr(const void* xbuf);
 int eigh_backtransform(tnml_ctx* c, const double* V, const double* tau, int n, const double* Z, int ldz, double* U, int ldu, int ncols, hipStream_t st = nullptr);   // Z == nullptr: U = H_0 ... H_{n-2}
 
 // ---- local_comm.hip ----
 void local_comm_release(tnml_ctx* c);
 int local_comm_size(const tnml_ctx* c);
-int local_comm_exchange(tnml_ctx* c, double* buf, size_t count, int op);   // 0 sum, 1 broadcast from rank 0, 2 max of uint64 patterns
+int local_comm_exchange(tnml_ctx* c, double* buf, size_t count, int op);   // 0 sum, 1 broadcast from rank 0
 
 // rank 0's values to every rank, in stream order (no-op without a communicator)
 int bcast_rank0(tnml_ctx* c, double* buf, size_t count);

@@ -101,6 +101,12 @@ class TrainStates:
     def replica_repairs(self):
         return self._L.tnml_replica_repairs(self._h)
 
+    def collective_stats(self):
+        """(sum all-reduces, broadcasts) this rank has entered so far"""
+        a, b = C.c_int64(), C.c_int64()
+        self._ck(self._L.tnml_collective_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def set_option(self, name, value):
         self._ck(self._L.tnml_set_option(self._h, name.encode(), int(value)))
 
@@ -198,6 +204,12 @@ class TrainStates:
         self._ck(self._L.tnml_quadcost(self._h, _lib.dptr(_lib.flat(B)), lam, C.byref(cost), _lib.dptr(lc),
                                        C.byref(cr), C.byref(nc)))
         return cost.value, lc, cr.value, nc.value
+
+    def pAp(self, p, lam):
+        """sum_n |p*t.v_n|^2 + lambda |p|^2 (fixedL.cc:394-403)"""
+        out = C.c_double()
+        self._ck(self._L.tnml_pAp(self._h, _lib.dptr(_lib.flat(p)), lam, C.byref(out)))
+        return out.value
 
     def cgrad(self, B, npass, lam, cconv):
         buf = _lib.flat(B)
