@@ -449,3 +449,79 @@ def test_test_set_accuracy_within_a_tenth_of_a_percent_on_10000_images(tmp_path)
           "fulltest and toverlap: %d / %d" % (gpu_trained_correct, runs[1]["correct"], runs[8]["correct"], same_net_correct, runs[8]["correct"]))
     assert 0.80 * NTEST < runs[8]["correct"] < 0.995 * NTEST             # hard enough to resolve, easy enough to have learned
     assert d <= 0.001 * NTEST + spread
+
+
+@pytest.mark.gpu
+def test_c5_bond_updates_at_maxm_300_in_fp64_fp32_and_bf16():
+    """BASELINE config 5 (maxm = 300: fp64 vs fp32 vs bf16 bond contraction) on the HIP kernels, bond update by bond update in
+    lockstep with the oracle: bonds 10..13 of a 24-site chain at m = 300 (Label on the right environment, on B twice, on the left
+    environment), 24 images (the oracle's dense t.v is 29 MB per image at this bond dimension).  Each arithmetic starts every bond
+    update from the oracle's state.  The split is the 600 x 600 (6000 on the Label-on-B bonds) problem of eigh_mc.hip.
+      f64      fp64 MFMA, fp64 storage                         gated: cost 1e-8, bond dimension and #correct exact
+      f64_e32  fp64 MFMA over fp32-stored environments         gated: cost 1e-5
+      f32      v_mfma_f32_16x16x4_f32                          interior bonds gated at 1e-3
+      bf16x3   v_mfma_f32_16x16x32_bf16, operands hi + lo      forward map gated at 1e-4 (the kernel's operand layout), costs reported
+      bf16     v_mfma_f32_16x16x32_bf16                        forward map gated at 3e-2, costs reported (report-don't-gate)
+    The printed table is the m = 300 row set of DESIGN.md's tolerance study."""
+    from oracle import pyoracle
+    from tnml_amd.fixedl import TrainStates
+    from conftest import make_problem
+    N, NT, m = 24, 24, 300
+    npass, lam, cconv, cutoff, minm = 4, 1e-3, 1e-10, 1e-10, 150
+    pixels, labels, phi, W = make_problem(N, NT, m, 5, pixel_boost=200.0)
+    bonds = [10, 11, 12, 13]
+    o = pyoracle.Oracle(phi, labels, W, nthread=min(8, os.cpu_count() or 1))
+    o.init()
+    for bb in range(1, bonds[0]):
+        o.shiftE(bb, True)
+    ref = []                                                                   # the oracle's bond updates, once for all arithmetics
+    rng = np.random.default_rng(0)
+    for b in bonds:
+        o.set_bond(b)
+        B0 = o.bond_tensor(b)
+        Bt = B0 + 0.05 * np.abs(B0).max() * rng.standard_normal(B0.shape)       # a direction for the single-evaluation check
+        Pt = o.forward(Bt)
+        before = (o.get_site(b).copy(), o.get_site(b + 1).copy())
+        B, tr = o.cgrad(B0, npass, lam, cconv)
+        newm, te, _ = o.svd_split(B, b, 1, cutoff, m, minm)
+        C, lc, cr, nc = o.quadcost(o.bond_tensor(b), lam)
+        o.shiftE(b, True)
+        ref.append(dict(b=b, Bt=Bt, Pt=Pt, before=before, after=(o.get_site(b).copy(), o.get_site(b + 1).copy()), newm=newm, te=te, C=C, nc=nc,
+                        cg=tr["cost"]))
+    rows = []
+    for dtype in ("f64", "f64_e32", "f32", "bf16x3", "bf16"):
+        ts = TrainStates(labels, N, m, phi=phi, dtype=dtype)
+        ts.set_mps(W)
+        ts.init()
+        for bb in range(1, bonds[0]):
+            ts.shiftE(bb, True)
+        worst = {"interior": 0.0, "label_on_B": 0.0}
+        fwd = 0.0
+        dm = dn = 0
+        for r0 in ref:
+            b = r0["b"]
+            ts.set_site(b, r0["before"][0]); ts.set_site(b + 1, r0["before"][1])
+            ts.setBond(b)
+            fwd = max(fwd, _rel(ts.forward(r0["Bt"]), r0["Pt"]))
+            r = ts.bond_update(b, 1, m, minm, cutoff, npass, lam, cconv)
+            kind = "label_on_B" if r["label_on_B"] else "interior"
+            worst[kind] = max(worst[kind], abs(r["cost"] / r0["C"] - 1))
+            dm += int(r["newm"] != r0["newm"]); dn += abs(int(r["ncorrect"]) - int(r0["nc"]))
+            if dtype == "f64":
+                np.testing.assert_allclose(r["cg"]["cost"][:npass - 1], r0["cg"][:npass - 1], rtol=1e-8)
+                assert r["truncerr"] == pytest.approx(r0["te"], rel=1e-5, abs=1e-16)
+            ts.set_site(b, r0["after"][0]); ts.set_site(b + 1, r0["after"][1])   # lockstep: the next bond starts from the oracle's state
+            ts.shiftE(b, True)
+        stats = ts.svd_stats()
+        rows.append((dtype, fwd, worst["interior"], worst["label_on_B"], dm, dn, stats["fallbacks"]))
+        ts.close()
+    print("\nC5 (maxm = 300) lockstep, 4 bond updates per arithmetic: max rel. error of one forward evaluation | of the after-SVD cost, interior bonds | "
+          "Label-on-B bonds | bond-dimension mismatches | #correct differences | eigensolver fallbacks")
+    for rw in rows:
+        print("  %-8s %.2e | %.2e | %.2e | %d | %d | %d" % rw)
+    by = {r[0]: r for r in rows}
+    assert by["f64"][1] < 1e-11 and max(by["f64"][2], by["f64"][3]) < 1e-8 and by["f64"][4] == 0 and by["f64"][5] == 0 and by["f64"][6] == 0
+    assert by["f64_e32"][1] < 5e-5 and max(by["f64_e32"][2], by["f64_e32"][3]) < 1e-5 and by["f64_e32"][4] == 0
+    assert by["f32"][1] < 1e-4 and by["f32"][2] < 1e-3
+    assert by["bf16x3"][1] < 1e-4                                              # a wrong operand layout would give O(1)
+    assert by["bf16"][1] < 3e-2
