@@ -265,7 +265,12 @@ __global__ __launch_bounds__(MC_THREADS) void k_sytrd_mc(McArgs T) {
             double part = 0.;
             if (on) {
                 const double* yc = Ycol + c * MC_T + (cq & 7);
-                for (int Rr = Ci + 1 + h; Rr < nb; Rr += 4) part += yc[Rr * MC_LDC];
+                int Rr = Ci + 1 + h;
+                for (; Rr + 12 < nb; Rr += 16) {                     // four table rows per trip: their loads are in flight together (same order of addition)
+                    const double t0 = yc[Rr * MC_LDC], t1 = yc[(Rr + 4) * MC_LDC], t2 = yc[(Rr + 8) * MC_LDC], t3 = yc[(Rr + 12) * MC_LDC];
+                    part += t0; part += t1; part += t2; part += t3;
+                }
+                for (; Rr < nb; Rr += 4) part += yc[Rr * MC_LDC];
             }
             part += dpp_quad<0xB1>(part);                           // quad_perm [1,0,3,2]
             part += dpp_quad<0x4E>(part);                           // quad_perm [2,3,0,1]: (h0 + h1) + (h2 + h3) in every lane

@@ -707,6 +707,21 @@ int launch_fgemm64(tnml_ctx* c, const Fgemm64Args& a) {
             default: fgemm64_go<2, 4, 4, 2, 8>(c, a); break;    // 128 x 128, 8 waves, KT 8: best of tools/tune_shift.sh (profiles/r01_tune_shift.txt)
         }
     }
+    else if (a.Np > 256) {                                    // forward pass at maxm > 120 (BASELINE config 5: 600 columns)
+        static const int bcfg = getenv("TNML_FG64_BIG_CFG") ? atoi(getenv("TNML_FG64_BIG_CFG")) : 0;   // tools/tune_m300.sh, profiles/r03_tune_m300.txt
+        switch (bcfg) {
+            case 1:  fgemm64_go<2, 4, 2, 2, 16>(c, a); break;   // 64 x 128, 4 waves (the round-2 choice below 24 576 images)
+            case 2:  fgemm64_go<2, 4, 4, 2, 16>(c, a); break;   // 128 x 128, 8 waves
+            case 3:  fgemm64_go<2, 4, 4, 2, 8>(c, a); break;    // 128 x 128, 8 waves, KT 8
+            case 4:  fgemm64_go<1, 4, 4, 2, 16>(c, a); break;   // 64 x 128, 8 waves
+            case 5:  fgemm64_go<2, 5, 4, 2, 16>(c, a); break;   // 128 x 160, 8 waves
+            case 6:  fgemm64_go<1, 5, 4, 4, 16>(c, a); break;   // 64 x 320, 16 waves
+            case 7:  fgemm64_go<2, 5, 4, 3, 16>(c, a); break;   // 128 x 240, 12 waves (the m = 120 tile)
+            case 8:  fgemm64_go<1, 5, 4, 3, 16>(c, a); break;   // 64 x 240, 12 waves
+            case 9:  fgemm64_go<2, 2, 4, 4, 16>(c, a); break;   // 128 x 128, 16 waves
+            default: fgemm64_go<2, 5, 4, 2, 16>(c, a); break;   // 128 x 160, 8 waves: 122 us at m = 300, 7 500 images (64 x 128, 4 waves: 199 us)
+        }
+    }
     else if (a.Np > 64) {                                     // forward pass at 32 < m <= 64 (bonds that have shrunk towards minm)
         static const int gcfg = getenv("TNML_FG64_GEN_CFG") ? atoi(getenv("TNML_FG64_GEN_CFG")) : 0;   // tools/tune_m60.sh, profiles/r02_tune_m60.txt
         switch (gcfg) {
@@ -1013,6 +1028,28 @@ int launch_bgemm64(tnml_ctx* c, const Bgemm64Args& a, double* G) {
             if (gcfg == 3) return bgemm64_go<4, 2, 2, 4, 1>(c, a, G);                                  // 128 x 128, 8 waves: 151 us
             if (gcfg == 4) return bgemm64_go<2, 2, 4, 4, 1>(c, a, G);                                  // 128 x 128, 16 waves: 124 us
             if (gcfg != 7) return bgemm64_go<2, 2, 4, 2, 1>(c, a, G);                                  // 128 x 64, 8 waves: 70 us at m = 60 (96 x 64 tiles: 133 us)
+        }
+        if (a.Kp >= 256 && a.Np >= 256) {                                                              // maxm > 120 (BASELINE config 5: 600 x 600)
+            static const int lcfg = getenv("TNML_BGF_BIG_CFG") ? atoi(getenv("TNML_BGF_BIG_CFG")) : 0;   // tools/tune_m300.sh, profiles/r03_tune_m300.txt
+            switch (lcfg) {
+                case 1:  return bgemm64_go<2, 2, 3, 2, 1>(c, a, G);                                    // 96 x 64, 6 waves (the round-2 fallback: 336 us at m = 300, 7 500 images)
+                case 2:  return bgemm64_go<4, 2, 2, 4, 1>(c, a, G);                                    // 128 x 128, 8 waves
+                case 3:  return bgemm64_go<2, 2, 4, 4, 1>(c, a, G);                                    // 128 x 128, 16 waves
+                case 4:  return bgemm64_go<2, 2, 4, 2, 1>(c, a, G);                                    // 128 x 64, 8 waves
+                case 5:  return bgemm64_go<5, 1, 2, 6, 1>(c, a, G);                                    // 160 x 96, 12 waves
+                case 6:  return bgemm64_go<5, 2, 2, 4, 1>(c, a, G);                                    // 160 x 128, 8 waves
+                case 7:  return bgemm64_go<5, 1, 4, 4, 1>(c, a, G, 255 * a.L);                         // 320 x 64, 16 waves
+                case 8:  return bgemm64_go<5, 1, 3, 4, 1>(c, a, G, 256 * a.L);                         // 240 x 64, 12 waves (the m = 120 tile)
+                case 9:  return bgemm64_go<4, 1, 4, 4, 1>(c, a, G);                                    // 256 x 64, 16 waves
+                case 10: return bgemm64_go<5, 1, 2, 8, 1>(c, a, G);                                    // 160 x 128, 16 waves
+                case 11: return bgemm64_go<5, 1, 2, 4, 1>(c, a, G);                                    // 160 x 64, 8 waves
+                case 12: return bgemm64_go<4, 1, 2, 6, 1>(c, a, G);                                    // 128 x 96, 12 waves
+                case 13: return bgemm64_go<6, 1, 2, 6, 1>(c, a, G);                                    // 192 x 96, 12 waves
+                case 14: return bgemm64_go<5, 1, 2, 5, 1>(c, a, G);                                    // 160 x 80, 10 waves
+                case 15: return bgemm64_go<5, 1, 2, 6, 1>(c, a, G, 512);                               // 160 x 96, fewer image splits
+                case 16: return bgemm64_go<5, 1, 2, 6, 1>(c, a, G, 1024);                              // 160 x 96, more image splits
+                default: return bgemm64_go<5, 1, 2, 6, 1>(c, a, G);                                    // 160 x 96, 12 waves: 198 us at m = 300, 7 500 images (96 x 64: 336 us)
+            }
         }
         return bgemm64_go<2, 2, 3, 2, 1>(c, a, G);                                                     // 96 x 64, 6 waves
     }
