@@ -784,14 +784,20 @@ def test_single_and_separate_fulltest_cli(tmp_path):
     by = [list(np.flatnonzero(lab == l)) for l in range(10)]
     order = [by[l][k] for k in range(per_label) for l in range(10)]
     phi = pyoracle.features_single(px[order], True)
+    # BASELINE config 4: the ten per-label trainings through the driver's own launcher (`labels = all`: one child `single` per label in
+    # its directory L<n>; on this one-GPU box `share_device = yes` runs them one after the other on device 0)
+    allinp = tmp_path / "input_all"
+    allinp.write_text("input\n{\n%slabels = all\nshare_device = yes\nNtrain = %d\nNsweep = 1\ncutoff = 1E-10\nmaxm = 5\nminm = 2\nninitial = 3\n"
+                      "lambda = 1E-3\nNpass = 3\nseed = 4\nnthread = 2\n}\n" % (keys, per_label))
+    launch = subprocess.run([os.path.join(root, "tnml_amd", "single"), str(allinp)], capture_output=True, text=True, cwd=tmp_path, timeout=900)
+    assert launch.returncode == 0, launch.stdout[-1500:] + launch.stderr[-1500:]
+    assert "10 of 10 per-label trainings finished" in launch.stdout
     for L in range(10):
         wd = tmp_path / ("L%d" % L)
-        wd.mkdir()
-        inp = wd / "input"
-        inp.write_text("input\n{\n%slabel = %d\nNtrain = %d\nNsweep = 1\ncutoff = 1E-10\nmaxm = 5\nminm = 2\nninitial = 3\n"
-                       "lambda = 1E-3\nNpass = 3\nseed = 4\nnthread = 2\n}\n" % (keys, L, per_label))
-        run = subprocess.run([os.path.join(root, "tnml_amd", "single"), str(inp)], capture_output=True, text=True, cwd=wd, timeout=300)
-        assert run.returncode == 0, run.stdout[-1500:] + run.stderr[-1500:]
+        assert "label %d -> device 0, directory L%d" % (L, L) in launch.stdout and "label %d on device 0: done" % L in launch.stdout
+
+        class run:                                          # the child's log, where the per-label run used to be captured
+            stdout = (wd / "log").read_text()
         assert os.path.exists(wd / ("W%d" % L)) and "%d training images with selected label L=%d" % (per_label, L) in run.stdout
         if L in (3, 8):                                     # full trajectory check on two of the ten
             w0 = str(tmp_path / ("W0ref%d" % L))

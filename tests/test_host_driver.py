@@ -1,6 +1,7 @@
 """CPU tests of the host side of the fixedL drop-in (tnml_amd/host): input-file grammar, idx-ubyte
 reader with the reference's per-label selection, TNMLW1 weight files, initial-W builder."""
 import os
+import re
 import subprocess
 
 import numpy as np
@@ -170,3 +171,25 @@ def test_initial_w_of_the_per_label_variant(tmp_path):
     out2 = str(tmp_path / "W4b")
     hostlib.build_initial_single(data, per_label, 4, 5, 7, True, out2)
     assert all(np.array_equal(a, b) for a, b in zip(W, hostlib.read_mps(out2)))
+
+
+def test_per_label_launcher_plan_without_a_gpu(tmp_path):
+    """BASELINE config 4 ("single.cc per-label MPS x10, one label per GPU"): `single` with `labels = all` is a launcher -- one child per
+    label, at most one per GPU, the next label as soon as a device is free.  `dry_run = yes` prints the plan (no GPU, no data needed):
+    ten labels over four devices from device 2 on, and a comma list over the default eight."""
+    inp = tmp_path / "in"
+    inp.write_text("input\n{\nlabels = all\nngpu = 4\ndevice = 2\ndry_run = yes\n}\n")
+    run = subprocess.run([os.path.join(ROOT, "tnml_amd", "single"), str(inp)], capture_output=True, text=True, cwd=tmp_path, timeout=60)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "Per-label training of 10 labels on 4 GPUs" in run.stdout
+    plan = re.findall(r"label (\d) -> device (\d), directory L(\d), writes L(\d)/W(\d)", run.stdout)
+    assert [int(p[0]) for p in plan] == list(range(10)) and all(p[0] == p[2] == p[3] == p[4] for p in plan)
+    assert [int(p[1]) for p in plan] == [2, 3, 4, 5, 2, 3, 4, 5, 2, 3]
+    assert not any(os.path.isdir(tmp_path / ("L%d" % l)) for l in range(10))             # a dry run touches nothing
+    inp.write_text("input\n{\nlabels = 3,7\ndry_run = yes\n}\n")
+    run = subprocess.run([os.path.join(ROOT, "tnml_amd", "single"), str(inp)], capture_output=True, text=True, cwd=tmp_path, timeout=60)
+    assert run.returncode == 0 and "Per-label training of 2 labels on 8 GPUs" in run.stdout
+    assert re.findall(r"label (\d) -> device (\d)", run.stdout) == [("3", "0"), ("7", "1")]
+    inp.write_text("input\n{\nlabels = 3,12\ndry_run = yes\n}\n")
+    run = subprocess.run([os.path.join(ROOT, "tnml_amd", "single"), str(inp)], capture_output=True, text=True, cwd=tmp_path, timeout=60)
+    assert run.returncode != 0 and "not in 0..9" in run.stdout

@@ -1019,6 +1019,11 @@ int launch_bgemm64(tnml_ctx* c, const Bgemm64Args& a, double* G) {
         if (a.Kp % 240 == 0 && a.Np % 240 == 0) {
             if (fcfg == 1) return bgemm64_go<5, 1, 3, 5, 1>(c, a, G, 255 * a.L);   // 240 x 80, 15 waves (128-VGPR cap: spills)
             if (fcfg == 2) return bgemm64_go<5, 1, 3, 3, 1>(c, a, G, 255 * a.L);   // 240 x 48, 9 waves
+            if (fcfg == 3) return bgemm64_go<5, 2, 3, 4, 1>(c, a, G, 256 * a.L);   // 240 x 128, 12 waves: the Label-free environment is read twice, not four times
+            if (fcfg == 4) return bgemm64_go<4, 2, 2, 4, 1>(c, a, G, 256 * a.L);   // 128 x 128, 8 waves
+            if (fcfg == 6) return bgemm64_go<5, 2, 3, 2, 1>(c, a, G, 256 * a.L);   // 240 x 64, 6 waves
+            if (fcfg == 7) return bgemm64_go<5, 2, 3, 4, 1>(c, a, G, 512 * a.L);   // 240 x 128, two workgroups' worth of image splits per CU
+            if (fcfg == 8) return bgemm64_go<5, 1, 3, 4, 1>(c, a, G, 512 * a.L);   // 240 x 64, 12 waves, twice the image splits
             return bgemm64_go<5, 1, 3, 4, 1>(c, a, G, 256 * a.L);                  // 240 x 64, 12 waves: 187 us vs 153+90 unfused
         }
         if (a.Kp % 80 == 0 && a.Np % 80 == 0) return bgemm64_go<1, 5, 5, 1, 1>(c, a, G);               // 80 x 80, 5 waves

@@ -86,6 +86,7 @@ int main(int argc, const char* argv[]) {
         const int device = (int)input.getInt("device", 0);                              // extension: first HIP ordinal
         const long ngpu = input.getInt("ngpu", 1);                                      // extension: GPUs (ranks) to shard the images over; 0 = all visible
         const bool share_device = input.getYesNo("share_device", false);                // extension: all ranks on `device` (in-process communicator; one-GPU boxes)
+        const bool pipeline = input.getYesNo("pipeline", true);                         // extension: enqueue bond k+1 before fetching the report of bond k (see the sweep loop)
         const std::string precision = input.getString("precision", "f64");              // extension: f64 | mixed | f32
         const long imglen = input.getInt("imglen", 0);                                   // extension: 0 = keep the file's size
         const double feature_scale = input.getReal("feature_scale", 1.);                 // extension
@@ -224,59 +225,75 @@ int main(int argc, const char* argv[]) {
 
             double lam = lambda;
             const double lambda_cost = lambda;                                              // cargs copy, :467
+            // One bond update is enqueued (tnml_bond_update_begin) before the report of the previous one is fetched
+            // (tnml_bond_update_end), so the GPU never waits for the host at a bond boundary and, with several ranks, the previous
+            // bond's cost partials ride in this bond's first all-reduce.  The log lines of a bond therefore appear while the next one
+            // runs, and the WRITE_WF / LAMBDA hooks act one bond later than in the reference (input key `pipeline = no`, or
+            // pause_step, restores the strict order).  Nothing is in flight across a sweep boundary.
+            struct InFlight { long sw; int b, ha; double lam; bool on = false; } fl;
+            auto finish = [&]() {                                                           // report + log + hooks of the bond update in flight
+                if (!fl.on) return;
+                fl.on = false;
+                const long sw = fl.sw; const int b = fl.b, ha = fl.ha;
+                tnml_bond_report rep;
+                CK(ctx, tnml_bond_update_end(ctx, &rep));
+                if (root) {
+                    const tnml_bond_report& r_ = rep;
+                    std::printf("Sweep %ld Half %d Bond %d\n", sw, ha, r_.c);           // :490
+                    std::printf("In cgrad, lambda = %.3E\n", fl.lam);                   // :358
+                    for (int p = 0; p < r_.cg.npass_done; ++p) {
+                        std::printf("  Conj grad pass %d\n", p + 1);                    // :391
+                        const bool has_cost = r_.cg.converged ? true : p + 1 < r_.cg.npass_done || r_.cg.npass_done < Npass;
+                        if (has_cost && (p + 1 < Npass)) {
+                            std::printf("  Cost = %.10f\n", r_.cg.cost[p] / totNtrain); // :429
+                            if (r_.cg.converged && p + 1 == r_.cg.npass_done) std::printf("  |r| = %.1E < %.1E, breaking\n", r_.cg.rnorm[p], cconv);   // :434
+                            else std::printf("  |r| = %.1E\n", r_.cg.rnorm[p]);         // :439
+                        }
+                    }
+                    std::printf("Sweep %ld Half %d Bond %d\n", sw, ha, r_.c);           // :510
+                    std::printf("SVD trunc err = %.2E\n", r_.truncerr);                 // :523
+                    std::printf("Original m=%d, New m=%d\n", r_.origm, r_.newm);        // :525
+                    std::printf("norm(newB) = %.12g\n", r_.norm_newB);                  // :528
+                    std::printf("rank(newB) = %d\n", r_.label_on_B ? 5 : 4);            // :529 (tensor order)
+                    std::printf("|B-newB| = %.3E\n", r_.diff_B_newB);                   // :530
+                    for (int l = 0; l < 10; ++l) std::printf("  Label l=%d C%d = %.10f\n", l, l, r_.label_cost[l] / totNtrain);   // :334
+                    std::printf("  Reg. cost CR = %.10f\n", r_.reg_cost / totNtrain);   // :337
+                    std::printf("Percent correct = %.4f%%, # incorrect = %lld/%d\n", r_.ncorrect * 100. / totNtrain,
+                                (long long)(totNtrain - r_.ncorrect), totNtrain);       // :341-342
+                    std::printf("--> After SVD, Cost = %.10f\n", r_.cost_after_svd / totNtrain);   // :533
+                    const int cs = ha == 1 ? b : b + 1, prevc = ha == 1 ? b - 1 : b + 2;    // :196-209
+                    if (prevc >= 1 && prevc <= N) std::printf("## Advancing E from %d to %d\n", prevc, cs);
+                    else std::printf("## Making new E at %d\n", cs);
+                    // file hooks: rank 0 looks, every rank follows
+                    if (file_exists("WRITE_WF")) {                                      // :542-548
+                        std::printf("File WRITE_WF found\n");
+                        std::remove("WRITE_WF");
+                        std::printf("Writing W to disk\n");
+                        write_mps("W", download(ctx, N));                               // (pipelined: the network as the bond update in flight leaves it)
+                    }
+                    if (file_exists("LAMBDA")) {                                        // :550-559
+                        std::ifstream lf("LAMBDA"); lf >> lambda_shared; lf.close();
+                        std::remove("LAMBDA");
+                        std::cout << "new lambda = " << lambda_shared << std::endl;
+                    }
+                    if (pause_step) { std::printf("PAUSE"); std::fflush(stdout); std::getchar(); }   // :561
+                    std::fflush(stdout);
+                }
+                if (nranks > 1) bar.wait();
+                lam = lambda_shared;
+                if (nranks > 1) bar.wait();                                             // nobody re-enters the hooks before everyone has read lambda
+            };
             for (long sw = 1; sw <= Nsweep; ++sw) {                                         // mldmrg, :470
                 if (root) std::printf("\nSweep %ld maxm=%ld minm=%ld\n", sw, maxm, minm);  // :472
                 for (int b = 1, ha = 1; ha <= 2; tnml_sweepnext(&b, &ha, N)) {              // :478
                     tnml_sweep_params sp{(int)std::min<long>(maxm, cfg.maxm), (int)std::min<long>(minm, cfg.maxm), cutoff, (int)Npass, lam, lambda_cost, cconv, 0};
-                    tnml_bond_report rep;
-                    CK(ctx, tnml_bond_update(ctx, b, ha, &sp, &rep));
-                    if (root) {
-                        const tnml_bond_report& r_ = rep;
-                        std::printf("Sweep %ld Half %d Bond %d\n", sw, ha, r_.c);           // :490
-                        std::printf("In cgrad, lambda = %.3E\n", lam);                      // :358
-                        for (int p = 0; p < r_.cg.npass_done; ++p) {
-                            std::printf("  Conj grad pass %d\n", p + 1);                    // :391
-                            const bool has_cost = r_.cg.converged ? true : p + 1 < r_.cg.npass_done || r_.cg.npass_done < Npass;
-                            if (has_cost && (p + 1 < Npass)) {
-                                std::printf("  Cost = %.10f\n", r_.cg.cost[p] / totNtrain); // :429
-                                if (r_.cg.converged && p + 1 == r_.cg.npass_done) std::printf("  |r| = %.1E < %.1E, breaking\n", r_.cg.rnorm[p], cconv);   // :434
-                                else std::printf("  |r| = %.1E\n", r_.cg.rnorm[p]);         // :439
-                            }
-                        }
-                        std::printf("Sweep %ld Half %d Bond %d\n", sw, ha, r_.c);           // :510
-                        std::printf("SVD trunc err = %.2E\n", r_.truncerr);                 // :523
-                        std::printf("Original m=%d, New m=%d\n", r_.origm, r_.newm);        // :525
-                        std::printf("norm(newB) = %.12g\n", r_.norm_newB);                  // :528
-                        std::printf("rank(newB) = %d\n", r_.label_on_B ? 5 : 4);            // :529 (tensor order)
-                        std::printf("|B-newB| = %.3E\n", r_.diff_B_newB);                   // :530
-                        for (int l = 0; l < 10; ++l) std::printf("  Label l=%d C%d = %.10f\n", l, l, r_.label_cost[l] / totNtrain);   // :334
-                        std::printf("  Reg. cost CR = %.10f\n", r_.reg_cost / totNtrain);   // :337
-                        std::printf("Percent correct = %.4f%%, # incorrect = %lld/%d\n", r_.ncorrect * 100. / totNtrain,
-                                    (long long)(totNtrain - r_.ncorrect), totNtrain);       // :341-342
-                        std::printf("--> After SVD, Cost = %.10f\n", r_.cost_after_svd / totNtrain);   // :533
-                        const int cs = ha == 1 ? b : b + 1, prevc = ha == 1 ? b - 1 : b + 2;    // :196-209
-                        if (prevc >= 1 && prevc <= N) std::printf("## Advancing E from %d to %d\n", prevc, cs);
-                        else std::printf("## Making new E at %d\n", cs);
-                        // file hooks: rank 0 looks, every rank follows
-                        write_wf = false;
-                        if (file_exists("WRITE_WF")) {                                      // :542-548
-                            std::printf("File WRITE_WF found\n");
-                            std::remove("WRITE_WF");
-                            std::printf("Writing W to disk\n");
-                            write_mps("W", download(ctx, N));
-                        }
-                        if (file_exists("LAMBDA")) {                                        // :550-559
-                            std::ifstream lf("LAMBDA"); lf >> lambda_shared; lf.close();
-                            std::remove("LAMBDA");
-                            std::cout << "new lambda = " << lambda_shared << std::endl;
-                        }
-                        if (pause_step) { std::printf("PAUSE"); std::fflush(stdout); std::getchar(); }   // :561
-                        std::fflush(stdout);
-                    }
-                    if (nranks > 1) bar.wait();
-                    lam = lambda_shared;
-                    if (nranks > 1) bar.wait();                                             // nobody re-enters the hooks before everyone has read lambda
+                    const InFlight next{sw, b, ha, lam, true};
+                    CK(ctx, tnml_bond_update_begin(ctx, b, ha, &sp));
+                    finish();                                                               // the previous bond update (none at the start of a sweep)
+                    fl = next;
+                    if (!pipeline || pause_step) finish();
                 }
+                finish();
                 if (root) {
                     std::printf("Writing W to disk\n");                                     // :565
                     write_mps("W", download(ctx, N));                                       // :566

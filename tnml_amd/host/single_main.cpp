@@ -6,8 +6,14 @@
 // image order (labels taken round-robin, single.cc:156-181) and the log lines.  One tnml_bond_update per bond.
 // Built: method = conj | fast_conj | exact.  Not built: method = pinv (random start, single.h:404-517) and the `noise` density-matrix term (single.h:648-672); they
 // stop with a message.  Extensions (never read by the reference): `seed`, `device`, `precision`, `imglen`,
-// `feature_scale` as in the fixedL driver.
+// `feature_scale` as in the fixedL driver; `labels`, `ngpu`, `share_device`, `dry_run`: the one-label-per-GPU launcher
+// of BASELINE config 4 (launch_per_label below).
+#include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
 #include <array>
+#include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
@@ -35,12 +41,95 @@ static HostMPS download(tnml_ctx* ctx, int N) {
     return W;
 }
 
+// BASELINE config 4: "single.cc per-label MPS x10, one label per GPU (embarrassingly parallel, no collectives)".  The reference trains
+// the ten networks as ten runs of `single` with ten input files, each in its own directory L<n> (separate_fulltest.cc:158 reads
+// L%d/W%d).  Extension key `labels = all` (or a comma list): this process becomes a launcher -- one child `single` per label, the
+// label and the device handed over in the environment, working directory L<label>, at most one running child per GPU (key `ngpu`,
+// default: every visible device), the next label taken as soon as a device is free; `share_device = yes` keeps all children on
+// `device` one after the other (one-GPU boxes); `dry_run = yes` prints the plan only.  Replicas only: no collective anywhere.
+static int launch_per_label(const char* self, const char* inputfile, const InputGroup& input) {
+    std::vector<int> labels;
+    const std::string spec = input.getString("labels", "");
+    if (spec == "all") for (int l = 0; l < 10; ++l) labels.push_back(l);
+    else {
+        size_t pos = 0;
+        while (pos < spec.size()) {
+            size_t e = spec.find(',', pos); if (e == std::string::npos) e = spec.size();
+            const int l = std::atoi(spec.substr(pos, e - pos).c_str());
+            if (l < 0 || l > 9) { std::printf("labels: %d is not in 0..9\n", l); return 1; }
+            labels.push_back(l); pos = e + 1;
+        }
+    }
+    if (labels.empty()) { std::printf("labels: nothing to do\n"); return 1; }
+    const bool dry = input.getYesNo("dry_run", false), share = input.getYesNo("share_device", false);
+    const int dev0 = (int)input.getInt("device", 0);
+    int ngpu = (int)input.getInt("ngpu", 0);
+    if (share) ngpu = 1;
+    if (ngpu <= 0) {
+        if (dry) ngpu = 8;
+        else { int64_t f, t; ngpu = 0; while (tnml_device_memory(dev0 + ngpu, &f, &t) == 0) ++ngpu; }
+        if (ngpu == 0) { std::fprintf(stderr, "no HIP device: %s\n", tnml_last_error(nullptr)); return 1; }
+    }
+    char inabs[PATH_MAX], selfabs[PATH_MAX], ddabs[PATH_MAX];
+    if (!realpath(inputfile, inabs)) { std::perror(inputfile); return 1; }
+    if (!realpath(self, selfabs)) std::snprintf(selfabs, sizeof selfabs, "%s", self);
+    const std::string dd = input.getString("datadir", "");
+    const bool have_dd = !dd.empty() && realpath(dd.c_str(), ddabs) != nullptr;
+    std::printf("Per-label training of %zu labels on %d GPU%s (one `single` process per label, no collectives)\n", labels.size(), ngpu, ngpu == 1 ? "" : "s");
+    std::vector<pid_t> busy(ngpu, 0); std::vector<int> busy_label(ngpu, -1);
+    int failed = 0;
+    size_t next = 0, running = 0;
+    auto reap = [&](bool block) {
+        int st = 0;
+        const pid_t pid = waitpid(-1, &st, block ? 0 : WNOHANG);
+        if (pid <= 0) return false;
+        for (int d = 0; d < ngpu; ++d) if (busy[d] == pid) {
+            const bool ok = WIFEXITED(st) && WEXITSTATUS(st) == 0;
+            std::printf("label %d on device %d: %s (log: L%d/log)\n", busy_label[d], dev0 + d, ok ? "done" : "FAILED", busy_label[d]);
+            if (!ok) ++failed;
+            busy[d] = 0; busy_label[d] = -1; --running;
+        }
+        return true;
+    };
+    while (next < labels.size() || running) {
+        int d = -1;
+        if (dry) d = (int)(next % (size_t)ngpu);                    // the plan: as if every training took the same time
+        else for (int k = 0; k < ngpu && next < labels.size(); ++k) if (!busy[k]) { d = k; break; }
+        if (d < 0) { reap(true); continue; }
+        const int l = labels[next++];
+        char dir[16]; std::snprintf(dir, sizeof dir, "L%d", l);
+        std::printf("label %d -> device %d, directory %s, writes %s/W%d\n", l, dev0 + d, dir, dir, l);
+        if (dry) continue;
+        std::fflush(stdout);
+        mkdir(dir, 0777);
+        const pid_t pid = fork();
+        if (pid < 0) { std::perror("fork"); return 1; }
+        if (pid == 0) {
+            if (chdir(dir) != 0) _exit(111);
+            if (!freopen("log", "w", stdout)) _exit(112);
+            char buf[32];
+            std::snprintf(buf, sizeof buf, "%d", l); setenv("TNML_SINGLE_LABEL", buf, 1);
+            std::snprintf(buf, sizeof buf, "%d", dev0 + d); setenv("TNML_SINGLE_DEVICE", buf, 1);
+            if (have_dd) setenv("TNML_SINGLE_DATADIR", ddabs, 1);
+            execl(selfabs, selfabs, inabs, (char*)nullptr);
+            _exit(113);
+        }
+        busy[d] = pid; busy_label[d] = l; ++running;
+    }
+    if (dry) return 0;
+    std::printf("%zu of %zu per-label trainings finished%s\n", labels.size() - failed, labels.size(), failed ? "" : "; evaluate with `separate_fulltest <inputfile>` from this directory");
+    return failed ? 1 : 0;
+}
+
 int main(int argc, const char* argv[]) {
     if (argc != 2) { std::printf("Usage: %s inputfile\n", argv[0]); return 0; }       // single.cc:11-15
     try {
         InputGroup input(argv[1], "input");
-        const std::string datadir = input.getString("datadir", "/Users/mstoudenmire/software/tnml/mllib/MNIST");
-        const int L = (int)input.getInt("label", 0);
+        const char* env_label = std::getenv("TNML_SINGLE_LABEL");                       // set by the launcher for its children
+        if (!env_label && !input.getString("labels", "").empty()) return launch_per_label(argv[0], argv[1], input);
+        const char* env_dd = std::getenv("TNML_SINGLE_DATADIR");
+        const std::string datadir = env_dd ? std::string(env_dd) : input.getString("datadir", "/Users/mstoudenmire/software/tnml/mllib/MNIST");
+        const int L = env_label ? std::atoi(env_label) : (int)input.getInt("label", 0);
         const long Ntrain = input.getInt("Ntrain", 60000);
         const long Nsweep = input.getInt("Nsweep", 50);
         const double cutoff = input.getReal("cutoff", 1E-8);
@@ -61,7 +150,7 @@ int main(int argc, const char* argv[]) {
         const double cconv = input.getReal("cconv", 1E-10);
         (void)input.getInt("Ntarget", 10); const double pcut = input.getReal("pcut", 1E-8); (void)input.getYesNo("precalc", true);
         const uint64_t seed = (uint64_t)input.getInt("seed", 1);
-        const int device = (int)input.getInt("device", 0);
+        const int device = std::getenv("TNML_SINGLE_DEVICE") ? std::atoi(std::getenv("TNML_SINGLE_DEVICE")) : (int)input.getInt("device", 0);
         const std::string precision = input.getString("precision", "f64");
         const long imglen = input.getInt("imglen", 0);
         const double feature_scale = input.getReal("feature_scale", 1.);
