@@ -40,6 +40,7 @@ if ROOT not in sys.path:
 
 F64_MFMA_PEAK_TF = 78.6      # MI355X FP64 matrix peak (AMD spec); 77.4 TF measured (profiles/r01_probe64.txt)
 F32_MFMA_PEAK_TF = 157.3     # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TF = 2500.0   # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA", dense
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md "HBM3E peak BW"
 
 
@@ -73,6 +74,22 @@ def pmc_traffic(kernel_class):
         return None, None
     return e["bytes_per_launch"], {"kernel": e["kernel"], "commit": rec.get("commit"), "kernels_src_sha16": rec.get("kernels_src_sha16"),
                                    "file": "profiles/" + os.path.basename(files[-1])}
+
+
+def pmc_step_traffic():
+    """HBM bytes of one whole bond update from the same PMC record (every dispatch between the splits of consecutive bond updates,
+    FETCH_SIZE x 2 + WRITE_SIZE summed); None when the record is stale or has no such entry"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        rec = json.load(open(files[-1]))
+    except (OSError, ValueError):
+        return None
+    if rec.get("kernels_src_sha16") != kernel_source_sha16():
+        return None
+    return rec.get("step")
 
 
 def cpu_quota():
@@ -167,7 +184,7 @@ def hbm_roofline(prof_all, NTl, timed, args, world):
                 "frac": ach / HBM_PEAK_GBS, "traffic": tr, "traffic_source": src, "avg_launch_ms": avg_ms, "launches": n_ff, "bytes_per_launch": by}
     if not n_ld or not timed:
         return None
-    esz = 4 if args.dtype == "f32" else 8
+    esz = 8 if args.dtype in ("f64", "f64_e32") else 4
     env_sz = 8 if args.dtype == "f64" else 4
     nl = 1 if args.single_label is not None else 10
     by = float(np.mean([NTl * (nl * min(r["mL"], r["mR"]) * (esz if r["label_on_B"] else env_sz) +
@@ -219,7 +236,7 @@ def main():
     ap.add_argument("--npass", type=int, default=4)
     ap.add_argument("--minm", type=int, default=None, help="default maxm: every interior bond stays at m = maxm whatever the "
                     "spectrum of the synthetic data (the reference default max(10, maxm/2) lets trained bonds shrink)")
-    ap.add_argument("--dtype", default="f64", choices=["f64", "f64_e32", "f32"])
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f64_e32", "f32", "bf16x3", "bf16"], help="bf16 / bf16x3: BASELINE config 5's study modes (forward feature GEMM on the bf16 matrix pipe)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="the SURVEY.md 8(d) CPU sample (2000 images, 20 bonds: minutes) instead of the bounded one")
     ap.add_argument("--literal-steps", type=int, default=None, help="bond updates timed in the reference's literal evaluation order "
@@ -228,10 +245,17 @@ def main():
                     "sweep with minm = maxm/2 from the random-init W, then the timed bonds with minm = maxm/2")
     ap.add_argument("--single-label", type=int, default=None, help="bench the per-label variant (single.cc, BASELINE config 4: one such "
                     "training per label, replicas only) for this label instead of the fixedL sweep")
+    ap.add_argument("--no-extras", action="store_true", help="skip the two secondary measurements of the default line: the two Label-on-B centre bonds "
+                    "(centre_bond_ms) and the SURVEY.md 8(d) workload (value_8d)")
+    ap.add_argument("--plain", action="store_true", help="main window + breakdown steps only (no literal-order, unfused-forward, centre-bond or 8(d) "
+                    "measurements): what the profiler runs of tools/*.sh use, so that the last bond updates of the run are ordinary ones")
     ap.add_argument("--dry-run", action="store_true", help="control plane only (launcher, rendezvous, shard bounds, max-over-ranks clock): no GPU work")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 2 * (args.sites - 1)
+    if args.plain:
+        args.no_extras = True
+        args.literal_steps = 0
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args.gpus))
@@ -361,6 +385,7 @@ def main():
     ts.profile(os.environ.get("TNML_BENCH_NOPROF", "0") != "1", only="fgemm_fwd,fwd_fused,svd")
     ts.profile_reset()
     sync()
+    coll0 = ts.collective_stats()
     t0 = time.perf_counter()
     step_marks = []
     for _ in range(args.steps):
@@ -369,6 +394,7 @@ def main():
             step_marks.append(time.perf_counter() - t0)
     sync()
     elapsed = time.perf_counter() - t0
+    coll1 = ts.collective_stats()
     if step_marks and rank == 0:
         print("host time at the end of each timed step (ms):", " ".join("%.2f" % (1e3 * t) for t in step_marks), "| total %.2f" % (1e3 * elapsed), file=sys.stderr)
     ts.profile(False)
@@ -406,7 +432,7 @@ def main():
         ts.set_option("reuse_p", 1)
     # the two kernels k_fwd_fused replaces, timed in the same run (untimed steps): stand-alone feature GEMM and label dot
     unfused = None
-    if prof_all.get("fwd_fused", (0, 0))[0] > 0:
+    if prof_all.get("fwd_fused", (0, 0))[0] > 0 and not args.plain:
         drain()
         ts.set_option("fused_fwd", 0)
         ts.profile(True, only="fgemm_fwd,labeldot")
@@ -417,6 +443,50 @@ def main():
         ts.profile(False)
         unfused = ts.profile_read()
         ts.set_option("fused_fwd", 1)
+    # ---- secondary measurements of the default line: the two Label-on-B centre bonds, and the 8(d) workload itself
+    centre_ms = None
+    rate_8d = None
+    if not args.no_extras and not single and N >= 64 and args.workload == "default":
+        drain()
+        c0 = N // 2
+        for attempt in range(2):                                 # the first round loads the Label-on-B kernel instantiations; the second is timed
+            ts.set_mps(W)
+            ts.init()
+            for bb in range(1, c0 - 1):
+                ts.shiftE(bb, True)
+            ts.bond_update(c0 - 2, 1, maxm, minm, cutoff, npass, lam, cconv)        # brings P/dP up to date like a sweep arriving here
+            cm = []
+            for bc in (c0 - 1, c0):                              # Label on B: c0 = b + 1, then c0 = b (fixedL.cc:482-496)
+                sync()
+                tc = time.perf_counter()
+                rc_ = ts.bond_update(bc, 1, maxm, minm, cutoff, npass, lam, cconv)
+                ts.synchronize()
+                cm.append(1e3 * (time.perf_counter() - tc))
+                assert rc_["label_on_B"]
+            centre_ms = cm
+        if world > 1:
+            tcm = torch.tensor(centre_ms, dtype=torch.float64)
+            dist.all_reduce(tcm, op=dist.ReduceOp.MAX)
+            centre_ms = [float(x) for x in tcm]
+        # SURVEY.md 8(d) literally: one untimed warm-up sweep with minm = maxm/2 from the random-init W, then interior bonds of the second sweep
+        ts.set_mps(W)
+        ts.init()
+        b, ha = 1, 1
+        minm_main, minm = minm, maxm // 2
+        for _ in range(2 * (N - 1) + N // 4):
+            step()
+        sync()
+        n8 = 60
+        t8 = time.perf_counter()
+        for _ in range(n8):
+            step()
+        sync()
+        rate_8d = n8 / (time.perf_counter() - t8)
+        minm = minm_main
+        if world > 1:
+            t8t = torch.tensor([rate_8d], dtype=torch.float64)
+            dist.all_reduce(t8t, op=dist.ReduceOp.MIN)
+            rate_8d = float(t8t[0])
     if world > 1:
         t = torch.tensor([elapsed, elapsed_lit or 0.0], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -436,17 +506,11 @@ def main():
         # every timed bond calls the feature GEMM with its own (mL, mR); average the flops
         fl = [2.0 * NTl * (2 * r["mL"]) * (2 * r["mR"]) * (10 if (r["label_on_B"] and not single) else 1) for r in timed]
         flops_per_pass = float(np.mean(fl)) if fl else 0.0
-        # two-queue forward pass: the images go through the feature GEMM in two launches, and class "fgemm_fwd" holds only the
-        # first one (the half that has the machine to itself); the second runs beside the label dot of the first half
-        split = prof_all.get("fgemm_fwd_overlapped", (0, 0))[0] > 0
-        NTp = (NTl + 255) // 256 * 256
-        nblk = NTp // 128
-        img_fg = ((nblk + 1) // 2) * 128 if split else NTl            # images of one "fgemm_fwd" launch (all real: the padding sits at the end)
-        img_ld = NTl - img_fg if split else NTl                        # images of one "labeldot" launch
-        flops_per_launch = flops_per_pass * img_fg / NTl
+        img_fg = img_ld = NTl
+        flops_per_launch = flops_per_pass
         avg_ms = ms_fg / max(n_fg, 1)
         achieved_tf = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        peak = F64_MFMA_PEAK_TF if args.dtype != "f32" else F32_MFMA_PEAK_TF
+        peak = F64_MFMA_PEAK_TF if args.dtype in ("f64", "f64_e32") else (F32_MFMA_PEAK_TF if args.dtype == "f32" else BF16_MFMA_PEAK_TF)
         ms_per_step = 1e3 * elapsed / args.steps
         kms = {k: v[1] / nbreak for k, v in prof_all.items() if v[0]}
         svd_after = kms.get("svd", 0.0)
@@ -460,8 +524,7 @@ def main():
         exec_gf = ((nf_step + nb_step) * flops_per_pass + sh) / 1e9
         m_avg = float(np.mean([0.5 * (r["mL"] + r["mR"]) for r in timed])) if timed else 0.0
         alg_gf = ((3 * npass + 1) * (flops_per_pass + 2.0 * NTl * 2 * m_avg * (1 if single else 10)) + sh + 22.0 * (2 * m_avg) ** 3) / 1e9
-        # (the label dot of the first image half, class labeldot_overlapped, runs beside fgemm_fwd_overlapped: counted once)
-        grad_classes = ("fgemm_fwd", "fgemm_fwd_overlapped", "fwd_fused", "labeldot", "p_update", "bgemm", "slab_reduce", "zprime", "allreduce")
+        grad_classes = ("fgemm_fwd", "fwd_fused", "labeldot", "p_update", "bgemm", "slab_reduce", "zprime", "allreduce")
         tr_fg, src_fg = pmc_traffic("fwd_fused" if fused else "fgemm_fwd") if args.dtype == "f64" and maxm == 120 and NT == 60000 and world == 1 else (None, None)
         shortcuts_on = os.environ.get("TNML_FAST_CG", "1") != "0" or os.environ.get("TNML_REUSE_P", "1") != "0"
         out = {
@@ -481,7 +544,9 @@ def main():
                       "oracle/, a line-cited restatement of fixedL.cc cross-checked by an independent numpy restatement)",
             "config": {"workload": "fixedL N=%d, maxm=%d, %d images (BASELINE config 3), Npass=%d, lambda=%g, minm=%d, "
                                    "%s; %s; timed bonds %d..%d (%s, m=%.0f)" % (N, maxm, NT, npass, lam, minm,
-                                                                               {"f64": "fp64 throughout", "f64_e32": "fp64 MFMA over fp32-stored environments", "f32": "fp32 study mode"}[args.dtype],
+                                                                               {"f64": "fp64 throughout", "f64_e32": "fp64 MFMA over fp32-stored environments", "f32": "fp32 study mode",
+                                                                                "bf16x3": "fp32 storage, forward feature GEMM on bf16 MFMA with hi + lo operands (study mode)",
+                                                                                "bf16": "fp32 storage, forward feature GEMM on bf16 MFMA (study mode)"}[args.dtype],
                                                                                "random-init W at m=maxm" if args.workload == "default" else "SURVEY 8(d): after one warm-up sweep from the random-init W",
                                                                                timed[0]["bond"] if timed else 0,
                                                                                timed[-1]["bond"] if timed else 0,
@@ -490,15 +555,14 @@ def main():
                                                                                m_avg),
                        "global_images": NT, "sites": N, "maxm": maxm, "parallelism": "dp%d (image sharding + RCCL all-reduce)" % world,
                        "rccl_ranks": comm_ranks},
-            "roofline": {"bound": "mfma", "kernel": "k_fwd_fused" if fused else ("k_fgemm64" if args.dtype != "f32" else "k_fgemm"),
+            "roofline": {"bound": "mfma", "kernel": "k_fwd_fused" if fused else ("k_fgemm64" if args.dtype in ("f64", "f64_e32") else ("k_fgemm" if args.dtype == "f32" else "k_fgemm_bf16")),
                          "achieved": achieved_tf, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved_tf / peak,
                          "traffic": tr_fg, "traffic_source": src_fg,
                          "avg_launch_ms": avg_ms, "launches": n_fg, "flops_per_launch": flops_per_launch, "images_per_launch": img_fg,
                          "note": ("k_fwd_fused = the feature GEMM (these flops) with the label dot of the previous 64-image tile running on four extra "
                                   "waves of the same workgroup: its launch time replaces feature GEMM + label dot (kernel_ms_per_step.fwd_fused); "
-                                  "bytes streamed beside the flops: roofline_hbm") if fused else ("forward pass split over two queues: this is the launch of the first image half, which has the GPU to itself; "
-                                  "the second half runs beside the label dot of the first (kernel_ms_per_step.fgemm_fwd_overlapped)") if split else None},
+                                  "bytes streamed beside the flops: roofline_hbm") if fused else None},
             "roofline_step": {"bound": "mfma", "peak": peak, "unit": "TFLOP/s",
                               "executed_gflop_per_step": exec_gf, "executed": exec_gf / ms_per_step, "frac_executed": exec_gf / ms_per_step / peak,
                               "algorithmic_gflop_per_step": alg_gf, "algorithmic": alg_gf / ms_per_step, "frac_algorithmic": alg_gf / ms_per_step / peak,
@@ -527,7 +591,26 @@ def main():
             "last_cost_per_image": timed[-1]["cost"] / NT if timed else None,
             "svd_stats": ts.svd_stats(),
             "replica_repairs": ts.replica_repairs(),
+            "centre_bond_ms": None if centre_ms is None else {
+                "label_on_B_bond_%d" % (N // 2 - 1): centre_ms[0], "label_on_B_bond_%d" % (N // 2): centre_ms[1],
+                "note": "the two bond updates whose bond tensor carries the Label index (10x the GEMM columns, split of a 240 x 2400 matrix), "
+                        "timed one by one after the main window (SURVEY.md 8(d))"},
+            "value_8d": None if rate_8d is None else {
+                "value": rate_8d, "unit": "bond updates/s",
+                "note": "SURVEY.md 8(d) workload: one warm-up sweep from the random-init W with minm = maxm/2, then 60 consecutive interior bonds "
+                        "of the second sweep (trained bonds shrink towards maxm/2, so this is NOT the shape of `value`)"},
+            "collectives": None if world == 1 else {
+                "allreduces_per_bond_update": (coll1[0] - coll0[0]) / args.steps, "broadcasts_per_bond_update": (coll1[1] - coll0[1]) / args.steps,
+                "allreduce_ms_per_bond_update": kms.get("allreduce", 0.0),
+                "note": "sum all-reduces of the packed [scalars | gradient or A p] buffer (merged CG passes, carried after-SVD scalars) and "
+                        "broadcasts of rank 0's eigenvalues, per bond update of the timed region; allreduce ms from HIP events on the breakdown steps"},
         }
+        st = pmc_step_traffic() if args.dtype == "f64" and maxm == 120 and NT == 60000 and world == 1 and not full_sweeps else None
+        if st:
+            out["roofline_step"]["traffic"] = st["bytes_per_step"]
+            out["roofline_step"]["traffic_gbs"] = st["bytes_per_step"] / (ms_per_step * 1e-3) / 1e9
+            out["roofline_step"]["traffic_frac_of_hbm_peak"] = st["bytes_per_step"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS
+            out["roofline_step"]["traffic_source"] = st.get("source")
         if world == 1 and not args.no_cpu_baseline and not single:
             ncore = cpu_quota()
             out["cpu_baseline"] = cpu_baseline(maxm, npass, lam, cutoff, min(16, ncore), NT, full=args.cpu_baseline_full)   # paralleldo.h:55-56 caps at 16

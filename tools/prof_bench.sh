@@ -4,7 +4,7 @@ tag=${1:-run}; shift
 cd /tmp && export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 mkdir -p $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out -o trace -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --literal-steps 0 "$@" > $out/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -o trace -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --plain "$@" > $out/bench.log 2>&1
 tail -1 $out/bench.log | cut -c1-300
 f=$(find $out -name '*kernel_stats.csv' | head -1)
 python - "$f" <<'PY'

@@ -4,7 +4,7 @@
 out=${1:-gpurun_out/tune_m300.txt}
 : > $out
 run() {
-  python bench.py --maxm 300 --images $IM --steps 8 --warmup 3 --no-cpu-baseline --literal-steps 0 2>/dev/null | python -c "
+  python bench.py --maxm 300 --images $IM --steps 8 --warmup 3 --no-cpu-baseline --plain 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernel_ms_per_step']
 print('%-34s images %6d: %7.2f bond updates/s | fgemm_fwd %.3f ms (5 launches)  bgemm %.3f ms (4 launches)  shift %.3f  svd %.3f' % ('$1', $IM, d['value'], k.get('fgemm_fwd',0), k.get('bgemm',0), k.get('fgemm_shift',0), k.get('svd',0)))" >> $out
