@@ -384,6 +384,12 @@ def main():
     # random-init and 14-27 later in a long window -- so it is taken inside the timed region, not on the breakdown steps after it)
     ts.profile(os.environ.get("TNML_BENCH_NOPROF", "0") != "1", only="fgemm_fwd,fwd_fused,svd")
     ts.profile_reset()
+    # no cyclic garbage collection inside the timed region: a generation-2 pass over this process's heap takes ~40 ms -- the time of
+    # 30 bond updates of an 8-GPU shard -- and where it lands depends on the allocation count (seen as one 40 ms step in an otherwise
+    # flat 1.4 ms series, profiles/r03_gc_pause_in_timed_region.txt)
+    import gc
+    gc.collect()
+    gc.disable()
     sync()
     coll0 = ts.collective_stats()
     t0 = time.perf_counter()
@@ -394,6 +400,7 @@ def main():
             step_marks.append(time.perf_counter() - t0)
     sync()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     coll1 = ts.collective_stats()
     if step_marks and rank == 0:
         print("host time at the end of each timed step (ms):", " ".join("%.2f" % (1e3 * t) for t in step_marks), "| total %.2f" % (1e3 * elapsed), file=sys.stderr)
