@@ -125,6 +125,8 @@ typedef struct {
 int tnml_create(tnml_ctx** out, const tnml_config* cfg);
 int tnml_destroy(tnml_ctx* ctx);
 const char* tnml_last_error(const tnml_ctx* ctx);      /* ctx may be NULL: error of the failed create */
+/* last non-fatal notice of ctx ("" if none): e.g. the split clamped maxm to the context's maxm and so truncates harder than asked */
+const char* tnml_last_warning(const tnml_ctx* ctx);
 
 /* RCCL communicator over xGMI.  Rank 0 obtains a 128-byte unique id, the host transports it to
    the other ranks (any channel), every rank then calls tnml_comm_init.  Replaces the host-side

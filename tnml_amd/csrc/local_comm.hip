@@ -10,6 +10,7 @@
 //
 // It is a correctness vehicle (tests, `ngpu` > visible devices in the drivers), not a performance path: ranks on
 // different devices use RCCL over xGMI (tnml_comm_init).
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 
@@ -26,13 +27,19 @@ struct LocalComm {
     int refs = 0;
     // host barrier (generation counting)
     std::mutex mu; std::condition_variable cv; int waiting = 0; long bgen = 0;
-    void barrier() {
+    bool aborted = false;                 // a rank failed (or never arrived): every later collective fails at once instead of hanging
+    bool barrier() {                      // false: the communicator is aborted
         std::unique_lock<std::mutex> lk(mu);
+        if (aborted) return false;
         const long g = bgen;
-        if (++waiting == n) { waiting = 0; ++bgen; cv.notify_all(); }
-        else cv.wait(lk, [&] { return bgen != g; });
+        if (++waiting == n) { waiting = 0; ++bgen; cv.notify_all(); return true; }
+        const bool ok = cv.wait_for(lk, std::chrono::seconds(120), [&] { return bgen != g || aborted; });
+        if (!ok || aborted) { aborted = true; cv.notify_all(); return false; }     // a peer left the protocol (error return on its side, or it never entered)
+        return true;
     }
+    void abort() { std::lock_guard<std::mutex> lk(mu); aborted = true; cv.notify_all(); }
 };
+#define LCK(c, lc, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (lc)->abort(); return tnml_fail((c), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } } while (0)
 
 __global__ void k_lc_sum(const double* __restrict__ st, int n, size_t cap, size_t count, double* __restrict__ out) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
@@ -91,22 +98,24 @@ int local_comm_size(const tnml_ctx* c) { return c->local ? c->local->n : 0; }
 // op: 0 = sum of doubles, 1 = copy of rank 0's values
 int local_comm_exchange(tnml_ctx* c, double* buf, size_t count, int op) {
     LocalComm* lc = c->local;
-    if (count > lc->cap) return tnml_fail(c, "local communicator: %zu elements exceed the staging capacity %zu", count, lc->cap);
+    if (count > lc->cap) { lc->abort(); return tnml_fail(c, "local communicator: %zu elements exceed the staging capacity %zu", count, lc->cap); }
     const int r = c->cfg.rank, n = lc->n;
     const int p = (int)(lc->gen[r]++ & 1);
     hipStream_t st = c->stream;
     // the slot of this parity was read two collectives ago: wait for those readers
-    for (int j = 0; j < n; ++j) if (lc->read_rec[p][j]) HIPCK(c, hipStreamWaitEvent(st, lc->read_done[p][j], 0));
-    if (op != 1 || r == 0) HIPCK(c, hipMemcpyAsync(lc->staging[p] + (size_t)r * lc->cap, buf, sizeof(double) * count, hipMemcpyDeviceToDevice, st));
-    HIPCK(c, hipEventRecord(lc->written[p][r], st));
-    lc->barrier();                                        // every rank has recorded its `written` event
-    for (int j = 0; j < n; ++j) if (j != r) HIPCK(c, hipStreamWaitEvent(st, lc->written[p][j], 0));
+    for (int j = 0; j < n; ++j) if (lc->read_rec[p][j]) LCK(c, lc, hipStreamWaitEvent(st, lc->read_done[p][j], 0));
+    if (op != 1 || r == 0) LCK(c, lc, hipMemcpyAsync(lc->staging[p] + (size_t)r * lc->cap, buf, sizeof(double) * count, hipMemcpyDeviceToDevice, st));
+    LCK(c, lc, hipEventRecord(lc->written[p][r], st));
+    if (!lc->barrier()) return tnml_fail(c, "local communicator: a rank left the collective (aborted)");   // every rank has recorded its `written` event
+    for (int j = 0; j < n; ++j) if (j != r) LCK(c, lc, hipStreamWaitEvent(st, lc->written[p][j], 0));
     const int nb = (int)((count + 255) / 256 > 1024 ? 1024 : (count + 255) / 256);
     if (op == 0)      hipLaunchKernelGGL(k_lc_sum, dim3(nb), dim3(256), 0, st, (const double*)lc->staging[p], n, lc->cap, count, buf);
     else              hipLaunchKernelGGL(k_lc_copy, dim3(nb), dim3(256), 0, st, (const double*)lc->staging[p], count, buf);
-    HIPCK(c, hipGetLastError());
-    HIPCK(c, hipEventRecord(lc->read_done[p][r], st));
-    lc->barrier();                                        // ... and its `read_done` event, before anyone re-uses the parity
+    LCK(c, lc, hipGetLastError());
+    LCK(c, lc, hipEventRecord(lc->read_done[p][r], st));
+    if (!lc->barrier()) return tnml_fail(c, "local communicator: a rank left the collective (aborted)");   // ... and its `read_done` event, before anyone re-uses the parity
     lc->read_rec[p][r] = 1;
     return 0;
 }
+// a rank that fails outside a collective (tnml_fail in a bond update) tells its peers, so that they do not wait for it
+void local_comm_abort(tnml_ctx* c) { if (c->local) c->local->abort(); }

@@ -97,7 +97,12 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
     const int n = nl < nr ? nl : nr;
     if (n > c->svd_n) return tnml_fail(c, "svd_split: matrix side %d exceeds workspace %d (raise maxm)", n, c->svd_n);
     if (maxm < 1 || minm < 0) return tnml_fail(c, "svd_split: maxm must be >= 1 and minm >= 0");
-    if (maxm > c->maxm) maxm = c->maxm;                  // the workspaces (sS, sCm, sQ1, sF) are sized by the context's maxm
+    if (maxm > c->maxm) {                                // the workspaces (sS, sCm, sQ1, sF) are sized by the context's maxm
+        char wb[256];
+        snprintf(wb, sizeof wb, "svd_split: maxm = %d exceeds the context's maxm = %d (tnml_plan_maxm / tnml_create): the truncation keeps at most %d", maxm, c->maxm, c->maxm);
+        c->warn = wb;
+        maxm = c->maxm;
+    }
     if (minm > maxm) minm = maxm;
     hipStream_t st = c->stream;
 

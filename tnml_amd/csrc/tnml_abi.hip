@@ -15,10 +15,11 @@ static std::string g_create_err;
 int tnml_fail(tnml_ctx* c, const char* fmt, ...) {
     char buf[512];
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
-    if (c) c->err = buf; else g_create_err = buf;
+    if (c) { c->err = buf; if (c->local) local_comm_abort(c); } else g_create_err = buf;   // (peers of an in-process communicator must not wait for a rank that has failed)
     return 1;
 }
 const char* tnml_last_error(const tnml_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+const char* tnml_last_warning(const tnml_ctx* c) { return c ? c->warn.c_str() : ""; }
 
 // ---- profiling ------------------------------------------------------------------------------
 static hipEvent_t prof_event(tnml_ctx* c) {

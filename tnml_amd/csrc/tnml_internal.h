@@ -99,6 +99,7 @@ struct tnml_ctx {
     ncclComm_t comm = nullptr;
     struct LocalComm* local = nullptr;   // in-process communicator of ranks sharing one device (local_comm.hip)
     std::string err;
+    std::string warn;               // last non-fatal notice (tnml_last_warning): e.g. maxm / minm clamped to the context's maxm by the split
     int64_t bytes = 0;
 
     void* phi = nullptr;       // [N][2][NTp], env-typed
@@ -346,6 +347,7 @@ int eigh_backtransform(tnml_ctx* c, const double* V, const double* tau, int n, c
 // ---- local_comm.hip ----
 void local_comm_release(tnml_ctx* c);
 int local_comm_size(const tnml_ctx* c);
+void local_comm_abort(tnml_ctx* c);
 int local_comm_exchange(tnml_ctx* c, double* buf, size_t count, int op);   // 0 sum, 1 broadcast from rank 0
 
 // rank 0's values to every rank, in stream order (no-op without a communicator)

@@ -26,7 +26,7 @@ EXPORTS = [
     "tnml_cgrad", "tnml_svd_split", "tnml_bond_update", "tnml_truncate", "tnml_sweepnext",
     "tnml_shard_bounds", "tnml_profile_enable", "tnml_profile_select", "tnml_profile_count", "tnml_profile_get",
     "tnml_profile_reset", "tnml_synchronize", "tnml_device_bytes", "tnml_svd_stats", "tnml_classify", "tnml_replica_check",
-    "tnml_estimate_bytes", "tnml_device_memory", "tnml_plan_maxm", "tnml_set_option", "tnml_comm_init_local", "tnml_bond_update_begin", "tnml_bond_update_end", "tnml_replica_repairs", "tnml_pAp", "tnml_collective_stats",
+    "tnml_estimate_bytes", "tnml_device_memory", "tnml_plan_maxm", "tnml_set_option", "tnml_comm_init_local", "tnml_bond_update_begin", "tnml_bond_update_end", "tnml_replica_repairs", "tnml_pAp", "tnml_collective_stats", "tnml_last_warning",
     "tnml_exact", "tnml_set_option_real",
 ]
 
@@ -117,6 +117,8 @@ def load():
     L.tnml_replica_repairs.restype = C.c_int64
     L.tnml_collective_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.tnml_pAp.argtypes = [vp, dp, C.c_double, dp]
+    L.tnml_last_warning.argtypes = [vp]
+    L.tnml_last_warning.restype = C.c_char_p
     L.tnml_comm_init_local.argtypes = [C.POINTER(vp), C.c_int]
     L.tnml_set_option.argtypes = [vp, C.c_char_p, C.c_int]
     L.tnml_estimate_bytes.argtypes = [C.POINTER(Config)]
