@@ -941,6 +941,74 @@ def test_svd_split_hard_spectra(name, sv0):
     assert st["fallbacks"] <= 2, st
 
 
+def _spectra_300():
+    rng = np.random.default_rng(78)
+    yield "identity (300-fold degenerate)", np.ones(300)
+    yield "two plateaus", np.concatenate([np.full(70, 3.0), np.full(230, 0.5)])
+    yield "rank one", np.concatenate([[2.0], np.zeros(299)])
+    yield "rank 149 then exact zeros", np.concatenate([np.linspace(2.0, 1.0, 149), np.zeros(151)])
+    yield "geometric 1e0..1e-14", np.logspace(0, -14, 300)
+    yield "cluster of 50 within 1e-13", np.concatenate([np.linspace(2, 1, 120), 0.5 + 1e-13 * rng.random(50), np.logspace(-1, -6, 130)])
+    yield "random uniform", np.sort(rng.random(300))[::-1]
+
+
+@pytest.mark.parametrize("name,sv0", list(_spectra_300()), ids=[n for n, _ in _spectra_300()])
+def test_svd_split_hard_spectra_on_the_workgroup_cluster(name, sv0):
+    """the same hard spectra at maxm = 150 (Gram side n = 300 > 240): tridiagonalisation on the cluster of workgroups (eigh_mc.hip,
+    with and without its rank-adaptive exit), tridiagonal kernels in their n <= 640 instantiations, Cholesky QR on rocSOLVER dpotrf"""
+    from tnml_amd import synth
+    from tnml_amd.fixedl import TrainStates
+    N, m, NT = 24, 150, 16                                             # bond 10 of 24 sites: 150 x 150, Label on the right environment (c0 = 12)
+    labels = synth.synthetic_labels(NT, seed=1)
+    ts = TrainStates(labels, N, m, pixels=synth.synthetic_images(N, labels, seed=1))
+    ts.set_mps(synth.random_mps(N, m, seed=2))
+    rng = np.random.default_rng(len(name))
+    sv0 = np.sort(np.asarray(sv0, dtype=float))[::-1]
+    U0, _ = np.linalg.qr(rng.standard_normal((300, 300)))
+    V0, _ = np.linalg.qr(rng.standard_normal((300, 300)))
+    M = (U0 * sv0) @ V0.T
+    B = M.reshape(150, 2, 2, 150, order="F")
+    best_err = np.sqrt(np.sum(sv0[150:] ** 2))
+    for ha, exit_on in ((1, 1), (2, 1), (1, 0)):
+        ts.set_option("sytrd_exit", exit_on)
+        mg, te, sv = ts.svd_split(B, 10, ha, 0.0, 150, 150)
+        assert mg == 150
+        np.testing.assert_allclose(sv ** 2, sv0 ** 2, rtol=1e-7, atol=3e-14 * sv0[0] ** 2)
+        assert te == pytest.approx(np.sum(sv0[150:] ** 2) / np.sum(sv0 ** 2), rel=1e-6, abs=1e-13)
+        newB = ts.bond_tensor(10).reshape(300, 300, order="F")
+        err = np.linalg.norm(newB - M)
+        assert err <= best_err * (1 + 1e-6) + 2e-7 * sv0[0], (err, best_err)
+        A = ts.get_site(10 if ha == 1 else 11)
+        Q = A.reshape(300, 150, order="F") if ha == 1 else A.reshape(150, 300, order="F").T
+        if ha == 1:
+            np.testing.assert_allclose(Q.T @ Q, np.eye(150), atol=1e-9)
+    st = ts.svd_stats()
+    assert st["fallbacks"] <= 2, st
+
+
+def test_workgroup_cluster_that_gives_up_falls_back_to_rocsolver():
+    """k_sytrd_mc never hangs the GPU: a workgroup that waits in vain for a peer sets the abort word, every workgroup leaves, the
+    host sees the status and redoes the split with rocsolver_dsyevd.  Option mc_spin_max = 0 makes the very first failed poll give up."""
+    from tnml_amd import synth
+    from tnml_amd.fixedl import TrainStates
+    N, m, NT = 24, 150, 16                                             # bond 10 of 24 sites: 150 x 150, Label on the right environment (c0 = 12)
+    labels = synth.synthetic_labels(NT, seed=1)
+    ts = TrainStates(labels, N, m, pixels=synth.synthetic_images(N, labels, seed=1))
+    ts.set_mps(synth.random_mps(N, m, seed=2))
+    ts.set_option("mc_spin_max", 0)
+    rng = np.random.default_rng(5)
+    sv0 = np.exp(-0.05 * np.arange(300))
+    U0, _ = np.linalg.qr(rng.standard_normal((300, 300)))
+    V0, _ = np.linalg.qr(rng.standard_normal((300, 300)))
+    M = (U0 * sv0) @ V0.T
+    for rep in range(2):                                               # the second call finds the abort word cleared
+        mg, te, sv = ts.svd_split(M.reshape(150, 2, 2, 150, order="F"), 10, 1, 0.0, 150, 150)
+        assert mg == 150
+        np.testing.assert_allclose(sv, sv0, rtol=1e-7, atol=1e-7)
+        assert np.abs(ts.bond_tensor(10).reshape(300, 300, order="F") - (U0[:, :150] * sv0[:150]) @ V0[:, :150].T).max() < 1e-9
+    assert ts.svd_stats()["fallbacks"] == 2
+
+
 def test_invariants_of_the_split_and_of_the_gauge():
     """SURVEY.md section 4, invariants 2 and 4 on the HIP path itself (no oracle involved):
     |B - newB|^2 = sum of the discarded sigma^2 = truncerr * sum sigma^2; the data cost evaluated with the

@@ -215,3 +215,24 @@ def test_a_pipelined_bond_update_enters_five_payload_allreduces():
     np.testing.assert_allclose(new[0]["cost"], old[0]["cost"], rtol=1e-3)
     for a, b in zip(new[0]["cg"][:8], old[0]["cg"][:8]):                          # the per-pass costs the reference prints (:429)
         np.testing.assert_allclose(a, b, rtol=1e-9)
+
+
+def test_split_on_the_workgroup_cluster_keeps_the_replicas_identical():
+    """bond dimension 150 (Gram side > 240): every rank runs its own multi-workgroup tridiagonalisation (eigh_mc.hip) -- the partial
+    sums are exchanged through tagged granules and summed in workgroup order, so two ranks (two concurrent clusters on one GPU)
+    must produce bit-identical site tensors; checked by the fingerprint of every bond update and by tnml_replica_check"""
+    from tnml_amd.fixedl import mldmrg
+    N, NT, m = 20, 48, 150
+    pixels, labels, phi, W = make_problem(N, NT, m, 9, pixel_boost=200.0)
+    args = (1, m, m // 2, 1e-10, 2, 1e-3, 1e-10)
+
+    def body(ts, r):
+        ts.init()
+        reps = mldmrg(ts, *args, max_bonds=11, pipelined=True)
+        ts.replica_check()
+        return dict(cost=[x["cost"] for x in reps], newm=[x["newm"] for x in reps], fb=ts.svd_stats()["fallbacks"])
+    two = _run_ranks(2, labels, phi, W, N, m, body)
+    one = _run_ranks(1, labels, phi, W, N, m, body)[0]
+    assert two[0]["cost"] == two[1]["cost"] and two[0]["newm"] == two[1]["newm"] == one["newm"]
+    assert max(one["newm"]) == 150 and two[0]["fb"] == 0 and one["fb"] == 0
+    np.testing.assert_allclose(two[0]["cost"], one["cost"], rtol=1e-7)

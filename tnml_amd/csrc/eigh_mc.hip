@@ -51,6 +51,7 @@ struct McArgs {
     int P;
     int same_xcd;                          // 1: the grid is 8 P workgroups of which those with blockIdx % 8 == 0 work (all on one XCD, verified by the caller's probe): hand-offs through that XCD's L2
     int nap_first, nap_retry;              // back-off of the pollers, in units of 16 * 64 cycles
+    int spin_max;                          // polls before a waiting thread gives up and aborts the launch
     long long* dbg;                        // MC_PROF builds: per-phase cycle counters of workgroup 0, wave dbg[15]
 };
 
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(MC_THREADS) void k_sytrd_mc(McArgs T) {
                     }
                     ok = ok && (unsigned)(g[2 * MC_PMAX] >> 32) == tag && (unsigned)(g[2 * MC_PMAX + 1] >> 32) == tag;
                     if (ok) break;
-                    if (++spin > MC_SPIN_MAX || ((spin & 255) == 0 && mc_ld(abortw) != 0)) { aborted = true; break; }
+                    if (++spin > T.spin_max || ((spin & 255) == 0 && mc_ld(abortw) != 0)) { aborted = true; break; }
                     for (int jn = 0; jn < T.nap_retry; ++jn) __builtin_amdgcn_s_sleep(16);
                 }
 #ifdef MC_PROF
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(MC_THREADS) void k_sytrd_mc(McArgs T) {
                     if (lane < P) ok = ok && (unsigned)(g2 >> 32) == tag && (unsigned)(g3 >> 32) == tag;
                 }
                 if (ok) break;
-                if (++spin > MC_SPIN_MAX || ((spin & 255) == 0 && mc_ld(abortw) != 0)) { aborted = true; break; }
+                if (++spin > T.spin_max || ((spin & 255) == 0 && mc_ld(abortw) != 0)) { aborted = true; break; }
                 for (int jn = 0; jn < T.nap_retry; ++jn) __builtin_amdgcn_s_sleep(16);
             }
 #ifdef MC_PROF
@@ -486,12 +487,13 @@ int eigh_mc_max_n() { return MC_MAXN; }
 // A (n x n symmetric, device) -> D, E, tau (tau[n-1] = number of reflectors), V on `st`.  xbuf: eigh_mc_xbuf_bytes() of device memory,
 // zeroed once at allocation; *epoch is advanced per launch.  The kernel reports through xbuf's status word (eigh_mc_status).
 int eigh_mc_tridiagonalize(tnml_ctx* c, hipStream_t st, const double* A, int n, double* D, double* E, double* tau, double* V, double psd_tol,
-                           void* xbuf, unsigned* epoch, long long* dbg, int nap_first, int nap_retry, int same_xcd) {
+                           void* xbuf, unsigned* epoch, long long* dbg, int nap_first, int nap_retry, int same_xcd, int spin_max) {
     if (n > MC_MAXN || n < 3) return tnml_fail(c, "eigh_mc_tridiagonalize: n=%d outside 3..%d", n, MC_MAXN);
     const int P = mc_workgroups(n);
     if (P == 0) return tnml_fail(c, "eigh_mc_tridiagonalize: no workgroup count fits n=%d", n);
     *epoch = (*epoch % 4000000u) + 1u;
-    McArgs t{A, n, n, D, E, tau, V, n, tau + (n - 1), psd_tol, (mc_u64*)xbuf, *epoch * 1024u, P, same_xcd, nap_first, nap_retry, dbg};
+    if (spin_max < 0) spin_max = MC_SPIN_MAX;                  // (0: the first failed poll aborts -- the fallback test)
+    McArgs t{A, n, n, D, E, tau, V, n, tau + (n - 1), psd_tol, (mc_u64*)xbuf, *epoch * 1024u, P, same_xcd, nap_first, nap_retry, spin_max, dbg};
     // (per launch: the attribute is per device, a process may drive several, and this kernel runs for milliseconds)
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_sytrd_mc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MC_SMEM_DOUBLES * sizeof(double))) != hipSuccess)
         return tnml_fail(c, "eigh_mc_tridiagonalize: cannot reserve %zu bytes of LDS", MC_SMEM_DOUBLES * sizeof(double));

@@ -166,6 +166,7 @@ struct tnml_ctx {
     double *sW = nullptr, *sScr = nullptr, *sS = nullptr, *sCm = nullptr, *sQ1 = nullptr, *sDev = nullptr;   // own tridiagonal eigensolver + Newton-Schulz polish
     void* mc_xbuf = nullptr;   // exchange buffer of the multi-workgroup tridiagonalisation (eigh_mc.hip), contexts with maxm > 120 only
     unsigned mc_epoch = 0;
+    int mc_spin_max = -1;      // polls before a waiting thread of k_sytrd_mc gives up (-1: default; option "mc_spin_max", 0 in the fallback test)
     bool attr_sytrd = false, attr_invit = false, attr_fused = false;   // per-device function attributes set (a process may drive several devices)
     int cu_count = 0;
     double svd_last_dev0 = 0., svd_last_dev1 = 0.;   // max|Q^T Q - I| before the 1st / 2nd polish step of the last split
@@ -340,7 +341,7 @@ int eigh_chol_rinv(tnml_ctx* c, const double* S, int m, double* Rinv, double* fl
 size_t eigh_mc_xbuf_bytes();
 int eigh_mc_max_n();
 int eigh_mc_tridiagonalize(tnml_ctx* c, hipStream_t st, const double* A, int n, double* D, double* E, double* tau, double* V, double psd_tol,
-                           void* xbuf, unsigned* epoch, long long* dbg = nullptr, int nap_first = 0, int nap_retry = 0, int same_xcd = 0);
+                           void* xbuf, unsigned* epoch, long long* dbg = nullptr, int nap_first = 0, int nap_retry = 0, int same_xcd = 0, int spin_max = -1);
 const void* eigh_mc_status_ptr(const void* xbuf);
 int eigh_backtransform(tnml_ctx* c, const double* V, const double* tau, int n, const double* Z, int ldz, double* U, int ldu, int ncols, hipStream_t st = nullptr);   // Z == nullptr: U = H_0 ... H_{n-2}
 
