@@ -87,12 +87,13 @@ int main(int argc, const char* argv[]) {
         const long ngpu = input.getInt("ngpu", 1);                                      // extension: GPUs (ranks) to shard the images over; 0 = all visible
         const bool share_device = input.getYesNo("share_device", false);                // extension: all ranks on `device` (in-process communicator; one-GPU boxes)
         const bool pipeline = input.getYesNo("pipeline", true);                         // extension: enqueue bond k+1 before fetching the report of bond k (see the sweep loop)
-        const std::string precision = input.getString("precision", "f64");              // extension: f64 | mixed | f32
+        const std::string precision = input.getString("precision", "f64");              // extension: f64 | mixed | f32 | bf16x3 | bf16
         const long imglen = input.getInt("imglen", 0);                                   // extension: 0 = keep the file's size
         const double feature_scale = input.getReal("feature_scale", 1.);                 // extension
         int dtype = TNML_F64;
         if (precision == "mixed") dtype = TNML_F64_E32; else if (precision == "f32") dtype = TNML_F32;
-        else if (precision != "f64" && precision != "strict") { std::printf("precision must be f64, mixed or f32\n"); return 1; }
+        else if (precision == "bf16x3") dtype = TNML_BF16X3; else if (precision == "bf16") dtype = TNML_BF16;   // study modes (forward contraction on the bf16 matrix pipe)
+        else if (precision != "f64" && precision != "strict") { std::printf("precision must be f64, mixed, f32, bf16x3 or bf16\n"); return 1; }
         if (method != "conj") { std::printf("method type \"%s\" not recognized\n", method.c_str()); return 1; }   // :505
 
         Dataset train = read_mnist(datadir, true, Ntrain);                              // :613
