@@ -357,7 +357,7 @@ int eigh_tridiagonalize(tnml_ctx* c, const double* A, int n, double* D, double* 
     if (tol_env >= 0.) psd_tol = psd_tol > 0. ? tol_env : 0.;
     if (n > TRI_MAXN) {                                // the multi-workgroup kernel (eigh_mc.hip)
         if (!c->mc_xbuf) return tnml_fail(c, "eigh_tridiagonalize: n=%d needs the multi-workgroup exchange buffer (context created with maxm <= %d)", n, TRI_MAXN / 2);
-        return eigh_mc_tridiagonalize(c, c->stream, A, n, D, E, tau, V, psd_tol, c->mc_xbuf, &c->mc_epoch, nullptr, 0, 0, 0, c->mc_spin_max);
+        return eigh_mc_tridiagonalize(c, c->stream, A, n, D, E, tau, V, psd_tol, c->mc_xbuf, &c->mc_epoch, nullptr, 0, c->mc_spin_max);
     }
     TriArgs t{A, n, n, D, E, tau, V, n, nullptr, tau + (n - 1), psd_tol};
     if (!c->attr_sytrd) {                              // function attributes are per device: remembered per context, not per process

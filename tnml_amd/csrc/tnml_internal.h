@@ -341,7 +341,8 @@ int eigh_chol_rinv(tnml_ctx* c, const double* S, int m, double* Rinv, double* fl
 size_t eigh_mc_xbuf_bytes();
 int eigh_mc_max_n();
 int eigh_mc_tridiagonalize(tnml_ctx* c, hipStream_t st, const double* A, int n, double* D, double* E, double* tau, double* V, double psd_tol,
-                           void* xbuf, unsigned* epoch, long long* dbg = nullptr, int nap_first = 0, int nap_retry = 0, int same_xcd = 0, int spin_max = -1);
+                           void* xbuf, unsigned* epoch, long long* dbg = nullptr, int xp = 0, int spin_max = -1);
+int eigh_mc_workgroups(int n);
 const void* eigh_mc_status_ptr(const void* xbuf);
 int eigh_backtransform(tnml_ctx* c, const double* V, const double* tau, int n, const double* Z, int ldz, double* U, int ldu, int ncols, hipStream_t st = nullptr);   // Z == nullptr: U = H_0 ... H_{n-2}
 

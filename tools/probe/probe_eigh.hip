@@ -10,7 +10,7 @@
 int tnml_fail(tnml_ctx*, const char* fmt, ...) { va_list ap; va_start(ap, fmt); vprintf(fmt, ap); va_end(ap); printf("\n"); return 1; }
 void prof_begin(tnml_ctx*, int, hipEvent_t*) {}
 void prof_end(tnml_ctx*, int, hipEvent_t) {}
-int eigh_mc_tridiagonalize(tnml_ctx*, hipStream_t, const double*, int, double*, double*, double*, double*, double, void*, unsigned*, long long*, int, int, int, int) { return 1; }   // n > 240: tools/probe/probe_mc.hip
+int eigh_mc_tridiagonalize(tnml_ctx*, hipStream_t, const double*, int, double*, double*, double*, double*, double, void*, unsigned*, long long*, int, int) { return 1; }   // n > 240: tools/probe/probe_mc.hip
 #define HC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s failed: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 int main() {
     for (int n : {240, 200, 37}) {

@@ -13,10 +13,7 @@ static double urand() { return rand() / (double)RAND_MAX - 0.5; }
 
 int main(int argc, char** argv) {
     const int only = argc > 1 ? atoi(argv[1]) : 0;
-    const int nap1 = argc > 2 ? atoi(argv[2]) : 0, nap2 = argc > 3 ? atoi(argv[3]) : 0, sx = argc > 4 ? atoi(argv[4]) : 0;
-    const int variant = argc > 5 ? atoi(argv[5]) : 1;                 // 0: k_sytrd_mc, 1: k_sytrd_ro
-    eigh_mc_set_variant(variant);
-    printf("variant %d\n", variant);
+    const int xp = argc > 2 ? atoi(argv[2]) : 0;                      // 99 / 98 / 97: timing experiments without validation / publishes / polls (results are garbage)
     void* xbuf; HC(hipMalloc(&xbuf, eigh_mc_xbuf_bytes())); HC(hipMemset(xbuf, 0, eigh_mc_xbuf_bytes()));
     unsigned epoch = 0;
     long long* dbg; HC(hipMalloc(&dbg, 128)); HC(hipMemset(dbg, 0, 128));
@@ -48,11 +45,14 @@ int main(int argc, char** argv) {
             HC(hipMemset(dV, 0, 8 * (size_t)n * n)); HC(hipMemset(dD, 0, 8 * n)); HC(hipMemset(dE, 0, 8 * n)); HC(hipMemset(dT, 0, 8 * n));
             HC(hipEventRecord(e0));
             { long long pwv = rep == 3 ? 6 : 0; HC(hipMemcpy(dbg + 15, &pwv, 8, hipMemcpyHostToDevice)); }
-            if (eigh_mc_tridiagonalize(nullptr, 0, dA, n, dD, dE, dT, dV, cs.tol, xbuf, &epoch, dbg, nap1, nap2, sx)) return 1;
+            if (eigh_mc_tridiagonalize(nullptr, 0, dA, n, dD, dE, dT, dV, cs.tol, xbuf, &epoch, dbg, xp)) return 1;
             HC(hipEventRecord(e1)); HC(hipEventSynchronize(e1));
             float ms; HC(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
-            if (rep >= 2) { long long h[15]; HC(hipMemcpy(h, dbg, 120, hipMemcpyDeviceToHost)); printf("   after barrier 1 (cycles, summed): thread 511 starts its gather %lld, has it %lld | thread 0 starts polling its reduced row %lld, has it %lld\n", h[11], h[12], h[13], h[14]); printf("   failed polls: gather (thread 511) %lld, reduced row (thread 0) %lld, (thread 448) %lld\n", h[8], h[9], h[10]); if (variant == 0) printf("   cycles wg0 wave %d: A %lld  B %lld  bar1 %lld  C1 publish %lld  C2 scalars %lld  C2 rows %lld  bar2 %lld  D %lld\n", rep == 3 ? 6 : 0, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
-                else printf("   cycles wg0 wave %d: A %lld  B %lld  bar1 %lld  C1 publish %lld  C2 poll %lld  bar2 %lld  D %lld | failed polls lane 0 (scalars + row) %lld, lane 1 %lld, lane 20 (row only) %lld\n", rep == 3 ? 6 : 0, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9]); }
+            if (rep >= 2) {
+                long long h[15]; HC(hipMemcpy(h, dbg, 120, hipMemcpyDeviceToHost));
+                printf("   cycles wg0 wave %d: A scalars %lld  B block products %lld  bar1 %lld  C1 row sums + publish %lld  C2 poll + next column %lld  bar2 %lld  D rank-2 update %lld | failed polls lane 0 (scalars + row) %lld, lane 1 %lld, lane 20 (row only) %lld\n",
+                       rep == 3 ? 6 : 0, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9]);
+            }
             unsigned long long status = 0; HC(hipMemcpy(&status, eigh_mc_status_ptr(xbuf), 8, hipMemcpyDeviceToHost));
             if (status) { printf("n=%d: kernel aborted (status %llu)\n", n, status); return 1; }
             HC(hipMemcpy(rep ? D2.data() : D.data(), dD, 8 * n, hipMemcpyDeviceToHost));
