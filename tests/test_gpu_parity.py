@@ -1162,6 +1162,24 @@ def test_properties_at_the_full_baseline_size():
     assert _relmax(Gs, G) < 1e-11
 
 
+@pytest.mark.parametrize("N,NT,m,dtype", [(20, 300, 8, "f64"), (16, 700, 24, "f64_e32"), (24, 48, 150, "f64")])
+def test_memory_estimate_covers_what_a_sweep_allocates(N, NT, m, dtype):
+    """tnml_estimate_bytes is what the drivers size maxm with (tnml_plan_maxm) before any environment exists; the
+    environment slabs are allocated lazily during the first sweep.  An estimate below the real footprint would surface
+    as a failed hipMalloc in the middle of a sweep: after a full sweep the context must hold no more than estimated
+    (and not absurdly less: the plan would give memory away)."""
+    from tnml_amd.fixedl import TrainStates, mldmrg
+    pixels, labels, phi, W = make_problem(N, NT, min(m, 8), 3, pixel_boost=200.0)
+    ts = TrainStates(labels, N, m, pixels=pixels, dtype=dtype)
+    ts.set_mps(W)
+    ts.init()
+    mldmrg(ts, 1, m, max(2, m // 2), 1e-10, 2, 1e-3, 1e-10)
+    used, est = ts.device_bytes(), ts.estimate_bytes()
+    ts.close()
+    assert est > 0 and used <= est, (used, est)
+    assert used > 0.25 * est, (used, est)
+
+
 @pytest.mark.parametrize("m,NT", [(150, 48), (300, 24)])
 def test_bond_dimension_above_120_splits_on_the_workgroup_cluster(m, NT):
     """maxm > 120 (BASELINE config 5 goes to 300): Gram side n = 2m > 240, beyond the one-workgroup tridiagonalisation;

@@ -41,6 +41,7 @@ class TrainStates:
         self.dtype = dtype
         cfg = _lib.Config(device, rank, nranks, self.N, self.NT, self.NT_total, self.maxm, _lib.DTYPES[dtype], 0,
                           1 if self.single else 0, int(single_label) if self.single else 0)
+        self._cfg = cfg
         rc = self._L.tnml_create(C.byref(self._h), C.byref(cfg))
         if rc != 0:
             self._h = C.c_void_p()
@@ -123,6 +124,10 @@ class TrainStates:
 
     def device_bytes(self):
         return self._L.tnml_device_bytes(self._h)
+
+    def estimate_bytes(self):
+        """tnml_estimate_bytes for this context's configuration: what the drivers plan maxm with (tnml_plan_maxm)"""
+        return int(self._L.tnml_estimate_bytes(C.byref(self._cfg)))
 
     def classify(self):
         """toverlap / fullTest (util.h:19-40,123-200) over the local images: returns (weights[NT,10], pred[NT],
