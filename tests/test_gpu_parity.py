@@ -1180,7 +1180,33 @@ def test_memory_estimate_covers_what_a_sweep_allocates(N, NT, m, dtype):
     assert used > 0.25 * est, (used, est)
 
 
-@pytest.mark.parametrize("m,NT", [(150, 48), (300, 24)])
+@pytest.mark.parametrize("m", [121, 123, 124, 125, 127, 128, 129, 160, 161, 200, 224, 225, 240, 256, 257, 300, 319, 320])
+def test_split_at_every_size_between_the_one_workgroup_kernel_and_the_cluster_limit(m):
+    """every Gram side n = 2m from 242 to 640 takes some combination of the cluster tridiagonalisation's workgroup count (4..14), the
+    inverse iteration's vectors per workgroup (16 / 8 / 4, with or without byte flags) and the back transformation's reflectors per pass:
+    the singular values of a random bond tensor against numpy at the sizes on either side of each switch (n = 256 once fell into a gap
+    between two LDS layouts and failed in the middle of a sweep)."""
+    from tnml_amd.fixedl import TrainStates
+    N, NT, b = 24, 8, 10
+    pixels, labels, phi, W = make_problem(N, NT, m, 3, pixel_boost=200.0)
+    ts = TrainStates(labels, N, m, phi=phi)
+    ts.set_mps(W)
+    ts.init()
+    for bb in range(1, b):
+        ts.shiftE(bb, True)
+    ts.setBond(b)
+    rng = np.random.default_rng(m)
+    Bn = rng.standard_normal((m, 2, 2, m)) * np.logspace(0, -9, 2 * m)[rng.permutation(2 * m)].reshape(m, 2, 1, 1)   # graded rows: a spectrum over 9 decades
+    mg, teg, svg = ts.svd_split(Bn, b, 1, 1e-12, m, m)
+    sv = np.linalg.svd(Bn.reshape(2 * m, 2 * m), compute_uv=False)
+    assert mg == m
+    np.testing.assert_allclose(svg[:m], sv[:m], rtol=1e-7, atol=1e-9 * sv[0])
+    assert _relmax(ts.bond_tensor(b).reshape(2 * m, 2 * m), (lambda U, S, Vt: (U[:, :m] * S[:m]) @ Vt[:m])(*np.linalg.svd(Bn.reshape(2 * m, 2 * m)))) < 1e-7
+    assert ts.svd_stats()["fallbacks"] == 0
+    ts.close()
+
+
+@pytest.mark.parametrize("m,NT", [(150, 48), (300, 24), (124, 40), (125, 40), (128, 40)])     # n = 248 / 250 / 256: either side of the inverse iteration's 16-vector LDS layout
 def test_bond_dimension_above_120_splits_on_the_workgroup_cluster(m, NT):
     """maxm > 120 (BASELINE config 5 goes to 300): Gram side n = 2m > 240, beyond the one-workgroup tridiagonalisation;
     the split runs on the multi-workgroup kernel (eigh_mc.hip) with the Cholesky QR on rocSOLVER dpotrf, the GEMMs on the

@@ -526,7 +526,7 @@ __global__ __launch_bounds__(1024) void k_tridiag_rank(TeigArgs T) {
 
 // eigenvectors of the mk largest eigenvalues by inverse iteration inside the owning block; 16 vectors per
 // workgroup, their LU factors and iterates live in LDS as [array][k][lane]
-// IV_L: vectors per workgroup (16 up to n = 256; 8 / 4 for the larger blocks of eigh_mc.hip, whose LU factors would not fit otherwise);
+// IV_L: vectors per workgroup (16 up to n = 248; 8 / 4 for larger blocks, whose LU factors would not fit otherwise);
 // BIG: the interchange flags live in LDS bytes instead of four 64-bit registers
 template <int IV_L, bool BIG>
 __global__ __launch_bounds__(64) void k_tridiag_invit(TeigArgs T) {
@@ -645,8 +645,8 @@ int eigh_tridiag_eig(tnml_ctx* c, const double* D, const double* E, int n, doubl
     hipLaunchKernelGGL(k_tridiag_eigvals, dim3(n), dim3(64), 0, c->stream, t);
     hipLaunchKernelGGL(k_tridiag_rank, dim3(1), dim3(1024), 0, c->stream, t);
     const int ns = (n + 63) & ~63;
-    const int ivl = n <= 256 ? 16 : (n <= 448 ? 8 : 4);
-    const size_t lds = sizeof(double) * (2 * (size_t)ns + (size_t)5 * n * ivl) + (n > 256 ? (size_t)n * ivl : 0);
+    const int ivl = n <= 248 ? 16 : (n <= 448 ? 8 : 4);        // (16 vectors of 249..256 rows would need 161-168 KB)
+    const size_t lds = sizeof(double) * (2 * (size_t)ns + (size_t)5 * n * ivl) + (ivl != 16 ? (size_t)n * ivl : 0);   // + the byte flags of the BIG instantiations
     if (lds > 160 * 1024) return tnml_fail(c, "eigh_tridiag_eig: %zu bytes of LDS for n=%d", lds, n);
     if (!c->attr_invit) {
         (void)hipFuncSetAttribute((const void*)k_tridiag_invit<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
