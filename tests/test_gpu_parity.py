@@ -1180,6 +1180,92 @@ def test_memory_estimate_covers_what_a_sweep_allocates(N, NT, m, dtype):
     assert used > 0.25 * est, (used, est)
 
 
+def _mps_with_dims(dims, seed):
+    """random weight MPS with the given bond dimensions d_0 = 1, d_1, ..., d_N = 1 (Label index on site N/2), any shapes"""
+    rng = np.random.default_rng(seed)
+    N = len(dims) - 1
+    W = []
+    for j in range(1, N + 1):
+        ml, mr = dims[j - 1], dims[j]
+        shape = (ml, 2, mr, 10) if j == N // 2 else (ml, 2, mr)
+        A = rng.standard_normal(shape) / np.sqrt(2. * max(ml, mr) * (10 if j == N // 2 else 1))
+        A[:, 0] += (np.eye(ml, mr) if A.ndim == 3 else np.eye(ml, mr)[:, :, None] / np.sqrt(10.))
+        W.append(A)
+    return W
+
+
+@pytest.mark.parametrize("dims", [[1, 2, 3, 5, 9, 17, 33, 65, 120, 2, 1],
+                                  [1, 2, 120, 97, 64, 60, 61, 128, 33, 2, 1],
+                                  [1, 2, 4, 150, 129, 200, 300, 257, 16, 2, 1]])
+def test_bonds_with_unequal_and_odd_dimensions(dims):
+    """real sweeps leave bonds of every size (minm <= m <= maxm, left and right dimension different, odd): every kernel dispatch on
+    (Kp, Np) -- feature / gradient GEMM tile classes, label-dot variants, pack / unpack, the shift forms -- must agree with the
+    oracle on shapes it was not tuned for.  Walks a 10-site chain with prescribed bond dimensions and checks environments, forward
+    map, gradient and cost at every bond."""
+    from oracle import pyoracle
+    from tnml_amd.fixedl import TrainStates
+    N, NT = len(dims) - 1, 40
+    pixels, labels, phi, _ = make_problem(N, NT, 2, 5, pixel_boost=200.0)
+    W = _mps_with_dims(dims, 11)
+    ts = TrainStates(labels, N, max(dims), phi=phi)
+    o = pyoracle.Oracle(phi, labels, W)
+    ts.set_mps(W)
+    o.init()
+    ts.init()
+    rng = np.random.default_rng(2)
+    for b in range(1, N):
+        ts.setBond(b)
+        o.set_bond(b)
+        B = o.bond_tensor(b)
+        assert B.shape[0] == dims[b - 1] and B.shape[3] == dims[b + 1]
+        B = B + 0.1 * np.abs(B).max() * rng.standard_normal(B.shape)
+        assert _relmax(ts.forward(B), o.forward(B)) < 1e-10, b
+        assert _relmax(ts.gradient(B), o.gradient(B)) < 1e-8, b
+        Cg, Co = ts.quadcost(B, 1e-3), o.quadcost(B, 1e-3)
+        assert Cg[0] == pytest.approx(Co[0], rel=1e-10) and Cg[3] == Co[3], b
+        ts.shiftE(b, True)
+        o.shiftE(b, True)
+        assert _relmax(ts.env(b), o.env(b)) < 1e-10, b
+    ts.close()
+
+
+@pytest.mark.parametrize("dims,maxm,minm", [([1, 2, 4, 7, 13, 24, 31, 17, 8, 4, 2, 1], 29, 5),
+                                            ([1, 2, 4, 8, 16, 97, 120, 64, 33, 2, 1], 101, 60)])
+def test_a_sweep_over_bonds_of_unequal_dimensions_in_lockstep(dims, maxm, minm):
+    """whole bond updates (CG, split with truncation to an odd maxm, after-SVD cost, environment shift) on a chain whose bond
+    dimensions differ left and right and change under the sweep: one full sweep in lockstep with the oracle"""
+    from oracle import pyoracle
+    from tnml_amd import lib
+    from tnml_amd.fixedl import TrainStates
+    N, NT = len(dims) - 1, 50
+    pixels, labels, phi, _ = make_problem(N, NT, 2, 5, pixel_boost=200.0)
+    W = _mps_with_dims(dims, 4)
+    ts = TrainStates(labels, N, max(max(dims), maxm), phi=phi)
+    o = pyoracle.Oracle(phi, labels, W)
+    ts.set_mps(W)
+    o.init()
+    ts.init()
+    b, ha, n = 1, 1, 0
+    while ha <= 2:
+        r = ts.bond_update(b, ha, maxm, minm, 1e-10, 3, 1e-3, 1e-10)
+        o.set_bond(b)
+        B, tr = o.cgrad(o.bond_tensor(b), 3, 1e-3, 1e-10)
+        newm, te, _ = o.svd_split(B, b, ha, 1e-10, maxm, minm)
+        C, lc, cr, nc = o.quadcost(o.bond_tensor(b), 1e-3)
+        o.shiftE(b, ha == 1)
+        assert r["newm"] == newm, (b, ha)
+        assert r["cost"] == pytest.approx(C, rel=1e-8), (b, ha)
+        assert r["ncorrect"] == nc, (b, ha)
+        np.testing.assert_allclose(r["cg"]["cost"], tr["cost"], rtol=1e-8)
+        ts.set_site(b, o.get_site(b))
+        ts.set_site(b + 1, o.get_site(b + 1))
+        ts.shiftE(b, ha == 1)
+        n += 1
+        b, ha = lib.sweepnext(b, ha, N)
+    assert n == 2 * (N - 1)
+    ts.close()
+
+
 @pytest.mark.parametrize("m", [121, 123, 124, 125, 127, 128, 129, 160, 161, 200, 224, 225, 240, 256, 257, 300, 319, 320])
 def test_split_at_every_size_between_the_one_workgroup_kernel_and_the_cluster_limit(m):
     """every Gram side n = 2m from 242 to 640 takes some combination of the cluster tridiagonalisation's workgroup count (4..14), the
