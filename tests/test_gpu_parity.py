@@ -1194,10 +1194,11 @@ def _mps_with_dims(dims, seed):
     return W
 
 
+@pytest.mark.parametrize("dtype,ftol,gtol", [("f64", 1e-10, 1e-8), ("f64_e32", 5e-6, 5e-6), ("f32", 2e-5, 5e-4)])
 @pytest.mark.parametrize("dims", [[1, 2, 3, 5, 9, 17, 33, 65, 120, 2, 1],
                                   [1, 2, 120, 97, 64, 60, 61, 128, 33, 2, 1],
                                   [1, 2, 4, 150, 129, 200, 300, 257, 16, 2, 1]])
-def test_bonds_with_unequal_and_odd_dimensions(dims):
+def test_bonds_with_unequal_and_odd_dimensions(dims, dtype, ftol, gtol):
     """real sweeps leave bonds of every size (minm <= m <= maxm, left and right dimension different, odd): every kernel dispatch on
     (Kp, Np) -- feature / gradient GEMM tile classes, label-dot variants, pack / unpack, the shift forms -- must agree with the
     oracle on shapes it was not tuned for.  Walks a 10-site chain with prescribed bond dimensions and checks environments, forward
@@ -1207,30 +1208,33 @@ def test_bonds_with_unequal_and_odd_dimensions(dims):
     N, NT = len(dims) - 1, 40
     pixels, labels, phi, _ = make_problem(N, NT, 2, 5, pixel_boost=200.0)
     W = _mps_with_dims(dims, 11)
-    ts = TrainStates(labels, N, max(dims), phi=phi)
+    ts = TrainStates(labels, N, max(dims), phi=phi, dtype=dtype)
     o = pyoracle.Oracle(phi, labels, W)
     ts.set_mps(W)
     o.init()
     ts.init()
     rng = np.random.default_rng(2)
+    exact = dtype == "f64"
     for b in range(1, N):
         ts.setBond(b)
         o.set_bond(b)
         B = o.bond_tensor(b)
         assert B.shape[0] == dims[b - 1] and B.shape[3] == dims[b + 1]
         B = B + 0.1 * np.abs(B).max() * rng.standard_normal(B.shape)
-        assert _relmax(ts.forward(B), o.forward(B)) < 1e-10, b
-        assert _relmax(ts.gradient(B), o.gradient(B)) < 1e-8, b
+        assert _relmax(ts.forward(B), o.forward(B)) < ftol, b
+        assert _relmax(ts.gradient(B), o.gradient(B)) < gtol, b
         Cg, Co = ts.quadcost(B, 1e-3), o.quadcost(B, 1e-3)
-        assert Cg[0] == pytest.approx(Co[0], rel=1e-10) and Cg[3] == Co[3], b
+        assert Cg[0] == pytest.approx(Co[0], rel=1e-10 if exact else 10 * ftol), b
+        assert Cg[3] == Co[3] or not exact, b
         ts.shiftE(b, True)
         o.shiftE(b, True)
-        assert _relmax(ts.env(b), o.env(b)) < 1e-10, b
+        assert _relmax(ts.env(b), o.env(b)) < (1e-10 if exact else ftol), b
     ts.close()
 
 
 @pytest.mark.parametrize("dims,maxm,minm", [([1, 2, 4, 7, 13, 24, 31, 17, 8, 4, 2, 1], 29, 5),
-                                            ([1, 2, 4, 8, 16, 97, 120, 64, 33, 2, 1], 101, 60)])
+                                            ([1, 2, 4, 8, 16, 97, 120, 64, 33, 2, 1], 101, 60),
+                                            ([1, 2, 4, 8, 16, 150, 129, 200, 64, 4, 2, 1], 161, 80)])     # splits of 258 ... 400 rows on the workgroup cluster
 def test_a_sweep_over_bonds_of_unequal_dimensions_in_lockstep(dims, maxm, minm):
     """whole bond updates (CG, split with truncation to an odd maxm, after-SVD cost, environment shift) on a chain whose bond
     dimensions differ left and right and change under the sweep: one full sweep in lockstep with the oracle"""
