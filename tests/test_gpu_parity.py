@@ -1215,6 +1215,9 @@ def test_bonds_with_unequal_and_odd_dimensions(dims, dtype, ftol, gtol):
     ts.init()
     rng = np.random.default_rng(2)
     exact = dtype == "f64"
+    w = ts.classify()[0]                                       # inference (tnml_classify) on the same odd shapes
+    wo = np.stack([o.toverlap(i) for i in range(NT)])
+    assert _relmax(w, wo) < (1e-11 if exact else 10 * ftol)
     for b in range(1, N):
         ts.setBond(b)
         o.set_bond(b)
