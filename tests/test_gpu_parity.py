@@ -1194,11 +1194,11 @@ def _mps_with_dims(dims, seed):
     return W
 
 
-@pytest.mark.parametrize("dtype,ftol,gtol", [("f64", 1e-10, 1e-8), ("f64_e32", 5e-6, 5e-6), ("f32", 2e-5, 5e-4)])
+@pytest.mark.parametrize("dtype,ftol,gtol,boost", [("f64", 1e-10, 1e-8, 200.0), ("f64", 1e-10, 1e-8, 1.0), ("f64_e32", 5e-6, 5e-6, 200.0), ("f32", 2e-5, 5e-4, 200.0)])   # boost 1: the reference's own feature map [1, byte/260100]
 @pytest.mark.parametrize("dims", [[1, 2, 3, 5, 9, 17, 33, 65, 120, 2, 1],
                                   [1, 2, 120, 97, 64, 60, 61, 128, 33, 2, 1],
                                   [1, 2, 4, 150, 129, 200, 300, 257, 16, 2, 1]])
-def test_bonds_with_unequal_and_odd_dimensions(dims, dtype, ftol, gtol):
+def test_bonds_with_unequal_and_odd_dimensions(dims, dtype, ftol, gtol, boost):
     """real sweeps leave bonds of every size (minm <= m <= maxm, left and right dimension different, odd): every kernel dispatch on
     (Kp, Np) -- feature / gradient GEMM tile classes, label-dot variants, pack / unpack, the shift forms -- must agree with the
     oracle on shapes it was not tuned for.  Walks a 10-site chain with prescribed bond dimensions and checks environments, forward
@@ -1206,7 +1206,7 @@ def test_bonds_with_unequal_and_odd_dimensions(dims, dtype, ftol, gtol):
     from oracle import pyoracle
     from tnml_amd.fixedl import TrainStates
     N, NT = len(dims) - 1, 40
-    pixels, labels, phi, _ = make_problem(N, NT, 2, 5, pixel_boost=200.0)
+    pixels, labels, phi, _ = make_problem(N, NT, 2, 5, pixel_boost=boost)
     W = _mps_with_dims(dims, 11)
     ts = TrainStates(labels, N, max(dims), phi=phi, dtype=dtype)
     o = pyoracle.Oracle(phi, labels, W)
