@@ -375,6 +375,38 @@ def test_fixedl_cli_driver_end_to_end(tmp_path):
         assert "Total # test images = %d" % len(tl) in run.stdout
 
 
+@pytest.mark.parametrize("pipeline", ["yes", "no"])
+def test_fixedl_cli_file_hooks(tmp_path, pipeline):
+    """the WRITE_WF / LAMBDA hooks of mldmrg (fixedL.cc:542-559): files dropped in the working directory are noticed after a bond
+    update, removed, W is written, the new lambda takes effect for the following bond updates -- with the pipelined sweep loop
+    (one bond later than in the reference, by construction) and with `pipeline = no`"""
+    import re
+    import subprocess
+    from tnml_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    N, per_label = 16, 6
+    labels = synth.synthetic_labels(10 * per_label, seed=9, per_label=per_label)
+    pixels = np.clip(synth.synthetic_images(N, labels, seed=9).astype(np.int32) * 3, 0, 255).astype(np.uint8)
+    data = str(tmp_path / "data")
+    synth.write_idx(data, pixels, labels)
+    inp = tmp_path / "input"
+    inp.write_text("input\n{\ndatadir = %s\nfeature_scale = 255\nNtrain = %d\nNbatch = 3\nNsweep = 1\ncutoff = 1E-10\nmaxm = 5\nminm = 2\n"
+                   "ninitial = 2\nlambda = 1E-3\nNpass = 2\nseed = 5\npipeline = %s\n}\n" % (data, per_label, pipeline))
+    (tmp_path / "WRITE_WF").write_text("")
+    (tmp_path / "LAMBDA").write_text("0.02\n")
+    run = subprocess.run([os.path.join(root, "tnml_amd", "fixedL"), str(inp)], capture_output=True, text=True, cwd=tmp_path, timeout=300)
+    assert run.returncode == 0, run.stdout[-1000:] + run.stderr[-2000:]
+    log = run.stdout
+    assert log.count("File WRITE_WF found") == 1 and log.count("new lambda = 0.02") == 1
+    assert not (tmp_path / "WRITE_WF").exists() and not (tmp_path / "LAMBDA").exists()
+    assert (tmp_path / "W").exists()
+    lams = [float(x) for x in re.findall(r"In cgrad, lambda = ([0-9.eE+-]+)", log)]
+    assert len(lams) == 2 * (N - 1)
+    first_new = lams.index(2e-2)
+    assert lams[:first_new] == [1e-3] * first_new and lams[first_new:] == [2e-2] * (len(lams) - first_new)
+    assert first_new == (1 if pipeline == "no" else 2)        # strict order: the second bond update; pipelined: the third (its predecessor was already issued)
+
+
 @pytest.mark.parametrize("precision,rtol", [("f64", 1e-6), ("mixed", 2e-2)])
 def test_fixedl_cli_imglen_and_feature_scale(tmp_path, precision, rtol):
     """driver extensions: `imglen` (8x8 -> 4x4 block means) and `feature_scale = 255` (the README's [1, x/4] map, well
