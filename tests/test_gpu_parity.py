@@ -375,6 +375,42 @@ def test_fixedl_cli_driver_end_to_end(tmp_path):
         assert "Total # test images = %d" % len(tl) in run.stdout
 
 
+def test_fixedl_cli_resumes_from_the_W_it_wrote(tmp_path):
+    """checkpoint / resume (fixedL.cc:671-681, :565): a run that finds `W` and `sites` in its directory continues from them.  One run of
+    two sweeps against two runs of one sweep each in the same directory: the second run reads the first one's W, starts at the cost the
+    first one ended with and reproduces the second sweep of the long run (W is stored in fp64, the environments are rebuilt by the same
+    kernels)."""
+    import re
+    import shutil
+    import subprocess
+    from tnml_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    N, per_label = 16, 8
+    labels = synth.synthetic_labels(10 * per_label, seed=9, per_label=per_label)
+    pixels = np.clip(synth.synthetic_images(N, labels, seed=9).astype(np.int32) * 3, 0, 255).astype(np.uint8)
+    data = str(tmp_path / "data")
+    synth.write_idx(data, pixels, labels)
+
+    def run(wd, nsweep):
+        wd.mkdir(exist_ok=True)
+        (wd / "input").write_text("input\n{\ndatadir = %s\nfeature_scale = 255\nNtrain = %d\nNbatch = 4\nNsweep = %d\ncutoff = 1E-10\nmaxm = 6\n"
+                                  "minm = 3\nninitial = 2\nlambda = 1E-3\nNpass = 2\nseed = 5\n}\n" % (data, per_label, nsweep))
+        r = subprocess.run([os.path.join(root, "tnml_amd", "fixedL"), str(wd / "input")], capture_output=True, text=True, cwd=wd, timeout=300)
+        assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+        return r.stdout, [float(x) for x in re.findall(r"--> After SVD, Cost = ([0-9.eE+-]+)", r.stdout)]
+    log_a, cost_a = run(tmp_path / "long", 2)
+    log_b1, cost_b1 = run(tmp_path / "short", 1)
+    assert "Reading W from disk" not in log_b1
+    log_b2, cost_b2 = run(tmp_path / "short", 1)
+    assert "Reading W from disk" in log_b2 and "Done making initial W" not in log_b2
+    nb = 2 * (N - 1)
+    assert len(cost_a) == 2 * nb and len(cost_b1) == nb and len(cost_b2) == nb
+    np.testing.assert_allclose(cost_b1, cost_a[:nb], rtol=1e-12)
+    start = float(re.search(r"Before starting DMRG Cost = ([0-9.eE+-]+)", log_b2).group(1))
+    assert start == pytest.approx(cost_b1[-1], rel=1e-8)
+    np.testing.assert_allclose(cost_b2, cost_a[nb:], rtol=1e-8)
+
+
 @pytest.mark.parametrize("pipeline", ["yes", "no"])
 def test_fixedl_cli_file_hooks(tmp_path, pipeline):
     """the WRITE_WF / LAMBDA hooks of mldmrg (fixedL.cc:542-559): files dropped in the working directory are noticed after a bond
