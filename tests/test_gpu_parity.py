@@ -394,7 +394,7 @@ def test_fixedl_cli_resumes_from_the_W_it_wrote(tmp_path):
     def run(wd, nsweep):
         wd.mkdir(exist_ok=True)
         (wd / "input").write_text("input\n{\ndatadir = %s\nfeature_scale = 255\nNtrain = %d\nNbatch = 4\nNsweep = %d\ncutoff = 1E-10\nmaxm = 6\n"
-                                  "minm = 3\nninitial = 2\nlambda = 1E-3\nNpass = 2\nseed = 5\n}\n" % (data, per_label, nsweep))
+                                  "minm = 3\nninitial = 2\nlambda = 1E-3\nNpass = 2\nseed = 5\nbond_log = bonds.csv\n}\n" % (data, per_label, nsweep))
         r = subprocess.run([os.path.join(root, "tnml_amd", "fixedL"), str(wd / "input")], capture_output=True, text=True, cwd=wd, timeout=300)
         assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
         return r.stdout, [float(x) for x in re.findall(r"--> After SVD, Cost = ([0-9.eE+-]+)", r.stdout)]
@@ -409,6 +409,13 @@ def test_fixedl_cli_resumes_from_the_W_it_wrote(tmp_path):
     start = float(re.search(r"Before starting DMRG Cost = ([0-9.eE+-]+)", log_b2).group(1))
     assert start == pytest.approx(cost_b1[-1], rel=1e-8)
     np.testing.assert_allclose(cost_b2, cost_a[nb:], rtol=1e-8)
+    # the machine-readable log (extension key bond_log): one CSV line per bond update with the numbers of the text log
+    import csv
+    rows = list(csv.DictReader(open(tmp_path / "long" / "bonds.csv")))
+    assert len(rows) == 2 * nb and [int(r["sweep"]) for r in rows] == [1] * nb + [2] * nb
+    np.testing.assert_allclose([float(r["cost_after_svd"]) for r in rows], cost_a, rtol=1e-9)
+    assert [int(r["new_m"]) for r in rows] == [int(x) for x in re.findall(r"New m=(\d+)", log_a)]
+    assert all(float(r["seconds"]) >= 0. and int(r["ntrain"]) == 10 * per_label for r in rows)
 
 
 @pytest.mark.parametrize("pipeline", ["yes", "no"])

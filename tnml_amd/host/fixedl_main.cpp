@@ -9,8 +9,10 @@
 // reference, all optional): `seed` (initial-W RNG), `device` (first HIP ordinal), `ngpu`, `precision` (f64 = fp64 everywhere [default], mixed = fp64 MFMA over
 // fp32-stored environments, f32 = fp32 MFMA study mode), `imglen` (block-mean down-sampling of the images to
 // imglen x imglen; present in the reference's sample input but never read by fixedL.cc), `feature_scale`
-// (multiplies the second feature component; 1 = the reference's double normalisation).
+// (multiplies the second feature component; 1 = the reference's double normalisation), `pipeline`, `bond_log`
+// (a CSV line per bond update: cost, #correct, bond dimensions, truncation error, seconds).
 #include <array>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -86,6 +88,7 @@ int main(int argc, const char* argv[]) {
         const int device = (int)input.getInt("device", 0);                              // extension: first HIP ordinal
         const long ngpu = input.getInt("ngpu", 1);                                      // extension: GPUs (ranks) to shard the images over; 0 = all visible
         const bool share_device = input.getYesNo("share_device", false);                // extension: all ranks on `device` (in-process communicator; one-GPU boxes)
+        const std::string bond_log = input.getString("bond_log", "");                      // extension: a CSV line per bond update (machine-readable log for parity and bond updates/s)
         const bool pipeline = input.getYesNo("pipeline", true);                         // extension: enqueue bond k+1 before fetching the report of bond k (see the sweep loop)
         const std::string precision = input.getString("precision", "f64");              // extension: f64 | mixed | f32 | bf16x3 | bf16
         const long imglen = input.getInt("imglen", 0);                                   // extension: 0 = keep the file's size
@@ -232,6 +235,9 @@ int main(int argc, const char* argv[]) {
             // runs, and the WRITE_WF / LAMBDA hooks act one bond later than in the reference (input key `pipeline = no`, or
             // pause_step, restores the strict order).  Nothing is in flight across a sweep boundary.
             struct InFlight { long sw; int b, ha; double lam; bool on = false; } fl;
+            FILE* blog = (root && !bond_log.empty()) ? std::fopen(bond_log.c_str(), "w") : nullptr;
+            if (blog) std::fprintf(blog, "sweep,half,bond,lambda,cg_passes,cost_after_svd,reg_cost,ncorrect,ntrain,orig_m,new_m,trunc_err,seconds\n");
+            auto t_last = std::chrono::steady_clock::now();
             auto finish = [&]() {                                                           // report + log + hooks of the bond update in flight
                 if (!fl.on) return;
                 fl.on = false;
@@ -262,6 +268,12 @@ int main(int argc, const char* argv[]) {
                     std::printf("Percent correct = %.4f%%, # incorrect = %lld/%d\n", r_.ncorrect * 100. / totNtrain,
                                 (long long)(totNtrain - r_.ncorrect), totNtrain);       // :341-342
                     std::printf("--> After SVD, Cost = %.10f\n", r_.cost_after_svd / totNtrain);   // :533
+                    if (blog) {                                                         // seconds: wall time since the previous report (pipelined: one bond update of GPU time)
+                        const auto t_now = std::chrono::steady_clock::now();
+                        std::fprintf(blog, "%ld,%d,%d,%.6e,%d,%.17g,%.17g,%lld,%d,%d,%d,%.6e,%.6f\n", sw, ha, r_.c, fl.lam, r_.cg.npass_done, r_.cost_after_svd / totNtrain,
+                                     r_.reg_cost / totNtrain, (long long)r_.ncorrect, totNtrain, r_.origm, r_.newm, r_.truncerr, std::chrono::duration<double>(t_now - t_last).count());
+                        t_last = t_now;
+                    }
                     const int cs = ha == 1 ? b : b + 1, prevc = ha == 1 ? b - 1 : b + 2;    // :196-209
                     if (prevc >= 1 && prevc <= N) std::printf("## Advancing E from %d to %d\n", prevc, cs);
                     else std::printf("## Making new E at %d\n", cs);
@@ -304,6 +316,7 @@ int main(int argc, const char* argv[]) {
                 std::printf("Writing W to disk\n");                                         // :763
                 write_mps("W", download(ctx, N));                                           // :764
             }
+            if (blog) std::fclose(blog);
             if (nranks > 1) { CK(ctx, tnml_replica_check(ctx, nullptr)); bar.wait(); }
             tnml_destroy(ctx);
         };
