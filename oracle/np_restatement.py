@@ -374,6 +374,43 @@ class NpSingle:
             self.W[b + 1] = Vt.reshape(m, 2, mR)
         return m, te
 
+    def noise_split(self, B, b, ha, noise, cutoff, maxm, minm):              # single.h:648-672
+        """density-matrix split with a noise term, written on the tensors themselves: rho over the indices (link, site) of site c, the
+        images' contribution dr_n = (B . E_n) (x) E_n contracted with itself over the indices of the other site"""
+        mL, _, _, mR = B.shape
+        c = b if ha == 1 else b + 1
+        if ha == 1:                                                          # site c = b carries (a, s); the other site (t, r)
+            rho = np.einsum('astr,butr->asbu', B, B)
+            if c > 1:
+                E = self.E[c - 1]
+                T = np.einsum('na,astr->nstr', E, B)
+                w = np.einsum('nstr,nutr->nsu', T, T)
+                drho = np.einsum('nsu,na,nb->asbu', w, E, E)
+            else:
+                drho = self.NT * rho
+            rho = (rho + noise * drho).reshape(2 * mL, 2 * mL)               # C order: row index (a, s)
+        else:                                                                # site c = b + 1 carries (t, r); the other site (a, s)
+            rho = np.einsum('astr,asuq->truq', B, B)
+            if c < self.N:
+                E = self.E[c + 1]
+                T = np.einsum('nr,astr->nast', E, B)
+                w = np.einsum('nast,nasu->ntu', T, T)
+                drho = np.einsum('ntu,nr,nq->truq', w, E, E)
+            else:
+                drho = self.NT * rho
+            rho = (rho + noise * drho).reshape(2 * mR, 2 * mR)               # row index (t, r)
+        ev, U = np.linalg.eigh(rho)
+        ev, U = ev[::-1], U[:, ::-1]
+        m, te = truncate(np.maximum(ev, 0.), maxm, minm, cutoff)
+        U = U[:, :m]
+        if ha == 1:
+            self.W[b] = U.reshape(mL, 2, m)
+            self.W[b + 1] = np.einsum('asg,astr->gtr', self.W[b], B)
+        else:
+            self.W[b + 1] = U.reshape(2, mR, m).transpose(2, 0, 1)
+            self.W[b] = np.einsum('gtr,astr->asg', self.W[b + 1], B)
+        return m, te
+
     def mldmrg(self, nsweep, maxm, minm, cutoff, npass, lam, cconv, max_bonds=0):
         out = []
         for sw in range(1, nsweep + 1):
@@ -386,7 +423,10 @@ class NpSingle:
                 B, tr = self.cgrad(oB, npass, lam, cconv)
                 rep = dict(c=b if ha == 1 else b + 1, half=ha, origm=self.W[b].shape[2], cost_old=self.quadcost(oB, lam),
                            cost_cg=self.quadcost(B, lam), cg_skipped=tr["skipped"])
-                rep["newm"], rep["truncerr"] = self.svd_split(B, b, ha, cutoff, maxm, minm)
+                if getattr(self, "noise", 0.) < 1e-14:
+                    rep["newm"], rep["truncerr"] = self.svd_split(B, b, ha, cutoff, maxm, minm)
+                else:
+                    rep["newm"], rep["truncerr"] = self.noise_split(B, b, ha, self.noise, cutoff, maxm, minm)
                 rep["cost"] = self.quadcost(self.bond_tensor(b), lam)
                 self.shiftE(b, ha == 1)
                 out.append(rep)

@@ -268,6 +268,8 @@ def _slib():
         L.sorc_fast_cgrad.argtypes = [vp, dp, C.c_int, C.c_double, C.c_double, C.POINTER(CgTrace)]
         L.sorc_set_method.argtypes = [vp, C.c_int]
         L.sorc_set_pcut.argtypes = [vp, C.c_double]
+        L.sorc_set_noise.argtypes = [vp, C.c_double]
+        L.sorc_noise_split.argtypes = [vp, dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, dp, ip]
         L.sorc_exact.argtypes = [vp, dp, C.c_double, C.c_double]
         L.sorc_svd_split.argtypes = [vp, dp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, dp, ip, dp, ip]
         L.sorc_mldmrg.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int,
@@ -312,11 +314,14 @@ class SingleOracle:
             raise RuntimeError("single oracle call failed")
         return rc
 
+    def set_site(self, j, A):
+        A = np.asarray(A, dtype=np.float64)
+        assert A.ndim == 3
+        self._ck(self._L.sorc_set_site(self._h, j, A.shape[0], A.shape[2], _dp(_f(A))))
+
     def set_mps(self, W):
         for j, A in enumerate(W, start=1):
-            A = np.asarray(A, dtype=np.float64)
-            assert A.ndim == 3
-            self._ck(self._L.sorc_set_site(self._h, j, A.shape[0], A.shape[2], _dp(_f(A))))
+            self.set_site(j, A)
 
     def get_site(self, j):
         ml, mr = C.c_int(), C.c_int()
@@ -401,6 +406,15 @@ class SingleOracle:
         """optimiser of mldmrg: "conj" (cgrad), "fast_conj" (fast_cgrad) or "exact", single.h:598-600"""
         self._ck(self._L.sorc_set_method(self._h, {"conj": 0, "fast_conj": 1, "exact": 2}[method]))
         self._ck(self._L.sorc_set_pcut(self._h, pcut))
+
+    def set_noise(self, noise):
+        """sweeps.noise() of single.cc:25,222: >= 1e-14 makes mldmrg split through rho + noise * drho (single.h:648-672)"""
+        self._ck(self._L.sorc_set_noise(self._h, noise))
+
+    def noise_split(self, B, b, ha, noise, cutoff, maxm, minm):
+        te, m = C.c_double(), C.c_int()
+        self._ck(self._L.sorc_noise_split(self._h, _dp(_f(B)), b, ha, noise, cutoff, maxm, minm, C.byref(te), C.byref(m)))
+        return m.value, te.value
 
     def svd_split(self, B, b, ha, cutoff, maxm, minm):
         te, m, nsv = C.c_double(), C.c_int(), C.c_int()

@@ -1,6 +1,7 @@
 /* single_oracle.c -- CPU restatement of the per-label variant of the reference:
  *   /root/reference/single.cc   main: features (71-84), initial projections (181-199), precalc (204-216)
  *   /root/reference/single.h    TState (19-25), quadcost (82-112), exact (117-160), cgrad (162-288), fast_cgrad (290-398), mldmrg (523-728)
+ *                               incl. the density-matrix split with a noise term (648-672)
  *   /root/reference/paralleldo.h static chunking, fork-join
  * TEST INFRASTRUCTURE ONLY (see single_oracle.h).  PARITY UNPINNED (no reference tests, ITensor absent).
  *
@@ -35,6 +36,7 @@ struct sorc {
     int sw, b, ha;
     int method;     /* 0 = conj (cgrad), 1 = fast_conj (fast_cgrad), 2 = exact: single.h:598-600 */
     double pcut;    /* PCut of the exact solver (single.cc: pcut key, default 1E-8) */
+    double noise;   /* sweeps.noise() (single.cc:25,222): >= 1E-14 selects the density-matrix split of single.h:648-672 */
 };
 
 static int sfail(const char* msg) { fprintf(stderr, "single_oracle: %s\n", msg); return -1; }
@@ -372,6 +374,7 @@ int sorc_exact(const sorc* o, double* B, double lambda, double pcut) {
     return 0;
 }
 int sorc_set_pcut(sorc* o, double pcut) { o->pcut = pcut; return 0; }
+int sorc_set_noise(sorc* o, double noise) { if (!(noise >= 0.)) return sfail("noise must be >= 0"); o->noise = noise; return 0; }
 int sorc_set_method(sorc* o, int method) { if (method < 0 || method > 2) return sfail("method must be 0 (conj), 1 (fast_conj) or 2 (exact)"); o->method = method; return 0; }
 /* svd(B,U,S,V,svd_args) with U on the indices of W.A(c); W.A(c) = U, W.A(c+dc) = S*V  (single.h:636-646) */
 int sorc_svd_split(sorc* o, const double* B, int b, int ha, double cutoff, int maxm, int minm,
@@ -415,8 +418,81 @@ int sorc_svd_split(sorc* o, const double* B, int b, int ha, double cutoff, int m
     o->currb = -1;
     return 0;
 }
+/* the split of single.h:648-672 (noise >= 1E-14): rho = B B^dag over the indices of site c (c = b for ha = 1, b + 1 for ha = 2),
+ *   drho = sum_n dr_n dr_n^dag with dr_n = (B * E_n) (x) E_n, E_n the environment on the outer link of site c (single.h:655-664; at the
+ *   chain ends there is no such environment and dr_n = B for every image), rho += noise * drho, diagHermitian(rho) with the truncation
+ *   parameters of the sweep (single.h:666), W_c = UU, W_{c+dc} = UU * B (single.h:667-668).  The truncation rule acts on the eigenvalues
+ *   of rho as it acts on the squared singular values in sorc_svd_split [ITensor-recall, as there]. */
+int sorc_noise_split(sorc* o, const double* B, int b, int ha, double noise, double cutoff, int maxm, int minm, double* truncerr, int* newm) {
+    int mL, mR; if (sorc_bond_dims(o, b, &mL, &mR)) return -1;
+    const int nl = 2 * mL, nr = 2 * mR;
+    const int R = ha == 1 ? nl : nr, C = ha == 1 ? nr : nl;          /* rows: the indices of site c */
+    double* M = (double*)malloc(sizeof(double) * (size_t)R * C);
+    for (int be = 0; be < mR; ++be) for (int t = 0; t < 2; ++t) for (int s = 0; s < 2; ++s) for (int a = 0; a < mL; ++a) {
+        const int il = a + mL * s, ir = t + 2 * be;
+        const double x = B[a + (size_t)mL * (s + 2 * (t + 2 * be))];
+        if (ha == 1) M[il + (size_t)R * ir] = x; else M[ir + (size_t)R * il] = x;
+    }
+    double* rho = (double*)calloc((size_t)R * R, sizeof(double));
+    double* drho = (double*)calloc((size_t)R * R, sizeof(double));
+    for (int j = 0; j < R; ++j) for (int i = 0; i < R; ++i) { double t = 0.; for (int y = 0; y < C; ++y) t += M[i + (size_t)R * y] * M[j + (size_t)R * y]; rho[i + (size_t)R * j] = t; }   /* :651-653 */
+    const int c = ha == 1 ? b : b + 1;
+    const int envsite = ha == 1 ? c - 1 : c + 1;
+    const int have_env = ha == 1 ? c > 1 : c < o->N;                  /* :658,663 */
+    if (!have_env) {
+        for (size_t k = 0; k < (size_t)R * R; ++k) drho[k] = (double)o->NT * rho[k];      /* dr = B for every image */
+    } else {
+        const int mE = ha == 1 ? mL : mR;
+        if (o->E[envsite].m != mE || !o->E[envsite].e) { free(M); free(rho); free(drho); return sfail("noise split: environment missing"); }
+        double* T = (double*)malloc(sizeof(double) * (size_t)2 * C);  /* (B * E_n)[site index of c][other indices] */
+        for (int n = 0; n < o->NT; ++n) {
+            const double* E = o->E[envsite].e + (size_t)n * mE;
+            /* row index of M: il = a + mL s (ha = 1), ir = t + 2 be (ha = 2): contract the link of site c with E_n */
+            for (int sc = 0; sc < 2; ++sc) for (int y = 0; y < C; ++y) {
+                double t = 0.;
+                for (int e = 0; e < mE; ++e) { const int row = ha == 1 ? e + mL * sc : sc + 2 * e; t += E[e] * M[row + (size_t)R * y]; }
+                T[sc + 2 * (size_t)y] = t;
+            }
+            double w[2][2] = {{0., 0.}, {0., 0.}};
+            for (int y = 0; y < C; ++y) for (int s1 = 0; s1 < 2; ++s1) for (int s2 = 0; s2 < 2; ++s2) w[s1][s2] += T[s1 + 2 * (size_t)y] * T[s2 + 2 * (size_t)y];
+            for (int s2 = 0; s2 < 2; ++s2) for (int e2 = 0; e2 < mE; ++e2) for (int s1 = 0; s1 < 2; ++s1) for (int e1 = 0; e1 < mE; ++e1) {
+                const int r1 = ha == 1 ? e1 + mL * s1 : s1 + 2 * e1, r2 = ha == 1 ? e2 + mL * s2 : s2 + 2 * e2;
+                drho[r1 + (size_t)R * r2] += w[s1][s2] * E[e1] * E[e2];                   /* :664-665 */
+            }
+        }
+        free(T);
+    }
+    for (size_t k = 0; k < (size_t)R * R; ++k) rho[k] += noise * drho[k];                 /* :665 */
+    double* U = (double*)malloc(sizeof(double) * (size_t)R * R); double* ev = (double*)malloc(sizeof(double) * (size_t)R);
+    double* Vt = (double*)malloc(sizeof(double) * (size_t)R * R);
+    orc_thin_svd(R, R, rho, U, ev, Vt);                               /* symmetric positive semidefinite: singular values = eigenvalues, U = eigenvectors */
+    double te = 0.;
+    const int m = orc_truncate(ev, R, maxm, minm, cutoff, &te);       /* :666 diagHermitian(rho,UU,DD,svd_args) */
+    if (truncerr) *truncerr = te;
+    if (newm) *newm = m;
+    ssite_t* Sl = &o->W[b]; ssite_t* Sr = &o->W[b + 1];
+    free(Sl->a); free(Sr->a);
+    Sl->ml = mL; Sl->mr = m; Sr->ml = m; Sr->mr = mR;
+    Sl->a = (double*)malloc(sizeof(double) * (size_t)mL * 2 * m);
+    Sr->a = (double*)malloc(sizeof(double) * (size_t)m * 2 * mR);
+    for (int g = 0; g < m; ++g) {
+        /* UU on site c (:668), UU * B on the other site (:667): (U^T M)[g][y] */
+        for (int i = 0; i < R; ++i) {
+            if (ha == 1) Sl->a[(i % mL) + (size_t)mL * ((i / mL) + 2 * g)] = U[i + (size_t)R * g];
+            else         Sr->a[g + (size_t)m * i] = U[i + (size_t)R * g];
+        }
+        for (int y = 0; y < C; ++y) {
+            double t = 0.; for (int i = 0; i < R; ++i) t += U[i + (size_t)R * g] * M[i + (size_t)R * y];
+            if (ha == 1) Sr->a[g + (size_t)m * y] = t;
+            else         Sl->a[(y % mL) + (size_t)mL * ((y / mL) + 2 * g)] = t;
+        }
+    }
+    free(M); free(rho); free(drho); free(U); free(ev); free(Vt);
+    o->currb = -1;
+    return 0;
+}
 int sorc_mldmrg(sorc* o, int nsweep, int maxm, int minm, double cutoff, int npass, double lambda,
-                double cconv, int max_bonds, sorc_bond_report* reports) {     /* single.h:523-728, Method = conj | fast_conj (sorc_set_method), noise = 0 */
+                double cconv, int max_bonds, sorc_bond_report* reports) {     /* single.h:523-728, Method = conj | fast_conj | exact (sorc_set_method), noise (sorc_set_noise) */
     int done = 0;
     while (o->sw <= nsweep) {
         while (o->ha <= 2) {
@@ -440,7 +516,8 @@ int sorc_mldmrg(sorc* o, int nsweep, int maxm, int minm, double cutoff, int npas
             rp->cg_skipped = rc;
             rp->cost_old = sorc_quadcost(o, oB, lambda, NULL);                 /* :621 */
             rp->cost_cg = sorc_quadcost(o, B, lambda, &rp->reg_cost);          /* :622,626 */
-            if (sorc_svd_split(o, B, b, ha, cutoff, maxm, minm, &rp->truncerr, &rp->newm, NULL, NULL)) return -1;   /* :636-646 */
+            if (o->noise < 1E-14) { if (sorc_svd_split(o, B, b, ha, cutoff, maxm, minm, &rp->truncerr, &rp->newm, NULL, NULL)) return -1; }   /* :626-646 */
+            else if (sorc_noise_split(o, B, b, ha, o->noise, cutoff, maxm, minm, &rp->truncerr, &rp->newm)) return -1;                      /* :647-672 */
             double* newB = (double*)malloc(sizeof(double) * n);
             if (sorc_bond_tensor(o, b, newB)) return -1;                       /* :680 */
             rp->norm_newB = sqrt(ssq(newB, n));

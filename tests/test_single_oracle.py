@@ -187,3 +187,63 @@ def test_exact_method_in_the_sweep():
     assert len(ro) == 14 and all(r["cg_alpha"] == [] for r in ro)
     assert all(r["cost_cg"] <= r["cost_old"] * (1 + 1e-9) for r in ro)     # the exact minimiser never does worse than the incoming tensor
     assert ro[-1]["cost"] < 0.5 * ro[0]["cost_old"]
+
+
+@pytest.mark.parametrize("noise", [1e-6, 1e-2])
+def test_noise_split_matches_numpy_and_is_a_gauge_of_the_bond_tensor(noise):
+    """single.h:648-672: the density-matrix split with a noise term, C oracle against the einsum restatement at interior bonds in both
+    half sweeps and at the chain ends (no environment there: drho = NT rho).  The basis on site c is orthonormal, the other site is
+    UU * B, and without truncation the product of the two sites is B again whatever the noise."""
+    pixels, labels, phi, W = problem(N=8, NT=40, m=3)
+    phi = phi.copy(); phi[..., 1] *= 300.0
+    for ha, bonds in ((1, (1, 3, 5)), (2, (7, 5, 2))):
+        o = pyoracle.SingleOracle(phi, labels, 1, W, nthread=2)
+        n = npr.NpSingle(phi, labels, 1, W)
+        o.init(); n.init()
+        if ha == 2:                                                  # half sweep 2 runs right to left: build the left environments first
+            for b in range(1, 8):
+                o.shiftE(b, True); n.shiftE(b, True)
+        walk = range(1, 8) if ha == 1 else range(7, 0, -1)
+        for b in walk:
+            if b in bonds:
+                B = o.bond_tensor(b) * (1.0 + 0.1 * np.cos(np.arange(o.bond_tensor(b).size)).reshape(o.bond_tensor(b).shape))
+                full = 2 * max(B.shape[0], B.shape[3])
+                mo, teo = o.noise_split(B, b, ha, noise, 0.0, full, full)     # keep everything
+                mn, ten = n.noise_split(B, b, ha, noise, 0.0, full, full)
+                assert mo == mn
+                np.testing.assert_allclose(o.bond_tensor(b), B, rtol=1e-9, atol=1e-11)
+                np.testing.assert_allclose(n.bond_tensor(b), B, rtol=1e-9, atol=1e-11)
+                A = o.get_site(b if ha == 1 else b + 1)
+                G = np.einsum('asg,ash->gh', A, A) if ha == 1 else np.einsum('gtr,htr->gh', A, A)
+                np.testing.assert_allclose(G, np.eye(G.shape[0]), atol=1e-10)
+                # with truncation both restatements keep the same subspace: compare the truncated bond tensors
+                keep = max(1, min(B.shape[0], B.shape[3]))
+                mo, teo = o.noise_split(B, b, ha, noise, 1e-12, keep, 1)
+                mn, ten = n.noise_split(B, b, ha, noise, 1e-12, keep, 1)
+                assert mo == mn and teo == pytest.approx(ten, rel=1e-6, abs=1e-14)
+                np.testing.assert_allclose(o.bond_tensor(b), n.bond_tensor(b), rtol=1e-6, atol=1e-9)
+                # restore the original sites so that the walk goes on from the same network
+                for j in (b, b + 1):
+                    o.set_site(j, W[j - 1]); n.W[j] = np.array(W[j - 1])
+            o.shiftE(b, ha == 1); n.shiftE(b, ha == 1)
+
+
+def test_sweep_with_noise_matches_numpy():
+    pixels, labels, phi, W = problem(N=8, NT=60, m=3)
+    phi = phi.copy(); phi[..., 1] *= 300.0
+    o = pyoracle.SingleOracle(phi, labels, 1, W, nthread=2)
+    n = npr.NpSingle(phi, labels, 1, W)
+    o.set_noise(1e-5); n.noise = 1e-5
+    o.init(); n.init()
+    ro = o.mldmrg(2, 4, 2, 1e-10, 3, 1e-3, 1e-10)
+    rn = n.mldmrg(2, 4, 2, 1e-10, 3, 1e-3, 1e-10)
+    assert len(ro) == len(rn) == 2 * 2 * 7
+    for a, b in zip(ro, rn):
+        assert (a["c"], a["half"], a["origm"], a["newm"]) == (b["c"], b["half"], b["origm"], b["newm"])
+        assert a["cost_cg"] == pytest.approx(b["cost_cg"], rel=1e-7)
+        assert a["cost"] == pytest.approx(b["cost"], rel=1e-7)
+    # the noise changes the kept subspace: not the same run as without it
+    o0 = pyoracle.SingleOracle(phi, labels, 1, W, nthread=2)
+    o0.init()
+    r0 = o0.mldmrg(2, 4, 2, 1e-10, 3, 1e-3, 1e-10)
+    assert any(abs(a["cost"] - b["cost"]) > 1e-9 * abs(b["cost"]) for a, b in zip(ro, r0))
