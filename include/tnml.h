@@ -265,7 +265,9 @@ int tnml_synchronize(tnml_ctx* ctx);
                       (trace <= 1e-15 trace(G); default 1; 0 = all n-2 Householder steps)
    fast_cg = reuse_p = 0 is the reference's literal evaluation order (fixedL.cc:374-421). */
 int tnml_set_option(tnml_ctx* ctx, const char* name, int value);
-/* real-valued options: "pcut" (PCut of the exact solver inside tnml_bond_update, single.cc:50, default 1E-8) */
+/* real-valued options: "pcut" (PCut of the exact solver inside tnml_bond_update, single.cc:50, default 1E-8);
+   "noise" (TNML_MODE_SINGLE, fp64 storage: the noise of the sweeps, single.cc:25,222 -- from 1E-14 on tnml_svd_split / tnml_bond_update split
+   through the density matrix of site c plus noise * sum_n dr_n dr_n^dag, single.h:648-672: W_c = UU, W_{c+dc} = UU * B) */
 int tnml_set_option_real(tnml_ctx* ctx, const char* name, double value);
 /* health of the in-house eigensolver: number of fallbacks to rocSOLVER so far, number of splits whose kept basis
    held an eigenvalue cluster and was re-orthonormalised by Cholesky QR, and max|Q^T Q - I| of the kept basis

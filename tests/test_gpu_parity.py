@@ -813,6 +813,55 @@ def test_single_fast_conj_sweep_matches_the_oracle():
     assert ro[-1]["cost"] < ro[0]["cost_old"]
 
 
+@pytest.mark.parametrize("noise", [1e-6, 1e-3])
+def test_single_noise_split_matches_the_oracle(noise):
+    """the density-matrix split with a noise term of the per-label variant (single.h:648-672) on the device -- rho from the Gram matrix
+    the split forms anyway, drho from one GEMM over the images, a streaming kernel for the 2 x 2 weights and three weighted Gram matrices
+    of the environment -- against the oracle: interior bonds in both half sweeps, the chain ends (no environment: drho = NT rho),
+    kept dimension, truncation error and the two site tensors' product"""
+    N = 10
+    for ha in (1, 2):
+        ts, o = _single_pair(N=N, NT=60, m=4, target=3, maxm=8)
+        ts.set_option_real("noise", noise)
+        if ha == 2:
+            for b in range(1, N):
+                ts.shiftE(b, True); o.shiftE(b, True)
+        for b in (range(1, N) if ha == 1 else range(N - 1, 0, -1)):
+            ts.setBond(b); o.set_bond(b)
+            B0 = o.bond_tensor(b)
+            B = B0 * (1.0 + 0.2 * np.cos(1.0 + np.arange(B0.size)).reshape(B0.shape))
+            keep = max(2, min(B.shape[0], B.shape[3]))
+            mg, teg, _ = ts.svd_split(B, b, ha, 1e-12, keep, 1)
+            mo, teo = o.noise_split(B, b, ha, noise, 1e-12, keep, 1)
+            assert mg == mo, (ha, b)
+            assert teg == pytest.approx(teo, rel=1e-5, abs=1e-13), (ha, b)
+            assert _relmax(ts.bond_tensor(b), o.bond_tensor(b)) < 1e-7, (ha, b)
+            A = ts.get_site(b if ha == 1 else b + 1)
+            G = np.einsum('asg,ash->gh', A, A) if ha == 1 else np.einsum('gtr,htr->gh', A, A)
+            assert np.abs(G - np.eye(G.shape[0])).max() < 1e-10, (ha, b)
+            ts.set_site(b, o.get_site(b)); ts.set_site(b + 1, o.get_site(b + 1))      # lockstep
+            ts.shiftE(b, ha == 1); o.shiftE(b, ha == 1)
+        ts.close()
+
+
+def test_single_sweeps_with_noise_match_the_oracle():
+    ts, o = _single_pair(N=10, NT=80, m=3, target=7, maxm=5)
+    from tnml_amd.fixedl import mldmrg
+    ts.set_option_real("noise", 1e-5)
+    o.set_noise(1e-5)
+    rg = mldmrg(ts, 2, 5, 2, 1e-10, 3, 1e-3, 1e-10)
+    ro = o.mldmrg(2, 5, 2, 1e-10, 3, 1e-3, 1e-10)
+    assert len(rg) == len(ro) == 2 * 2 * 9
+    for a, b in zip(rg, ro):
+        assert (a["c"], a["half"], a["origm"], a["newm"]) == (b["c"], b["half"], b["origm"], b["newm"])
+        assert a["cost_cg"] == pytest.approx(b["cost_cg"], rel=1e-7)
+        assert a["cost"] == pytest.approx(b["cost"], rel=1e-7)
+        assert a["truncerr"] == pytest.approx(b["truncerr"], rel=1e-3, abs=1e-12)
+    with pytest.raises(Exception):                             # the fixedL variant has no such split (fixedL.cc has no noise)
+        ts2, _ = _pair(N=8, NT=20, m=2)
+        ts2.set_option_real("noise", 1e-5)
+
+
 @pytest.mark.parametrize("normal", [True, False])
 def test_single_full_sweeps_and_decision_function(normal):
     ts, o = _single_pair(N=10, NT=80, m=3, target=7, normal=normal, maxm=5)
@@ -930,6 +979,20 @@ def test_single_and_separate_fulltest_cli(tmp_path):
     assert len(c_cg) == len(ro)
     np.testing.assert_allclose(c_cg[:10], [r["cost_cg"] / float(len(lab)) for r in ro][:10], rtol=1e-4, atol=1e-9)
     assert "Conj grad pass" not in run.stdout
+    # noise = 1E-5 through the command line: the density-matrix split (single.h:648-672), "Trunc err" instead of "SVD trunc err" (:669)
+    wdn = tmp_path / "Lnoise"
+    wdn.mkdir()
+    nz = wdn / "input_noise"
+    nz.write_text(inp.read_text().replace("method = fast_conj", "method = conj\nnoise = 1E-5"))
+    run = subprocess.run([os.path.join(root, "tnml_amd", "single"), str(nz)], capture_output=True, text=True, cwd=wdn, timeout=300)
+    assert run.returncode == 0, run.stdout[-1500:] + run.stderr[-1500:]
+    o = pyoracle.SingleOracle(phi, lab[order], 3, hostlib.read_mps(str(tmp_path / "W0ref3")))
+    o.init()
+    o.set_noise(1e-5)
+    ro = o.mldmrg(1, 5, 2, 1e-10, 3, 1e-3, 1e-10)
+    c_svd = [float(x) for x in re.findall(r"--> After SVD, Cost = ([0-9.eE+-]+) \(", run.stdout)]
+    assert len(c_svd) == len(ro) and "SVD trunc err" not in run.stdout and run.stdout.count("Trunc err = ") == len(ro)
+    np.testing.assert_allclose(c_svd, [r["cost"] / float(len(lab)) for r in ro], rtol=1e-6, atol=1e-10)
     bad = wd / "input_bad"
     bad.write_text(inp.read_text().replace("fast_conj", "pinv"))
     run = subprocess.run([os.path.join(root, "tnml_amd", "single"), str(bad)], capture_output=True, text=True, cwd=wd, timeout=300)

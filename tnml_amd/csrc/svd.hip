@@ -86,6 +86,76 @@ __global__ void k_potrf_flags(const int* __restrict__ info, double* __restrict__
 
 #define RBCK(c, expr) do { rocblas_status s_ = (expr); if (s_ != rocblas_status_success) return tnml_fail((c), "%s failed: rocblas status %d (%s:%d)", #expr, (int)s_, __FILE__, __LINE__); } while (0)
 
+// ---- density-matrix split with a noise term (per-label variant, single.h:648-672) ------------------------------------------------
+// rho = B B^dag over the indices of site c is the Gram matrix the split forms anyway; the images add
+//   drho = sum_n dr_n dr_n^dag,  dr_n = (B * E_n) (x) E_n,  E_n = environment on the outer link of site c,
+// i.e. drho[(e1,s1),(e2,s2)] = sum_n w_{s1 s2}[n] E_n[e1] E_n[e2] with the 2 x 2 weights w[n] = T_n T_n^T, T_n = B * E_n as a
+// (site index of c) x (indices of the other site) matrix: one GEMM for T over all images, a streaming kernel for the three weights,
+// three weighted Gram matrices of the environment (dgemm over the images), summed over the ranks, added to rho.
+__global__ void k_noise_weights(const double* __restrict__ T, int NTp, int NT, int ny, size_t stride_s, size_t stride_y, double* __restrict__ w) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= NTp) return;
+    double w00 = 0., w01 = 0., w11 = 0.;
+    if (n < NT)
+        for (int y = 0; y < ny; ++y) {
+            const double t0 = T[n + (size_t)NTp * (y * stride_y)], t1 = T[n + (size_t)NTp * (stride_s + y * stride_y)];
+            w00 = fma(t0, t0, w00); w01 = fma(t0, t1, w01); w11 = fma(t1, t1, w11);
+        }
+    w[n] = w00; w[NTp + n] = w01; w[2 * (size_t)NTp + n] = w11;      // images beyond NT (padding) weigh nothing
+}
+__global__ void k_noise_scale_rows(const double* __restrict__ E, const double* __restrict__ w, double* __restrict__ Es, int mE, int NTp) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= (size_t)mE * NTp) return;
+    Es[i] = E[i] * w[i % NTp];
+}
+// rho[(e1,s1),(e2,s2)] += noise * blk_{s1 s2}[e1][e2]; row index e + mE s on the left site (ha = 1), s + 2 e on the right site (ha = 2)
+__global__ void k_noise_add(double* __restrict__ rho, int n, const double* __restrict__ blk, int mE, int ha, double noise) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= (size_t)n * n) return;
+    const int r1 = (int)(i % n), r2 = (int)(i / n);
+    const int e1 = ha == 1 ? r1 % mE : r1 / 2, s1 = ha == 1 ? r1 / mE : r1 % 2;
+    const int e2 = ha == 1 ? r2 % mE : r2 / 2, s2 = ha == 1 ? r2 / mE : r2 % 2;
+    const int k = s1 + s2;                                           // 0: w00, 1: w01 (= w10), 2: w11
+    rho[i] += noise * blk[(size_t)k * mE * mE + e1 + (size_t)mE * e2];
+}
+__global__ void k_scale_all(double* __restrict__ x, size_t n, double f) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) x[i] *= f;
+}
+// G (n x n, the Gram matrix over the indices of site c) += noise * drho.  B_it: the bond tensor in ITensor order [a][s][t][be].
+static int noise_add(tnml_ctx* c, const double* B_it, int b, int ha, int mL, int mR, double* G, int n) {
+    hipStream_t st = c->stream;
+    const int cs = ha == 1 ? b : b + 1, envsite = ha == 1 ? cs - 1 : cs + 1;
+    const bool have_env = ha == 1 ? cs > 1 : cs < c->N;              // single.h:658,663
+    if (!have_env) {                                                 // chain end: dr_n = B for every image, drho = NT rho
+        hipLaunchKernelGGL(k_scale_all, dim3(nblk((size_t)n * n)), dim3(256), 0, st, G, (size_t)n * n, 1. + c->noise * (double)c->cfg.NT_total);
+        HIPCK(c, hipGetLastError());
+        return 0;
+    }
+    const int mE = ha == 1 ? mL : mR, mOth = ha == 1 ? mR : mL, NTp = c->NTp;
+    if (!c->env[envsite].ptr || c->env[envsite].m != mE || c->env[envsite].L != 1) return tnml_fail(c, "noise split: environment of site %d missing", envsite);
+    const double* E = (const double*)c->env[envsite].ptr;             // [mE][NTp], fp64 (checked when the option was set)
+    if (!c->noise_ws) TCK(ctx_alloc_doubles(c, &c->noise_ws, (size_t)5 * c->maxm * NTp + (size_t)3 * NTp + (size_t)3 * c->maxm * c->maxm));
+    double* T = c->noise_ws;                                         // [NTp][4 mOth]
+    double* Es = T + (size_t)4 * c->maxm * NTp;                      // [mE][NTp]
+    double* w = Es + (size_t)c->maxm * NTp;                          // [3][NTp]
+    double* blk = w + (size_t)3 * NTp;                               // [3][mE][mE]
+    const double one = 1.0, zero = 0.0;
+    if (ha == 1) RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, NTp, 4 * mOth, mE, &one, E, NTp, B_it, mL, &zero, T, NTp));
+    else         RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_transpose, NTp, 4 * mOth, mE, &one, E, NTp, B_it, 4 * mL, &zero, T, NTp));
+    // columns of T: (s, t, be) = s + 2 (t + 2 be) on the left site; (a, s, t) = (a + mL s) + 2 mL t on the right site
+    hipLaunchKernelGGL(k_noise_weights, dim3((NTp + 255) / 256), dim3(256), 0, st, (const double*)T, NTp, c->NT, 2 * mOth,
+                       ha == 1 ? (size_t)1 : (size_t)2 * mL, ha == 1 ? (size_t)2 : (size_t)1, w);
+    for (int k = 0; k < 3; ++k) {
+        hipLaunchKernelGGL(k_noise_scale_rows, dim3(nblk((size_t)mE * NTp)), dim3(256), 0, st, E, (const double*)(w + (size_t)k * NTp), Es, mE, NTp);
+        RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, mE, mE, NTp, &one, E, NTp, Es, NTp, &zero, blk + (size_t)k * mE * mE, mE));
+    }
+    TCK(allreduce_sum(c, blk, (size_t)3 * mE * mE));                 // the sum over the images of all ranks
+    hipLaunchKernelGGL(k_noise_add, dim3(nblk((size_t)n * n)), dim3(256), 0, st, G, n, (const double*)blk, mE, ha, c->noise);
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
+
 int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cutoff, int maxm, int minm,
                      double* truncerr, int* newm, double* sv_host, int* nsv) {
     ProfScope ps(c, KC_SVD);
@@ -94,7 +164,9 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
     const int mL = Sl.ml, mR = Sr.mr;
     const bool labL = (c->c0 == b), labR = (c->c0 == b + 1);
     const int nl = 2 * mL * (labL ? TNML_NL : 1), nr = 2 * mR * (labR ? TNML_NL : 1);
-    const int n = nl < nr ? nl : nr;
+    const bool dm = c->single() && c->noise >= 1e-14;    // density-matrix split with a noise term (single.h:648-672): rho lives on site c, whatever its size
+    const bool left = dm ? ha == 1 : (nl < nr) || (nl == nr && ha == 1);
+    const int n = dm ? (left ? nl : nr) : (nl < nr ? nl : nr);
     if (n > c->svd_n) return tnml_fail(c, "svd_split: matrix side %d exceeds workspace %d (raise maxm)", n, c->svd_n);
     if (maxm < 1 || minm < 0) return tnml_fail(c, "svd_split: maxm must be >= 1 and minm >= 0");
     if (maxm > c->maxm) {                                // the workspaces (sS, sCm, sQ1, sF) are sized by the context's maxm
@@ -111,11 +183,11 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
         hipLaunchKernelGGL(k_perm_labL_fwd, dim3(nblk((size_t)nl * nr)), dim3(256), 0, st, B_it, c->sM, 2 * mL, nr);
         M = c->sM;
     }
-    const bool left = (nl < nr) || (nl == nr && ha == 1);
     const double one = 1.0, zero = 0.0;
     const int gstrips = (left ? nr : nl) >= 1024 ? 8 : 4;     // the Label-on-B bonds reduce over 2400: 133 us as one call, 17 us as 8 strips
     if (left) RBCK(c, dgemm_strips(c->blas, rocblas_operation_none, rocblas_operation_transpose, nl, nl, nr, M, nl, M, nl, c->sG, nl, gstrips));
     else      RBCK(c, dgemm_strips(c->blas, rocblas_operation_transpose, rocblas_operation_none, nr, nr, nl, M, nl, M, nl, c->sG, nr, gstrips));
+    if (dm) TCK(noise_add(c, B_it, b, ha, mL, mR, c->sG, n));           // rho += noise * drho (single.h:654-665)
     // eigen-decomposition of rho.  backend 0 (default): in-house Householder tridiagonalisation (one workgroup up to n = 240,
     // eigh.hip; a cluster of workgroups up to n = 640, eigh_mc.hip) + in-house bisection / inverse iteration + back
     // transformation, verified, with rocSOLVER as the fallback; 2: in-house tridiagonalisation + rocSOLVER dstedc; 1: stock
@@ -187,6 +259,7 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
         HIPCK(c, hipMemsetAsync(const_cast<void*>(static_cast<const void*>(static_cast<const char*>(eigh_mc_status_ptr(c->mc_xbuf)) - 8)), 0, 16, st));
         if (left) RBCK(c, dgemm_strips(c->blas, rocblas_operation_none, rocblas_operation_transpose, nl, nl, nr, M, nl, M, nl, c->sG, nl, gstrips));
         else      RBCK(c, dgemm_strips(c->blas, rocblas_operation_transpose, rocblas_operation_none, nr, nr, nl, M, nl, M, nl, c->sG, nr, gstrips));
+        if (dm) TCK(noise_add(c, B_it, b, ha, mL, mR, c->sG, n));
         RBCK(c, rocsolver_dsyevd(c->blas, rocblas_evect_original, rocblas_fill_upper, n, c->sG, n, c->sD, c->sE, c->sInfo));
         evals = c->sD; own_eig = false; stock = true; Q = c->sF; direct_left = false;
         TCK(bcast_rank0(c, const_cast<double*>(evals), n));

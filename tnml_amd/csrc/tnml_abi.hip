@@ -141,6 +141,7 @@ static int dmalloc(tnml_ctx* c, T** p, size_t n) {
     c->bytes += (int64_t)(n * sizeof(T));
     return 0;
 }
+int ctx_alloc_doubles(tnml_ctx* c, double** p, size_t n) { return dmalloc(c, p, n); }
 static inline int ru16(int x) { return (x + 15) / 16 * 16; }
 
 // Device memory a context of this configuration will own once a sweep has touched every environment: the workspaces of
@@ -318,7 +319,7 @@ int tnml_destroy(tnml_ctx* c) {
     for (auto& p : c->prof_pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     for (auto e : c->prof_free) (void)hipEventDestroy(e);
     void* ptrs[] = {c->phi, c->label, c->ones, c->U, c->P, c->dP, c->Pp, c->Zp, c->Mf, c->slab, c->partials, c->vB, c->vR, c->vP,
-                    c->arbuf, c->locals, c->scal, c->vpart, c->tB, c->tB2, c->sM, c->sG, c->sD, c->sE, c->sF, c->sInfo, c->sE2, c->sTau, c->sV, c->sC, c->sW, c->sScr, c->sS, c->sCm, c->sQ1, c->sDev, c->mc_xbuf, c->fprint};
+                    c->arbuf, c->locals, c->scal, c->vpart, c->tB, c->tB2, c->sM, c->sG, c->sD, c->sE, c->sF, c->sInfo, c->sE2, c->sTau, c->sV, c->sC, c->sW, c->sScr, c->sS, c->sCm, c->sQ1, c->sDev, c->mc_xbuf, c->fprint, c->noise_ws};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& s : c->W) if (s.a) (void)hipFree(s.a);
     for (auto& sl : c->slabs) if (sl.base) (void)hipFree(sl.base);
@@ -360,6 +361,7 @@ static int allreduce(tnml_ctx* c, double* buf, size_t count) {
     if (r != ncclSuccess) return tnml_fail(c, "ncclAllReduce failed: %s", ncclGetErrorString(r));
     return 0;
 }
+int allreduce_sum(tnml_ctx* c, double* buf, size_t count) { return allreduce(c, buf, count); }
 static double* pend_host(tnml_ctx* c, int slot) { return c->h_scal + 2 * c->svd_n + 64 + SC_N + 4 * TNML_MAX_PASS + 64 * slot; }
 // the carried slots of a finished bond update (after-SVD cost partials, fingerprint pieces) have just been summed over the ranks by an
 // all-reduce that covered them: hand them to the host report they belong to
@@ -1070,6 +1072,12 @@ int tnml_exact(tnml_ctx* c, double* B, double lambda, double pcut) {   // single
 }
 int tnml_set_option_real(tnml_ctx* c, const char* name, double value) {
     if (!strcmp(name, "pcut")) { if (!(value >= 0.)) return tnml_fail(c, "pcut must be >= 0"); c->pcut = value; return 0; }
+    if (!strcmp(name, "noise")) {                                     // single.cc:25,222: the noise of every sweep
+        if (!(value >= 0.)) return tnml_fail(c, "noise must be >= 0");
+        if (value >= 1e-14 && !c->single()) return tnml_fail(c, "noise: the density-matrix split exists in the per-label variant only (single.h:648-672)");
+        if (value >= 1e-14 && !c->env64()) return tnml_fail(c, "noise: needs fp64 environments (dtype f64)");
+        c->noise = value; return 0;
+    }
     return tnml_fail(c, "tnml_set_option_real: unknown option %s", name);
 }
 int tnml_cgrad(tnml_ctx* c, double* B, int npass, double lambda, double cconv, tnml_cg_trace* trace) {

@@ -94,6 +94,8 @@ struct tnml_ctx {
     int fused_fwd = 1;               // forward pass as one persistent kernel (kernels_fused.hip): 1 = from 14 336 images per rank on, 0 never, 2 always; env TNML_FUSED_FWD / option "fused_fwd"
     int cg_method = 0;               // per-label variant: 0 = conj (single.h:162-288), 1 = fast_conj (single.h:290-398), 2 = exact (single.h:117-160); option "cg_method"
     double pcut = 1e-8;              // PCut of the exact solver (single.cc:50); tnml_set_option_real "pcut"
+    double noise = 0.;               // per-label variant: sweeps.noise() (single.cc:25,222); >= 1e-14 selects the density-matrix split of single.h:648-672; tnml_set_option_real "noise"
+    double* noise_ws = nullptr;      // its workspace, allocated with the first such split
     int sytrd_exit = 1;              // rank-adaptive exit of the tridiagonalisation of the split's Gram matrix (eigh.hip); option "sytrd_exit", env TNML_SYTRD_TOL=0 disables
     rocblas_handle blas = nullptr;
     ncclComm_t comm = nullptr;
@@ -354,6 +356,8 @@ int local_comm_exchange(tnml_ctx* c, double* buf, size_t count, int op);   // 0 
 
 // rank 0's values to every rank, in stream order (no-op without a communicator)
 int bcast_rank0(tnml_ctx* c, double* buf, size_t count);
+int allreduce_sum(tnml_ctx* c, double* buf, size_t count);      // sum over the ranks, in stream order (no-op on one rank)
+int ctx_alloc_doubles(tnml_ctx* c, double** p, size_t n);       // device memory owned by the context (counted in tnml_device_bytes)
 
 // ---- svd.hip ------------------------------------------------------------------------------
 int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cutoff, int maxm, int minm,

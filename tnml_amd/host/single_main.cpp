@@ -4,8 +4,8 @@
 // Keeps the reference's surface (single.cc:6-244 and the mldmrg of single.h:523-728): input keys, the files `sites`
 // and `W<label>` in the working directory, the `WRITE_WF` hook, the idx-ubyte training set under `datadir`, the
 // image order (labels taken round-robin, single.cc:156-181) and the log lines.  One tnml_bond_update per bond.
-// Built: method = conj | fast_conj | exact.  Not built: method = pinv (random start, single.h:404-517) and the `noise` density-matrix term (single.h:648-672); they
-// stop with a message.  Extensions (never read by the reference): `seed`, `device`, `precision`, `imglen`,
+// Built: method = conj | fast_conj | exact and the `noise` density-matrix split (single.h:648-672).  Not built: method = pinv (a diagnostic
+// from a time-seeded random start, single.h:404-517; the update itself is cgrad): it stops with a message.  Extensions (never read by the reference): `seed`, `device`, `precision`, `imglen`,
 // `feature_scale` as in the fixedL driver; `labels`, `ngpu`, `share_device`, `dry_run`: the one-label-per-GPU launcher
 // of BASELINE config 4 (launch_per_label below).
 #include <sys/stat.h>
@@ -162,7 +162,6 @@ int main(int argc, const char* argv[]) {
         if (method != "conj" && method != "fast_conj" && method != "exact") { std::printf("method type \"%s\" not recognized\n", method.c_str()); return 1; }   // single.h:611
         const bool fast_conj = method == "fast_conj";                                  // single.h:599
         const bool exact = method == "exact";                                          // single.h:600
-        if (noise >= 1E-14) { std::printf("noise > 0 (density-matrix split, single.h:648-672) is not built here\n"); return 1; }
 
         char wname[32]; std::snprintf(wname, sizeof wname, "W%d", L);                  // :53
         Dataset train = read_mnist(datadir, true, Ntrain);                              // :56
@@ -231,6 +230,7 @@ int main(int argc, const char* argv[]) {
         if (tnml_create(&ctx, &cfg) != 0) die(nullptr, "tnml_create");
         if (fast_conj) CK(ctx, tnml_set_option(ctx, "cg_method", 1));
         if (exact) { CK(ctx, tnml_set_option(ctx, "cg_method", 2)); CK(ctx, tnml_set_option_real(ctx, "pcut", pcut)); }
+        if (noise >= 1E-14) CK(ctx, tnml_set_option_real(ctx, "noise", noise));           // sweeps.noise() = noise, single.cc:222
         CK(ctx, tnml_set_data_phi(ctx, phi.data(), labels.data()));
         phi.clear(); phi.shrink_to_fit();
         for (int j = 1; j <= N; ++j) CK(ctx, tnml_set_site(ctx, j, W.A[j].ml, W.A[j].mr, 0, W.A[j].a.data()));
@@ -277,7 +277,8 @@ int main(int argc, const char* argv[]) {
                     std::printf("Reg. cost RC = %.10f (%.10f)\n", r.reg_cost_cg / NT, r.reg_cost_cg);                       // :627
                     std::printf("Cost - RC = %.10f (%.10f)\n", (r.cost_cg - r.reg_cost_cg) / NT, r.cost_cg - r.reg_cost_cg);   // :628
                 }
-                std::printf("SVD trunc err = %.2E\n", r.truncerr);                      // :646
+                if (noise < 1E-14) std::printf("SVD trunc err = %.2E\n", r.truncerr);   // :646
+                else               std::printf("Trunc err = %.2E\n", r.truncerr);       // :669 (density-matrix split)
                 std::printf("Original m=%d, New m=%d\n", r.origm, r.newm);              // :678
                 std::printf("norm(newB) = %.12g\n", r.norm_newB);                       // :681
                 std::printf("--> After SVD, Cost = %.10f (%.10f)\n", r.cost_after_svd / NT, r.cost_after_svd);   // :684
