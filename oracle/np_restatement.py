@@ -329,6 +329,32 @@ class NpSingle:
         f = np.where(sv > pcut, sv / (sv * sv + lam), 0.0)
         return ((self.y @ U) * f @ Vt).reshape(shp)
 
+    def pinv(self, V0, npass, lam, pcut=1e-8):                               # single.h:404-517
+        """subspace iteration on A = Phi^T Phi from the start V0 [D, r] (D in Fortran order of (a, s, t, r)), then B = yUS Einv"""
+        shp = self.v.shape[1:]
+        Phi = np.stack([x.reshape(-1, order="F") for x in self.v])          # [n][D], D column-major like the C oracle's tensors
+        Uv, _, Wv = np.linalg.svd(V0, full_matrices=False)
+        V = Uv @ Wv                                                          # polarU
+        E = (Phi @ V).T @ Phi                                                # r x D
+        last = float(np.sum(V.T * E))
+        ve = [last]
+        F = Dg = G = None
+        for _ in range(npass):
+            E = (Phi @ V).T @ Phi
+            F, Dg, G = np.linalg.svd(E, full_matrices=False)                 # E = F diag(D) G
+            V = (F @ G).T
+            VE = float(np.sum(V.T * E))
+            ve.append(VE)
+            if abs(VE - last) < 1e-4:
+                break
+            last = VE
+        if F is None:
+            return np.zeros(shp), np.array(ve), None
+        f = np.where(Dg > pcut, Dg / (Dg * Dg + lam), 0.0)
+        yus = (self.y @ Phi) @ V
+        B = ((yus @ F) * f) @ G
+        return B.reshape(shp, order="F"), np.array(ve), Dg
+
     def fast_cgrad(self, B, npass, lam, cconv):                              # single.h:290-398
         """one contraction with the images per step: p.v gives pAp and A p; residual by recurrence, with the reference's
         'nr = nr - lambda*B' (:379) as written"""

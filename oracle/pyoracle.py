@@ -269,6 +269,7 @@ def _slib():
         L.sorc_set_method.argtypes = [vp, C.c_int]
         L.sorc_set_pcut.argtypes = [vp, C.c_double]
         L.sorc_set_noise.argtypes = [vp, C.c_double]
+        L.sorc_pinv.argtypes = [vp, dp, C.c_int, C.c_int, C.c_double, C.c_double, dp, dp, ip, dp]
         L.sorc_noise_split.argtypes = [vp, dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, dp, ip]
         L.sorc_exact.argtypes = [vp, dp, C.c_double, C.c_double]
         L.sorc_svd_split.argtypes = [vp, dp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, dp, ip, dp, ip]
@@ -406,6 +407,15 @@ class SingleOracle:
         """optimiser of mldmrg: "conj" (cgrad), "fast_conj" (fast_cgrad) or "exact", single.h:598-600"""
         self._ck(self._L.sorc_set_method(self._h, {"conj": 0, "fast_conj": 1, "exact": 2}[method]))
         self._ck(self._L.sorc_set_pcut(self._h, pcut))
+
+    def pinv(self, b, V0, npass, lam, pcut=1e-8):
+        """single.h:404-517 from the start V0 [D, r] (columns = r tensors in ITensor order, flattened column-major); returns (B, trace of V*E, D)"""
+        V0 = np.asfortranarray(V0, dtype=np.float64)
+        D, r = V0.shape
+        assert D == int(np.prod(self.bond_shape(b)))
+        B = np.zeros(D); ve = np.zeros(npass + 1); Dsv = np.zeros(r); done = C.c_int()
+        self._ck(self._L.sorc_pinv(self._h, _dp(V0), r, npass, lam, pcut, _dp(B), _dp(ve), C.byref(done), _dp(Dsv)))
+        return B.reshape(self.bond_shape(b), order="F"), ve[:done.value + 1].copy(), Dsv
 
     def set_noise(self, noise):
         """sweeps.noise() of single.cc:25,222: >= 1e-14 makes mldmrg split through rho + noise * drho (single.h:648-672)"""

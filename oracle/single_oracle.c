@@ -1,7 +1,7 @@
 /* single_oracle.c -- CPU restatement of the per-label variant of the reference:
  *   /root/reference/single.cc   main: features (71-84), initial projections (181-199), precalc (204-216)
  *   /root/reference/single.h    TState (19-25), quadcost (82-112), exact (117-160), cgrad (162-288), fast_cgrad (290-398), mldmrg (523-728)
- *                               incl. the density-matrix split with a noise term (648-672)
+ *                               incl. the density-matrix split with a noise term (648-672); pinv (404-517) from a given start
  *   /root/reference/paralleldo.h static chunking, fork-join
  * TEST INFRASTRUCTURE ONLY (see single_oracle.h).  PARITY UNPINNED (no reference tests, ITensor absent).
  *
@@ -371,6 +371,61 @@ int sorc_exact(const sorc* o, double* B, double lambda, double pcut) {
         for (int i = 0; i < D; ++i) B[i] += yv * f * U[i + (size_t)D * g];    /* ... * Sinv * V (:158-159) */
     }
     free(Phi); free(U); free(sv); free(Vt);
+    return 0;
+}
+/* pinv (single.h:404-517): the "truncated pseudo inverse solver" -- a subspace iteration on A = sum_n v_n v_n^T from an r-dimensional
+ * start V (r = Ntarget): E = V^T A (:469-473,482-486), V <- polar factor of E through its SVD E = F D G (:492-495), until V*E = sum(D)
+ * moves by less than 1E-4 (:500) or Npass passes; then B = yUS * Einv with Einv = F pseudoInv(D) G (:510), yUS = sum over the images of
+ * the target label of v_n * V (:513-518).  In the reference the start is random(...) from a time-seeded generator (:457) and the result is
+ * only PRINTED (its cost, single.h:596-601: the update that follows is cgrad on the untouched B), so there is nothing to be bit-compatible
+ * with: here the start V0 (D x r, column major) is an argument.  ve[0] = the initial V*E, ve[p] = V*E after pass p; Dsv = the last D. */
+int sorc_pinv(const sorc* o, const double* V0, int r, int npass, double lambda, double pcut, double* B, double* ve, int* npass_done, double* Dsv) {
+    if (!o->v) return sfail("setBond not called");
+    const int D = (int)o->vsz, NT = o->NT;
+    if (r < 1 || r > D) return sfail("pinv: Ntarget out of range");
+    double* V = (double*)malloc(sizeof(double) * (size_t)D * r); double* E = (double*)malloc(sizeof(double) * (size_t)D * r);   /* column k = V_k, E_k */
+    double* U = (double*)malloc(sizeof(double) * (size_t)D * r); double* sv = (double*)malloc(sizeof(double) * (size_t)r);
+    double* Wt = (double*)malloc(sizeof(double) * (size_t)r * r); double* pk = (double*)malloc(sizeof(double) * (size_t)NT);
+    /* V = polarU(V0) (:458): V0 = U S Wt -> U Wt */
+    orc_thin_svd(D, r, V0, U, sv, Wt);
+    for (int k = 0; k < r; ++k) for (int d = 0; d < D; ++d) { double t = 0.; for (int g = 0; g < r; ++g) t += U[d + (size_t)D * g] * Wt[g + (size_t)r * k]; V[d + (size_t)D * k] = t; }
+#define SORC_MAKE_E() do { \
+        for (int k = 0; k < r; ++k) { \
+            for (int n = 0; n < NT; ++n) pk[n] = sdot(V + (size_t)D * k, o->v + (size_t)n * o->vsz, (size_t)D); \
+            double* Ek = E + (size_t)D * k; memset(Ek, 0, sizeof(double) * (size_t)D); \
+            for (int n = 0; n < NT; ++n) { const double* vn = o->v + (size_t)n * o->vsz; for (int d = 0; d < D; ++d) Ek[d] += pk[n] * vn[d]; } \
+        } } while (0)
+    SORC_MAKE_E();
+    double last = sdot(V, E, (size_t)D * r);                          /* :475 lastVE */
+    if (ve) ve[0] = last;
+    int done = 0;
+    for (int pass = 1; pass <= npass; ++pass) {
+        SORC_MAKE_E();                                                /* :482-486 */
+        orc_thin_svd(D, r, E, U, sv, Wt);                             /* E^T (D x r) = U S Wt: F[a][g] = Wt[g][a], G[g][:] = U[:][g]  (:492) */
+        for (int a = 0; a < r; ++a) for (int d = 0; d < D; ++d) { double t = 0.; for (int g = 0; g < r; ++g) t += Wt[g + (size_t)r * a] * U[d + (size_t)D * g]; V[d + (size_t)D * a] = t; }   /* :495 */
+        const double VE = sdot(V, E, (size_t)D * r);                  /* :497 */
+        done = pass;
+        if (ve) ve[pass] = VE;
+        if (fabs(VE - last) < 1E-4) break;                            /* :500 */
+        last = VE;
+    }
+    if (npass_done) *npass_done = done;
+    memset(B, 0, sizeof(double) * (size_t)D);
+    if (done > 0) {
+        if (Dsv) memcpy(Dsv, sv, sizeof(double) * (size_t)r);
+        /* yUS (:513-518) with the V of the last pass; B = yUS * F pseudoInv(D) G (:510,519) */
+        for (int a = 0; a < r; ++a) {
+            double yus = 0.;
+            for (int n = 0; n < NT; ++n) if (o->labels[n] == o->target) yus += sdot(V + (size_t)D * a, o->v + (size_t)n * o->vsz, (size_t)D);
+            for (int g = 0; g < r; ++g) {
+                const double f = sv[g] > pcut ? sv[g] / (sv[g] * sv[g] + lambda) : 0.;      /* :417-421 */
+                const double cf = yus * Wt[g + (size_t)r * a] * f;
+                if (cf != 0.) for (int d = 0; d < D; ++d) B[d] += cf * U[d + (size_t)D * g];
+            }
+        }
+    }
+#undef SORC_MAKE_E
+    free(V); free(E); free(U); free(sv); free(Wt); free(pk);
     return 0;
 }
 int sorc_set_pcut(sorc* o, double pcut) { o->pcut = pcut; return 0; }

@@ -61,6 +61,9 @@ int sorc_exact(const sorc* o, double* B, double lambda, double pcut);
 /* optimiser used by sorc_mldmrg: 0 = conj (default), 1 = fast_conj, 2 = exact (single.h:598-600); pcut of the exact solver (default 1E-8) */
 int sorc_set_method(sorc* o, int method);
 int sorc_set_pcut(sorc* o, double pcut);
+/* pinv (single.h:404-517) from the start V0 (D x r, column major; the reference's is random and time-seeded): B (out, D), ve[0..npass] the V*E
+   trace, the passes run, the singular values of the last E */
+int sorc_pinv(const sorc* o, const double* V0, int r, int npass, double lambda, double pcut, double* B, double* ve, int* npass_done, double* Dsv);
 /* noise of the sweeps (single.cc:25,222): >= 1E-14 makes sorc_mldmrg split through the density matrix rho + noise * drho (single.h:648-672) */
 int sorc_set_noise(sorc* o, double noise);
 int sorc_noise_split(sorc* o, const double* B, int b, int ha, double noise, double cutoff, int maxm, int minm, double* truncerr, int* newm);

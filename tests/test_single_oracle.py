@@ -247,3 +247,35 @@ def test_sweep_with_noise_matches_numpy():
     o0.init()
     r0 = o0.mldmrg(2, 4, 2, 1e-10, 3, 1e-3, 1e-10)
     assert any(abs(a["cost"] - b["cost"]) > 1e-9 * abs(b["cost"]) for a, b in zip(ro, r0))
+
+
+@pytest.mark.parametrize("b,r", [(1, 3), (4, 6), (9, 4)])
+def test_pinv_matches_numpy_and_approaches_the_exact_solver(b, r):
+    """single.h:404-517 from a given start (the reference's is random and time-seeded): C oracle against the numpy restatement -- the V*E
+    trace, the singular values, the resulting B -- and, with r = D (the whole space), the iteration is the exact solver"""
+    pixels, labels, phi, W = problem(N=10, NT=50, m=3)
+    phi = phi.copy(); phi[..., 1] *= 300.0
+    o = pyoracle.SingleOracle(phi, labels, 1, W, nthread=1)
+    n = npr.NpSingle(phi, labels, 1, W)
+    o.init(); n.init()
+    for bb in range(1, b):
+        o.shiftE(bb, True); n.shiftE(bb, True)
+    o.set_bond(b); n.set_bond(b)
+    D = int(np.prod(o.bond_shape(b)))
+    V0 = np.random.default_rng(b).standard_normal((D, min(r, D)))
+    Bo, veo, Do = o.pinv(b, V0, 6, 1e-3)
+    Bn, ven, Dn = n.pinv(V0, 6, 1e-3)
+    assert len(veo) == len(ven)
+    np.testing.assert_allclose(veo, ven, rtol=1e-9)
+    np.testing.assert_allclose(Do, Dn, rtol=1e-8)
+    np.testing.assert_allclose(Bo, Bn, rtol=1e-6, atol=1e-9 * np.abs(Bn).max())
+    assert all(veo[i + 1] >= veo[i] * (1 - 1e-12) for i in range(len(veo) - 1))      # the trace norm of V^T A grows towards the top-r eigenvalue sum
+    # the whole space: E = V^T A with V orthogonal, so yUS Einv = y Phi A^+ filtered -- the exact solver's B up to the different filter
+    # argument (pinv filters the eigenvalues of A, exact the singular values of Phi): compare with lambda = 0, pcut = 0 on a full-rank case
+    if D <= 24:
+        Vf = np.random.default_rng(7).standard_normal((D, D))
+        Bf, _, _ = o.pinv(b, Vf, 2, 0.0, 0.0)
+        Phi = np.stack([x.reshape(-1, order="F") for x in n.v])
+        y = (labels == 1).astype(float)
+        if np.linalg.matrix_rank(Phi) == D:
+            np.testing.assert_allclose(Bf.reshape(-1, order="F"), np.linalg.solve(Phi.T @ Phi, Phi.T @ y), rtol=1e-5, atol=1e-8)
