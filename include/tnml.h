@@ -189,6 +189,12 @@ int tnml_cgrad(tnml_ctx* ctx, double* B, int npass, double lambda, double cconv,
    that small singular values stay accurate), with the reference's filtered inverse s/(s^2 + lambda) for s > pcut.
    B (ITensor layout, D doubles) is output only.  Meant for small problems, like the reference's (single.h:114). */
 int tnml_exact(tnml_ctx* ctx, double* B, double lambda, double pcut);
+/* pinv of the per-label variant (single.h:404-517; TNML_MODE_SINGLE, one rank, after tnml_set_bond): a subspace iteration on sum_n v_n v_n^T
+   from the start V0 (D x r column-major, D = 4 mL mR in ITensor order, r = the reference's Ntarget <= 64), V <- polar factor of E = V^T A
+   until V*E moves by less than 1E-4 or npass passes, then B = yUS * F pseudoInv(D) G.  In the reference the start is random and time-seeded and
+   the result only has its cost printed (single.h:596-601; the update that follows is cgrad): a diagnostic.  ve[0..npass]: the V*E trace,
+   Dsv[r]: the singular values of the last E. */
+int tnml_pinv(tnml_ctx* ctx, const double* V0, int r, int npass, double lambda, double pcut, double* B, double* ve, int* npass_done, double* Dsv);
 
 /* ---- svd(B, W.Aref(c), S, W.Aref(c+dc)); W.Aref(c+dc) *= S  (fixedL.cc:519-521) ---------- */
 /* ha = 1: c = b (sweeping right), ha = 2: c = b+1 (sweeping left).  Updates the W replica.

@@ -813,6 +813,24 @@ def test_single_fast_conj_sweep_matches_the_oracle():
     assert ro[-1]["cost"] < ro[0]["cost_old"]
 
 
+@pytest.mark.parametrize("b,r", [(1, 3), (5, 6), (11, 4)])
+def test_single_pinv_matches_the_oracle(b, r):
+    """tnml_pinv (single.h:404-517 from a given start; the reference's is random and time-seeded): E = A V through the CG's own forward +
+    weighted-gradient passes, the r x r algebra on the host, against the oracle's dense iteration -- V*E trace, singular values, B"""
+    ts, o = _single_pair(N=12, NT=70, m=4, target=3)
+    _walk(ts, o, b)
+    D = int(np.prod(o.bond_shape(b)))
+    V0 = np.random.default_rng(10 + b).standard_normal((D, min(r, D)))
+    Bg, veg, Dg = ts.pinv(b, V0, 5, 1e-3)
+    Bo, veo, Do = o.pinv(b, V0, 5, 1e-3)
+    assert len(veg) == len(veo)
+    np.testing.assert_allclose(veg, veo, rtol=1e-9)
+    np.testing.assert_allclose(np.sort(Dg)[::-1], np.sort(Do)[::-1], rtol=1e-8)
+    assert _relmax(Bg, Bo) < 1e-6
+    Cg = ts.quadcost(Bg, 1e-3)[0]                              # what the reference prints: "After pinv, Cost"
+    assert Cg == pytest.approx(o.quadcost(Bo, 1e-3)[0], rel=1e-7)
+
+
 @pytest.mark.parametrize("noise", [1e-6, 1e-3])
 def test_single_noise_split_matches_the_oracle(noise):
     """the density-matrix split with a noise term of the per-label variant (single.h:648-672) on the device -- rho from the Gram matrix
@@ -993,10 +1011,26 @@ def test_single_and_separate_fulltest_cli(tmp_path):
     c_svd = [float(x) for x in re.findall(r"--> After SVD, Cost = ([0-9.eE+-]+) \(", run.stdout)]
     assert len(c_svd) == len(ro) and "SVD trunc err" not in run.stdout and run.stdout.count("Trunc err = ") == len(ro)
     np.testing.assert_allclose(c_svd, [r["cost"] / float(len(lab)) for r in ro], rtol=1e-6, atol=1e-10)
+    # method = pinv (single.h:596-604): the pseudo-inverse solution is a diagnostic -- its cost is printed -- and the update is cgrad: the
+    # same sweep as method = conj, plus one block of diagnostic lines per bond update
+    logs = {}
+    for meth in ("conj", "pinv"):
+        wdm = tmp_path / ("L" + meth)
+        wdm.mkdir()
+        im = wdm / "input_m"
+        im.write_text(inp.read_text().replace("method = fast_conj", "method = %s\nNtarget = 4" % meth))
+        run = subprocess.run([os.path.join(root, "tnml_amd", "single"), str(im)], capture_output=True, text=True, cwd=wdm, timeout=300)
+        assert run.returncode == 0, run.stdout[-1500:] + run.stderr[-1500:]
+        logs[meth] = run.stdout
+    after = {k: re.findall(r"--> After SVD, Cost = [0-9.eE+-]+ \(", v) for k, v in logs.items()}
+    assert after["pinv"] == after["conj"] and len(after["pinv"]) == 2 * (N - 1)
+    pc = [float(x) for x in re.findall(r"After pinv, Cost = ([0-9.eE+-]+)", logs["pinv"])]
+    assert len(pc) == 2 * (N - 1) and all(np.isfinite(pc)) and "After pinv" not in logs["conj"]
+    assert logs["pinv"].count("Using pcut = 1.00E-08") == 2 * (N - 1) and logs["pinv"].count("Initial V*E = ") == 2 * (N - 1)
     bad = wd / "input_bad"
-    bad.write_text(inp.read_text().replace("fast_conj", "pinv"))
+    bad.write_text(inp.read_text().replace("fast_conj", "newton"))
     run = subprocess.run([os.path.join(root, "tnml_amd", "single"), str(bad)], capture_output=True, text=True, cwd=wd, timeout=300)
-    assert run.returncode != 0 and "not built here" in run.stdout
+    assert run.returncode != 0 and "not recognized" in run.stdout
     # evaluator on the ten weight files
     (tmp_path / "sites").write_bytes((tmp_path / "L0" / "sites").read_bytes())
     tin = tmp_path / "input_test"

@@ -1063,6 +1063,90 @@ int tnml_quadcost(tnml_ctx* c, const double* B, double lambda, double* cost, dou
     TCK(upload_bond(c, B));
     return quadcost_device(c, lambda, cost, label_cost, reg_cost, ncorrect, false);
 }
+// pinv (single.h:404-517, per-label variant): subspace iteration on A = sum_n v_n v_n^T from the start V0 (D x r, columns in ITensor
+// order).  E_k = A V_k is the CG's own pair of passes -- a forward pass of V_k (its outputs V_k.v_n stay in Pp) and the gradient GEMM
+// weighted with them -- so the dense v_n are not formed here either; the r x r algebra (polar factor, SVD of E through a one-sided Jacobi
+// on its r columns, the filtered inverse) runs on the host.  The reference starts from a time-seeded random V and only prints the cost of
+// the result (single.h:596-601): a diagnostic, with the start an argument here.  One rank only.
+int tnml_pinv(tnml_ctx* c, const double* V0, int r, int npass, double lambda, double pcut, double* B, double* ve, int* npass_done, double* Dsv) {
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    if (!c->single()) return tnml_fail(c, "tnml_pinv: only the per-label variant (TNML_MODE_SINGLE) has this solver");
+    if (c->currb < 1) return tnml_fail(c, "tnml_pinv: setBond has not been called");
+    if (c->cfg.nranks > 1) return tnml_fail(c, "tnml_pinv: one rank only");
+    const BondPlan p = c->plan;
+    const int D = p.mL * 4 * p.mR, NT = c->NT;
+    if (r < 1 || r > D || r > 64) return tnml_fail(c, "tnml_pinv: Ntarget = %d outside 1..min(%d, 64)", r, D);
+    if (npass < 0) return tnml_fail(c, "tnml_pinv: Npass must be >= 0");
+    c->p_valid = false;
+    std::vector<double> V((size_t)D * r), E((size_t)D * r), A((size_t)D * r), sv((size_t)r), W((size_t)r * r), hp((size_t)c->NTp);
+    std::vector<int> lab((size_t)NT);
+    HIPCK(c, hipMemcpy(lab.data(), c->label, sizeof(int) * NT, hipMemcpyDeviceToHost));
+    // V = polarU(V0) (:458): V0 W = U S  ->  U W^T
+    A.assign(V0, V0 + (size_t)D * r);
+    if (!hestenes_svd(D, r, A.data(), sv.data(), W.data())) return tnml_fail(c, "tnml_pinv: the Jacobi SVD of the start did not converge");
+    auto polar_from = [&](std::vector<double>& out) {                  // columns of A are u_g s_g, W the right vectors: out = U W^T
+        for (int g = 0; g < r; ++g) if (!(sv[g] > 0.)) return false;
+        for (int k = 0; k < r; ++k) for (int d = 0; d < D; ++d) { double t = 0.; for (int g = 0; g < r; ++g) t += A[d + (size_t)D * g] / sv[g] * W[k + (size_t)r * g]; out[d + (size_t)D * k] = t; }
+        return true;
+    };
+    if (!polar_from(V)) return tnml_fail(c, "tnml_pinv: the start V0 has linearly dependent columns");
+    std::vector<double> yus((size_t)r);
+    auto make_E = [&](bool want_yus) -> int {                          // E_k = A V_k for all k (:469-473, :482-486); optionally yUS_k (:513-518)
+        for (int k = 0; k < r; ++k) {
+            TCK(upload_bond(c, V.data() + (size_t)D * k));
+            HIPCK(c, hipMemcpyAsync(c->vP, c->vB, sizeof(double) * p.msize(), hipMemcpyDeviceToDevice, c->stream));
+            TCK(forward_pass(c, c->vP, LD_MODE_PAP, c->tail, true));   // Pp[n] = V_k . v_n
+            if (want_yus) {
+                HIPCK(c, hipMemcpyAsync(hp.data(), c->Pp, sizeof(double) * c->NTp, hipMemcpyDeviceToHost, c->stream));
+                HIPCK(c, hipStreamSynchronize(c->stream));
+                double t = 0.; for (int n = 0; n < NT; ++n) if (lab[n] == c->target()) t += hp[n];
+                yus[k] = t;
+            } else {
+                TCK(grad_eval(c, false, false, true, false));          // vG = sum_n (V_k . v_n) v_n
+                TCK(download_bond(c, c->vG, E.data() + (size_t)D * k));
+            }
+        }
+        return 0;
+    };
+    auto dotVE = [&]() { double t = 0.; for (size_t i = 0; i < (size_t)D * r; ++i) t += V[i] * E[i]; return t; };
+    TCK(make_E(false));
+    double last = dotVE();                                             // :475
+    if (ve) ve[0] = last;
+    int done = 0;
+    for (int pass = 1; pass <= npass; ++pass) {
+        TCK(make_E(false));
+        A = E;                                                         // E^T (D x r): columns E_k; E W = U S -> F[a][g] = W[a + r g], G[g][:] = U[:, g]
+        if (!hestenes_svd(D, r, A.data(), sv.data(), W.data())) return tnml_fail(c, "tnml_pinv: the Jacobi SVD of E did not converge");
+        // sort by singular value (descending) so that D reads like the reference's PrintData(D)
+        std::vector<int> ord((size_t)r); for (int g = 0; g < r; ++g) ord[g] = g;
+        std::sort(ord.begin(), ord.end(), [&](int x, int y) { return sv[x] > sv[y]; });
+        std::vector<double> A2((size_t)D * r), W2((size_t)r * r), s2((size_t)r);
+        for (int g = 0; g < r; ++g) { s2[g] = sv[ord[g]]; std::copy(A.begin() + (size_t)D * ord[g], A.begin() + (size_t)D * (ord[g] + 1), A2.begin() + (size_t)D * g); std::copy(W.begin() + (size_t)r * ord[g], W.begin() + (size_t)r * (ord[g] + 1), W2.begin() + (size_t)r * g); }
+        A.swap(A2); W.swap(W2); sv.swap(s2);
+        if (!polar_from(V)) {                                          // rank-deficient E: the polar factor over the non-zero part only
+            for (int k = 0; k < r; ++k) for (int d = 0; d < D; ++d) { double t = 0.; for (int g = 0; g < r; ++g) if (sv[g] > 0.) t += A[d + (size_t)D * g] / sv[g] * W[k + (size_t)r * g]; V[d + (size_t)D * k] = t; }
+        }
+        const double VE = dotVE();                                     // :497 (= sum of the singular values)
+        done = pass;
+        if (ve) ve[pass] = VE;
+        if (std::fabs(VE - last) < 1E-4) break;                        // :500
+        last = VE;
+    }
+    if (npass_done) *npass_done = done;
+    std::fill(B, B + D, 0.);
+    if (done > 0) {
+        if (Dsv) std::copy(sv.begin(), sv.end(), Dsv);
+        TCK(make_E(true));                                             // yUS with the V of the last pass
+        for (int a = 0; a < r; ++a)
+            for (int g = 0; g < r; ++g) {
+                const double s1 = sv[g];
+                if (!(s1 > pcut)) continue;                            // pseudoInv :417-421
+                const double cf = yus[a] * W[a + (size_t)r * g] / (s1 * s1 + lambda);   // F[a][g] s/(s^2+lambda) G[g][:], G = column / s
+                for (int d = 0; d < D; ++d) B[d] += cf * A[d + (size_t)D * g];
+            }
+    }
+    return 0;
+}
 int tnml_exact(tnml_ctx* c, double* B, double lambda, double pcut) {   // single.h:117-160 on the bond chosen by tnml_set_bond
     HIPCK(c, hipSetDevice(c->cfg.device));
     if (c->currb < 1) return tnml_fail(c, "tnml_exact: setBond has not been called");

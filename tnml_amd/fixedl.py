@@ -229,6 +229,16 @@ class TrainStates:
         self._ck(self._L.tnml_exact(self._h, _lib.dptr(buf), lam, pcut))
         return buf.reshape(shape, order="F")
 
+    def pinv(self, b, V0, npass, lam, pcut=1e-8):
+        """single.h:404-517 on the bond chosen by setBond(b) from the start V0 [D, r]: (B, trace of V*E, singular values of the last E)"""
+        shape = self.bond_tensor(b).shape
+        V0 = np.asfortranarray(V0, dtype=np.float64)
+        D, r = V0.shape
+        assert D == int(np.prod(shape))
+        B = np.zeros(D); ve = np.zeros(npass + 1); Dsv = np.zeros(r); done = C.c_int()
+        self._ck(self._L.tnml_pinv(self._h, _lib.dptr(V0), r, npass, lam, pcut, _lib.dptr(B), _lib.dptr(ve), C.byref(done), _lib.dptr(Dsv)))
+        return B.reshape(shape, order="F"), ve[:done.value + 1].copy(), Dsv
+
     def set_option_real(self, name, value):
         self._ck(self._L.tnml_set_option_real(self._h, name.encode(), float(value)))
 

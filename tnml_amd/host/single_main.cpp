@@ -4,8 +4,9 @@
 // Keeps the reference's surface (single.cc:6-244 and the mldmrg of single.h:523-728): input keys, the files `sites`
 // and `W<label>` in the working directory, the `WRITE_WF` hook, the idx-ubyte training set under `datadir`, the
 // image order (labels taken round-robin, single.cc:156-181) and the log lines.  One tnml_bond_update per bond.
-// Built: method = conj | fast_conj | exact and the `noise` density-matrix split (single.h:648-672).  Not built: method = pinv (a diagnostic
-// from a time-seeded random start, single.h:404-517; the update itself is cgrad): it stops with a message.  Extensions (never read by the reference): `seed`, `device`, `precision`, `imglen`,
+// Built: method = conj | fast_conj | exact | pinv and the `noise` density-matrix split (single.h:648-672).  method = pinv is what it is in the
+// reference (single.h:596-604): the cost of the pseudo-inverse solution is printed, the update itself is cgrad; its random start comes from
+// `seed` here (the reference's is time-seeded).  Extensions (never read by the reference): `seed`, `device`, `precision`, `imglen`,
 // `feature_scale` as in the fixedL driver; `labels`, `ngpu`, `share_device`, `dry_run`: the one-label-per-GPU launcher
 // of BASELINE config 4 (launch_per_label below).
 #include <sys/stat.h>
@@ -148,7 +149,7 @@ int main(int argc, const char* argv[]) {
         (void)input.getReal("alpha", 1.0); (void)input.getReal("clip", 1.0);
         const long Npass = input.getInt("Npass", 4);
         const double cconv = input.getReal("cconv", 1E-10);
-        (void)input.getInt("Ntarget", 10); const double pcut = input.getReal("pcut", 1E-8); (void)input.getYesNo("precalc", true);
+        const long Ntarget = input.getInt("Ntarget", 10); const double pcut = input.getReal("pcut", 1E-8); (void)input.getYesNo("precalc", true);
         const uint64_t seed = (uint64_t)input.getInt("seed", 1);
         const int device = std::getenv("TNML_SINGLE_DEVICE") ? std::atoi(std::getenv("TNML_SINGLE_DEVICE")) : (int)input.getInt("device", 0);
         const std::string precision = input.getString("precision", "f64");
@@ -158,10 +159,10 @@ int main(int argc, const char* argv[]) {
         if (precision == "mixed") dtype = TNML_F64_E32; else if (precision == "f32") dtype = TNML_F32;
         else if (precision != "f64" && precision != "strict") { std::printf("precision must be f64, mixed or f32\n"); return 1; }
         if (L < 0 || L > 9) { std::printf("label must be in 0..9\n"); return 1; }
-        if (method == "pinv") { std::printf("method \"%s\" is not built here (conj, fast_conj and exact are)\n", method.c_str()); return 1; }
-        if (method != "conj" && method != "fast_conj" && method != "exact") { std::printf("method type \"%s\" not recognized\n", method.c_str()); return 1; }   // single.h:611
+        if (method != "conj" && method != "fast_conj" && method != "exact" && method != "pinv") { std::printf("method type \"%s\" not recognized\n", method.c_str()); return 1; }   // single.h:611
         const bool fast_conj = method == "fast_conj";                                  // single.h:599
         const bool exact = method == "exact";                                          // single.h:600
+        const bool pinv = method == "pinv";                                            // single.h:596
 
         char wname[32]; std::snprintf(wname, sizeof wname, "W%d", L);                  // :53
         Dataset train = read_mnist(datadir, true, Ntrain);                              // :56
@@ -251,9 +252,27 @@ int main(int argc, const char* argv[]) {
             for (int b = 1, ha = 1; ha <= 2; tnml_sweepnext(&b, &ha, N)) {              // :554
                 tnml_sweep_params sp{(int)std::min<long>(maxm, cfg.maxm), (int)std::min<long>(minm, cfg.maxm), cutoff, (int)Npass, lambda, lambda, cconv, 1};
                 tnml_bond_report r;
+                double pinv_cost = 0.; std::vector<double> pve, pD; int pdone = 0;
+                if (pinv) {                                                             // single.h:596-601: BB = B; pinv(BB,...); quadcost(BB)
+                    int mL, mR, lab; CK(ctx, tnml_set_bond(ctx, b)); CK(ctx, tnml_bond_dims(ctx, b, &mL, &mR, &lab));
+                    const int D = mL * 4 * mR, rr = (int)std::min<long>(std::min<long>(Ntarget, D), 64);
+                    std::vector<double> V0((size_t)D * rr), BB((size_t)D);
+                    uint64_t st = (uint64_t)seed * 0x9E3779B97F4A7C15ull + (uint64_t)(sw * 100003 + ha * 1009 + b);   // random(...) of :457, seeded
+                    for (double& x : V0) { st = st * 6364136223846793005ull + 1442695040888963407ull; x = (double)((st >> 11) & 0xFFFFFFFFFFFFFull) / 4503599627370496.0 - 0.5; }
+                    pve.assign((size_t)Npass + 1, 0.); pD.assign((size_t)rr, 0.);
+                    CK(ctx, tnml_pinv(ctx, V0.data(), rr, (int)Npass, lambda, pcut, BB.data(), pve.data(), &pdone, pD.data()));
+                    CK(ctx, tnml_quadcost(ctx, BB.data(), lambda, &pinv_cost, nullptr, nullptr, nullptr));
+                }
                 CK(ctx, tnml_bond_update(ctx, b, ha, &sp, &r));
                 std::printf("Sweep %ld Half %d Bond %d\n", sw, ha, r.c);                // :566
                 std::printf("norm(oB) = %.12g\n", r.norm_oB);                           // :572
+                if (pinv) {
+                    std::printf("Using pcut = %.2E\n", pcut);                             // :415
+                    std::printf("Initial V*E = %.20f\n", pve[0]);                         // :476
+                    for (int p = 1; p <= pdone; ++p) { std::printf("Making E\nPolar U\n%d V*E = %.20f\n", p, pve[(size_t)p]); }   // :481,489,498
+                    std::printf("D ="); for (double x : pD) std::printf(" %.10g", x); std::printf("\n");   // :508 PrintData(D)
+                    std::printf("After pinv, Cost = %.20f\n", pinv_cost / NT);             // :601
+                }
                 if (r.cg.converged == 2) std::printf("  |r| < %.1E, not optimizing\n", cconv);   // :204 (|r| itself stays on the device)
                 for (int p = 0; fast_conj && p < r.cg.npass_done; ++p) {                // fast_cgrad prints pass and |r| on one line, no cost (single.h:337,373,387-393)
                     std::printf("  Conj grad pass %d ", p + 1);

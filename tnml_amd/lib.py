@@ -27,7 +27,7 @@ EXPORTS = [
     "tnml_shard_bounds", "tnml_profile_enable", "tnml_profile_select", "tnml_profile_count", "tnml_profile_get",
     "tnml_profile_reset", "tnml_synchronize", "tnml_device_bytes", "tnml_svd_stats", "tnml_classify", "tnml_replica_check",
     "tnml_estimate_bytes", "tnml_device_memory", "tnml_plan_maxm", "tnml_set_option", "tnml_comm_init_local", "tnml_bond_update_begin", "tnml_bond_update_end", "tnml_replica_repairs", "tnml_pAp", "tnml_collective_stats", "tnml_last_warning",
-    "tnml_exact", "tnml_set_option_real",
+    "tnml_exact", "tnml_set_option_real", "tnml_pinv",
 ]
 
 
@@ -92,6 +92,7 @@ def load():
     L.tnml_quadcost.argtypes = [vp, dp, C.c_double, dp, dp, dp, C.POINTER(C.c_int64)]
     L.tnml_cgrad.argtypes = [vp, dp, C.c_int, C.c_double, C.c_double, C.POINTER(CgTrace)]
     L.tnml_exact.argtypes = [vp, dp, C.c_double, C.c_double]
+    L.tnml_pinv.argtypes = [vp, dp, C.c_int, C.c_int, C.c_double, C.c_double, dp, dp, C.POINTER(C.c_int), dp]
     L.tnml_set_option_real.argtypes = [vp, C.c_char_p, C.c_double]
     L.tnml_svd_split.argtypes = [vp, dp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, dp, ip, dp, ip]
     L.tnml_bond_update.argtypes = [vp, C.c_int, C.c_int, C.POINTER(SweepParams), C.POINTER(BondReport)]
