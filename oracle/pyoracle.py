@@ -107,10 +107,13 @@ class Oracle:
         if rc != 0:
             raise RuntimeError(self._L.orc_last_error().decode())
 
+    def set_site(self, j, A):
+        A = np.asarray(A, dtype=np.float64)
+        self._ck(self._L.orc_set_site(self._h, j, A.shape[0], A.shape[2], int(A.ndim == 4), _dp(_f(A))))
+
     def set_mps(self, W):
         for j, A in enumerate(W, start=1):
-            A = np.asarray(A, dtype=np.float64)
-            self._ck(self._L.orc_set_site(self._h, j, A.shape[0], A.shape[2], int(A.ndim == 4), _dp(_f(A))))
+            self.set_site(j, A)
 
     def get_site(self, j):
         ml, mr, hl = C.c_int(), C.c_int(), C.c_int()
