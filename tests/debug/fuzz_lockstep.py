@@ -22,17 +22,19 @@ from test_gpu_parity import _mps_with_dims  # noqa: E402
 
 
 def one_case(rng, idx):
-    N = int(rng.integers(4, 15))
+    huge = bool(os.environ.get("FUZZ_HUGE"))                        # FUZZ_HUGE=1: short chains with bond dimensions up to 320 (the split's size classes)
+    N = int(rng.integers(4, 7)) if huge else int(rng.integers(4, 15))
     big = rng.random() < 0.15
-    cap = 160 if big else 40
+    cap = 320 if huge else (160 if big else 40)
     dims = [1]
     for j in range(1, N):
-        lim = min(cap, 2 * dims[-1], 2 ** min(N - j, 12))
-        dims.append(int(rng.integers(1, max(2, lim + 1))))
+        lim = min(cap, 2 * dims[-1], 2 ** min(N - j, 12)) if not huge else cap
+        dims.append(int(rng.integers(100, lim + 1)) if huge else int(rng.integers(1, max(2, min(lim, 2 * dims[-1]) + 1))))
     dims.append(1)
     for j in range(N - 1, 0, -1):
-        dims[j] = min(dims[j], 2 * dims[j + 1])
-    NT = int(rng.choice([1, 7, 33, 64, 100, 257]))
+        if not huge:
+            dims[j] = min(dims[j], 2 * dims[j + 1])
+    NT = int(rng.choice([7, 33])) if huge else int(rng.choice([1, 7, 33, 64, 100, 257]))
     boost = float(rng.choice([1.0, 30.0, 200.0]))
     dtype = str(rng.choice(["f64", "f64", "f64", "f64_e32", "f32"]))
     maxm = int(rng.integers(2, max(3, max(dims) + 3)))
@@ -51,16 +53,29 @@ def one_case(rng, idx):
     o = pyoracle.Oracle(phi, labels, W)
     o3 = pyoracle.Oracle(phi, labels, W, nthread=3)
     ts.set_mps(W); o.init(); o3.init(); ts.init()
+    tl = None
+    if os.environ.get("FUZZ_TRACE") == str(idx):                       # a second HIP context in the literal evaluation order (no P recurrence, no carried outputs)
+        tl = TrainStates(labels, N, max(max(dims), maxm), phi=phi, dtype=dtype)
+        tl.set_option("fast_cg", 0); tl.set_option("reuse_p", 0)
+        tl.set_mps(W); tl.init()
     b, ha, worst, bad = 1, 1, 0.0, []
     while ha <= 2:
         r = ts.bond_update(b, ha, maxm, minm, cutoff, npass, lam, 1e-10)
         o.set_bond(b)
         B, tr = o.cgrad(o.bond_tensor(b), npass, lam, 1e-10)
+        trace = os.environ.get("FUZZ_TRACE") == str(idx)
         newm, te, sv = o.svd_split(B, b, ha, cutoff, maxm, minm)
         C, lc, cr, nc = o.quadcost(o.bond_tensor(b), lam)
         o.shiftE(b, ha == 1)
         o3.set_bond(b)
-        B3, _ = o3.cgrad(o3.bond_tensor(b), npass, lam, 1e-10)
+        B3, tr3 = o3.cgrad(o3.bond_tensor(b), npass, lam, 1e-10)
+        if trace:                                                       # FUZZ_TRACE=<case>: the CG step sizes of the three runs, bond by bond
+            rl = tl.bond_update(b, ha, maxm, minm, cutoff, npass, lam, 1e-10)
+            tl.set_site(b, o.get_site(b)); tl.set_site(b + 1, o.get_site(b + 1)); tl.shiftE(b, ha == 1)
+            f = lambda v: ["%.6g" % x for x in v]
+            print("   bond %d half %d: alpha  oracle(1 thread) %s | oracle(3 threads) %s | HIP %s | HIP literal order %s" % (b, ha, f(tr["alpha"]), f(tr3["alpha"]), f(r["cg"]["alpha"]), f(rl["cg"]["alpha"])))
+            print("                  |r|    oracle(1 thread) %s | oracle(3 threads) %s | HIP %s | HIP literal order %s" % (f(tr["rnorm"]), f(tr3["rnorm"]), f(r["cg"]["rnorm"]), f(rl["cg"]["rnorm"])))
+            print("                  cost   oracle(1 thread) %s | HIP %s | HIP literal order %s" % (f(tr["cost"]), f(r["cg"]["cost"]), f(rl["cg"]["cost"])))
         o3.svd_split(B3, b, ha, cutoff, maxm, minm)
         C3 = o3.quadcost(o3.bond_tensor(b), lam)[0]
         o3.set_site(b, o.get_site(b)); o3.set_site(b + 1, o.get_site(b + 1)); o3.shiftE(b, ha == 1)
