@@ -236,3 +236,64 @@ def test_split_on_the_workgroup_cluster_keeps_the_replicas_identical():
     assert two[0]["cost"] == two[1]["cost"] and two[0]["newm"] == two[1]["newm"] == one["newm"]
     assert max(one["newm"]) == 150 and two[0]["fb"] == 0 and one["fb"] == 0
     np.testing.assert_allclose(two[0]["cost"], one["cost"], rtol=1e-7)
+
+
+@pytest.mark.parametrize("noise", [0.0, 1e-5])
+def test_per_label_variant_on_two_ranks_with_and_without_noise(noise):
+    """TNML_MODE_SINGLE with the images sharded over two ranks: the sums of the CG and -- with noise > 0 -- the images' term of the
+    density-matrix split (three weighted Gram matrices of the environment, all-reduced before they are added to rho, single.h:654-665)
+    are sums over ranks; costs and kept dimensions must match the one-rank run and the oracle, the replicas must stay bit-identical."""
+    from oracle import pyoracle
+    from tnml_amd import lib, synth
+    from tnml_amd.fixedl import TrainStates, mldmrg
+    N, NT, m, target = 10, 90, 3, 7
+    labels = synth.synthetic_labels(NT, seed=4, per_label=NT // 10)
+    pixels = synth.synthetic_images(N, labels, seed=4)
+    phi = pyoracle.features_single(pixels, True).copy()
+    phi[..., 1] *= 300.0
+    W = synth.random_mps(N, m, seed=11)
+    W[N // 2 - 1] = W[N // 2 - 1][..., 0] * 3.0
+    o = pyoracle.SingleOracle(phi, labels, target, W)
+    o.set_noise(noise)
+    o.init()
+    ro = o.mldmrg(1, 5, 2, 1e-10, 3, 1e-3, 1e-10)
+
+    def run(nranks):
+        states = []
+        for r in range(nranks):
+            lo, hi = lib.shard_bounds(NT, nranks, r)
+            states.append(TrainStates(labels[lo:hi], N, 5, phi=phi[lo:hi], rank=r, nranks=nranks, NT_total=NT, single_label=target))
+        if nranks > 1:
+            TrainStates.comm_init_local(states)
+        out, err = [None] * nranks, [None] * nranks
+
+        def work(r):
+            try:
+                ts = states[r]
+                ts.set_mps(W)
+                if noise:
+                    ts.set_option_real("noise", noise)
+                ts.init()
+                reps = mldmrg(ts, 1, 5, 2, 1e-10, 3, 1e-3, 1e-10)
+                out[r] = (reps, [ts.get_site(j) for j in range(1, N + 1)])
+            except Exception as e:                               # noqa: BLE001
+                err[r] = e
+        th = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=600)
+        assert not any(t.is_alive() for t in th), "a rank hung"
+        for e in err:
+            if e is not None:
+                raise e
+        for ts in states:
+            ts.close()
+        return out
+    one, two = run(1), run(2)
+    for a, b, c in zip(two[0][0], one[0][0], ro):
+        assert a["newm"] == b["newm"] == c["newm"]
+        assert a["cost"] == pytest.approx(b["cost"], rel=1e-9) and a["cost"] == pytest.approx(c["cost"], rel=1e-7)
+        assert a["truncerr"] == pytest.approx(c["truncerr"], rel=1e-3, abs=1e-12)
+    for A0, A1 in zip(two[0][1], two[1][1]):
+        assert np.array_equal(A0, A1)                              # replicas bit-identical
