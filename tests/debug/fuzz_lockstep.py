@@ -45,6 +45,9 @@ def one_case(rng, idx):
     # sizes reach 1e5 and more and its later passes are rounding noise in ANY implementation (the oracle run with 3 threads differs from
     # the oracle run with 1 thread by orders of magnitude in cost) -- nothing to compare there
     lam = float(rng.choice([1e-3, 1e-2, 1e-1]))
+    if os.environ.get("FUZZ_STRICT"):                                 # FUZZ_STRICT=1: the well-conditioned regime only, where fp64 must follow the oracle to 1e-7
+        dtype, boost, lam = "f64", float(rng.choice([30.0, 200.0])), float(rng.choice([1e-2, 1e-1]))
+        NT = max(NT, 33)
     tol = {"f64": 1e-7, "f64_e32": 2e-3, "f32": 5e-2}[dtype]
     desc = dict(case=idx, N=N, dims=dims, NT=NT, boost=boost, dtype=dtype, maxm=maxm, minm=minm, cutoff=cutoff, npass=npass, lam=lam)
     pixels, labels, phi, _ = make_problem(N, NT, 2, 5 + idx, pixel_boost=boost)
