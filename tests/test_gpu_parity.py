@@ -1352,6 +1352,40 @@ def test_memory_estimate_covers_what_a_sweep_allocates(N, NT, m, dtype):
     assert used > 0.25 * est, (used, est)
 
 
+def test_cg_on_ill_conditioned_bonds_is_at_least_as_close_to_extended_precision_as_the_oracle():
+    """Label-on-B bonds have CG step sizes of 10^2 and the late passes are conditioning-limited: two fp64 implementations agree on the
+    first three step sizes to 1e-9 and differ in the fourth by percents.  Which one is right?  The numpy restatement of the same CG run in
+    80-bit extended precision (np.longdouble) is the referee: the HIP path's third residual norm must be at least as close to it as the C
+    oracle's (it is 2-50x closer: blocked MFMA accumulation and fixed-order tree sums against sequential sums over 1e4-1e6 terms)."""
+    from oracle import np_restatement as npr
+    from oracle import pyoracle
+    from tnml_amd.fixedl import TrainStates
+    if np.finfo(np.longdouble).eps > 1e-18:
+        pytest.skip("np.longdouble is not an extended type here")
+    for (N, dims, NT, boost, lam, seed) in ((4, [1, 2, 2, 1, 1], 257, 200.0, 1e-2, 7), (6, [1, 2, 2, 4, 2, 1, 1], 100, 30.0, 1e-2, 13)):
+        pixels, labels, phi, _ = make_problem(N, NT, 2, seed, pixel_boost=boost)
+        W = _mps_with_dims(dims, 100 + seed)
+        for b in (1, 2):
+            o = pyoracle.Oracle(phi, labels, W); o.init()
+            ts = TrainStates(labels, N, max(dims), phi=phi); ts.set_mps(W); ts.init()
+            n = npr.NpFixedL(phi, labels, W)
+            n.phi = n.phi.astype(np.longdouble); n.W = [None] + [x.astype(np.longdouble) for x in n.W[1:]]; n.delta = n.delta.astype(np.longdouble)
+            n.init()
+            for bb in range(1, b):
+                o.shiftE(bb, True); ts.shiftE(bb, True); n.shiftE(bb, True)
+            o.set_bond(b); ts.setBond(b); n.set_bond(b)
+            B0 = o.bond_tensor(b)
+            _, to = o.cgrad(B0, 4, lam, 0.0)
+            _, tg = ts.cgrad(B0, 4, lam, 0.0)
+            _, tx = n.cgrad(n.bond_tensor(b), 4, np.longdouble(lam), 0.0)
+            np.testing.assert_allclose(tg["alpha"][:3], [float(x) for x in tx["alpha"][:3]], rtol=1e-8)
+            np.testing.assert_allclose(to["alpha"][:3], [float(x) for x in tx["alpha"][:3]], rtol=1e-8)
+            rx = float(tx["rnorm"][2])
+            err_hip, err_orc = abs(tg["rnorm"][2] - rx) / rx, abs(to["rnorm"][2] - rx) / rx
+            assert err_hip <= 1.5 * err_orc + 1e-12, (N, b, err_hip, err_orc)
+            ts.close()
+
+
 def _mps_with_dims(dims, seed):
     """random weight MPS with the given bond dimensions d_0 = 1, d_1, ..., d_N = 1 (Label index on site N/2), any shapes"""
     rng = np.random.default_rng(seed)
