@@ -1386,6 +1386,34 @@ def test_cg_on_ill_conditioned_bonds_is_at_least_as_close_to_extended_precision_
             ts.close()
 
 
+@pytest.mark.parametrize("b", [2, 6, 9])
+def test_forward_gradient_and_cost_against_an_extended_precision_evaluation(b):
+    """absolute accuracy, not just agreement of two fp64 codes: the numpy restatement evaluated in 80-bit extended precision is the
+    referee for B*t.v, the gradient and the cost of one bond (Label on the right environment, on B, on the left environment) -- the HIP
+    path and the C oracle must both sit within a few hundred fp64 ulps of it"""
+    from oracle import np_restatement as npr
+    if np.finfo(np.longdouble).eps > 1e-18:
+        pytest.skip("np.longdouble is not an extended type here")
+    ts, o = _pair(N=12, NT=200, m=8)
+    pixels, labels, phi, W = make_problem(12, 200, 8, 3, pixel_boost=200.0)
+    n = npr.NpFixedL(phi, labels, W)
+    n.phi = n.phi.astype(np.longdouble); n.W = [None] + [x.astype(np.longdouble) for x in n.W[1:]]; n.delta = n.delta.astype(np.longdouble)
+    n.init()
+    for bb in range(1, b):
+        ts.shiftE(bb, True); o.shiftE(bb, True); n.shiftE(bb, True)
+    ts.setBond(b); o.set_bond(b); n.set_bond(b)
+    B = o.bond_tensor(b) + 0.05 * np.random.default_rng(b).standard_normal(o.bond_tensor(b).shape)
+    Bx = B.astype(np.longdouble)
+    Px, Gx = n.forward(Bx), n.gradient(Bx)
+    Cx = float(n.quadcost(Bx, np.longdouble(1e-3))[0])
+    for name, impl in (("HIP", ts), ("oracle", o)):
+        P, G = impl.forward(B), impl.gradient(B)
+        assert float(np.abs(P - Px).max() / np.abs(Px).max()) < 2e-14, name
+        assert float(np.abs(G - Gx).max() / np.abs(Gx).max()) < 1e-13, name
+        assert impl.quadcost(B, 1e-3)[0] == pytest.approx(Cx, rel=1e-13), name
+    ts.close()
+
+
 def _mps_with_dims(dims, seed):
     """random weight MPS with the given bond dimensions d_0 = 1, d_1, ..., d_N = 1 (Label index on site N/2), any shapes"""
     rng = np.random.default_rng(seed)
