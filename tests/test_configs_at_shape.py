@@ -230,19 +230,28 @@ def test_c3_kernel_instantiations_of_the_benchmark_match_the_oracle():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("NT", [300, 1100])
-def test_fused_forward_kernel_matches_the_oracle(NT):
-    """k_fwd_fused (feature GEMM + label dot of the previous tile in one persistent workgroup; option "fused_fwd") forced at
-    an oracle-sized image count: 300 images = 8 tiles on 8 workgroups (one tile + the drain round each), 1100 images = 20 tiles
-    on 20 workgroups; with a grid cap of 4 workgroups (fused_fwd = 4) every workgroup runs several rounds.  Forward map,
-    gradient, cost / #correct, the CG (its pAp passes use the |P|^2 mode) and a bond update, for both bond kinds it serves."""
+@pytest.mark.parametrize("NT,kernel", [(300, "fwd_fused"), (1100, "fwd_fused"), (300, "fwd_res"), (1100, "fwd_res"), (2100, "fwd_res")])
+def test_fused_forward_kernel_matches_the_oracle(NT, kernel):
+    """The two one-launch forms of B*t.v that the BASELINE config 3 shape runs, forced at oracle-sized image counts.
+    k_fwd_fused (feature GEMM + label dot of the previous tile in one persistent workgroup; option "fused_fwd"): 300 images = 8
+    tiles on 8 workgroups (one tile + the drain round each), 1100 images = 20 tiles on 20 workgroups; with a grid cap of 4
+    workgroups (fused_fwd = 4) every workgroup runs several rounds.  k_fwd_res (the bond matrix resident in the registers of a
+    pair of workgroups, kernels_res.hip; option "fwd_res") + k_pfinish: 300 images = 16 tiles of 32 on 8 pairs (two rounds + fill
+    and drain), 1100 images = 40 tiles on 16 pairs (ragged: 3 rounds on half of the pairs, 2 on the others), 2100 images = 72 tiles
+    on 8 pairs (res_grid caps the grid: 9 rounds each).  Forward map, gradient, cost / #correct, the CG (its pAp passes use the |P|^2 mode) and a bond update, for
+    both bond kinds the kernels serve."""
     from oracle import pyoracle
     from tnml_amd.fixedl import TrainStates
     from conftest import make_problem
     N, m = 20, 120
     pixels, labels, phi, W = make_problem(N, NT, m, 7, pixel_boost=200.0)
     ts = TrainStates(labels, N, m, phi=phi)
-    ts.set_option("fused_fwd", 4 if NT > 1000 else 2)
+    if kernel == "fwd_fused":
+        ts.set_option("fwd_res", 0)
+        ts.set_option("fused_fwd", 4 if NT > 1000 else 2)
+    else:
+        ts.set_option("fwd_res", 2)
+        ts.set_option("res_grid", 32 if NT == 1100 else 16)
     ts.set_mps(W)
     ts.init()
     o = pyoracle.Oracle(phi, labels, W, nthread=min(8, os.cpu_count() or 1))
@@ -271,7 +280,7 @@ def test_fused_forward_kernel_matches_the_oracle(NT):
     ts.profile(True)
     r = ts.bond_update(12, 1, m, m // 2, 1e-10, 3, 1e-3, 1e-10)
     ts.profile(False)
-    assert ts.profile_read()["fwd_fused"][0] > 0                      # the fused kernel really ran
+    assert ts.profile_read()[kernel][0] > 0                           # the kernel under test really ran
     o.set_bond(12)
     B, _ = o.cgrad(o.bond_tensor(12), 3, 1e-3, 1e-10)
     newm, te, _ = o.svd_split(B, 12, 1, 1e-10, m, m // 2)

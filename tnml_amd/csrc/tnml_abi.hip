@@ -82,6 +82,9 @@ int tnml_set_option(tnml_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "defer_tail")) { if (c->pend_count) return tnml_fail(c, "defer_tail: a bond update is in flight"); c->defer_tail = value != 0; }
     else if (!strcmp(name, "check_replicas")) { c->check_replicas = value != 0; c->check_replicas_mode = value; }
     else if (!strcmp(name, "fused_fwd")) c->fused_fwd = value;
+    else if (!strcmp(name, "fwd_res")) c->fwd_res = value;
+    else if (!strcmp(name, "res_grid")) c->res_grid = value;
+    else if (!strcmp(name, "res_pace")) c->res_pace = value;
     else if (!strcmp(name, "sytrd_exit")) c->sytrd_exit = value;
     else if (!strcmp(name, "cg_method")) { if (value < 0 || value > 2 || (value >= 1 && !c->single())) return tnml_fail(c, "cg_method: 0 (conj) or, in TNML_MODE_SINGLE, 1 (fast_conj) / 2 (exact)"); c->cg_method = value; }
     else if (!strcmp(name, "debug_nudge_rank")) c->debug_nudge_rank = value;
@@ -222,6 +225,8 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     auto bail = [&](int r) { g_create_err = c->err; tnml_destroy(c); return r; };
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(tnml_fail(c, "hipStreamCreate failed"));
     if (const char* e = getenv("TNML_FUSED_FWD")) c->fused_fwd = atoi(e);
+    if (const char* e = getenv("TNML_FWD_RES")) c->fwd_res = atoi(e);
+    if (const char* e = getenv("TNML_RES_PACE")) c->res_pace = atoi(e);
     if (rocblas_create_handle(&c->blas) != rocblas_status_success) return bail(tnml_fail(c, "rocblas_create_handle failed"));
     rocblas_set_stream(c->blas, c->stream);
     // replicas of W must stay bit-identical over the ranks: no atomics-based split-K inside rocBLAS
@@ -255,6 +260,9 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     if ((rc = dmalloc(c, &c->Mf, c->mcap))) return bail(rc);
     if ((rc = dmalloc(c, (char**)&c->slab, c->slab_bytes))) return bail(rc);
     if ((rc = dmalloc(c, &c->partials, (size_t)c->partial_cap * 12))) return bail(rc);
+    if ((rc = dmalloc(c, &c->counters, 16))) return bail(rc);
+    if (hipMemsetAsync(c->counters, 0, 16 * sizeof(unsigned), c->stream) != hipSuccess) return bail(tnml_fail(c, "memset failed"));
+    if (cfg->dtype == TNML_F64 && cfg->mode == TNML_MODE_FIXEDL && c->maxm >= 120 && (rc = dmalloc(c, &c->Ppart, (size_t)2 * TNML_NL * NTp))) return bail(rc);   // k_fwd_res
     if ((rc = dmalloc(c, &c->vB, c->mcap))) return bail(rc);
     if ((rc = dmalloc(c, &c->vR, c->mcap))) return bail(rc);
     if ((rc = dmalloc(c, &c->vP, c->mcap))) return bail(rc);
@@ -319,7 +327,7 @@ int tnml_destroy(tnml_ctx* c) {
     for (auto& p : c->prof_pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     for (auto e : c->prof_free) (void)hipEventDestroy(e);
     void* ptrs[] = {c->phi, c->label, c->ones, c->U, c->P, c->dP, c->Pp, c->Zp, c->Mf, c->slab, c->partials, c->vB, c->vR, c->vP,
-                    c->arbuf, c->locals, c->scal, c->vpart, c->tB, c->tB2, c->sM, c->sG, c->sD, c->sE, c->sF, c->sInfo, c->sE2, c->sTau, c->sV, c->sC, c->sW, c->sScr, c->sS, c->sCm, c->sQ1, c->sDev, c->mc_xbuf, c->fprint, c->noise_ws};
+                    c->arbuf, c->locals, c->scal, c->vpart, c->counters, c->Ppart, c->tB, c->tB2, c->sM, c->sG, c->sD, c->sE, c->sF, c->sInfo, c->sE2, c->sTau, c->sV, c->sC, c->sW, c->sScr, c->sS, c->sCm, c->sQ1, c->sDev, c->mc_xbuf, c->fprint, c->noise_ws};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& s : c->W) if (s.a) (void)hipFree(s.a);
     for (auto& sl : c->slabs) if (sl.base) (void)hipFree(sl.base);
@@ -763,6 +771,16 @@ static int forward_pass(tnml_ctx* c, const double* vec, int mode, double* tail, 
         f.phiO = p.phiO;
         f.out = (double*)c->U; f.out_lstride = ustride; f.mO = p.mO;
         f.NTp = c->NTp; f.L = p.LB; f.env64 = c->env64();
+        // the bond matrix resident in the registers of a pair of workgroups (kernels_res.hip): from 30 720 images per rank on (the
+        // launch has a fill and a drain round of one 32-image tile per workgroup pair: 2 of 17 rounds at 60 000 images, 2 of 4 at 7 500)
+        if (c->fwd_res && c->Ppart && c->env64() && !c->single() && p.kind != 2 && p.Kp == 240 && p.Np == 240 && p.mI == 120 && p.mO == 120 &&
+            (c->fwd_res >= 2 || c->NTp >= 30720)) {
+            FwdResArgs fr{(const double*)p.EI, (const double*)p.phiI, vec, (const double*)p.phiO, (const double*)p.EX, ustride, c->NTp, c->NTp / 32, c->Ppart};
+            TCK(launch_fwd_res(c, fr));
+            PfinishArgs pf{2, c->Ppart, nullptr, nullptr, nullptr, nullptr, c->label, c->NTp, (double*)a.P, (double*)a.dP, mode, c->partials, c->counters, tail, mode == LD_MODE_PAP ? 1 : 0};
+            TCK(launch_pfinish(c, pf));
+            return launch_labeldot_reduce(c, c->NTp / 64, tail, mode == LD_MODE_PAP ? 1 : 0);
+        }
         // one persistent kernel for both halves of B*t.v where it pays (kernels_fused.hip)
         if (c->fused_fwd && c->env64() && !c->single() && p.kind != 2 && p.Kp == 240 && p.Np == 240 && p.mI == 120 && p.mO == 120 &&
             (c->fused_fwd >= 2 || c->NTp / 64 >= 224)) {

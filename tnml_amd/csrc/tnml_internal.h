@@ -31,11 +31,11 @@
 
 enum KClass {
     KC_FGEMM_FWD = 0, KC_FGEMM_SHIFT, KC_LABELDOT, KC_ZPRIME, KC_BGEMM, KC_SLABRED, KC_PACK, KC_VEC,
-    KC_SMALLGEMM, KC_SVD, KC_ALLREDUCE, KC_PUPDATE, KC_FWD_FUSED, KC_COUNT
+    KC_SMALLGEMM, KC_SVD, KC_ALLREDUCE, KC_PUPDATE, KC_FWD_FUSED, KC_FWD_RES, KC_COUNT
 };
 static const char* const kclass_names[KC_COUNT] = {
     "fgemm_fwd", "fgemm_shift", "labeldot", "zprime", "bgemm", "slab_reduce", "pack", "cg_vec",
-    "small_gemm", "svd", "allreduce", "p_update", "fwd_fused"};
+    "small_gemm", "svd", "allreduce", "p_update", "fwd_fused", "fwd_res"};
 
 struct EnvSlot {
     void* ptr = nullptr;    // [L][m][NTp], fp32 or fp64 elements (tnml_ctx::env64)
@@ -169,6 +169,12 @@ struct tnml_ctx {
     void* mc_xbuf = nullptr;   // exchange buffer of the multi-workgroup tridiagonalisation (eigh_mc.hip), contexts with maxm > 120 only
     unsigned mc_epoch = 0;
     int mc_spin_max = -1;      // polls before a waiting thread of k_sytrd_mc gives up (-1: default; option "mc_spin_max", 0 in the fallback test)
+    bool attr_res = false, attr_gres = false;        // kernels_res.hip
+    int res_pace = 0;                // pacing of the GEMM waves of k_fwd_res (0: default; option "res_pace")
+    int fwd_res = 1;                 // forward pass on k_fwd_res (kernels_res.hip): 1 = from 30 720 images per rank on, 0 never, 2 always; option "fwd_res"
+    int res_grid = 0;                // test knob: workgroups of the resident-operand kernels (0: one per CU)
+    unsigned* counters = nullptr;    // [16] device: arrival counters of the "last workgroup reduces" kernels (zero between launches)
+    double* Ppart = nullptr;         // [2][10][NTp]: per-half outputs of k_fwd_res
     bool attr_sytrd = false, attr_invit = false, attr_fused = false;   // per-device function attributes set (a process may drive several devices)
     int cu_count = 0;
     double svd_last_dev0 = 0., svd_last_dev1 = 0.;   // max|Q^T Q - I| before the 1st / 2nd polish step of the last split
@@ -297,6 +303,31 @@ struct FwdFusedArgs {
     double* partials;                                 // [ntiles][12]
 };
 int launch_fwd_fused(tnml_ctx* c, const FwdFusedArgs& a);
+
+// ---- kernels_res.hip: the small operand resident in registers (m = 120, fp64 storage, Label on an environment) ----
+struct FwdResArgs {
+    const double* EI; const double* phiI;             // Label-free input environment [120][NTp], its site features [2][NTp]
+    const double* M;                                  // bond matrix, M-layout [240][240]
+    const double* phiO;                               // output-site features [2][NTp]
+    const double* EL; size_t EL_lstride;              // Label-carrying environment [10][120][NTp]
+    int NTp, ntiles;                                  // ntiles = NTp / 32
+    double* Ppart;                                    // out: [2][10][NTp], the label dot over the output links of each half
+    long long* dbg = nullptr;                         // probe builds: per-wave cycle counters of workgroup 0
+};
+int launch_fwd_res(tnml_ctx* c, const FwdResArgs& a);
+struct PfinishArgs {
+    int npart;                                        // 2: P = Ppart[0] + Ppart[1]; 0: P = P + alpha Pp (fast CG update)
+    const double* Ppart;                              // [2][10][NTp]
+    const double* P; const double* Pp; const double* alpha;
+    const double* conv;                               // device flag (may be null): non-zero -> the launch does nothing
+    const int* label; int NTp;
+    double* Pout; double* dP;                         // [10][NTp], either may be null
+    int mode;                                         // LD_MODE_COST / LD_MODE_PAP
+    double* partials;                                 // [NTp / 64][12]
+    unsigned* counter;                                // zero before and after the launch
+    double* out; int only_sum;                        // [12] sums over all images (only_sum: slot 11 alone)
+};
+int launch_pfinish(tnml_ctx* c, const PfinishArgs& a);
 
 // ---- kernels_small.hip --------------------------------------------------------------------
 struct PackDesc {       // M[l][2x+s][TO==2 ? 2y+t : y] <-> T[off + x*sx + s*ss + y*sy + t*st + l*sl]
