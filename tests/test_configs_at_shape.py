@@ -251,6 +251,7 @@ def test_fused_forward_kernel_matches_the_oracle(NT, kernel):
         ts.set_option("fused_fwd", 4 if NT > 1000 else 2)
     else:
         ts.set_option("fwd_res", 2)
+        ts.set_option("grad_res", 2)                       # k_grad_res (accumulators resident; off by default) takes the gradient GEMMs of this run
         ts.set_option("res_grid", 32 if NT == 1100 else 16)
     ts.set_mps(W)
     ts.init()

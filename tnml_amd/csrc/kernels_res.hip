@@ -260,6 +260,224 @@ __global__ __launch_bounds__(768) void k_fwd_res(FwdResArgs A) {
     }
 }
 
+// ==========================================================================================================================
+// k_grad_res -- dP*dag(t.v) (fixedL.cc:379,418) with the OUTPUT resident: G[2a+s][2q+t] = sum_n E_n[a] phiI_n[s] phiO_n[t] Z_n[q],
+// Z_n[q] = sum_l EL_n[l][q] w_n[l].  A pair of workgroups owns all 240 x 240 accumulators (half = output links q of 64 half ..):
+// GEMM wave w keeps the 128 x 32 block (a padded to 128) x (q tiles 2 (w & 1), +1) of the site-index combination (s, t) = w >> 1
+// in 128 VGPRs for the whole launch and the pair walks its 32-image tiles; the k_bgemm64 this replaces re-reads the Label-free
+// environment once per 64-column tile (4x) and alternates staging and MFMA phases between barriers.  Operands: E rows raw (LDS-DMA,
+// one 256-byte row per piece into 272-byte padded rows -- the MFMA operand reads run ACROSS rows, so unpadded rows would be
+// 16-way bank conflicts), Z rows built by the streaming waves (ring of asm loads as in k_fwd_res), the two site features
+// multiplied into the Z fragment by the GEMM wave itself (2 VALU per 32 MFMAs, in its own instruction stream).
+// Round j: streaming waves build Z(j) and stage E(j), phi(j), w(j+1); GEMM waves accumulate tile j-1.  One barrier per round.
+// ==========================================================================================================================
+#define GR_ES 34                                   // padded row length (doubles) of the E and Z tiles
+#define GR_EROWS 128
+#define GR_LDS_DOUBLES (2 * GR_EROWS * GR_ES + 2 * 64 * GR_ES + 2 * 4 * FR_TI + 2 * 12 * FR_TI)
+
+template <int PS, int PK, int ABL>
+__global__ __launch_bounds__(768) void k_grad_res(GradResArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double gr_lds[];
+    double* Es = gr_lds;                               // [2][128][34]
+    double* Zs = Es + 2 * GR_EROWS * GR_ES;            // [2][64][34]
+    double* Ps = Zs + 2 * 64 * GR_ES;                  // [2][4][32]: phiI[0..1], phiO[0..1]
+    double* Ws = Ps + 2 * 4 * FR_TI;                   // [2][12][32]: the per-image weights (10 rows used)
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x;
+    const int half = (b >> 3) & 1, pair = (b & 7) + 8 * (b >> 4), npairs = gridDim.x >> 1;
+    const int NTp = A.NTp;
+    const int nq = half ? 56 : 64;
+    const int niter = (A.ntiles - pair + npairs - 1) / npairs;      // >= 1
+    for (int i = tid; i < GR_LDS_DOUBLES; i += 768) gr_lds[i] = 0.;      // padding rows (E rows 120.., Z rows nq..) stay zero
+    __syncthreads();
+
+    if (wid < 8) {
+        // ---------------- GEMM role ----------------
+        const int w = wid, st = w >> 1, qt0 = 2 * (w & 1);
+        f64x4r acc[8][2];
+#pragma unroll
+        for (int rt = 0; rt < 8; ++rt) { acc[rt][0] = f64x4r{0., 0., 0., 0.}; acc[rt][1] = f64x4r{0., 0., 0., 0.}; }
+        fr_barrier();                                  // prologue
+        for (int it = 0; it <= niter; ++it) {
+            if (it >= 1 && ABL != 2) {
+                const int buf = (it - 1) & 1;
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+                const int g = ln >> 4, i = ln & 15;
+                const double* Eb = Es + buf * GR_EROWS * GR_ES + i * GR_ES + 2 * g;          // + rt * 16 rows + 8 kp
+                const double* Zb = Zs + buf * 64 * GR_ES + (16 * qt0 + i) * GR_ES + 2 * g;   // q tile qt0; qt0 + 1 is 16 rows on
+                const double* Pb = Ps + buf * 4 * FR_TI + 2 * g;
+#pragma unroll
+                for (int kp = 0; kp < 4; ++kp) {
+                    // lane group g owns images 8 kp + 2 g, + 1 of both operands (a permutation of the reduction index)
+                    const double2 fi = *reinterpret_cast<const double2*>(Pb + (st >> 1) * FR_TI + 8 * kp);
+                    const double2 fo = *reinterpret_cast<const double2*>(Pb + (2 + (st & 1)) * FR_TI + 8 * kp);
+                    double2 z0 = *reinterpret_cast<const double2*>(Zb + 8 * kp);
+                    double2 z1 = *reinterpret_cast<const double2*>(Zb + 16 * GR_ES + 8 * kp);
+                    double2 a0 = *reinterpret_cast<const double2*>(Eb + 8 * kp);
+                    double2 a1 = *reinterpret_cast<const double2*>(Eb + 16 * GR_ES + 8 * kp);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+                    const double fx = fi.x * fo.x, fy = fi.y * fo.y;
+                    z0.x *= fx; z0.y *= fy; z1.x *= fx; z1.y *= fy;
+#pragma unroll
+                    for (int rt = 0; rt < 8; ++rt) {
+                        const double2 ac = a0;
+                        a0 = a1;
+                        if (rt + 2 < 8) { a1 = *reinterpret_cast<const double2*>(Eb + (rt + 2) * 16 * GR_ES + 8 * kp); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+                        acc[rt][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac.x, z0.x, acc[rt][0], 0, 0, 0);
+                        acc[rt][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac.x, z1.x, acc[rt][1], 0, 0, 0);
+                        acc[rt][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac.y, z0.y, acc[rt][0], 0, 0, 0);
+                        acc[rt][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac.y, z1.y, acc[rt][1], 0, 0, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                        if (PS > 0 && rt % PK == PK - 1) { __builtin_amdgcn_s_sleep(PS); __builtin_amdgcn_sched_barrier(0); }
+                    }
+                }
+            }
+            fr_barrier();
+        }
+        // lane (g, i) holds rows a = 16 rt + g + 4 e, output link q = 64 half + 16 (qt0 + c) + i: G[2 a + s][2 q + t]
+        const int g = lane >> 4, i = lane & 15;
+        double* slab = A.slab + (size_t)pair * 240 * 240;
+#pragma unroll
+        for (int rt = 0; rt < 8; ++rt)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int a = 16 * rt + g + 4 * e, ql = 16 * (qt0 + c) + i;
+                    if (a < 120 && ql < nq) slab[(size_t)(2 * a + (st >> 1)) * 240 + 2 * (64 * half + ql) + (st & 1)] = acc[rt][c][e];
+                }
+    } else {
+        // ---------------- streaming role ----------------
+        __builtin_amdgcn_s_setprio(3);
+        const int sw = wid - 8;
+        const int img = lane & 31, qs = lane >> 5;
+        const int nk = nq >> 3;
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)gr_lds));
+        // LDS-DMA pieces of a round (31 per wave, the same number on every wave: the counted waits below rely on it):
+        //   30 rows of the Label-free environment, one 256-byte row per piece (4 bytes per lane) into its padded row;
+        //   wave 8, 9, 10: 4 rows each of the NEXT tile's weights (16 bytes per lane); wave 11: the four feature rows
+        // (uniform 64-bit base in SGPRs + a 32-bit lane offset: no VALU instruction per piece)
+        const unsigned l4 = (unsigned)lane * 4u;
+        const unsigned c16 = (unsigned)(((size_t)(lane >> 4) * NTp + 2 * (lane & 15)) * sizeof(double));       // row lane >> 4 of a 4-row piece
+        const int wrow = 4 * sw + (lane >> 4);                                    // weights: rows 10, 11 (wave 10) read rows 8, 9 again
+        const unsigned w16 = (unsigned)(((size_t)(wrow < TNML_NL ? wrow : wrow - 2) * NTp + 2 * (lane & 15)) * sizeof(double));
+        const double* const ph0 = A.phiI < A.phiO ? A.phiI : A.phiO;
+        const unsigned poff = (unsigned)((((lane >> 4) < 2 ? A.phiI : A.phiO) - ph0 + (size_t)((lane >> 4) & 1) * NTp + 2 * (lane & 15)) * sizeof(double));
+        (void)c16;
+        auto dma4 = [&](const double* base, unsigned voff, unsigned dst) {
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff), "s"(dst), "s"(base) : "memory");
+        };
+        auto dma16 = [&](const double* base, unsigned voff, unsigned dst) {
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff), "s"(dst), "s"(base) : "memory");
+        };
+        const unsigned wsb = lds0 + (unsigned)((2 * GR_EROWS * GR_ES + 2 * 64 * GR_ES + 2 * 4 * FR_TI) * sizeof(double));     // Ws
+        const unsigned psb = lds0 + (unsigned)((2 * GR_EROWS * GR_ES + 2 * 64 * GR_ES) * sizeof(double));                     // Ps
+        // E(tile) -> Es[buf], phi(tile) -> Ps[buf] (wave 11), w(wtile) -> Ws[wbuf] (waves 8..10)
+        auto stage = [&](int tile, int buf, int wtile, int wbuf) {
+            const double* src = A.EI + (size_t)sw * NTp + (size_t)tile * FR_TI;                 // row sw, then every 4th
+            unsigned dst = lds0 + (unsigned)((buf * GR_EROWS * GR_ES + sw * GR_ES) * sizeof(double));
+#pragma unroll 1
+            for (int r = 0; r < 30; ++r) { dma4(src, l4, __builtin_amdgcn_readfirstlane(dst)); src += (size_t)4 * NTp; dst += 4 * GR_ES * sizeof(double); }
+            if (sw < 3) dma16(A.w + (size_t)wtile * FR_TI, w16, wsb + (unsigned)((wbuf * 12 * FR_TI + 4 * sw * FR_TI) * sizeof(double)));
+            else        dma16(ph0 + (size_t)tile * FR_TI, poff, psb + (unsigned)(buf * 4 * FR_TI * sizeof(double)));
+        };
+        const double* ELw = A.EL + (size_t)(64 * half + 2 * sw) * NTp;
+        const unsigned eoff = (unsigned)(((size_t)qs * NTp + img) * sizeof(double));
+        const unsigned zoff = (unsigned)((2 * sw + qs) * GR_ES + img);                // lane part of a Z write (doubles)
+        const size_t k7 = nk > 7 ? (size_t)56 * NTp : 0;
+        double ea[TNML_NL], eb[TNML_NL], ec[TNML_NL], ed[TNML_NL];
+        auto s_load = [&](int tile, size_t rowoff, double (&e)[TNML_NL]) {
+#pragma unroll
+            for (int l = 0; l < TNML_NL; ++l) {
+                const double* bp = ELw + (size_t)tile * FR_TI + (size_t)l * A.EL_lstride + rowoff;
+                if (ABL == 1) e[l] = 1.0;
+                else asm volatile("global_load_dwordx2 %0, %1, %2 nt" : "=v"(e[l]) : "v"(eoff), "s"(bp) : "memory");
+            }
+        };
+#define GR_WAIT(N, e) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6]), "+v"(e[7]), "+v"(e[8]), "+v"(e[9]) :: "memory")
+        // Z of a tile (its rows 0..3 are in the ring) -> Zb; requests rows 0..3 of tile `ntile`; mid(): the round's 31 DMA pieces
+        auto z_build = [&](int tile, int ntile, const double* Wb, double* Zb, auto&& mid) {
+            double wv[TNML_NL];
+#pragma unroll
+            for (int l = 0; l < TNML_NL; ++l) wv[l] = Wb[l * FR_TI + img];
+            auto s_use = [&](int k, const double (&e)[TNML_NL], bool on) {
+                double z = e[0] * wv[0];
+#pragma unroll
+                for (int l = 1; l < TNML_NL; ++l) z = fma(e[l], wv[l], z);
+                if (on) Zb[8 * k * GR_ES + zoff] = z;
+                asm volatile("" : "+v"(z) :: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            GR_WAIT(30, ea); s_use(0, ea, true); s_load(tile, (size_t)32 * NTp, ea);
+            GR_WAIT(30, eb); s_use(1, eb, true); s_load(tile, (size_t)40 * NTp, eb);
+            GR_WAIT(30, ec); s_use(2, ec, true); s_load(tile, (size_t)48 * NTp, ec);
+            GR_WAIT(30, ed); s_use(3, ed, true); s_load(tile, k7, ed);
+            mid();
+            // behind row 4: rows 5..7 (30) + 31 pieces
+            GR_WAIT(61, ea); s_use(4, ea, true); s_load(ntile, 0, ea);
+            GR_WAIT(61, eb); s_use(5, eb, true); s_load(ntile, (size_t)8 * NTp, eb);
+            GR_WAIT(61, ec); s_use(6, ec, true); s_load(ntile, (size_t)16 * NTp, ec);
+            GR_WAIT(61, ed); s_use(7, ed, nk > 7); s_load(ntile, (size_t)24 * NTp, ed);
+        };
+        // prologue: the first tile's weights; open the ring
+        if (sw < 3) dma16(A.w + (size_t)pair * FR_TI, w16, wsb + (unsigned)(4 * sw * FR_TI * sizeof(double)));
+        s_load(pair, 0, ea); s_load(pair, (size_t)8 * NTp, eb); s_load(pair, (size_t)16 * NTp, ec); s_load(pair, (size_t)24 * NTp, ed);
+        asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+        fr_barrier();
+        for (int it = 0; it < niter; ++it) {
+            const int tile = pair + it * npairs;
+            const int ntile = it + 1 < niter ? tile + npairs : tile;
+            z_build(tile, ntile, Ws + (it & 1) * 12 * FR_TI, Zs + (it & 1) * 64 * GR_ES, [&]() { stage(tile, it & 1, ntile, (it + 1) & 1); });
+            asm volatile("s_waitcnt vmcnt(40)" ::: "memory");    // all but the 40 row loads just requested: this round's pieces have landed
+            fr_barrier();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        fr_barrier();                                            // the GEMM waves' last round
+#undef GR_WAIT
+    }
+}
+
+template <int PS, int PK>
+static int grad_res_go(tnml_ctx* c, const GradResArgs& a, int grid) {
+    const size_t lds = sizeof(double) * GR_LDS_DOUBLES;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_grad_res<PS, PK, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return tnml_fail(c, "grad_res: cannot reserve %zu bytes of LDS", lds);
+    ProfScope ps(c, KC_BGEMM);
+    hipLaunchKernelGGL((k_grad_res<PS, PK, 0>), dim3(grid), dim3(768), lds, c->stream, a);
+    return 0;
+}
+// G (M-layout [240][240]) = sum over the images; split-K slabs of the workgroup pairs reduced in a fixed order
+int launch_grad_res(tnml_ctx* c, const GradResArgs& a_in, double* G) {
+    GradResArgs a = a_in;
+    if (a.NTp % 256) return tnml_fail(c, "grad_res: image count not a multiple of 256");
+    if ((size_t)TNML_NL * a.EL_lstride * sizeof(double) >= ((size_t)1 << 32)) return tnml_fail(c, "grad_res: environment larger than 4 GB (32-bit lane offsets)");
+    if (!c->cu_count) { hipDeviceProp_t pr; c->cu_count = hipGetDeviceProperties(&pr, c->cfg.device) == hipSuccess ? pr.multiProcessorCount : 256; }
+    int grid = c->cu_count / 16 * 16;
+    if (c->res_grid > 0 && c->res_grid < grid) grid = c->res_grid / 16 * 16;
+    if (grid < 16) grid = 16;
+    while (grid > 16 && (grid / 2) > a.ntiles) grid -= 16;
+    const size_t n = (size_t)240 * 240;
+    while (grid > 16 && (size_t)(grid / 2) * n * sizeof(double) > c->slab_bytes) grid -= 16;
+    if ((size_t)(grid / 2) * n * sizeof(double) > c->slab_bytes) return tnml_fail(c, "grad_res: slab workspace too small");
+    a.slab = (double*)c->slab;
+    switch (c->res_pace) {
+        case 1:  TCK((grad_res_go<0, 1>(c, a, grid))); break;
+        case 2:  TCK((grad_res_go<4, 2>(c, a, grid))); break;
+        case 3:  TCK((grad_res_go<6, 3>(c, a, grid))); break;
+        case 4:  TCK((grad_res_go<4, 1>(c, a, grid))); break;
+        default: TCK((grad_res_go<6, 2>(c, a, grid))); break;
+    }
+    {
+        ProfScope ps(c, KC_SLABRED);
+        launch_slab_reduce64(c, (const double*)c->slab, G, n, grid / 2);
+    }
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
+
 // wave-level cost buckets of 64 images -> out[12] (the epilogue of k_labeldot / k_fwd_fused)
 static __device__ __forceinline__ void res_wave_partials(double val, int lab, int cor, bool pap, double* out, int lane) {
     if (pap) {

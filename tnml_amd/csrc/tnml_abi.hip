@@ -83,6 +83,7 @@ int tnml_set_option(tnml_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "check_replicas")) { c->check_replicas = value != 0; c->check_replicas_mode = value; }
     else if (!strcmp(name, "fused_fwd")) c->fused_fwd = value;
     else if (!strcmp(name, "fwd_res")) c->fwd_res = value;
+    else if (!strcmp(name, "grad_res")) c->grad_res = value;
     else if (!strcmp(name, "res_grid")) c->res_grid = value;
     else if (!strcmp(name, "res_pace")) c->res_pace = value;
     else if (!strcmp(name, "sytrd_exit")) c->sytrd_exit = value;
@@ -226,6 +227,7 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(tnml_fail(c, "hipStreamCreate failed"));
     if (const char* e = getenv("TNML_FUSED_FWD")) c->fused_fwd = atoi(e);
     if (const char* e = getenv("TNML_FWD_RES")) c->fwd_res = atoi(e);
+    if (const char* e = getenv("TNML_GRAD_RES")) c->grad_res = atoi(e);
     if (const char* e = getenv("TNML_RES_PACE")) c->res_pace = atoi(e);
     if (rocblas_create_handle(&c->blas) != rocblas_status_success) return bail(tnml_fail(c, "rocblas_create_handle failed"));
     rocblas_set_stream(c->blas, c->stream);
@@ -817,7 +819,10 @@ static int grad_eval(tnml_ctx* c, bool from_P_update = false, bool outputs_curre
     const void* wsrc = weights_pp ? c->Pp : c->dP;           // the per-image weights of the sum
     const bool fuse = c->f64() && c->fuse_z && p.kind != 2;
     if (p.kind != 2 && !fuse) TCK(launch_zprime(c, p.EX, (size_t)p.mO * c->NTp, wsrc, c->Zp, p.mO, c->NTp));
-    if (c->f64()) {
+    if (fuse && c->grad_res >= 2 && c->env64() && !c->single() && p.Kp == 240 && p.Np == 240 && p.mI == 120 && p.mO == 120) {
+        GradResArgs gr{(const double*)p.EI, (const double*)p.phiI, (const double*)p.phiO, (const double*)p.EX, (size_t)p.mO * c->NTp, (const double*)wsrc, c->NTp, c->NTp / 32};
+        TCK(launch_grad_res(c, gr, c->vG));
+    } else if (c->f64()) {
         Bgemm64Args g;
         g.EL = nullptr; g.EL_lstride = 0; g.dPz = nullptr; g.env64 = c->env64();
         g.EI = p.EI; g.mI = p.mI; g.phiI = p.phiI; g.phiO = p.phiO; g.mO = p.mO;

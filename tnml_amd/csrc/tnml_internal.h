@@ -172,6 +172,7 @@ struct tnml_ctx {
     bool attr_res = false, attr_gres = false;        // kernels_res.hip
     int res_pace = 0;                // pacing of the GEMM waves of k_fwd_res (0: default; option "res_pace")
     int fwd_res = 1;                 // forward pass on k_fwd_res (kernels_res.hip): 1 = from 30 720 images per rank on, 0 never, 2 always; option "fwd_res"
+    int grad_res = 0;                // gradient GEMM on k_grad_res (kernels_res.hip): 0 never (default: no faster than k_bgemm64 yet), 2 always; option "grad_res"
     int res_grid = 0;                // test knob: workgroups of the resident-operand kernels (0: one per CU)
     unsigned* counters = nullptr;    // [16] device: arrival counters of the "last workgroup reduces" kernels (zero between launches)
     double* Ppart = nullptr;         // [2][10][NTp]: per-half outputs of k_fwd_res
@@ -328,6 +329,15 @@ struct PfinishArgs {
     double* out; int only_sum;                        // [12] sums over all images (only_sum: slot 11 alone)
 };
 int launch_pfinish(tnml_ctx* c, const PfinishArgs& a);
+struct GradResArgs {
+    const double* EI; const double* phiI;             // Label-free environment [120][NTp], its site features [2][NTp]
+    const double* phiO;                               // output-site features [2][NTp]
+    const double* EL; size_t EL_lstride;              // Label-carrying environment [10][120][NTp]
+    const double* w;                                  // per-image weights [10][NTp] (dP, or p.v of the pAp pass)
+    int NTp, ntiles;                                  // ntiles = NTp / 32
+    double* slab = nullptr;                           // split-K slabs [pairs][240][240] (set by the launcher)
+};
+int launch_grad_res(tnml_ctx* c, const GradResArgs& a, double* G);
 
 // ---- kernels_small.hip --------------------------------------------------------------------
 struct PackDesc {       // M[l][2x+s][TO==2 ? 2y+t : y] <-> T[off + x*sx + s*ss + y*sy + t*st + l*sl]

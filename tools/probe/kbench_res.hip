@@ -109,5 +109,31 @@ int main(int argc, char** argv) {
         printf("         k_fwd_fused + reduce %.1f us | k_fwd_res + k_pfinish %.1f us (kernel alone %.1f us = %.1f TF = %.1f %% of 78.6, %.2f TB/s)\n",
                t_old * 1e3, t_new * 1e3, t_k * 1e3, gf / t_k, 100. * gf / t_k / 78.6, mb / t_k / 1e3);
     }
+    {   // ---- gradient: k_bgemm64 (tiled, fused Z build) against k_grad_res, weights = the residuals dP of the cost run above
+        Bgemm64Args g;
+        g.EI = EI; g.mI = m; g.phiI = phiI; g.Zq64 = nullptr; g.Zq32 = nullptr; g.mO = m; g.phiO = phiO; g.EL = EL; g.EL_lstride = (size_t)m * NTp; g.dPz = dP1;
+        g.w = nullptr; g.w_lstride = 0; g.Kp = Kp; g.Np = Np; g.NTp = NTp; g.L = 1; g.env64 = 1;
+        GradResArgs gr{EI, phiI, phiO, EL, (size_t)m * NTp, dP1, NTp, NTp / 32};
+        launch_bgemm64(c, g, G0); CK(hipStreamSynchronize(c->stream));
+        launch_grad_res(c, gr, G1); CK(hipStreamSynchronize(c->stream)); CK(hipGetLastError());
+        std::vector<double> a((size_t)Kp * Np), b2((size_t)Kp * Np);
+        CK(hipMemcpy(a.data(), G1, a.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(b2.data(), G0, b2.size() * 8, hipMemcpyDeviceToHost));
+        printf("gradient: G max rel diff %.3e (|G|max %.4f)\n", maxrel(a, b2, a.size()), [&]() { double mx = 0; for (double x : b2) mx = fmax(mx, fabs(x)); return mx; }());
+        launch_grad_res(c, gr, G1); CK(hipStreamSynchronize(c->stream));
+        std::vector<double> a2((size_t)Kp * Np); CK(hipMemcpy(a2.data(), G1, a2.size() * 8, hipMemcpyDeviceToHost));
+        size_t nd = 0; for (size_t i = 0; i < a2.size(); ++i) nd += a2[i] != a[i];
+        printf("         repeat run: %zu differing entries\n", nd);
+        const float t_old = time_it([&]() { launch_bgemm64(c, g, G0); });
+        const float t_new = time_it([&]() { launch_grad_res(c, gr, G1); });
+        const double gf = 2.0 * NTp * Kp * Np / 1e9;
+        printf("         k_bgemm64 + slab reduce %.1f us | k_grad_res + slab reduce %.1f us (%.1f TF on the algorithmic flops)\n", t_old * 1e3, t_new * 1e3, gf / t_new);
+        const size_t lds = sizeof(double) * GR_LDS_DOUBLES;
+        gr.slab = (double*)c->slab;
+#define TRYG(PS, PK, ABL, what) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_grad_res<PS, PK, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            const float t_ = time_it([&]() { hipLaunchKernelGGL((k_grad_res<PS, PK, ABL>), dim3(256), dim3(768), lds, c->stream, gr); }); printf("         %-64s %.1f us\n", what, t_ * 1e3); }
+        TRYG(0, 1, 0, "kernel alone, GEMM waves never pause:") TRYG(6, 2, 0, "pause 384 cycles every 8 MFMAs (default):") TRYG(4, 2, 0, "256 cycles every 8 MFMAs:") TRYG(6, 3, 0, "384 cycles every 12 MFMAs:")
+        TRYG(4, 1, 0, "256 cycles every 4 MFMAs:") TRYG(8, 2, 0, "512 cycles every 8 MFMAs:") TRYG(8, 4, 0, "512 cycles every 16 MFMAs:")
+        TRYG(0, 1, 1, "GEMM role alone (no environment loads):") TRYG(0, 1, 2, "streaming role alone (no MFMAs):")
+    }
     return 0;
 }
