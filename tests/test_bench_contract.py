@@ -35,7 +35,8 @@ def test_bench_json_line_whole_sweep():
     assert r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert r["traffic"] is None                                       # the PMC record belongs to the full workload only
     rs = d["roofline_step"]
-    assert rs["executed"] > 0 and rs["algorithmic"] >= rs["executed"] and abs(rs["frac_executed"] - rs["executed"] / rs["peak"]) < 1e-12
+    assert rs["achieved"] > 0 and abs(rs["frac"] - rs["achieved"] / rs["peak"]) < 1e-12 and rs["frac"] == rs["frac_executed"]      # the step figure is the EXECUTED one
+    assert rs["algorithmic_gflop_per_step"] >= rs["executed_gflop_per_step"] > 0
     assert d["value_literal_order"] > 0 and d["value_literal_order"] < 1.2 * d["value"]
     assert d["gradient_phase_ms"] > 0 and d["parity"].startswith("unpinned-oracle")
     h = d["roofline_hbm"]

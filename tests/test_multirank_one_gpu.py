@@ -238,6 +238,29 @@ def test_split_on_the_workgroup_cluster_keeps_the_replicas_identical():
     np.testing.assert_allclose(two[0]["cost"], one["cost"], rtol=1e-7)
 
 
+def test_a_cluster_that_gives_up_on_one_rank_sends_every_rank_to_the_fallback():
+    """svd.hip: when the workgroup cluster of ONE rank gives up (mc_spin_max = 0 on rank 1 only), the redo with rocsolver_dsyevd contains
+    a broadcast -- every rank has to take it, on the summed status words, or the collective sequences of the ranks part ways (round-3
+    advisor finding).  Both ranks must report the same fallbacks, bit-identical tensors and the one-rank costs."""
+    from tnml_amd.fixedl import mldmrg
+    N, NT, m = 20, 48, 150
+    pixels, labels, phi, W = make_problem(N, NT, m, 9, pixel_boost=200.0)
+    args = (1, m, m // 2, 1e-10, 2, 1e-3, 1e-10)
+
+    def body(ts, r, spin=True):
+        if spin and r == 1:
+            ts.set_option("mc_spin_max", 0)
+        ts.init()
+        reps = mldmrg(ts, *args, max_bonds=11, pipelined=True)
+        ts.replica_check()
+        return dict(cost=[x["cost"] for x in reps], newm=[x["newm"] for x in reps], fb=ts.svd_stats()["fallbacks"])
+    two = _run_ranks(2, labels, phi, W, N, m, body)
+    one = _run_ranks(1, labels, phi, W, N, m, lambda ts, r: body(ts, r, False))[0]
+    assert two[0]["fb"] == two[1]["fb"] > 0 and one["fb"] == 0
+    assert two[0]["cost"] == two[1]["cost"] and two[0]["newm"] == two[1]["newm"] == one["newm"]
+    np.testing.assert_allclose(two[0]["cost"], one["cost"], rtol=1e-7)
+
+
 @pytest.mark.parametrize("noise", [0.0, 1e-5])
 def test_per_label_variant_on_two_ranks_with_and_without_noise(noise):
     """TNML_MODE_SINGLE with the images sharded over two ranks: the sums of the CG and -- with noise > 0 -- the images' term of the

@@ -144,6 +144,24 @@ static __device__ __forceinline__ void sum_partials(const double* part, int nb, 
     *s1 = block_sum(b, sh);
 }
 
+// column `col` of the per-image-block partial sums partials[nblk][12] of a forward pass / output update, by the whole workgroup:
+// lane k takes rows k, k + VB, ... in order, then the fixed block_sum tree -> the same value in every workgroup.  Lets the CG step
+// kernels consume the partial sums themselves instead of waiting for a k_reduce_partials launch of their own.
+static __device__ __forceinline__ double sum_column(const double* __restrict__ partials, int nblk, int col, double* sh) {
+    // the summation order of k_reduce_partials (lane i takes rows i, i + 64, ... in order, then its shuffle tree), so that a
+    // folded reduction gives the bits the separate launch gave: wave 0 sums, the workgroup reads the result
+    __syncthreads();                                        // readers of a previous call are done with sh
+    if (threadIdx.x < 64) {
+        double a = 0.;
+        for (int r = threadIdx.x; r < nblk; r += 64) a += partials[(size_t)r * 12 + col];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
+        if (threadIdx.x == 0) sh[0] = a;
+    }
+    __syncthreads();
+    return sh[0];
+}
+
 // r = G - lambda*B (fixedL.cc:385-386); p = r (:388); partial |r|^2
 __global__ __launch_bounds__(VB) void k_cg_init1(const double* __restrict__ G, const double* __restrict__ B, double* __restrict__ R,
                                                 double* __restrict__ Pv, size_t n, double lambda, double* __restrict__ part) {
@@ -182,7 +200,8 @@ __global__ __launch_bounds__(VB) void k_norm1(const double* __restrict__ x, cons
 // pAp = sum_n|p v_n|^2 + lambda|p|^2 (:402-403); a = |r|^2/pAp (:405); B = B + a p (:406)
 __global__ __launch_bounds__(VB) void k_cg_step2(double* __restrict__ B, const double* __restrict__ Pv, size_t n, double lambda,
                                                 const double* __restrict__ tail, const double* __restrict__ part, int nb,
-                                                double* __restrict__ scal, int rr_in, double* __restrict__ trace, int pass, int merged) {
+                                                double* __restrict__ scal, int rr_in, double* __restrict__ trace, int pass, int merged,
+                                                const double* __restrict__ pp_part, int npp) {
     // merged CG: the cost partials of the PREVIOUS pass's update (fixedL.cc:419,427-428) came with this pass's all-reduce
     if (merged && pass > 1 && blockIdx.x == 0 && threadIdx.x == 0 && scal[SC_CONVP + (pass & 1)] == 0.) {   // (slot of pass - 2: not converged before the previous pass)
         double cs = 0.;
@@ -191,11 +210,13 @@ __global__ __launch_bounds__(VB) void k_cg_step2(double* __restrict__ B, const d
         scal[SC_COST] = cst; trace[4 * (pass - 2) + 2] = cst;
     }
     if (scal[SC_CONVP + ((pass - 1) & 1)] != 0.) return;   // |r| < cconv was hit in an earlier pass (fixedL.cc:432-436)
-    __shared__ double sh[VB / 64];
+    __shared__ double sh[VB];
     // |p|^2: p = r in pass 1 (fixedL.cc:388), afterwards the partial sums left by k_cg_resid2 when it formed p = r + beta p
     double pn2, unused;
     if (pass == 1) pn2 = scal[rr_in]; else sum_partials(part, nb, &pn2, &unused, sh);
-    const double pAp = tail[SC_PP] + lambda * pn2;
+    // sum_n |p.v_n|^2: reduced already (tail), or still as the per-block partial sums of the pAp pass (column 11)
+    const double pp = pp_part ? sum_column(pp_part, npp, 11, sh) : tail[SC_PP];
+    const double pAp = pp + lambda * pn2;
     const double a = scal[rr_in] / pAp;
     size_t lo, hi; slice(n, &lo, &hi);
     for (size_t i = lo + threadIdx.x; i < hi; i += VB) B[i] = B[i] + a * Pv[i];
@@ -228,7 +249,8 @@ __global__ __launch_bounds__(VB) void k_cg_resid2(const double* __restrict__ G, 
                                                  double* __restrict__ Pv, size_t n, double lambda, double cconv,
                                                  const double* __restrict__ tail, const double* __restrict__ part, int nb,
                                                  double* __restrict__ scal, int rr_in, int rr_out,
-                                                 double* __restrict__ trace, int pass, double* __restrict__ part_p, int merged) {
+                                                 double* __restrict__ trace, int pass, double* __restrict__ part_p, int merged,
+                                                 const double* __restrict__ cost_part, int ncp) {
     const double was = scal[SC_CONVP + ((pass - 1) & 1)];
     if (was != 0.) {                                       // already converged: hand the flag on to the next pass's slot
         if (blockIdx.x == 0 && threadIdx.x == 0) scal[SC_CONVP + (pass & 1)] = was;
@@ -252,10 +274,14 @@ __global__ __launch_bounds__(VB) void k_cg_resid2(const double* __restrict__ G, 
     }
     const double ps = block_sum(pacc, sh);                 // partial |p|^2 of the next pass (k_cg_step2 sums them in block order)
     if (threadIdx.x == 0) { part_p[2 * blockIdx.x] = ps; part_p[2 * blockIdx.x + 1] = 0.; }
+    double csp = 0.;                                       // workgroup 0: the cost partials of the output update, when they have not been reduced yet
+    if (blockIdx.x == 0 && cost_part && !merged)
+        for (int l = 0; l < TNML_NL; ++l) csp += sum_column(cost_part, ncp, l, sh);      // label by label, as the reduced tail would be added
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (!merged) {                                    // (merged: this pass's cost partials are summed over the ranks by the next all-reduce)
             double cs = 0.;
-            for (int l = 0; l < TNML_NL; ++l) cs += tail[SC_COST0 + l];
+            if (cost_part) cs = csp;
+            else for (int l = 0; l < TNML_NL; ++l) cs += tail[SC_COST0 + l];
             scal[SC_COST] = cs + lambda * bn2;
             trace[4 * (pass - 1) + 2] = cs + lambda * bn2;
         }
@@ -280,7 +306,7 @@ __global__ __launch_bounds__(VB) void k_cg_fast_resid0(double* __restrict__ G, c
 __global__ __launch_bounds__(VB) void k_norm2(const double* __restrict__ part, int nb, double* __restrict__ out, int nout) {
     __shared__ double sh[VB / 64];
     double a, b; sum_partials(part, nb, &a, &b, sh);
-    if (threadIdx.x == 0) { out[0] = a; if (nout > 1) out[1] = b; }
+    if (threadIdx.x == 0) { out[0] = a; if (nout == 2) out[1] = b; if (nout == 3) { out[1] = a; out[2] = b; } }
 }
 __global__ __launch_bounds__(VB) void k_diffnorm1(const double* __restrict__ x, const double* __restrict__ y, size_t n, double* __restrict__ part) {
     __shared__ double sh[VB];
@@ -305,19 +331,19 @@ int launch_cg_init(tnml_ctx* c, size_t n, double lambda, double cconv0) {
     HIPCK(c, hipGetLastError());
     return 0;
 }
-int launch_cg_step(tnml_ctx* c, size_t n, double lambda, int pass, bool merged) {
+int launch_cg_step(tnml_ctx* c, size_t n, double lambda, int pass, bool merged, const double* pp_part, int npp) {
     ProfScope ps(c, KC_VEC);
     const int nb = vec_blocks(n);
-    hipLaunchKernelGGL(k_cg_step2, dim3(nb), dim3(VB), 0, c->stream, c->vB, c->vP, n, lambda, c->tail, c->vpart + 512, nb, c->scal, SC_RR + c->rr_slot, c->cgtrace, pass, merged ? 1 : 0);
+    hipLaunchKernelGGL(k_cg_step2, dim3(nb), dim3(VB), 0, c->stream, c->vB, c->vP, n, lambda, c->tail, c->vpart + 512, nb, c->scal, SC_RR + c->rr_slot, c->cgtrace, pass, merged ? 1 : 0, pp_part, npp);
     HIPCK(c, hipGetLastError());
     return 0;
 }
-int launch_cg_resid(tnml_ctx* c, size_t n, double lambda, double cconv, int pass, bool merged) {
+int launch_cg_resid(tnml_ctx* c, size_t n, double lambda, double cconv, int pass, bool merged, const double* cost_part, int ncp) {
     ProfScope ps(c, KC_VEC);
     const int nb = vec_blocks(n);
     const int in = SC_RR + c->rr_slot, out = SC_RR + (c->rr_slot ^ 1);
     hipLaunchKernelGGL(k_cg_resid1, dim3(nb), dim3(VB), 0, c->stream, c->vG, c->vB, n, lambda, c->vpart, merged ? (const double*)c->vR : (const double*)nullptr, (const double*)c->vP, (const double*)c->scal);
-    hipLaunchKernelGGL(k_cg_resid2, dim3(nb), dim3(VB), 0, c->stream, c->vG, c->vB, c->vR, c->vP, n, lambda, cconv, c->tail, c->vpart, nb, c->scal, in, out, c->cgtrace, pass, c->vpart + 512, merged ? 1 : 0);
+    hipLaunchKernelGGL(k_cg_resid2, dim3(nb), dim3(VB), 0, c->stream, c->vG, c->vB, c->vR, c->vP, n, lambda, cconv, c->tail, c->vpart, nb, c->scal, in, out, c->cgtrace, pass, c->vpart + 512, merged ? 1 : 0, cost_part, ncp);
     c->rr_slot ^= 1;
     HIPCK(c, hipGetLastError());
     return 0;
@@ -336,11 +362,11 @@ int launch_sqnorm(tnml_ctx* c, const double* x, size_t n, double* out) {
     HIPCK(c, hipGetLastError());
     return 0;
 }
-int launch_diffnorm(tnml_ctx* c, const double* x, const double* y, size_t n, double* out2) {
+int launch_diffnorm(tnml_ctx* c, const double* x, const double* y, size_t n, double* out2, int nout) {      // nout = 3: out = |x|^2, |x|^2, |x - y|^2
     ProfScope ps(c, KC_VEC);
     const int nb = vec_blocks(n);
     hipLaunchKernelGGL(k_diffnorm1, dim3(nb), dim3(VB), 0, c->stream, x, y, n, c->vpart);
-    hipLaunchKernelGGL(k_norm2, dim3(1), dim3(VB), 0, c->stream, c->vpart, nb, out2, 2);
+    hipLaunchKernelGGL(k_norm2, dim3(1), dim3(VB), 0, c->stream, c->vpart, nb, out2, nout);
     HIPCK(c, hipGetLastError());
     return 0;
 }

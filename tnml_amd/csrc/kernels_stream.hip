@@ -217,9 +217,11 @@ int launch_labeldot_reduce(tnml_ctx* c, int nblk_total, double* scal_out, int on
     HIPCK(c, hipGetLastError());
     return 0;
 }
-int launch_labeldot(tnml_ctx* c, const LdotArgs& a, double* scal_out) {
+int launch_labeldot(tnml_ctx* c, const LdotArgs& a, double* scal_out, bool reduce) {
     const int nblk = a.NTp / (labeldot_streaming(c, a.NTp) ? 128 : 64);
     TCK(launch_labeldot_blocks(c, a, 0, nblk, c->stream, KC_LABELDOT, 0));
+    c->part_n = nblk;
+    if (!reduce) return 0;
     return launch_labeldot_reduce(c, nblk, scal_out, a.mode == LD_MODE_PAP ? 1 : 0);
 }
 
@@ -289,12 +291,13 @@ __global__ __launch_bounds__(LD_IMGS) void k_pupdate(T* __restrict__ P, const T*
     sum_wave_partials(s_part, LD_IMGS / 64, partials + (size_t)blockIdx.x * 12, tid);
 }
 
-int launch_pupdate(tnml_ctx* c, const double* alpha_dev, double* scal_out) {
+int launch_pupdate(tnml_ctx* c, const double* alpha_dev, double* scal_out, bool reduce) {
     ProfScope ps(c, KC_PUPDATE);
     const int nblk = c->NTp / LD_IMGS;
+    c->part_n = nblk;
     if (c->f64()) hipLaunchKernelGGL(k_pupdate<double>, dim3(nblk), dim3(LD_IMGS), 0, c->stream, (double*)c->P, (const double*)c->Pp, (double*)c->dP, c->label, c->NTp, alpha_dev, c->scal + SC_CONVP + ((c->cg_pass - 1) & 1), c->partials, c->nl(), c->target());
     else          hipLaunchKernelGGL(k_pupdate<float>, dim3(nblk), dim3(LD_IMGS), 0, c->stream, (float*)c->P, (const float*)c->Pp, (float*)c->dP, c->label, c->NTp, alpha_dev, c->scal + SC_CONVP + ((c->cg_pass - 1) & 1), c->partials, c->nl(), c->target());
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(768), 0, c->stream, c->partials, nblk, scal_out, 0);
+    if (reduce) hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(768), 0, c->stream, c->partials, nblk, scal_out, 0);
     HIPCK(c, hipGetLastError());
     return 0;
 }

@@ -84,6 +84,11 @@ __global__ void k_potrf_flags(const int* __restrict__ info, double* __restrict__
     if (threadIdx.x == 0) { flag[0] = info[0] != 0 ? 1. : 0.; flag[1] = 1.; }
 }
 
+// the workgroup cluster's status word -> a double that can be summed over the ranks (1 = this rank's cluster gave up)
+__global__ void k_mc_flag(const unsigned long long* __restrict__ status, double* __restrict__ out) {
+    if (threadIdx.x == 0) out[0] = status[0] != 0ull ? 1. : 0.;
+}
+
 #define RBCK(c, expr) do { rocblas_status s_ = (expr); if (s_ != rocblas_status_success) return tnml_fail((c), "%s failed: rocblas status %d (%s:%d)", #expr, (int)s_, __FILE__, __LINE__); } while (0)
 
 // ---- density-matrix split with a noise term (per-label variant, single.h:648-672) ------------------------------------------------
@@ -245,14 +250,22 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
     // check), so that a last-bit difference between replicas can never produce different bond dimensions.
     const int nev = own_eig ? n + 4 : n;                 // the check values ride behind the eigenvalues: one broadcast, one copy
     TCK(bcast_rank0(c, const_cast<double*>(evals), nev));
+    // The workgroup cluster of ANY rank may have given up (a workgroup that never got a CU): the fallback below contains
+    // collectives, so every rank has to take it together -- the status words are summed over the ranks (one 8-byte all-reduce,
+    // splits above n = 240 with a communicator only) and every rank decides on the sum.
+    double* mcflag = c->sDev + 3;
+    if (mc) {
+        hipLaunchKernelGGL(k_mc_flag, dim3(1), dim3(64), 0, st, static_cast<const unsigned long long*>(eigh_mc_status_ptr(c->mc_xbuf)), mcflag);
+        TCK(allreduce_sum(c, mcflag, 1));
+    }
     double* h = c->h_scal;          // pinned, capacity >= 2*svd_n + 64
     HIPCK(c, hipMemcpyAsync(h, evals, sizeof(double) * nev, hipMemcpyDeviceToHost, st));
-    unsigned long long* h_mc = reinterpret_cast<unsigned long long*>(h + n + 8);
-    *h_mc = 0;
-    if (mc) HIPCK(c, hipMemcpyAsync(h_mc, eigh_mc_status_ptr(c->mc_xbuf), 8, hipMemcpyDeviceToHost, st));
+    double* h_mc = h + n + 8;
+    *h_mc = 0.;
+    if (mc) HIPCK(c, hipMemcpyAsync(h_mc, mcflag, 8, hipMemcpyDeviceToHost, st));
     HIPCK(c, hipStreamSynchronize(st));
     bool stock = !tri;                                   // eigenvectors of rho itself in sG (dsyevd)
-    if (mc && *h_mc) {
+    if (mc && *h_mc != 0.) {
         // the workgroup cluster gave up waiting for a peer (a workgroup that never got a CU): nothing it wrote is used.  Redo this
         // split with the stock solver: Gram matrix again (sG may have served as workspace), dsyevd, eigenvalues to the host.
         c->svd_fallbacks += 1;

@@ -82,6 +82,7 @@ int tnml_set_option(tnml_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "defer_tail")) { if (c->pend_count) return tnml_fail(c, "defer_tail: a bond update is in flight"); c->defer_tail = value != 0; }
     else if (!strcmp(name, "check_replicas")) { c->check_replicas = value != 0; c->check_replicas_mode = value; }
     else if (!strcmp(name, "fused_fwd")) c->fused_fwd = value;
+    else if (!strcmp(name, "fold_reduce")) c->fold_reduce = value != 0;
     else if (!strcmp(name, "fwd_res")) c->fwd_res = value;
     else if (!strcmp(name, "grad_res")) c->grad_res = value;
     else if (!strcmp(name, "res_grid")) c->res_grid = value;
@@ -758,7 +759,7 @@ int tnml_bond_tensor(tnml_ctx* c, int b, double* B) {
 // ---- per-image contractions -----------------------------------------------------------------------
 // forward pass with the M-layout fp64 vector `vec` as bond tensor: P = vec*t.v, then mode-specific
 // reductions into tail[0..11] (device)
-static int forward_pass(tnml_ctx* c, const double* vec, int mode, double* tail, bool want_P) {
+static int forward_pass(tnml_ctx* c, const double* vec, int mode, double* tail, bool want_P, bool reduce = true) {      // !reduce: the partial sums stay in c->partials[c->part_n][12]
     const BondPlan& p = c->plan;
     const size_t ustride = (size_t)p.mO * c->NTp;
     LdotArgs a;
@@ -781,7 +782,8 @@ static int forward_pass(tnml_ctx* c, const double* vec, int mode, double* tail, 
             TCK(launch_fwd_res(c, fr));
             PfinishArgs pf{2, c->Ppart, nullptr, nullptr, nullptr, nullptr, c->label, c->NTp, (double*)a.P, (double*)a.dP, mode, c->partials, c->counters, tail, mode == LD_MODE_PAP ? 1 : 0};
             TCK(launch_pfinish(c, pf));
-            return launch_labeldot_reduce(c, c->NTp / 64, tail, mode == LD_MODE_PAP ? 1 : 0);
+            c->part_n = c->NTp / 64;
+            return reduce ? launch_labeldot_reduce(c, c->NTp / 64, tail, mode == LD_MODE_PAP ? 1 : 0) : 0;
         }
         // one persistent kernel for both halves of B*t.v where it pays (kernels_fused.hip)
         if (c->fused_fwd && c->env64() && !c->single() && p.kind != 2 && p.Kp == 240 && p.Np == 240 && p.mI == 120 && p.mO == 120 &&
@@ -791,7 +793,8 @@ static int forward_pass(tnml_ctx* c, const double* vec, int mode, double* tail, 
             ff.phiO = (const double*)p.phiO; ff.EL = (const double*)p.EX; ff.EL_lstride = ustride; ff.mO = p.mO; ff.NTp = c->NTp; ff.ntiles = c->NTp / 64;
             ff.label = c->label; ff.P = (double*)a.P; ff.dP = (double*)a.dP; ff.mode = mode; ff.partials = c->partials;
             TCK(launch_fwd_fused(c, ff));
-            return launch_labeldot_reduce(c, ff.ntiles, tail, mode == LD_MODE_PAP ? 1 : 0);
+            c->part_n = ff.ntiles;
+            return reduce ? launch_labeldot_reduce(c, ff.ntiles, tail, mode == LD_MODE_PAP ? 1 : 0) : 0;
         }
         TCK(launch_fgemm64(c, f));
     } else {
@@ -804,17 +807,17 @@ static int forward_pass(tnml_ctx* c, const double* vec, int mode, double* tail, 
         f.NTp = c->NTp; f.L = p.LB;
         TCK(launch_fgemm(c, f));
     }
-    return launch_labeldot(c, a, tail);
+    return launch_labeldot(c, a, tail, reduce);
 }
 // G = sum_n dP_n*dag(t.v) over all ranks for the bond tensor in vB; cost partials ride in the tail.
 // weights_pp: the image sum A p = sum_n (p.v_n) v_n instead, weights p.v_n as left in Pp by the pAp pass (fast_conj of the per-label
 // variant, single.h:347-379, and the merged CG of every variant); the tail is left as it is
-static int grad_eval(tnml_ctx* c, bool from_P_update = false, bool outputs_current = false, bool weights_pp = false, bool reduce = true) {
+static int grad_eval(tnml_ctx* c, bool from_P_update = false, bool outputs_current = false, bool weights_pp = false, bool reduce = true, bool fold = false) {
     const BondPlan& p = c->plan;
     const size_t n = p.msize();
     if (weights_pp) {}
     else if (outputs_current)    { if (!c->tail_zeroed) HIPCK(c, hipMemsetAsync(c->tail, 0, sizeof(double) * TNML_NSCAL_AR, c->stream)); }   // P/dP already hold B*t.v and the residuals (the pack kernel of tnml_bond_update has cleared the tail)
-    else if (from_P_update) TCK(launch_pupdate(c, c->scal + SC_ALPHA, c->tail));          // P += a (p*t.v): no GEMM
+    else if (from_P_update) TCK(launch_pupdate(c, c->scal + SC_ALPHA, c->tail, !fold));   // P += a (p*t.v): no GEMM
     else                    TCK(forward_pass(c, c->vB, LD_MODE_COST, c->tail, c->fast_cg)); // keeps P when fast CG is on
     const void* wsrc = weights_pp ? c->Pp : c->dP;           // the per-image weights of the sum
     const bool fuse = c->f64() && c->fuse_z && p.kind != 2;
@@ -866,22 +869,25 @@ static int cgrad_device(tnml_ctx* c, int npass, double lambda, double cconv, boo
     // recurrence is not the reference's literal order: on the reference's own, badly conditioned feature map the fourth step size of
     // a Label-on-B bond moves by 1e-3 (the cost by 1e-10); merged_cg = 2 forces it on a single rank (parity tests), 0 disables it.
     const bool merged = c->fast_cg && !fastc && (c->merged_cg >= 2 || (c->merged_cg == 1 && (c->comm || c->local)));
+    // one rank, literal pass order: the per-block partial sums of a pAp pass / an output update are summed by the CG step kernel that
+    // consumes them (k_cg_step2: sum |p.v|^2, k_cg_resid2: the cost of the trace) -- seven k_reduce_partials launches less per bond update
+    const bool fold = c->fold_reduce && !(c->comm || c->local) && !merged && !fastc && c->fast_cg;
     TCK(grad_eval(c, false, outputs_current));           // :374-385
     TCK(launch_cg_init(c, n, lambda, c->single() ? cconv : -1.));   // :386-388 (single.h:200-208 with the entry check)
     for (int pass = 1; pass <= npass; ++pass) {          // :389
         c->cg_pass = pass;
-        TCK(forward_pass(c, c->vP, LD_MODE_PAP, c->tail, c->fast_cg || fastc));   // :394-401 (keeps p*t.v for the fast update)
+        TCK(forward_pass(c, c->vP, LD_MODE_PAP, c->tail, c->fast_cg || fastc, !fold));   // :394-401 (keeps p*t.v for the fast update)
         if (merged && pass < npass) TCK(grad_eval(c, false, false, true));        // A p, all-reduced with the tail
-        else TCK(allreduce(c, c->tail, TNML_NSCAL_AR));                            // :402
-        TCK(launch_cg_step(c, n, lambda, pass, merged)); // :403-407
+        else if (!fold) TCK(allreduce(c, c->tail, TNML_NSCAL_AR));                 // :402
+        TCK(launch_cg_step(c, n, lambda, pass, merged, fold ? c->partials : nullptr, c->part_n)); // :403-407
         if (pass == npass) break;                        // :409
         if (merged) {
             TCK(launch_pupdate(c, c->scal + SC_ALPHA, c->tail));                  // P, dP and the cost partials of the new B (:414-420, without the GEMM)
         } else if (fastc) {                              // single.h:347-379: A p from the p.v of this pass, residual by recurrence
             TCK(grad_eval(c, false, false, true));
             TCK(launch_cg_fast_resid0(c, n, pass));
-        } else TCK(grad_eval(c, c->fast_cg));            // :412-421
-        TCK(launch_cg_resid(c, n, lambda, cconv, pass, merged)); // :422-428, :432-436, :442
+        } else TCK(grad_eval(c, c->fast_cg, false, false, true, fold));           // :412-421
+        TCK(launch_cg_resid(c, n, lambda, cconv, pass, merged, fold ? c->partials : nullptr, c->part_n)); // :422-428, :432-436, :442
     }
     return 0;
 }
@@ -1275,8 +1281,7 @@ int tnml_bond_update_begin(tnml_ctx* c, int b, int ha, const tnml_sweep_params* 
     // :532 quadcost(newB); P and dP stay for the next bond update.  Its cost partials land in the CARRIED slots of the tail.
     TCK(forward_pass(c, c->vB, LD_MODE_COST, c->tail + TNML_CARRY, true));
     double* loc = c->locals + 16 * slot;                              // local scalars: slot 12 |newB|^2, 13/14 of :528,:530
-    TCK(launch_sqnorm(c, c->vB, c->plan.msize(), loc + 12));
-    TCK(launch_diffnorm(c, c->tB2, c->tB, ne, loc + 13));
+    TCK(launch_diffnorm(c, c->tB2, c->tB, ne, loc + 12, 3));          // |newB|^2 twice (slot 12 of quadcost, :528), |newB - B|^2 (:530)
     double* hq = pend_host(c, slot);
     HIPCK(c, hipMemcpyAsync(hq, loc, sizeof(double) * 16, hipMemcpyDeviceToHost, c->stream));
     const bool multi = c->comm || c->local;

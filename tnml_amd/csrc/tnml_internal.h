@@ -142,6 +142,8 @@ struct tnml_ctx {
     size_t eesz() const { return env64() ? 8 : 4; }
     double* partials = nullptr;  // [nblk][16]
     int partial_cap = 0;
+    int part_n = 0;              // rows of `partials` the last forward pass / output update wrote
+    bool fold_reduce = true;     // one rank: the CG step kernels sum those rows themselves (no k_reduce_partials launch inside a CG pass); option "fold_reduce"
     double *vB = nullptr, *vR = nullptr, *vP = nullptr;   // CG vectors, M-layout fp64
     double* arbuf = nullptr;   // the all-reduce buffer [tail | G]
     double* tail = nullptr;    // = arbuf
@@ -282,12 +284,12 @@ struct LdotArgs {
     int blk_off = 0;                    // first image block of this launch (blocks of 64 * images-per-lane)
 };
 // partial sums -> scal_out[0..11] (device); deterministic
-int launch_labeldot(tnml_ctx* c, const LdotArgs& a, double* scal_out);
+int launch_labeldot(tnml_ctx* c, const LdotArgs& a, double* scal_out, bool reduce = true);
 // the two halves of launch_labeldot for a split launch: blocks [blk_off, blk_off + nblk) on `st`, then the reduction of ALL partials
 int launch_labeldot_blocks(tnml_ctx* c, const LdotArgs& a, int blk_off, int nblk, hipStream_t st, int kclass, int form = 0);   // form 1: 128-image blocks, 2: 64-image blocks, 0: by image count
 int launch_labeldot_reduce(tnml_ctx* c, int nblk_total, double* scal_out, int only_sum = 0);   // only_sum: write slot 11 alone (the pAp pass must leave the cost partials in place)
 bool labeldot_streaming(const tnml_ctx* c, int NTp);   // the 128-images-per-workgroup form is in use
-int launch_pupdate(tnml_ctx* c, const double* alpha_dev, double* scal_out);     // uses c->nl(), c->target()
+int launch_pupdate(tnml_ctx* c, const double* alpha_dev, double* scal_out, bool reduce = true);     // uses c->nl(), c->target(); !reduce: the partial sums stay in c->partials[c->part_n][12]
 int launch_zprime(tnml_ctx* c, const void* EL, size_t lstride, const void* dP, void* Z, int mq, int NTp);
 int launch_features_u8(tnml_ctx* c, const uint8_t* d_pix, int N, int NT, int NTp, void* phi);
 
@@ -362,11 +364,11 @@ int launch_cvt(tnml_ctx* c, const double* src, float* dst, size_t n);
 int launch_bond_form(tnml_ctx* c, const SiteT& A1, const SiteT& A2, double* B);            // B = A1*A2, ITensor layout
 // CG vector algebra on device scalars (single-block kernels)
 int launch_cg_init(tnml_ctx* c, size_t n, double lambda, double cconv0);   // cconv0 < 0: no entry check          // r = G - lambda B ; p = r ; RR = |r|^2
-int launch_cg_step(tnml_ctx* c, size_t n, double lambda, int pass, bool merged = false);          // pAp, alpha, B += alpha p (merged: also the cost of the previous pass)
-int launch_cg_resid(tnml_ctx* c, size_t n, double lambda, double cconv, int pass, bool merged = false);   // merged: G holds A p, residual by recurrence
+int launch_cg_step(tnml_ctx* c, size_t n, double lambda, int pass, bool merged = false, const double* pp_part = nullptr, int npp = 0);   // pp_part: column 11 of the pAp pass's per-block partial sums, not reduced yet          // pAp, alpha, B += alpha p (merged: also the cost of the previous pass)
+int launch_cg_resid(tnml_ctx* c, size_t n, double lambda, double cconv, int pass, bool merged = false, const double* cost_part = nullptr, int ncp = 0);   // merged: G holds A p, residual by recurrence
 int launch_cg_fast_resid0(tnml_ctx* c, size_t n, int pass);      // fast_conj: G <- r - a*G before launch_cg_resid   // nr, beta, r, cost, conv, p
 int launch_sqnorm(tnml_ctx* c, const double* x, size_t n, double* out);    // out[0] = |x|^2
-int launch_diffnorm(tnml_ctx* c, const double* x, const double* y, size_t n, double* out2);  // out2[0]=|x|^2, out2[1]=|x-y|^2
+int launch_diffnorm(tnml_ctx* c, const double* x, const double* y, size_t n, double* out2, int nout = 2);  // out2[0]=|x|^2, out2[1]=|x-y|^2 (nout = 3: |x|^2, |x|^2, |x-y|^2)
 int launch_fill_f32(tnml_ctx* c, float* p, float v, size_t n);
 int launch_fill_f64(tnml_ctx* c, double* p, double v, size_t n);
 int launch_nudge(tnml_ctx* c, double* p);
