@@ -251,17 +251,22 @@ def test_fused_forward_kernel_matches_the_oracle(NT, kernel):
         ts.set_option("fused_fwd", 4 if NT > 1000 else 2)
     else:
         ts.set_option("fwd_res", 2)
+        ts.set_option("shift_res", 2)                      # k_shift_res builds the Label-carrying environments of init / shiftE (checked below)
         ts.set_option("grad_res", 2)                       # k_grad_res (accumulators resident; off by default) takes the gradient GEMMs of this run
         ts.set_option("res_grid", 32 if NT == 1100 else 16)
     ts.set_mps(W)
     ts.init()
     o = pyoracle.Oracle(phi, labels, W, nthread=min(8, os.cpu_count() or 1))
     o.init()
+    for j in (5, 8, 9, 10):                                   # right environments carrying the Label index, built by init (m = 120 from site 8 down)
+        assert _rel(ts.env(j), o.env(j)) < 1e-12, j
     rng = np.random.default_rng(1)
     at = 1
     for b, kind in ((8, "Label on RE"), (12, "Label on LE")):
         for bb in range(at, b):
             ts.shiftE(bb, True); o.shiftE(bb, True)
+            if bb >= 10:
+                assert _rel(ts.env(bb), o.env(bb)) < 1e-12, bb        # left environments carrying the Label index, built by shiftE
         at = b
         ts.setBond(b); o.set_bond(b)
         B = o.bond_tensor(b)

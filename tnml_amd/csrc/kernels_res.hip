@@ -478,6 +478,138 @@ int launch_grad_res(tnml_ctx* c, const GradResArgs& a_in, double* G) {
     return 0;
 }
 
+// ==========================================================================================================================
+// k_shift_res -- the Label-carrying environment shift (TrainStates::shiftE / init, fixedL.cc:142-149,221-228), m = 120:
+//   E'[l][y][n] = sum_{a,s} E[l][a][n] phi[s][n] A[a,s,y]  =  phi[0] (E M_even) + phi[1] (E M_odd),  M = the packed site matrix [240][128].
+// M (245 KB) fits the registers of ONE workgroup: 8 waves, wave w keeps column tile w (120 VGPRs) for the whole launch and the
+// workgroup walks 64-image tiles of the 10 x NTp rows.  No second role: every wave issues its share of the next tile's LDS-DMA
+// pieces at the top of a round, so nothing but MFMAs, LDS fragment reads and stores runs beside the matrix pipe.  The second half of a
+// tile's outputs is stored at the top of the NEXT round: the wait that lands the DMA pieces at the end of a round (vmcnt counts loads
+// and stores alike) then finds only stores that are half a round old.  One barrier per tile.
+// ==========================================================================================================================
+#define SR_TI 64
+#define SR_ROWS 122                                // 120 environment rows, phi[0], phi[1]
+#define SR_LDS_DOUBLES (2 * SR_ROWS * SR_TI)
+
+__global__ __launch_bounds__(512) void k_shift_res(ShiftResArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double sr_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NTp = A.NTp, tpl = NTp / SR_TI;
+    const int G = gridDim.x;
+    const int niter = (A.ntiles - (int)blockIdx.x + G - 1) / G;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)sr_lds));
+    const unsigned doff = (unsigned)(((size_t)(lane >> 5) * NTp + 2 * (lane & 31)) * sizeof(double));     // lane part of a piece's source: 2 rows x 64 images
+    auto dma16 = [&](const double* base, unsigned voff, unsigned dst) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff), "s"(dst), "s"(base) : "memory");
+    };
+    // tile t = rows n0 .. n0 + 63 of label l; 61 pieces of 2 rows (piece 60: the two feature rows); 8 per wave, the last slots repeat pieces
+    auto stage = [&](int t, int buf) {
+        const int l = t / tpl, n0 = (t - l * tpl) * SR_TI;
+        const double* eb = A.EI + (size_t)l * A.EI_lstride + n0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            int p = w + 8 * r;
+            if (p > 60) p -= 61;
+            dma16(p == 60 ? A.phiI + n0 : eb + (size_t)(2 * p) * NTp, doff, lds0 + (unsigned)((buf * SR_ROWS * SR_TI + 2 * p * SR_TI) * sizeof(double)));
+        }
+    };
+    double me[30], mo[30];
+    {
+        const int g = lane >> 4, i = lane & 15;
+#pragma unroll
+        for (int ks = 0; ks < 30; ++ks) {
+            me[ks] = A.M[(size_t)(2 * (4 * ks + g)) * 128 + 16 * w + i];
+            mo[ks] = A.M[(size_t)(2 * (4 * ks + g) + 1) * 128 + 16 * w + i];
+        }
+    }
+    if (niter > 0) stage(blockIdx.x, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    fr_barrier();
+    double ob[8];                                   // second-half outputs of the previous tile
+    double* obp = nullptr;
+    for (int it = 0; it < niter; ++it) {
+        const int t = blockIdx.x + it * G;
+        const int l = t / tpl, n0 = (t - l * tpl) * SR_TI;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        int g = ln >> 4, i = ln & 15;
+        if (obp) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const int y = 16 * w + g + 4 * (q & 3); if (y < A.mO) obp[(size_t)(4 * (q & 3)) * NTp + 16 * (q >> 2)] = ob[q]; }
+        }
+        if (it + 1 < niter) stage(t + G, (it + 1) & 1);
+        const double* Eb = sr_lds + (it & 1) * SR_ROWS * SR_TI;
+        double* op = A.out + (size_t)l * A.out_lstride + (size_t)(16 * w + g) * NTp + n0 + i;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const double* ep0 = Eb + g * SR_TI + 32 * pass + i;            // E[4 ks + g][32 pass + i], [.. + 16 + i]
+            const double* ep1 = ep0 + 16;
+            f64x4r ce0 = {0., 0., 0., 0.}, co0 = {0., 0., 0., 0.}, ce1 = {0., 0., 0., 0.}, co1 = {0., 0., 0., 0.};
+            double a0 = ep0[0], b0 = ep1[0], a1 = ep0[4 * SR_TI], b1 = ep1[4 * SR_TI];
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int ks = 0; ks < 30; ++ks) {
+                const double xa = a0, xb = b0;
+                a0 = a1; b0 = b1;
+                if (ks + 2 < 30) { a1 = ep0[4 * (ks + 2) * SR_TI]; b1 = ep1[4 * (ks + 2) * SR_TI]; __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
+                ce0 = __builtin_amdgcn_mfma_f64_16x16x4f64(me[ks], xa, ce0, 0, 0, 0);
+                co0 = __builtin_amdgcn_mfma_f64_16x16x4f64(mo[ks], xa, co0, 0, 0, 0);
+                ce1 = __builtin_amdgcn_mfma_f64_16x16x4f64(me[ks], xb, ce1, 0, 0, 0);
+                co1 = __builtin_amdgcn_mfma_f64_16x16x4f64(mo[ks], xb, co1, 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
+            // lane (g, i) holds output links y = 16 w + g + 4 e of images 32 pass + 16 grp + i
+            ln = lane;
+            asm volatile("" : "+v"(ln));
+            g = ln >> 4; i = ln & 15;
+#pragma unroll
+            for (int grp = 0; grp < 2; ++grp) {
+                const double pI0 = Eb[120 * SR_TI + 32 * pass + 16 * grp + i], pI1 = Eb[121 * SR_TI + 32 * pass + 16 * grp + i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const double v = fma(pI1, grp ? co1[e] : co0[e], pI0 * (grp ? ce1[e] : ce0[e]));
+                    if (pass == 0) { if (16 * w + g + 4 * e < A.mO) op[(size_t)(4 * e) * NTp + 16 * grp] = v; }
+                    else ob[4 * grp + e] = v;
+                }
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        obp = op + 32;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next tile's pieces have landed (the stores still counted are half a round old)
+        fr_barrier();
+    }
+    if (obp) {
+        const int g = lane >> 4;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const int y = 16 * w + g + 4 * (q & 3); if (y < A.mO) obp[(size_t)(4 * (q & 3)) * NTp + 16 * (q >> 2)] = ob[q]; }
+    }
+}
+
+int launch_shift_res(tnml_ctx* c, const ShiftResArgs& a_in) {
+    ShiftResArgs a = a_in;
+    if (a.NTp % SR_TI) return tnml_fail(c, "shift_res: image count not a multiple of %d", SR_TI);
+    if (((size_t)a.L * a.EI_lstride) * sizeof(double) >= ((size_t)1 << 32)) return tnml_fail(c, "shift_res: environment larger than 4 GB (32-bit lane offsets)");
+    if (!c->cu_count) { hipDeviceProp_t pr; c->cu_count = hipGetDeviceProperties(&pr, c->cfg.device) == hipSuccess ? pr.multiProcessorCount : 256; }
+    a.ntiles = a.L * (a.NTp / SR_TI);
+    int grid = c->cu_count;
+    if (c->res_grid > 0 && c->res_grid < grid) grid = c->res_grid;
+    if (grid > a.ntiles) grid = a.ntiles;
+    const size_t lds = sizeof(double) * SR_LDS_DOUBLES;
+    if (!c->attr_res) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_shift_res), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return tnml_fail(c, "shift_res: cannot reserve %zu bytes of LDS", lds);
+        c->attr_res = true;
+    }
+    {
+        ProfScope ps(c, KC_FGEMM_SHIFT);
+        hipLaunchKernelGGL(k_shift_res, dim3(grid), dim3(512), lds, c->stream, a);
+    }
+    HIPCK(c, hipGetLastError());
+    return 0;
+}
+
 // wave-level cost buckets of 64 images -> out[12] (the epilogue of k_labeldot / k_fwd_fused)
 static __device__ __forceinline__ void res_wave_partials(double val, int lab, int cor, bool pap, double* out, int lane) {
     if (pap) {

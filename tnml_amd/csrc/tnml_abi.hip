@@ -85,6 +85,7 @@ int tnml_set_option(tnml_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "fold_reduce")) c->fold_reduce = value != 0;
     else if (!strcmp(name, "fwd_res")) c->fwd_res = value;
     else if (!strcmp(name, "grad_res")) c->grad_res = value;
+    else if (!strcmp(name, "shift_res")) c->shift_res = value;
     else if (!strcmp(name, "res_grid")) c->res_grid = value;
     else if (!strcmp(name, "res_pace")) c->res_pace = value;
     else if (!strcmp(name, "sytrd_exit")) c->sytrd_exit = value;
@@ -229,6 +230,7 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     if (const char* e = getenv("TNML_FUSED_FWD")) c->fused_fwd = atoi(e);
     if (const char* e = getenv("TNML_FWD_RES")) c->fwd_res = atoi(e);
     if (const char* e = getenv("TNML_GRAD_RES")) c->grad_res = atoi(e);
+    if (const char* e = getenv("TNML_SHIFT_RES")) c->shift_res = atoi(e);
     if (const char* e = getenv("TNML_RES_PACE")) c->res_pace = atoi(e);
     if (rocblas_create_handle(&c->blas) != rocblas_status_success) return bail(tnml_fail(c, "rocblas_create_handle failed"));
     rocblas_set_stream(c->blas, c->stream);
@@ -568,6 +570,12 @@ static int shift_core(tnml_ctx* c, int cs, bool from_left, const void* src, int 
         f.phiO = nullptr;
         f.out = (double*)dst; f.out_lstride = (size_t)m_out * c->NTp; f.mO = m_out;
         f.NTp = c->NTp; f.L = Lout; f.env64 = c->env64();
+        // the Label-carrying shift at m = 120 with the site matrix resident in registers (kernels_res.hip)
+        if (c->shift_res && c->env64() && !acc_out && src && Le == TNML_NL && A.L == 1 && m_in == 120 && m_out == 120 && d.Kp == 240 && d.Np == 128 &&
+            (c->shift_res >= 2 || c->NTp >= 30720)) {
+            ShiftResArgs sa{(const double*)src, (size_t)m_in * c->NTp, (const double*)phi_site(c, cs), c->sM, (double*)dst, (size_t)m_out * c->NTp, m_out, c->NTp, Lout};
+            return launch_shift_res(c, sa);
+        }
         return launch_fgemm64(c, f);
     }
     TCK(launch_pack(c, d, A.a, nullptr, c->Mf));

@@ -174,6 +174,7 @@ struct tnml_ctx {
     bool attr_res = false, attr_gres = false;        // kernels_res.hip
     int res_pace = 0;                // pacing of the GEMM waves of k_fwd_res (0: default; option "res_pace")
     int fwd_res = 1;                 // forward pass on k_fwd_res (kernels_res.hip): 1 = from 30 720 images per rank on, 0 never, 2 always; option "fwd_res"
+    int shift_res = 1;               // Label-carrying environment shift on k_shift_res (kernels_res.hip): 1 = from 30 720 images per rank on, 0 never, 2 always; option "shift_res"
     int grad_res = 0;                // gradient GEMM on k_grad_res (kernels_res.hip): 0 never (default: no faster than k_bgemm64 yet), 2 always; option "grad_res"
     int res_grid = 0;                // test knob: workgroups of the resident-operand kernels (0: one per CU)
     unsigned* counters = nullptr;    // [16] device: arrival counters of the "last workgroup reduces" kernels (zero between launches)
@@ -340,6 +341,15 @@ struct GradResArgs {
     double* slab = nullptr;                           // split-K slabs [pairs][240][240] (set by the launcher)
 };
 int launch_grad_res(tnml_ctx* c, const GradResArgs& a, double* G);
+struct ShiftResArgs {
+    const double* EI; size_t EI_lstride;              // Label-carrying input environment [L][120][NTp]
+    const double* phiI;                               // features of the absorbed site [2][NTp]
+    const double* M;                                  // packed site matrix [240][128] (k = 2 x + s, j = y), zero padded
+    double* out; size_t out_lstride; int mO;          // [L][mO][NTp]
+    int NTp, L;
+    int ntiles = 0;                                   // set by the launcher: L * NTp / 64
+};
+int launch_shift_res(tnml_ctx* c, const ShiftResArgs& a);
 
 // ---- kernels_small.hip --------------------------------------------------------------------
 struct PackDesc {       // M[l][2x+s][TO==2 ? 2y+t : y] <-> T[off + x*sx + s*ss + y*sy + t*st + l*sl]
