@@ -572,7 +572,7 @@ static int shift_core(tnml_ctx* c, int cs, bool from_left, const void* src, int 
         f.NTp = c->NTp; f.L = Lout; f.env64 = c->env64();
         // the Label-carrying shift at m = 120 with the site matrix resident in registers (kernels_res.hip)
         if (c->shift_res && c->env64() && !acc_out && src && Le == TNML_NL && A.L == 1 && m_in == 120 && m_out == 120 && d.Kp == 240 && d.Np == 128 &&
-            (c->shift_res >= 2 || c->NTp >= 30720)) {
+            (c->shift_res >= 2 || c->NTp >= 7680)) {
             ShiftResArgs sa{(const double*)src, (size_t)m_in * c->NTp, (const double*)phi_site(c, cs), c->sM, (double*)dst, (size_t)m_out * c->NTp, m_out, c->NTp, Lout};
             return launch_shift_res(c, sa);
         }
@@ -782,10 +782,10 @@ static int forward_pass(tnml_ctx* c, const double* vec, int mode, double* tail, 
         f.phiO = p.phiO;
         f.out = (double*)c->U; f.out_lstride = ustride; f.mO = p.mO;
         f.NTp = c->NTp; f.L = p.LB; f.env64 = c->env64();
-        // the bond matrix resident in the registers of a pair of workgroups (kernels_res.hip): from 30 720 images per rank on (the
-        // launch has a fill and a drain round of one 32-image tile per workgroup pair: 2 of 17 rounds at 60 000 images, 2 of 4 at 7 500)
+        // the bond matrix resident in the registers of a pair of workgroups (kernels_res.hip): from 7 680 images per rank on (the 7 500-image
+        // shard of an 8-GPU run: 0.162 ms per bond update against 0.250 for the feature GEMM + label dot pair, profiles/r04_shard7500_res_kernels.txt)
         if (c->fwd_res && c->Ppart && c->env64() && !c->single() && p.kind != 2 && p.Kp == 240 && p.Np == 240 && p.mI == 120 && p.mO == 120 &&
-            (c->fwd_res >= 2 || c->NTp >= 30720)) {
+            (c->fwd_res >= 2 || c->NTp >= 7680)) {
             FwdResArgs fr{(const double*)p.EI, (const double*)p.phiI, vec, (const double*)p.phiO, (const double*)p.EX, ustride, c->NTp, c->NTp / 32, c->Ppart};
             TCK(launch_fwd_res(c, fr));
             PfinishArgs pf{2, c->Ppart, nullptr, nullptr, nullptr, nullptr, c->label, c->NTp, (double*)a.P, (double*)a.dP, mode, c->partials, c->counters, tail, mode == LD_MODE_PAP ? 1 : 0};

@@ -173,8 +173,8 @@ struct tnml_ctx {
     int mc_spin_max = -1;      // polls before a waiting thread of k_sytrd_mc gives up (-1: default; option "mc_spin_max", 0 in the fallback test)
     bool attr_res = false, attr_gres = false;        // kernels_res.hip
     int res_pace = 0;                // pacing of the GEMM waves of k_fwd_res (0: default; option "res_pace")
-    int fwd_res = 1;                 // forward pass on k_fwd_res (kernels_res.hip): 1 = from 30 720 images per rank on, 0 never, 2 always; option "fwd_res"
-    int shift_res = 1;               // Label-carrying environment shift on k_shift_res (kernels_res.hip): 1 = from 30 720 images per rank on, 0 never, 2 always; option "shift_res"
+    int fwd_res = 1;                 // forward pass on k_fwd_res (kernels_res.hip): 1 = from 7 680 images per rank on, 0 never, 2 always; option "fwd_res"
+    int shift_res = 1;               // Label-carrying environment shift on k_shift_res (kernels_res.hip): 1 = from 7 680 images per rank on, 0 never, 2 always; option "shift_res"
     int grad_res = 0;                // gradient GEMM on k_grad_res (kernels_res.hip): 0 never (default: no faster than k_bgemm64 yet), 2 always; option "grad_res"
     int res_grid = 0;                // test knob: workgroups of the resident-operand kernels (0: one per CU)
     unsigned* counters = nullptr;    // [16] device: arrival counters of the "last workgroup reduces" kernels (zero between launches)
