@@ -48,7 +48,7 @@ def kernel_source_sha16():
     """fingerprint of the kernel sources a PMC measurement belongs to"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("kernels_gemm.hip", "kernels_stream.hip", "kernels_fused.hip"):
+    for f in ("kernels_gemm.hip", "kernels_stream.hip", "kernels_fused.hip", "kernels_res.hip"):
         h.update(open(os.path.join(ROOT, "tnml_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

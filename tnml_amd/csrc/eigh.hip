@@ -353,8 +353,6 @@ __global__ __launch_bounds__(64) void k_backtransform(const double* __restrict__
 // receives the number of reflectors formed, which eigh_backtransform reads back on the device.  psd_tol > 0 promises a positive
 // semidefinite A (a Gram matrix) and lets k_sytrd_v3 stop once the trailing block's trace is <= psd_tol * trace(A).
 int eigh_tridiagonalize(tnml_ctx* c, const double* A, int n, double* D, double* E, double* tau, double* V, double psd_tol) {
-    static const double tol_env = getenv("TNML_SYTRD_TOL") ? atof(getenv("TNML_SYTRD_TOL")) : -1.;
-    if (tol_env >= 0.) psd_tol = psd_tol > 0. ? tol_env : 0.;
     if (n > TRI_MAXN) {                                // the multi-workgroup kernel (eigh_mc.hip)
         if (!c->mc_xbuf) return tnml_fail(c, "eigh_tridiagonalize: n=%d needs the multi-workgroup exchange buffer (context created with maxm <= %d)", n, TRI_MAXN / 2);
         return eigh_mc_tridiagonalize(c, c->stream, A, n, D, E, tau, V, psd_tol, c->mc_xbuf, &c->mc_epoch, nullptr, 0, c->mc_spin_max);

@@ -19,385 +19,6 @@
 
 #include "tnml_internal.h"
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-static __device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
-
-// ------------------------------------------------------------------------------------------
-template <int RT, int CT, int WR, int WC, int TO>
-__global__ __launch_bounds__(64 * WR * WC) void k_fgemm(FgemmArgs A) {
-    constexpr int T = 64 * WR * WC, BM = 16 * RT * WR, BN = 16 * CT * WC, KT = 16;
-    constexpr int XS = BM + 16;                         // row stride == 16 (mod 32): conflict-free fragment reads
-    constexpr int MS = BN + ((BN % 32 == 16) ? 0 : 16);
-    __shared__ __attribute__((aligned(16))) float lds[KT * XS + KT * MS];
-    float* Xs = lds;
-    float* Ms = lds + KT * XS;
-
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wr = wid / WC, wc = wid % WC;
-    const int n0 = blockIdx.x * BM, j0 = blockIdx.y * BN, l = blockIdx.z;
-    const float* E = A.EI + (size_t)l * A.EI_lstride;
-    const float* M = A.M + (size_t)l * A.M_lstride;
-    const int NTp = A.NTp;
-
-    f32x4 acc[RT][CT];
-#pragma unroll
-    for (int r = 0; r < RT; ++r)
-#pragma unroll
-        for (int c = 0; c < CT; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    for (int k0 = 0; k0 < A.Kp; k0 += KT) {
-        // stage X: KT/2 environment rows, each expanded to its two site-index rows
-        for (int idx = tid; idx < (KT / 2) * (BM / 4); idx += T) {
-            const int ar = idx / (BM / 4), c4 = idx % (BM / 4);
-            const int a = k0 / 2 + ar, n = n0 + c4 * 4;
-            float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a < A.mI) e = *reinterpret_cast<const float4*>(E + (size_t)a * NTp + n);
-            const float4 p0 = *reinterpret_cast<const float4*>(A.phiI + n);
-            const float4 p1 = *reinterpret_cast<const float4*>(A.phiI + NTp + n);
-            *reinterpret_cast<float4*>(&Xs[(2 * ar) * XS + c4 * 4]) = mul4(e, p0);
-            *reinterpret_cast<float4*>(&Xs[(2 * ar + 1) * XS + c4 * 4]) = mul4(e, p1);
-        }
-        // stage M: KT rows of the (zero padded) bond matrix
-        for (int idx = tid; idx < KT * (BN / 4); idx += T) {
-            const int r = idx / (BN / 4), c4 = idx % (BN / 4);
-            const int j = j0 + c4 * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (j < A.Np) v = *reinterpret_cast<const float4*>(M + (size_t)(k0 + r) * A.Np + j);
-            *reinterpret_cast<float4*>(&Ms[r * MS + c4 * 4]) = v;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < KT; kk += 4) {
-            float a[RT], b[CT];
-            const int krow = kk + (lane >> 4);
-#pragma unroll
-            for (int r = 0; r < RT; ++r) a[r] = Xs[krow * XS + (wr * RT + r) * 16 + (lane & 15)];
-#pragma unroll
-            for (int c = 0; c < CT; ++c) b[c] = Ms[krow * MS + (wc * CT + c) * 16 + (lane & 15)];
-#pragma unroll
-            for (int r = 0; r < RT; ++r)
-#pragma unroll
-                for (int c = 0; c < CT; ++c) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], b[c], acc[r][c], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-
-    // epilogue: C fragment = 4 consecutive images (rows) x 1 column per lane
-    float* out = A.out + (size_t)l * A.out_lstride;
-#pragma unroll
-    for (int r = 0; r < RT; ++r) {
-        const int n = n0 + (wr * RT + r) * 16 + (lane >> 4) * 4;
-#pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            const int j = j0 + (wc * CT + c) * 16 + (lane & 15);
-            if (TO == 2) {
-                const int t = j & 1, q = j >> 1;
-                const float4 ph = *reinterpret_cast<const float4*>(A.phiO + (size_t)t * NTp + n);
-                float4 v = make_float4(acc[r][c][0] * ph.x, acc[r][c][1] * ph.y, acc[r][c][2] * ph.z, acc[r][c][3] * ph.w);
-                v.x += __shfl_xor(v.x, 1); v.y += __shfl_xor(v.y, 1);
-                v.z += __shfl_xor(v.z, 1); v.w += __shfl_xor(v.w, 1);
-                if (t == 0 && q < A.mO) *reinterpret_cast<float4*>(out + (size_t)q * NTp + n) = v;
-            } else {
-                if (j < A.mO)
-                    *reinterpret_cast<float4*>(out + (size_t)j * NTp + n) = make_float4(acc[r][c][0], acc[r][c][1], acc[r][c][2], acc[r][c][3]);
-            }
-        }
-    }
-}
-
-template <int RT, int CT, int WR, int WC>
-static void fgemm_go(tnml_ctx* c, const FgemmArgs& a) {
-    constexpr int BM = 16 * RT * WR, BN = 16 * CT * WC;
-    dim3 grid(a.NTp / BM, (a.Np + BN - 1) / BN, a.L);
-    dim3 block(64 * WR * WC);
-    if (a.phiO) hipLaunchKernelGGL((k_fgemm<RT, CT, WR, WC, 2>), grid, block, 0, c->stream, a);
-    else        hipLaunchKernelGGL((k_fgemm<RT, CT, WR, WC, 1>), grid, block, 0, c->stream, a);
-}
-
-// ------------------------------------------------------------------------------------------
-// k_fgemm_bf16 -- the forward feature GEMM on the bf16 matrix pipe (TNML_BF16 / TNML_BF16X3; BASELINE config 5's "bf16 MFMA
-// bond contraction", a tolerance study): same tiling, same epilogue and the same C-fragment map as k_fgemm
-// (v_mfma_f32_16x16x32_bf16: col = lane & 15, row = 4 (lane >> 4) + reg), fp32 storage, fp32 accumulation.  The operands are
-// rounded to bf16 (round to nearest even) while they are staged: X_n = EI_n (x) phiI_n is formed in fp32 and then rounded, so
-// is every element of the bond matrix.  An A / B fragment is 8 consecutive reduction indices of one row / column
-// (k = 8 (lane >> 4) + 0..7), so the LDS tiles are [row][k] with k contiguous (80-byte rows: the four lane groups of a
-// 16-byte fragment read land on distinct banks).  SPLIT: every operand x = hi + lo with hi = bf16(x), lo = bf16(x - hi) and
-// three MFMAs per product, hi*hi + hi*lo + lo*hi (the lo*lo term is below fp32 round-off): ~16 mantissa bits.
-// ------------------------------------------------------------------------------------------
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-static __device__ __forceinline__ unsigned short f2bf(float x) {
-    const unsigned u = __float_as_uint(x);
-    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-}
-static __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
-
-template <int RT, int CT, int WR, int WC, int TO, int SPLIT>
-__global__ __launch_bounds__(64 * WR * WC) void k_fgemm_bf16(FgemmArgs A) {
-    constexpr int T = 64 * WR * WC, BM = 16 * RT * WR, BN = 16 * CT * WC, KT = 32, KS = KT + 8;     // KS: row stride in bf16 elements
-    constexpr int NP = SPLIT ? 2 : 1;
-    __shared__ __attribute__((aligned(16))) unsigned short lds[NP * (BM + BN) * KS];
-    unsigned short* Xs = lds;                               // [NP][BM][KS]
-    unsigned short* Ms = lds + NP * BM * KS;                // [NP][BN][KS]
-
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wr = wid / WC, wc = wid % WC;
-    const int n0 = blockIdx.x * BM, j0 = blockIdx.y * BN, l = blockIdx.z;
-    const float* E = A.EI + (size_t)l * A.EI_lstride;
-    const float* M = A.M + (size_t)l * A.M_lstride;
-    const int NTp = A.NTp;
-
-    f32x4 acc[RT][CT];
-#pragma unroll
-    for (int r = 0; r < RT; ++r)
-#pragma unroll
-        for (int c = 0; c < CT; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    for (int k0 = 0; k0 < A.Kp; k0 += KT) {
-        // stage X: KT/2 environment rows, each expanded to its two site-index rows, transposed to [image][k]
-        for (int idx = tid; idx < (KT / 2) * (BM / 4); idx += T) {
-            const int ar = idx / (BM / 4), c4 = idx % (BM / 4);
-            const int a = k0 / 2 + ar, n = n0 + c4 * 4;
-            float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a < A.mI) e = *reinterpret_cast<const float4*>(E + (size_t)a * NTp + n);
-            const float4 p0 = *reinterpret_cast<const float4*>(A.phiI + n);
-            const float4 p1 = *reinterpret_cast<const float4*>(A.phiI + NTp + n);
-            const float x0[4] = {e.x * p0.x, e.y * p0.y, e.z * p0.z, e.w * p0.w};
-            const float x1[4] = {e.x * p1.x, e.y * p1.y, e.z * p1.z, e.w * p1.w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int row = c4 * 4 + q;
-                const unsigned short h0 = f2bf(x0[q]), h1 = f2bf(x1[q]);
-                *reinterpret_cast<unsigned*>(&Xs[row * KS + 2 * ar]) = (unsigned)h0 | ((unsigned)h1 << 16);
-                if (SPLIT) {
-                    const unsigned short l0 = f2bf(x0[q] - bf2f(h0)), l1 = f2bf(x1[q] - bf2f(h1));
-                    *reinterpret_cast<unsigned*>(&Xs[BM * KS + row * KS + 2 * ar]) = (unsigned)l0 | ((unsigned)l1 << 16);
-                }
-            }
-        }
-        // stage M: KT rows of the (zero padded) bond matrix, transposed to [column][k]
-        for (int idx = tid; idx < KT * (BN / 4); idx += T) {
-            const int r = idx / (BN / 4), c4 = idx % (BN / 4);
-            const int j = j0 + c4 * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (j < A.Np) v = *reinterpret_cast<const float4*>(M + (size_t)(k0 + r) * A.Np + j);
-            const float mv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const unsigned short h = f2bf(mv[q]);
-                Ms[(c4 * 4 + q) * KS + r] = h;
-                if (SPLIT) Ms[BN * KS + (c4 * 4 + q) * KS + r] = f2bf(mv[q] - bf2f(h));
-            }
-        }
-        __syncthreads();
-        {
-            const int ko = 8 * (lane >> 4);
-            bf16x8 ah[RT], bh[CT], al[SPLIT ? RT : 1], bl[SPLIT ? CT : 1];
-#pragma unroll
-            for (int r = 0; r < RT; ++r) {
-                ah[r] = *reinterpret_cast<const bf16x8*>(&Xs[((wr * RT + r) * 16 + (lane & 15)) * KS + ko]);
-                if (SPLIT) al[r] = *reinterpret_cast<const bf16x8*>(&Xs[BM * KS + ((wr * RT + r) * 16 + (lane & 15)) * KS + ko]);
-            }
-#pragma unroll
-            for (int c = 0; c < CT; ++c) {
-                bh[c] = *reinterpret_cast<const bf16x8*>(&Ms[((wc * CT + c) * 16 + (lane & 15)) * KS + ko]);
-                if (SPLIT) bl[c] = *reinterpret_cast<const bf16x8*>(&Ms[BN * KS + ((wc * CT + c) * 16 + (lane & 15)) * KS + ko]);
-            }
-#pragma unroll
-            for (int r = 0; r < RT; ++r)
-#pragma unroll
-                for (int c = 0; c < CT; ++c) {
-                    if (SPLIT) {                                   // small terms first
-                        acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[r], bh[c], acc[r][c], 0, 0, 0);
-                        acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[r], bl[c], acc[r][c], 0, 0, 0);
-                    }
-                    acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[r], bh[c], acc[r][c], 0, 0, 0);
-                }
-        }
-        __syncthreads();
-    }
-
-    // epilogue: C fragment = 4 consecutive images (rows) x 1 column per lane (as k_fgemm)
-    float* out = A.out + (size_t)l * A.out_lstride;
-#pragma unroll
-    for (int r = 0; r < RT; ++r) {
-        const int n = n0 + (wr * RT + r) * 16 + (lane >> 4) * 4;
-#pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            const int j = j0 + (wc * CT + c) * 16 + (lane & 15);
-            if (TO == 2) {
-                const int t = j & 1, q = j >> 1;
-                const float4 ph = *reinterpret_cast<const float4*>(A.phiO + (size_t)t * NTp + n);
-                float4 v = make_float4(acc[r][c][0] * ph.x, acc[r][c][1] * ph.y, acc[r][c][2] * ph.z, acc[r][c][3] * ph.w);
-                v.x += __shfl_xor(v.x, 1); v.y += __shfl_xor(v.y, 1);
-                v.z += __shfl_xor(v.z, 1); v.w += __shfl_xor(v.w, 1);
-                if (t == 0 && q < A.mO) *reinterpret_cast<float4*>(out + (size_t)q * NTp + n) = v;
-            } else {
-                if (j < A.mO)
-                    *reinterpret_cast<float4*>(out + (size_t)j * NTp + n) = make_float4(acc[r][c][0], acc[r][c][1], acc[r][c][2], acc[r][c][3]);
-            }
-        }
-    }
-}
-
-template <int RT, int CT, int WR, int WC>
-static void fgemm_bf16_go(tnml_ctx* c, const FgemmArgs& a, int split) {
-    constexpr int BM = 16 * RT * WR, BN = 16 * CT * WC;
-    dim3 grid(a.NTp / BM, (a.Np + BN - 1) / BN, a.L);
-    dim3 block(64 * WR * WC);
-    if (split) hipLaunchKernelGGL((k_fgemm_bf16<RT, CT, WR, WC, 2, 1>), grid, block, 0, c->stream, a);
-    else       hipLaunchKernelGGL((k_fgemm_bf16<RT, CT, WR, WC, 2, 0>), grid, block, 0, c->stream, a);
-}
-
-int launch_fgemm(tnml_ctx* c, const FgemmArgs& a) {
-    ProfScope ps(c, a.phiO ? KC_FGEMM_FWD : KC_FGEMM_SHIFT);
-    if (a.NTp % TNML_NTPAD) return tnml_fail(c, "fgemm: NTp not padded");
-    if (c->bf16() && a.phiO) {                              // forward pass on the bf16 matrix pipe (the reduction runs in chunks of 32: Kp is a multiple of 16, the
-        if (a.Kp % 32) return tnml_fail(c, "fgemm (bf16): the padded reduction dimension %d is not a multiple of 32", a.Kp);   // bond plan pads to 32 in these modes)
-        if (a.Np > 64) fgemm_bf16_go<4, 4, 2, 2>(c, a, c->bf16() == 2);   // 128 x 128
-        else           fgemm_bf16_go<4, 2, 2, 2>(c, a, c->bf16() == 2);   // 128 x 64
-        HIPCK(c, hipGetLastError());
-        return 0;
-    }
-    if (a.Np == 240)      fgemm_go<4, 5, 2, 3>(c, a);      // m = 120: exactly 15 column tiles, no padding waste
-    else if (a.Np > 64)   fgemm_go<4, 4, 2, 2>(c, a);      // 128 x 128 tiles
-    else if (a.Np > 32)   fgemm_go<4, 2, 2, 2>(c, a);      // 128 x 64
-    else                  fgemm_go<4, 1, 2, 2>(c, a);      // 128 x 32
-    HIPCK(c, hipGetLastError());
-    return 0;
-}
-
-// ------------------------------------------------------------------------------------------
-struct BgemmKArgs {
-    BgemmArgs a;
-    float* slab;
-    int nsplit, imgs_per_split;
-};
-
-template <int RT, int CT, int WR, int WC>
-__global__ __launch_bounds__(64 * WR * WC) void k_bgemm(BgemmKArgs K) {
-    constexpr int T = 64 * WR * WC, BMr = 16 * RT * WR, BNc = 16 * CT * WC, KTn = 32, ST = KTn + 4;
-    __shared__ __attribute__((aligned(16))) float lds[(BMr + BNc) * ST];
-    float* As = lds;
-    float* Bs = lds + BMr * ST;
-    const BgemmArgs& A = K.a;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wr = wid / WC, wc = wid % WC;
-    const int i0 = blockIdx.x * BMr, j0 = blockIdx.y * BNc;
-    const int split = blockIdx.z % K.nsplit, l = blockIdx.z / K.nsplit;
-    const int NTp = A.NTp;
-    const int nbeg = split * K.imgs_per_split;
-    const int nend = min(nbeg + K.imgs_per_split, NTp);
-    const float* w = A.w ? A.w + (size_t)l * A.w_lstride : nullptr;
-
-    f32x4 acc[RT][CT];
-#pragma unroll
-    for (int r = 0; r < RT; ++r)
-#pragma unroll
-        for (int c = 0; c < CT; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    for (int nb = nbeg; nb < nend; nb += KTn) {
-        for (int idx = tid; idx < (BMr / 2) * (KTn / 4); idx += T) {
-            const int ar = idx / (KTn / 4), c4 = idx % (KTn / 4);
-            const int a = i0 / 2 + ar, n = nb + c4 * 4;
-            float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a < A.mI) e = *reinterpret_cast<const float4*>(A.EI + (size_t)a * NTp + n);
-            const float4 p0 = *reinterpret_cast<const float4*>(A.phiI + n);
-            const float4 p1 = *reinterpret_cast<const float4*>(A.phiI + NTp + n);
-            *reinterpret_cast<float4*>(&As[(2 * ar) * ST + c4 * 4]) = mul4(e, p0);
-            *reinterpret_cast<float4*>(&As[(2 * ar + 1) * ST + c4 * 4]) = mul4(e, p1);
-        }
-        for (int idx = tid; idx < (BNc / 2) * (KTn / 4); idx += T) {
-            const int qr = idx / (KTn / 4), c4 = idx % (KTn / 4);
-            const int q = j0 / 2 + qr, n = nb + c4 * 4;
-            float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (q < A.mO) z = *reinterpret_cast<const float4*>(A.Zq + (size_t)q * NTp + n);
-            if (w) z = mul4(z, *reinterpret_cast<const float4*>(w + n));
-            const float4 p0 = *reinterpret_cast<const float4*>(A.phiO + n);
-            const float4 p1 = *reinterpret_cast<const float4*>(A.phiO + NTp + n);
-            *reinterpret_cast<float4*>(&Bs[(2 * qr) * ST + c4 * 4]) = mul4(z, p0);
-            *reinterpret_cast<float4*>(&Bs[(2 * qr + 1) * ST + c4 * 4]) = mul4(z, p1);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < KTn; kk += 16) {
-            // lane group g = lane>>4 owns images kk+4g..kk+4g+3; MFMA step e uses element e of every
-            // group (a permutation of the reduction index, identical for A and B)
-            float4 a[RT], b[CT];
-            const int ko = kk + 4 * (lane >> 4);
-#pragma unroll
-            for (int r = 0; r < RT; ++r) a[r] = *reinterpret_cast<const float4*>(&As[((wr * RT + r) * 16 + (lane & 15)) * ST + ko]);
-#pragma unroll
-            for (int c = 0; c < CT; ++c) b[c] = *reinterpret_cast<const float4*>(&Bs[((wc * CT + c) * 16 + (lane & 15)) * ST + ko]);
-#pragma unroll
-            for (int r = 0; r < RT; ++r)
-#pragma unroll
-                for (int c = 0; c < CT; ++c) {
-                    acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].x, b[c].x, acc[r][c], 0, 0, 0);
-                    acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].y, b[c].y, acc[r][c], 0, 0, 0);
-                    acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].z, b[c].z, acc[r][c], 0, 0, 0);
-                    acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].w, b[c].w, acc[r][c], 0, 0, 0);
-                }
-        }
-        __syncthreads();
-    }
-
-    float* slab = K.slab + ((size_t)split * A.L + l) * A.Kp * A.Np;
-#pragma unroll
-    for (int r = 0; r < RT; ++r)
-#pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            const int j = j0 + (wc * CT + c) * 16 + (lane & 15);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int i = i0 + (wr * RT + r) * 16 + (lane >> 4) * 4 + e;
-                if (i < A.Kp && j < A.Np) slab[(size_t)i * A.Np + j] = acc[r][c][e];
-            }
-        }
-}
-
-__global__ void k_slab_reduce(const float* __restrict__ slab, double* __restrict__ G, size_t n, int nsplit) {
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double s = 0.;
-    for (int k = 0; k < nsplit; ++k) s += (double)slab[(size_t)k * n + i];
-    G[i] = s;
-}
-
-template <int RT, int CT, int WR, int WC>
-static int bgemm_go(tnml_ctx* c, const BgemmArgs& a, double* G) {
-    constexpr int BMr = 16 * RT * WR, BNc = 16 * CT * WC;
-    const int tiles = ((a.Kp + BMr - 1) / BMr) * ((a.Np + BNc - 1) / BNc) * a.L;
-    int nsplit = (1024 + tiles - 1) / tiles;
-    const int chunks = a.NTp / 32;
-    if (nsplit > chunks) nsplit = chunks;
-    if (nsplit < 1) nsplit = 1;
-    const size_t n = (size_t)a.L * a.Kp * a.Np;
-    const size_t cap = c->slab_bytes / sizeof(float);
-    while (nsplit > 1 && (size_t)nsplit * n > cap) --nsplit;
-    if ((size_t)nsplit * n > cap) return tnml_fail(c, "bgemm: slab workspace too small");
-    int per = ((chunks + nsplit - 1) / nsplit) * 32;
-    nsplit = (a.NTp + per - 1) / per;
-    BgemmKArgs K{a, (float*)c->slab, nsplit, per};
-    {
-        ProfScope ps(c, KC_BGEMM);
-        dim3 grid((a.Kp + BMr - 1) / BMr, (a.Np + BNc - 1) / BNc, nsplit * a.L);
-        hipLaunchKernelGGL((k_bgemm<RT, CT, WR, WC>), grid, dim3(64 * WR * WC), 0, c->stream, K);
-    }
-    {
-        ProfScope ps(c, KC_SLABRED);
-        hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const float*)c->slab, G, n, nsplit);
-    }
-    HIPCK(c, hipGetLastError());
-    return 0;
-}
-
-int launch_bgemm(tnml_ctx* c, const BgemmArgs& a, double* G) {
-    if (a.Kp % 80 == 0 && a.Np % 80 == 0) return bgemm_go<1, 5, 5, 1>(c, a, G);   // 80 x 80 tiles (m = 40k: 240 = 3*80)
-    if (a.Kp > 32 && a.Np > 32) return bgemm_go<2, 2, 2, 2>(c, a, G);             // 64 x 64
-    return bgemm_go<1, 1, 2, 2>(c, a, G);                                         // 32 x 32
-}
-
 // ==========================================================================================
 // fp64 MFMA flavour
 // ==========================================================================================
@@ -453,10 +74,11 @@ template <> struct V2<double> {
 // Software pipelined: the global loads of chunk k+1 are issued before the MFMA phase of chunk k and
 // land in registers; they are widened to fp64 and written to LDS after the MFMAs (two barriers per
 // chunk, one LDS buffer), so the L2/HBM latency of the operands hides behind the matrix pipe.
-// ABL (tools/probe/kbench_fgemm.hip only): 1 = no MFMA, 2 = no operand staging inside the loop, 3 = also no LDS fragment loads
+// (Double- and triple-buffered LDS variants and the ablation switches of rounds 1-3 are gone: their numbers are in
+// profiles/r01_tune_fgemm64*.txt, the kernel is the one-buffer form every launcher uses.)
 // TE: storage type of environments and features; TO = 2: contract with the output-site feature
 // (forward pass), TO = 1: no output site index (environment shift in strict fp64 mode).
-template <int RT, int CT, int WR, int WC, int KT, int DB, int ABL = 0, typename TE = float, int TO = 2>
+template <int RT, int CT, int WR, int WC, int KT, typename TE = float, int TO = 2>
 __global__ __launch_bounds__(64 * WR * WC) void k_fgemm64(Fgemm64Args A) {
     constexpr int T = 64 * WR * WC, BM = 16 * RT * WR, BN = 16 * CT * WC;
     constexpr int XS = BM + 16;                          // doubles; (XS*2) % 64 == 32 -> conflict-free ds_read_b64
@@ -466,7 +88,7 @@ __global__ __launch_bounds__(64 * WR * WC) void k_fgemm64(Fgemm64Args A) {
     constexpr int NX = (NXI + T - 1) / T, NM = (NMI + T - 1) / T;
     static_assert(T % (BM / 4) == 0, "feature columns must be fixed per thread");
     constexpr int LB = KT * XS + KT * MS;                // doubles per LDS buffer
-    __shared__ __attribute__((aligned(16))) double lds[(DB + 1) * LB];
+    __shared__ __attribute__((aligned(16))) double lds[LB];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid / WC, wc = wid % WC;
@@ -545,8 +167,7 @@ __global__ __launch_bounds__(64 * WR * WC) void k_fgemm64(Fgemm64Args A) {
         for (int c = 0; c < CT; ++c)
 #pragma unroll
             for (int r = 0; r < RT; ++r) {        // D[i = column j of M][j = image]
-                if (ABL == 1) acc[c][r][0] += mf[c] * xf[r];
-                else acc[c][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(mf[c], xf[r], acc[c][r], 0, 0, 0);
+                acc[c][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(mf[c], xf[r], acc[c][r], 0, 0, 0);
             }
     };
     constexpr int KS = KT / 4;
@@ -554,59 +175,24 @@ __global__ __launch_bounds__(64 * WR * WC) void k_fgemm64(Fgemm64Args A) {
     double xf[2][RT], mf[2][CT];
     const int nc = A.Kp / KT;
 
-    if (DB == 2) {
-        // three LDS buffers: chunk c lives in buffer c%3.  The barrier sits at the START of an iteration
-        // (it publishes the chunk stored one iteration ago and frees the buffer read two iterations
-        // ago); nothing right after it depends on this iteration's LDS writes, so the fragments of the
-        // next chunk are prefetched during the last k-step and the matrix pipe never drains.
-        load_chunk(0); store_chunk(lds, lds + KT * XS);
-        if (nc > 1) { load_chunk(KT); store_chunk(lds + LB, lds + LB + KT * XS); }
-        if (nc > 2) load_chunk(2 * KT);
-        __syncthreads();
-        frag_load(lds, lds + KT * XS, 0, xf[0], mf[0]);
-        for (int c = 0; c < nc; ++c) {
-            if (c > 0) __syncthreads();
-            if (ABL != 2) {
-                if (c + 2 < nc) { double* Xn = lds + ((c + 2) % 3) * LB; store_chunk(Xn, Xn + KT * XS); }
-                if (c + 3 < nc) load_chunk((c + 3) * KT);
-            }
-            const double* Xb = lds + (c % 3) * LB;
-            const double* Mb = Xb + KT * XS;
+    load_chunk(0);
+    store_chunk(lds, lds + KT * XS);
+    __syncthreads();
+    const double* Xb = lds;
+    const double* Mb = lds + KT * XS;
+    for (int k0 = 0; k0 < A.Kp; k0 += KT) {
+        const bool more = k0 + KT < A.Kp;
+        if (more) load_chunk(k0 + KT);                       // in flight during the MFMA phase
+        frag_load(Xb, Mb, 0, xf[0], mf[0]);
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                if (ks + 1 < KS) frag_load(Xb, Mb, ks + 1, xf[(ks + 1) & 1], mf[(ks + 1) & 1]);
-                else if (c + 1 < nc) { const double* Xn = lds + ((c + 1) % 3) * LB; frag_load(Xn, Xn + KT * XS, 0, xf[0], mf[0]); }
-                mfma_step(xf[ks & 1], mf[ks & 1]);
-            }
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 1 < KS) frag_load(Xb, Mb, ks + 1, xf[(ks + 1) & 1], mf[(ks + 1) & 1]);
+            mfma_step(xf[ks & 1], mf[ks & 1]);
         }
-    } else {
-        load_chunk(0);
-        store_chunk(lds, lds + KT * XS);
-        __syncthreads();
-        int cur = 0;
-        for (int k0 = 0; k0 < A.Kp; k0 += KT) {
-            const bool more = k0 + KT < A.Kp;
-            if (more && ABL != 2 && ABL != 3) load_chunk(k0 + KT);       // in flight during the MFMA phase
-            const double* Xb = lds + (DB ? cur * LB : 0);
-            const double* Mb = Xb + KT * XS;
-            if (ABL != 3 || k0 == 0) frag_load(Xb, Mb, 0, xf[0], mf[0]);
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                if (ks + 1 < KS && (ABL != 3 || k0 == 0)) frag_load(Xb, Mb, ks + 1, xf[(ks + 1) & 1], mf[(ks + 1) & 1]);
-                mfma_step(xf[ks & 1], mf[ks & 1]);
-            }
-            if (more && ABL != 2 && ABL != 3) {
-                if (DB) {                                    // other buffer: no wave can still be reading it
-                    double* Xn = lds + (cur ^ 1) * LB;
-                    store_chunk(Xn, Xn + KT * XS);
-                    __syncthreads();
-                    cur ^= 1;
-                } else {
-                    __syncthreads();                         // every wave is done reading this chunk
-                    store_chunk(lds, lds + KT * XS);
-                    __syncthreads();
-                }
-            }
+        if (more) {
+            __syncthreads();                                 // every wave is done reading this chunk
+            store_chunk(lds, lds + KT * XS);
+            __syncthreads();
         }
     }
 
@@ -636,7 +222,7 @@ __global__ __launch_bounds__(64 * WR * WC) void k_fgemm64(Fgemm64Args A) {
     }
 }
 
-template <int RT, int CT, int WR, int WC, int KT, int DB = 0>
+template <int RT, int CT, int WR, int WC, int KT>
 static void fgemm64_go(tnml_ctx* c, const Fgemm64Args& a) {
     constexpr int BM = 16 * RT * WR, BN = 16 * CT * WC;
     const int cnt = a.n_cnt ? a.n_cnt : a.NTp;
@@ -644,95 +230,34 @@ static void fgemm64_go(tnml_ctx* c, const Fgemm64Args& a) {
     dim3 block(64 * WR * WC);
     hipStream_t st = a.st ? a.st : c->stream;
     if (!a.phiO) {                                        // shift form (TO = 1): no second feature on the columns
-        if constexpr (DB == 0 && CT != 5) {
-            if (a.env64) hipLaunchKernelGGL((k_fgemm64<RT, CT, WR, WC, KT, 0, 0, double, 1>), grid, block, 0, st, a);
-            else         hipLaunchKernelGGL((k_fgemm64<RT, CT, WR, WC, KT, 0, 0, float, 1>), grid, block, 0, st, a);
+        if constexpr (CT != 5) {
+            if (a.env64) hipLaunchKernelGGL((k_fgemm64<RT, CT, WR, WC, KT, double, 1>), grid, block, 0, st, a);
+            else         hipLaunchKernelGGL((k_fgemm64<RT, CT, WR, WC, KT, float, 1>), grid, block, 0, st, a);
         }
     }
-    else if (!a.env64) hipLaunchKernelGGL((k_fgemm64<RT, CT, WR, WC, KT, DB, 0, float, 2>), grid, block, 0, st, a);
-    else               hipLaunchKernelGGL((k_fgemm64<RT, CT, WR, WC, KT, DB, 0, double, 2>), grid, block, 0, st, a);
+    else if (!a.env64) hipLaunchKernelGGL((k_fgemm64<RT, CT, WR, WC, KT, float, 2>), grid, block, 0, st, a);
+    else               hipLaunchKernelGGL((k_fgemm64<RT, CT, WR, WC, KT, double, 2>), grid, block, 0, st, a);
 }
 
 int launch_fgemm64(tnml_ctx* c, const Fgemm64Args& a) {
     ProfScope ps(c, a.kclass >= 0 ? a.kclass : (a.phiO ? KC_FGEMM_FWD : KC_FGEMM_SHIFT), a.st);
     if (a.NTp % TNML_NTPAD) return tnml_fail(c, "fgemm64: NTp not padded");
     if (a.n_cnt && (a.n_cnt % 128 || a.n_off % 128)) return tnml_fail(c, "fgemm64: image range must be a multiple of 128");
-    const int cfg = c->opt_fg64_cfg;                         // tuning knob (env TNML_FG64_CFG / tnml_set_option "fg64_cfg"; tools/tune_fgemm.sh)
+    // Tile choices: the winners of the tuning runs recorded under profiles/ (r01_tune_fgemm64*.txt, r01_tune_shift.txt, r02_tune_m60.txt,
+    // r03_tune_m300.txt, tools/tune_shard.sh); the losing instantiations are gone.  Option "fg64_cfg" = 2 forces the large-image-count
+    // tiles at any image count (the parity tests run BASELINE config 3's instantiations at oracle-sized image counts).
+    const bool big = c->opt_fg64_cfg == 2;
     if (a.Np == 240 && a.phiO) {                             // m = 120: exactly 15 column tiles, no padding waste
-        switch (cfg) {
-            case 1:  fgemm64_go<1, 5, 4, 3, 16>(c, a); break;   // 64 x 240, 12 waves
-            case 2:  fgemm64_go<2, 5, 4, 3, 16>(c, a); break;   // 128 x 240, 12 waves
-            case 3:  fgemm64_go<4, 5, 2, 3, 16>(c, a); break;   // 128 x 240, 6 waves
-            case 4:  fgemm64_go<2, 5, 2, 3, 8>(c, a); break;    // 64 x 240, 6 waves, KT 8
-            case 5:  fgemm64_go<1, 5, 4, 3, 8>(c, a); break;
-            case 6:  fgemm64_go<2, 3, 2, 5, 16>(c, a); break;   // 64 x 240, 10 waves
-            case 7:  fgemm64_go<4, 3, 2, 5, 16>(c, a); break;   // 128 x 240, 10 waves
-            case 8:  fgemm64_go<2, 5, 4, 3, 32>(c, a); break;   // 128 x 240, 12 waves, KT 32
-            case 9:  fgemm64_go<2, 5, 4, 3, 8>(c, a); break;    // 128 x 240, 12 waves, KT 8
-            case 10: fgemm64_go<1, 5, 4, 3, 32>(c, a); break;   // 64 x 240, 12 waves, KT 32
-            case 11: fgemm64_go<2, 5, 4, 3, 16, 1>(c, a); break; // 128 x 240, 12 waves, double-buffered LDS
-            case 12: fgemm64_go<1, 5, 4, 3, 16, 1>(c, a); break; // 64 x 240, 12 waves, double-buffered
-            case 13: fgemm64_go<2, 5, 4, 3, 8, 1>(c, a); break;  // KT 8, double-buffered
-            case 14: fgemm64_go<2, 5, 2, 3, 16, 1>(c, a); break; // 64 x 240, 6 waves, double-buffered
-            case 15: fgemm64_go<2, 5, 4, 3, 16, 2>(c, a); break; // 128 x 240, 12 waves, 3 LDS buffers
-            case 16: fgemm64_go<1, 5, 4, 3, 16, 2>(c, a); break; // 64 x 240, 12 waves, 3 LDS buffers
-            case 17: fgemm64_go<1, 5, 5, 3, 16, 2>(c, a); break; // 80 x 240, 15 waves, 3 LDS buffers
-            case 18: fgemm64_go<2, 5, 2, 3, 16>(c, a); break;   // 64 x 240, 6 waves
-            case 19: fgemm64_go<1, 5, 2, 3, 16>(c, a); break;   // 32 x 240, 6 waves (several workgroups per CU)
-            case 20: fgemm64_go<1, 5, 4, 3, 8>(c, a); break;    // 64 x 240, 12 waves, KT 8
-            case 21: fgemm64_go<1, 4, 4, 2, 16>(c, a); break;   // 64 x 128 (two column tiles), 8 waves
-            case 22: fgemm64_go<2, 4, 2, 2, 16>(c, a); break;   // 64 x 128, 4 waves
-            case 23: fgemm64_go<1, 4, 2, 2, 16>(c, a); break;   // 32 x 128, 4 waves
-            case 24: fgemm64_go<2, 4, 4, 2, 16>(c, a); break;   // 128 x 128, 8 waves
-            default:
-                // 128 x 240, 12 waves is the best tile when the images fill the chip (profiles/r01_tune_fgemm64.txt); a rank
-                // with few images (multi-GPU shards, small sets) gets smaller row tiles so that every CU has a workgroup
-                if (a.NTp / 128 >= 192)     fgemm64_go<2, 5, 4, 3, 16>(c, a);   // (an image half of a split launch keeps the tile of the whole)
-                else if (a.NTp / 64 >= 192) fgemm64_go<1, 5, 4, 3, 16>(c, a);   // 64 x 240, 12 waves
-                else                        fgemm64_go<1, 4, 4, 2, 16>(c, a);   // 64 x 128 (two column tiles), 8 waves: 7500 images 30.5 TF vs 26.2 with 32 x 240
-                break;
-        }
+        // a rank with few images (multi-GPU shards, small sets) gets smaller row tiles so that every CU has a workgroup
+        if (big || a.NTp / 128 >= 192) fgemm64_go<2, 5, 4, 3, 16>(c, a);   // 128 x 240, 12 waves
+        else if (a.NTp / 64 >= 192)    fgemm64_go<1, 5, 4, 3, 16>(c, a);   // 64 x 240, 12 waves
+        else                           fgemm64_go<1, 4, 4, 2, 16>(c, a);   // 64 x 128 (two column tiles), 8 waves: 7500 images 30.5 TF vs 26.2 with 32 x 240
     }
-    else if (a.Np > 64 && !a.phiO) {                          // shift form at m up to 128 (Label-carrying: grid.z = 10)
-        static const int scfg = getenv("TNML_FG64_SHIFT_CFG") ? atoi(getenv("TNML_FG64_SHIFT_CFG")) : 0;
-        switch (scfg) {
-            case 1:  fgemm64_go<2, 4, 4, 2, 16>(c, a); break;   // 128 x 128, 8 waves
-            case 2:  fgemm64_go<4, 4, 2, 2, 16>(c, a); break;   // 128 x 128, 4 waves
-            case 3:  fgemm64_go<2, 2, 4, 4, 16>(c, a); break;   // 128 x 128, 16 waves
-            case 4:  fgemm64_go<4, 2, 2, 4, 16>(c, a); break;   // 128 x 128, 8 waves
-            case 5:  fgemm64_go<2, 4, 2, 2, 16>(c, a); break;   // 64 x 128, 4 waves
-            case 6:  fgemm64_go<1, 4, 4, 2, 16>(c, a); break;   // 64 x 128, 8 waves
-            case 7:  fgemm64_go<2, 4, 6, 2, 16>(c, a); break;   // 192 x 128, 12 waves
-            case 8:  fgemm64_go<4, 4, 4, 2, 16>(c, a); break;   // 256 x 128, 8 waves
-            default: fgemm64_go<2, 4, 4, 2, 8>(c, a); break;    // 128 x 128, 8 waves, KT 8: best of tools/tune_shift.sh (profiles/r01_tune_shift.txt)
-        }
-    }
-    else if (a.Np > 256) {                                    // forward pass at maxm > 120 (BASELINE config 5: 600 columns)
-        static const int bcfg = getenv("TNML_FG64_BIG_CFG") ? atoi(getenv("TNML_FG64_BIG_CFG")) : 0;   // tools/tune_m300.sh, profiles/r03_tune_m300.txt
-        switch (bcfg) {
-            case 1:  fgemm64_go<2, 4, 2, 2, 16>(c, a); break;   // 64 x 128, 4 waves (the round-2 choice below 24 576 images)
-            case 2:  fgemm64_go<2, 4, 4, 2, 16>(c, a); break;   // 128 x 128, 8 waves
-            case 3:  fgemm64_go<2, 4, 4, 2, 8>(c, a); break;    // 128 x 128, 8 waves, KT 8
-            case 4:  fgemm64_go<1, 4, 4, 2, 16>(c, a); break;   // 64 x 128, 8 waves
-            case 5:  fgemm64_go<2, 5, 4, 2, 16>(c, a); break;   // 128 x 160, 8 waves
-            case 6:  fgemm64_go<1, 5, 4, 4, 16>(c, a); break;   // 64 x 320, 16 waves
-            case 7:  fgemm64_go<2, 5, 4, 3, 16>(c, a); break;   // 128 x 240, 12 waves (the m = 120 tile)
-            case 8:  fgemm64_go<1, 5, 4, 3, 16>(c, a); break;   // 64 x 240, 12 waves
-            case 9:  fgemm64_go<2, 2, 4, 4, 16>(c, a); break;   // 128 x 128, 16 waves
-            default: fgemm64_go<2, 5, 4, 2, 16>(c, a); break;   // 128 x 160, 8 waves: 122 us at m = 300, 7 500 images (64 x 128, 4 waves: 199 us)
-        }
-    }
+    else if (a.Np > 64 && !a.phiO) fgemm64_go<2, 4, 4, 2, 8>(c, a);         // shift form at m up to 128 (Label-carrying: grid.z = 10): 128 x 128, 8 waves, KT 8
+    else if (a.Np > 256)           fgemm64_go<2, 5, 4, 2, 16>(c, a);        // forward pass at maxm > 120 (BASELINE config 5: 600 columns): 128 x 160, 8 waves
     else if (a.Np > 64) {                                     // forward pass at 32 < m <= 64 (bonds that have shrunk towards minm)
-        static const int gcfg = getenv("TNML_FG64_GEN_CFG") ? atoi(getenv("TNML_FG64_GEN_CFG")) : 0;   // tools/tune_m60.sh, profiles/r02_tune_m60.txt
-        switch (gcfg) {
-            case 2:  fgemm64_go<2, 4, 4, 2, 16>(c, a); break;   // 128 x 128, 8 waves
-            case 3:  fgemm64_go<1, 4, 4, 2, 16>(c, a); break;   // 64 x 128, 8 waves
-            case 4:  fgemm64_go<2, 2, 4, 4, 16>(c, a); break;   // 128 x 128, 16 waves
-            case 5:  fgemm64_go<2, 4, 2, 2, 16>(c, a); break;   // 64 x 128, 4 waves (the round-1 choice: 53 us at m = 60)
-            default: if (a.NTp >= 128 * 192 || c->opt_fg64_cfg == 2) fgemm64_go<2, 4, 4, 2, 8>(c, a);   // 128 x 128, 8 waves, KT 8: 46 us at m = 60, 60 000 images ("fg64_cfg" = 2 forces it for parity tests)
-                     else                    fgemm64_go<2, 4, 2, 2, 16>(c, a);
-                     break;
-        }
+        if (big || a.NTp >= 128 * 192) fgemm64_go<2, 4, 4, 2, 8>(c, a);    // 128 x 128, 8 waves, KT 8: 46 us at m = 60, 60 000 images
+        else                           fgemm64_go<2, 4, 2, 2, 16>(c, a);   // 64 x 128, 4 waves
     }
     else if (a.Np > 32)   fgemm64_go<2, 2, 2, 2, 16>(c, a);     // 64 x 64
     else                  fgemm64_go<2, 1, 2, 2, 16>(c, a);     // 64 x 32
@@ -980,8 +505,7 @@ template <int RT, int CT, int WR, int WC, int FUSE = 0>
 static int bgemm64_go(tnml_ctx* c, const Bgemm64Args& a, double* G, int default_wgs = 768) {
     constexpr int BMr = 16 * RT * WR, BNc = 16 * CT * WC;
     const int tiles = ((a.Kp + BMr - 1) / BMr) * ((a.Np + BNc - 1) / BNc) * a.L;
-    static const int env_wgs = getenv("TNML_BG64_WGS") ? atoi(getenv("TNML_BG64_WGS")) : 0;
-    const int target_wgs = env_wgs > 0 ? env_wgs : default_wgs;
+    const int target_wgs = default_wgs;
     int nsplit = (target_wgs + tiles - 1) / tiles;
     const int chunks = a.NTp / 32;
     if (nsplit > chunks) nsplit = chunks;
@@ -992,8 +516,7 @@ static int bgemm64_go(tnml_ctx* c, const Bgemm64Args& a, double* G, int default_
     if ((size_t)nsplit * n > cap) return tnml_fail(c, "bgemm64: slab workspace too small");
     int per = ((chunks + nsplit - 1) / nsplit) * 32;
     nsplit = (a.NTp + per - 1) / per;
-    static const int nt = getenv("TNML_BG_NT") ? atoi(getenv("TNML_BG_NT")) : 1;
-    Bgemm64KArgs K{a, (double*)c->slab, nsplit, per, nt};
+    Bgemm64KArgs K{a, (double*)c->slab, nsplit, per, 1};       // non-temporal loads of the Label-carrying environment: +1.3 % (profiles/r01_ab_nt_loads.txt)
     {
         ProfScope ps(c, KC_BGEMM);
         dim3 grid((a.Kp + BMr - 1) / BMr, (a.Np + BNc - 1) / BNc, nsplit * a.L);
@@ -1013,62 +536,16 @@ void launch_slab_reduce64(tnml_ctx* c, const double* slab, double* G, size_t n, 
 }
 
 int launch_bgemm64(tnml_ctx* c, const Bgemm64Args& a, double* G) {
-    static const int cfg = getenv("TNML_BG64_CFG") ? atoi(getenv("TNML_BG64_CFG")) : 0;
+    // Tile choices: the winners of the tuning runs recorded under profiles/ (r01 tune_bgemm, r02_tune_m60.txt, r03_tune_m300.txt,
+    // r03_tune_bgemm_wide_tiles.txt, r03_ab_bgemm_double_buffer_and_ablation.txt); the losing instantiations are gone.
     if (a.EL) {                                             // fused Z build: >= 320 lanes per workgroup
-        static const int fcfg = getenv("TNML_BGF_CFG") ? atoi(getenv("TNML_BGF_CFG")) : 0;
-        if (a.Kp % 240 == 0 && a.Np % 240 == 0) {
-            if (fcfg == 1) return bgemm64_go<5, 1, 3, 5, 1>(c, a, G, 255 * a.L);   // 240 x 80, 15 waves (128-VGPR cap: spills)
-            if (fcfg == 2) return bgemm64_go<5, 1, 3, 3, 1>(c, a, G, 255 * a.L);   // 240 x 48, 9 waves
-            if (fcfg == 3) return bgemm64_go<5, 2, 3, 4, 1>(c, a, G, 256 * a.L);   // 240 x 128, 12 waves: the Label-free environment is read twice, not four times
-            if (fcfg == 4) return bgemm64_go<4, 2, 2, 4, 1>(c, a, G, 256 * a.L);   // 128 x 128, 8 waves
-            if (fcfg == 6) return bgemm64_go<5, 2, 3, 2, 1>(c, a, G, 256 * a.L);   // 240 x 64, 6 waves
-            if (fcfg == 7) return bgemm64_go<5, 2, 3, 4, 1>(c, a, G, 512 * a.L);   // 240 x 128, two workgroups' worth of image splits per CU
-            if (fcfg == 8) return bgemm64_go<5, 1, 3, 4, 1>(c, a, G, 512 * a.L);   // 240 x 64, 12 waves, twice the image splits
-            return bgemm64_go<5, 1, 3, 4, 1>(c, a, G, 256 * a.L);                  // 240 x 64, 12 waves: 187 us vs 153+90 unfused
-        }
-        if (a.Kp % 80 == 0 && a.Np % 80 == 0) return bgemm64_go<1, 5, 5, 1, 1>(c, a, G);               // 80 x 80, 5 waves
-        static const int gcfg = getenv("TNML_BGF_GEN_CFG") ? atoi(getenv("TNML_BGF_GEN_CFG")) : 0;
-        if (a.Kp % 128 == 0 && a.Np % 64 == 0) {                                                       // m = 33..64
-            if (gcfg == 1) return bgemm64_go<4, 1, 2, 4, 1>(c, a, G);                                  // 128 x 64, 8 waves
-            if (gcfg == 3) return bgemm64_go<4, 2, 2, 4, 1>(c, a, G);                                  // 128 x 128, 8 waves: 151 us
-            if (gcfg == 4) return bgemm64_go<2, 2, 4, 4, 1>(c, a, G);                                  // 128 x 128, 16 waves: 124 us
-            if (gcfg != 7) return bgemm64_go<2, 2, 4, 2, 1>(c, a, G);                                  // 128 x 64, 8 waves: 70 us at m = 60 (96 x 64 tiles: 133 us)
-        }
-        if (a.Kp >= 256 && a.Np >= 256) {                                                              // maxm > 120 (BASELINE config 5: 600 x 600)
-            static const int lcfg = getenv("TNML_BGF_BIG_CFG") ? atoi(getenv("TNML_BGF_BIG_CFG")) : 0;   // tools/tune_m300.sh, profiles/r03_tune_m300.txt
-            switch (lcfg) {
-                case 1:  return bgemm64_go<2, 2, 3, 2, 1>(c, a, G);                                    // 96 x 64, 6 waves (the round-2 fallback: 336 us at m = 300, 7 500 images)
-                case 2:  return bgemm64_go<4, 2, 2, 4, 1>(c, a, G);                                    // 128 x 128, 8 waves
-                case 3:  return bgemm64_go<2, 2, 4, 4, 1>(c, a, G);                                    // 128 x 128, 16 waves
-                case 4:  return bgemm64_go<2, 2, 4, 2, 1>(c, a, G);                                    // 128 x 64, 8 waves
-                case 5:  return bgemm64_go<5, 1, 2, 6, 1>(c, a, G);                                    // 160 x 96, 12 waves
-                case 6:  return bgemm64_go<5, 2, 2, 4, 1>(c, a, G);                                    // 160 x 128, 8 waves
-                case 7:  return bgemm64_go<5, 1, 4, 4, 1>(c, a, G, 255 * a.L);                         // 320 x 64, 16 waves
-                case 8:  return bgemm64_go<5, 1, 3, 4, 1>(c, a, G, 256 * a.L);                         // 240 x 64, 12 waves (the m = 120 tile)
-                case 9:  return bgemm64_go<4, 1, 4, 4, 1>(c, a, G);                                    // 256 x 64, 16 waves
-                case 10: return bgemm64_go<5, 1, 2, 8, 1>(c, a, G);                                    // 160 x 128, 16 waves
-                case 11: return bgemm64_go<5, 1, 2, 4, 1>(c, a, G);                                    // 160 x 64, 8 waves
-                case 12: return bgemm64_go<4, 1, 2, 6, 1>(c, a, G);                                    // 128 x 96, 12 waves
-                case 13: return bgemm64_go<6, 1, 2, 6, 1>(c, a, G);                                    // 192 x 96, 12 waves
-                case 14: return bgemm64_go<5, 1, 2, 5, 1>(c, a, G);                                    // 160 x 80, 10 waves
-                case 15: return bgemm64_go<5, 1, 2, 6, 1>(c, a, G, 512);                               // 160 x 96, fewer image splits
-                case 16: return bgemm64_go<5, 1, 2, 6, 1>(c, a, G, 1024);                              // 160 x 96, more image splits
-                default: return bgemm64_go<5, 1, 2, 6, 1>(c, a, G);                                    // 160 x 96, 12 waves: 198 us at m = 300, 7 500 images (96 x 64: 336 us)
-            }
-        }
+        if (a.Kp % 240 == 0 && a.Np % 240 == 0) return bgemm64_go<5, 1, 3, 4, 1>(c, a, G, 256 * a.L);   // 240 x 64, 12 waves: 181 us vs 153 + 90 unfused
+        if (a.Kp % 80 == 0 && a.Np % 80 == 0)   return bgemm64_go<1, 5, 5, 1, 1>(c, a, G);               // 80 x 80, 5 waves
+        if (a.Kp % 128 == 0 && a.Np % 64 == 0)  return bgemm64_go<2, 2, 4, 2, 1>(c, a, G);               // m = 33..64: 128 x 64, 8 waves: 70 us at m = 60
+        if (a.Kp >= 256 && a.Np >= 256)         return bgemm64_go<5, 1, 2, 6, 1>(c, a, G);               // maxm > 120 (BASELINE config 5): 160 x 96, 12 waves: 198 us at m = 300, 7 500 images
         return bgemm64_go<2, 2, 3, 2, 1>(c, a, G);                                                     // 96 x 64, 6 waves
     }
-    if (a.Kp % 240 == 0 && a.Np % 240 == 0) {
-        // 15-wave workgroups, one per CU (255 = 3 tiles x 85 image splits): tools/tune_bgemm.sh,
-        // gpurun_out/tune_bgemm_r01.txt
-        switch (cfg) {
-            case 1: return bgemm64_go<1, 5, 5, 3>(c, a, G, 255 * a.L);    // 80 x 240 tiles, 15 waves
-            case 3: return bgemm64_go<1, 5, 3, 3>(c, a, G);              // 48 x 240, 9 waves
-            case 4: return bgemm64_go<3, 5, 5, 1>(c, a, G);              // 240 x 80, 5 waves
-            case 5: return bgemm64_go<1, 5, 5, 1>(c, a, G);              // 80 x 80, 5 waves
-            default: return bgemm64_go<5, 1, 3, 5>(c, a, G, 255 * a.L);  // 240 x 80 tiles, 15 waves
-        }
-    }
+    if (a.Kp % 240 == 0 && a.Np % 240 == 0) return bgemm64_go<5, 1, 3, 5>(c, a, G, 255 * a.L);          // 240 x 80 tiles, 15 waves, one workgroup per CU
     if (a.Kp % 80 == 0 && a.Np % 80 == 0) return bgemm64_go<1, 5, 5, 1>(c, a, G);
     if (a.Kp > 32 && a.Np > 32) return bgemm64_go<2, 2, 2, 2>(c, a, G);
     return bgemm64_go<1, 1, 2, 2>(c, a, G);

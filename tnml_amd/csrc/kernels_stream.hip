@@ -186,10 +186,9 @@ bool labeldot_streaming(const tnml_ctx* c, int NTp) {
 }
 int launch_labeldot_blocks(tnml_ctx* c, const LdotArgs& a_in, int blk_off, int nblk, hipStream_t st, int kclass, int form) {
     // the Label-carrying operand is read exactly once per launch: non-temporal loads stream it at 6.4-6.5 TB/s
-    // instead of 5.6-5.7 (TNML_LDOT_NT=0 restores the default cache policy)
-    static const int nt = getenv("TNML_LDOT_NT") ? atoi(getenv("TNML_LDOT_NT")) : 1;
+    // instead of 5.6-5.7 with the default cache policy (profiles/r01_ab_nt_loads.txt)
     LdotArgs a = a_in;
-    a.nt = nt; a.blk_off = blk_off;
+    a.nt = 1; a.blk_off = blk_off;
     const bool small = form ? form == 2 : !labeldot_streaming(c, a.NTp);
     if (blk_off + nblk > c->partial_cap) return tnml_fail(c, "labeldot: partial buffer too small");
     if (!st) st = c->stream;
