@@ -138,6 +138,14 @@ int tnml_comm_init(tnml_ctx* ctx, const void* id128);
    collective entry point must be driven by one host thread per rank (they meet in a host barrier).  Same results as
    RCCL (rank-ordered sums, bit-identical on every rank); a correctness vehicle for one-GPU boxes, not a fast path. */
 int tnml_comm_init_local(tnml_ctx** ctxs, int n);
+/* One-shot all-reduce for the ranks of ONE process on several devices (one host thread per rank, as the fixedL driver runs them):
+   every rank writes its packed [scalars | gradient] buffer straight into its slot of every peer's receive region (peer stores over the
+   direct xGMI links, one hop), the streams meet through events, every rank sums its own n slots in rank order -- bit-identical sums
+   everywhere (replaces the ring all-reduce for the latency-bound 461 KB payloads of fixedL.cc:385,402,421,427).
+   Ranks may also share a device (how it is tested on one GPU).  Same calling rules as tnml_comm_init_local. */
+int tnml_comm_init_oneshot(tnml_ctx** ctxs, int n);
+/* which collective path this context uses: 0 none (one rank), 1 RCCL, 2 in-process staging buffer, 3 one-shot peer write */
+int tnml_collective_mode(tnml_ctx* ctx);
 /* Collective.  Verifies that the communicator really spans cfg.nranks ranks (ncclCommCount) and that every rank holds a
    bit-identical replica of the weight MPS (a 64-bit fingerprint of all site tensors, max/min-reduced over the ranks);
    non-zero + tnml_last_error on a mismatch.  The replicated CG/SVD algebra relies on identical replicas the way the

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run_ranks(nranks, labels, phi, W, N, maxm, body):
+def _run_ranks(nranks, labels, phi, W, N, maxm, body, oneshot=False):
     """one context + one host thread per rank on device 0; returns body(ts, rank) of every rank"""
     from tnml_amd import lib
     from tnml_amd.fixedl import TrainStates
@@ -28,7 +28,8 @@ def _run_ranks(nranks, labels, phi, W, N, maxm, body):
         lo, hi = lib.shard_bounds(NT, nranks, r)
         states.append(TrainStates(labels[lo:hi], N, maxm, phi=phi[lo:hi], rank=r, nranks=nranks, NT_total=NT))
     if nranks > 1:
-        TrainStates.comm_init_local(states)
+        TrainStates.comm_init_local(states, oneshot=oneshot)
+        assert all(ts.collective_mode() == (3 if oneshot else 2) for ts in states)
     out, err = [None] * nranks, [None] * nranks
 
     def work(r):
@@ -52,8 +53,8 @@ def _run_ranks(nranks, labels, phi, W, N, maxm, body):
     return out
 
 
-@pytest.mark.parametrize("nranks,NT", [(2, 151), (3, 150), (4, 257)])
-def test_sweep_on_several_ranks_matches_one_rank_and_the_oracle(nranks, NT):
+@pytest.mark.parametrize("nranks,NT,oneshot", [(2, 151, False), (3, 150, False), (4, 257, False), (2, 151, True), (4, 257, True)])
+def test_sweep_on_several_ranks_matches_one_rank_and_the_oracle(nranks, NT, oneshot):
     from oracle import pyoracle
     from tnml_amd.fixedl import mldmrg
     N, m = 12, 6
@@ -69,7 +70,7 @@ def test_sweep_on_several_ranks_matches_one_rank_and_the_oracle(nranks, NT):
         reps = mldmrg(ts, *args)
         ts.replica_check()
         return dict(n=n, G=G, C0=C0, reps=reps, W=ts.get_mps())
-    multi = _run_ranks(nranks, labels, phi, W, N, m, body)
+    multi = _run_ranks(nranks, labels, phi, W, N, m, body, oneshot=oneshot)      # oneshot: the peer-write all-reduce (tnml_comm_init_oneshot)
     single = _run_ranks(1, labels, phi, W, N, m, body)[0]
     o = pyoracle.Oracle(phi, labels, W)
     o.init()
@@ -121,7 +122,10 @@ def test_cpp_driver_with_two_ranks_prints_the_one_rank_log(tmp_path):
     data = str(tmp_path / "data")
     synth.write_idx(data, pixels[np.argsort(labels, kind="stable")], np.sort(labels), side=4)
     logs = {}
-    for tag, extra in (("one", ""), ("two", "ngpu = 2\nshare_device = yes\n")):
+
+    def costs_of(s):
+        return [float(x) for x in re.findall(r"--> After SVD, Cost = ([0-9.eE+-]+)", s)]
+    for tag, extra in (("one", ""), ("two", "ngpu = 2\nshare_device = yes\n"), ("shot", "ngpu = 2\nshare_device = yes\nallreduce = oneshot\n")):
         wd = tmp_path / tag
         wd.mkdir()
         inp = wd / "input"
@@ -130,7 +134,8 @@ def test_cpp_driver_with_two_ranks_prints_the_one_rank_log(tmp_path):
         run = subprocess.run([os.path.join(ROOT, "tnml_amd", "fixedL"), str(inp)], capture_output=True, text=True, cwd=wd, timeout=600)
         assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
         logs[tag] = run.stdout
-    assert "in-process communicator of 2 ranks" in logs["two"]
+    assert "in-process communicator of 2 ranks" in logs["two"] and "one-shot peer-write communicator of 2 ranks" in logs["shot"]
+    assert costs_of(logs["shot"]) == costs_of(logs["two"])        # both sum the two ranks' buffers in rank order: the same bits
     assert "Thread 1 150 -> 300 (150)" in logs["two"]
 
     def costs(s):

@@ -1,5 +1,14 @@
-// local_comm.hip -- an in-process communicator for ranks that share ONE device.
+// local_comm.hip -- in-process communicators: (a) for ranks that share ONE device, (b) the one-shot peer-write all-reduce for ranks
+// of one process on SEVERAL devices (tnml_comm_init_oneshot).
 //
+// (b) The five 461 KB all-reduces of a bond update are latency bound on a ring (2 (n-1) hops).  One shot instead: every rank WRITES its
+// [tail | G] buffer straight into its own slot of every peer's receive region (one kernel, peer stores over the direct xGMI links, all
+// seven links at once, one hop), the ranks' streams meet through HIP events, and every rank sums the n slots of its OWN receive region
+// in rank order -- local reads, bit-identical sums on every rank (what the replicated CG scalars and the split rely on).  Receive
+// regions have two parities; a slot is rewritten only after its reader's event of two collectives ago.  With all ranks on one device
+// the same code runs with plain device pointers: that is how it is tested on a one-GPU box (tests/test_multirank_one_gpu.py).
+//
+// (a)
 // RCCL refuses two ranks on the same GPU, so on a one-GPU box the multi-rank logic of the library (image shards,
 // packed [G | cost | ncorrect | pAp] all-reduce, collective truncation decision, replica fingerprints) could only ever
 // run with a 1-rank communicator.  This communicator gives every rank of one process its own context and stream on the
@@ -19,8 +28,11 @@
 struct LocalComm {
     int n = 0;
     int device = 0;
+    int oneshot = 0;                      // (b): per-rank receive regions, peer writes
     size_t cap = 0;                       // doubles per rank slot
     double* staging[2] = {nullptr, nullptr};
+    std::vector<double*> recv[2];         // (b) recv[p][j]: receive region of rank j ([n][cap] doubles, on rank j's device)
+    std::vector<int> devs;
     std::vector<hipEvent_t> written[2], read_done[2];
     std::vector<char> read_rec[2];        // read_done[p][r] has been recorded at least once
     std::vector<long> gen;                // per rank: collectives entered so far
@@ -48,29 +60,61 @@ __global__ void k_lc_sum(const double* __restrict__ st, int n, size_t cap, size_
         out[i] = s;
     }
 }
+// (b) this rank's buffer -> its slot in the receive region of every rank (blockIdx.y = destination rank; peer stores)
+struct LcPeers { double* dst[16]; };
+__global__ void k_lc_push(const double* __restrict__ buf, size_t count, LcPeers P, size_t slot_off) {
+    double* d = P.dst[blockIdx.y] + slot_off;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) d[i] = buf[i];
+}
 __global__ void k_lc_copy(const double* __restrict__ st, size_t count, double* __restrict__ out) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) out[i] = st[i];
 }
 
-int tnml_comm_init_local(tnml_ctx** ctxs, int n) {
-    if (!ctxs || n < 1) return tnml_fail(nullptr, "tnml_comm_init_local: bad arguments");
+static int comm_init_inproc(tnml_ctx** ctxs, int n, int oneshot) {
+    const char* who = oneshot ? "tnml_comm_init_oneshot" : "tnml_comm_init_local";
+    if (!ctxs || n < 1 || n > 16) return tnml_fail(nullptr, "%s: bad arguments (1..16 ranks)", who);
     size_t cap = 0;
     for (int r = 0; r < n; ++r) {
         tnml_ctx* c = ctxs[r];
-        if (!c) return tnml_fail(nullptr, "tnml_comm_init_local: null context");
-        if (c->cfg.nranks != n || c->cfg.rank != r) return tnml_fail(c, "tnml_comm_init_local: context %d was created as rank %d of %d", r, c->cfg.rank, c->cfg.nranks);
-        if (c->cfg.device != ctxs[0]->cfg.device) return tnml_fail(c, "tnml_comm_init_local: ranks on different devices use RCCL (tnml_comm_init)");
-        if (c->comm || c->local) return tnml_fail(c, "tnml_comm_init_local: context already has a communicator");
+        if (!c) return tnml_fail(nullptr, "%s: null context", who);
+        if (c->cfg.nranks != n || c->cfg.rank != r) return tnml_fail(c, "%s: context %d was created as rank %d of %d", who, r, c->cfg.rank, c->cfg.nranks);
+        if (!oneshot && c->cfg.device != ctxs[0]->cfg.device) return tnml_fail(c, "tnml_comm_init_local: ranks on different devices use tnml_comm_init_oneshot or RCCL (tnml_comm_init)");
+        if (c->comm || c->local) return tnml_fail(c, "%s: context already has a communicator", who);
         if (c->mcap + TNML_TAILN > cap) cap = c->mcap + TNML_TAILN;
-        if (c->mcap != ctxs[0]->mcap) return tnml_fail(c, "tnml_comm_init_local: contexts must share maxm");
+        if (c->mcap != ctxs[0]->mcap) return tnml_fail(c, "%s: contexts must share maxm", who);
     }
     LocalComm* lc = new LocalComm();
-    lc->n = n; lc->device = ctxs[0]->cfg.device; lc->cap = cap; lc->refs = n;
-    if (hipSetDevice(lc->device) != hipSuccess) { delete lc; return tnml_fail(ctxs[0], "hipSetDevice failed"); }
+    lc->n = n; lc->device = ctxs[0]->cfg.device; lc->cap = cap; lc->refs = n; lc->oneshot = oneshot;
+    lc->devs.resize(n);
+    for (int r = 0; r < n; ++r) lc->devs[r] = ctxs[r]->cfg.device;
+    auto fail = [&](tnml_ctx* c, const char* what) { for (int p = 0; p < 2; ++p) { if (lc->staging[p]) (void)hipFree(lc->staging[p]); for (double* q : lc->recv[p]) if (q) (void)hipFree(q); } delete lc; return tnml_fail(c, "%s: %s", who, what); };
+    if (oneshot) {
+        // every pair of distinct devices must be able to store into each other's memory (xGMI peer access)
+        for (int a = 0; a < n; ++a)
+            for (int b2 = 0; b2 < n; ++b2) {
+                if (lc->devs[a] == lc->devs[b2]) continue;
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, lc->devs[a], lc->devs[b2]) != hipSuccess || !can) return fail(ctxs[a], "no peer access between the devices of two ranks");
+                if (hipSetDevice(lc->devs[a]) != hipSuccess) return fail(ctxs[a], "hipSetDevice failed");
+                const hipError_t e = hipDeviceEnablePeerAccess(lc->devs[b2], 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(ctxs[a], "hipDeviceEnablePeerAccess failed");
+                (void)hipGetLastError();
+            }
+        for (int p = 0; p < 2; ++p) {
+            lc->recv[p].assign(n, nullptr);
+            for (int r = 0; r < n; ++r) {
+                if (hipSetDevice(lc->devs[r]) != hipSuccess || hipMalloc((void**)&lc->recv[p][r], sizeof(double) * cap * n) != hipSuccess) return fail(ctxs[r], "hipMalloc of a receive region failed");
+            }
+        }
+    } else {
+        if (hipSetDevice(lc->device) != hipSuccess) return fail(ctxs[0], "hipSetDevice failed");
+        for (int p = 0; p < 2; ++p)
+            if (hipMalloc((void**)&lc->staging[p], sizeof(double) * cap * n) != hipSuccess) return fail(ctxs[0], "hipMalloc failed");
+    }
     for (int p = 0; p < 2; ++p) {
-        if (hipMalloc((void**)&lc->staging[p], sizeof(double) * cap * n) != hipSuccess) { delete lc; return tnml_fail(ctxs[0], "tnml_comm_init_local: hipMalloc failed"); }
         lc->written[p].resize(n); lc->read_done[p].resize(n); lc->read_rec[p].assign(n, 0);
         for (int r = 0; r < n; ++r) {
+            (void)hipSetDevice(lc->devs[r]);
             (void)hipEventCreateWithFlags(&lc->written[p][r], hipEventDisableTiming);
             (void)hipEventCreateWithFlags(&lc->read_done[p][r], hipEventDisableTiming);
         }
@@ -79,6 +123,9 @@ int tnml_comm_init_local(tnml_ctx** ctxs, int n) {
     for (int r = 0; r < n; ++r) ctxs[r]->local = lc;
     return 0;
 }
+int tnml_comm_init_local(tnml_ctx** ctxs, int n) { return comm_init_inproc(ctxs, n, 0); }
+int tnml_comm_init_oneshot(tnml_ctx** ctxs, int n) { return comm_init_inproc(ctxs, n, 1); }
+int local_comm_mode(const tnml_ctx* c) { return c->local ? (c->local->oneshot ? 3 : 2) : 0; }
 void local_comm_release(tnml_ctx* c) {
     LocalComm* lc = c->local;
     if (!lc) return;
@@ -88,6 +135,7 @@ void local_comm_release(tnml_ctx* c) {
     if (!last) return;
     for (int p = 0; p < 2; ++p) {
         if (lc->staging[p]) (void)hipFree(lc->staging[p]);
+        for (double* q : lc->recv[p]) if (q) (void)hipFree(q);
         for (auto e : lc->written[p]) (void)hipEventDestroy(e);
         for (auto e : lc->read_done[p]) (void)hipEventDestroy(e);
     }
@@ -104,13 +152,22 @@ int local_comm_exchange(tnml_ctx* c, double* buf, size_t count, int op) {
     hipStream_t st = c->stream;
     // the slot of this parity was read two collectives ago: wait for those readers
     for (int j = 0; j < n; ++j) if (lc->read_rec[p][j]) LCK(c, lc, hipStreamWaitEvent(st, lc->read_done[p][j], 0));
-    if (op != 1 || r == 0) LCK(c, lc, hipMemcpyAsync(lc->staging[p] + (size_t)r * lc->cap, buf, sizeof(double) * count, hipMemcpyDeviceToDevice, st));
+    const int nb = (int)((count + 255) / 256 > 1024 ? 1024 : (count + 255) / 256);
+    if (lc->oneshot) {
+        // one shot: this rank's values into its slot of every rank's receive region (a broadcast: rank 0 alone writes)
+        if (op != 1 || r == 0) {
+            LcPeers P;
+            for (int j = 0; j < n; ++j) P.dst[j] = lc->recv[p][j];
+            hipLaunchKernelGGL(k_lc_push, dim3(nb > 256 ? 256 : nb, n), dim3(256), 0, st, (const double*)buf, count, P, (size_t)r * lc->cap);
+            LCK(c, lc, hipGetLastError());
+        }
+    } else if (op != 1 || r == 0) LCK(c, lc, hipMemcpyAsync(lc->staging[p] + (size_t)r * lc->cap, buf, sizeof(double) * count, hipMemcpyDeviceToDevice, st));
     LCK(c, lc, hipEventRecord(lc->written[p][r], st));
     if (!lc->barrier()) return tnml_fail(c, "local communicator: a rank left the collective (aborted)");   // every rank has recorded its `written` event
     for (int j = 0; j < n; ++j) if (j != r) LCK(c, lc, hipStreamWaitEvent(st, lc->written[p][j], 0));
-    const int nb = (int)((count + 255) / 256 > 1024 ? 1024 : (count + 255) / 256);
-    if (op == 0)      hipLaunchKernelGGL(k_lc_sum, dim3(nb), dim3(256), 0, st, (const double*)lc->staging[p], n, lc->cap, count, buf);
-    else              hipLaunchKernelGGL(k_lc_copy, dim3(nb), dim3(256), 0, st, (const double*)lc->staging[p], count, buf);
+    const double* src = lc->oneshot ? lc->recv[p][r] : lc->staging[p];                              // (one shot: the n slots of the OWN receive region)
+    if (op == 0)      hipLaunchKernelGGL(k_lc_sum, dim3(nb), dim3(256), 0, st, src, n, lc->cap, count, buf);
+    else              hipLaunchKernelGGL(k_lc_copy, dim3(nb), dim3(256), 0, st, src, count, buf);
     LCK(c, lc, hipGetLastError());
     LCK(c, lc, hipEventRecord(lc->read_done[p][r], st));
     if (!lc->barrier()) return tnml_fail(c, "local communicator: a rank left the collective (aborted)");   // ... and its `read_done` event, before anyone re-uses the parity

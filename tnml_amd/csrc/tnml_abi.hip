@@ -399,6 +399,7 @@ int bcast_rank0(tnml_ctx* c, double* buf, size_t count) {
     if (r != ncclSuccess) return tnml_fail(c, "ncclBroadcast failed: %s", ncclGetErrorString(r));
     return 0;
 }
+int tnml_collective_mode(tnml_ctx* c) { return c->local ? local_comm_mode(c) : (c->comm ? 1 : 0); }
 int tnml_collective_stats(tnml_ctx* c, int64_t* allreduces, int64_t* broadcasts) {
     if (allreduces) *allreduces = c->allreduce_calls;
     if (broadcasts) *broadcasts = c->bcast_calls;

@@ -404,6 +404,7 @@ int eigh_backtransform(tnml_ctx* c, const double* V, const double* tau, int n, c
 // ---- local_comm.hip ----
 void local_comm_release(tnml_ctx* c);
 int local_comm_size(const tnml_ctx* c);
+int local_comm_mode(const tnml_ctx* c);     // 0 none, 2 staging buffer on one device, 3 one-shot peer write
 void local_comm_abort(tnml_ctx* c);
 int local_comm_exchange(tnml_ctx* c, double* buf, size_t count, int op);   // 0 sum, 1 broadcast from rank 0
 

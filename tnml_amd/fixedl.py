@@ -79,12 +79,21 @@ class TrainStates:
         self._ck(self._L.tnml_comm_init(self._h, buf))
 
     @staticmethod
-    def comm_init_local(states):
-        """in-process communicator for ranks sharing one device (tnml_comm_init_local); afterwards drive every rank from its
-        own host thread"""
+    def comm_init_local(states, oneshot=False):
+        """in-process communicator: ranks sharing one device through a staging buffer (tnml_comm_init_local), or -- oneshot --
+        the peer-write all-reduce for the ranks of one process on any devices (tnml_comm_init_oneshot); afterwards drive every
+        rank from its own host thread"""
         arr = (C.c_void_p * len(states))(*[s._h for s in states])
-        if _lib.load().tnml_comm_init_local(arr, len(states)) != 0:
-            raise TnmlError(_lib.load().tnml_last_error(None).decode() or "tnml_comm_init_local failed")
+        f = _lib.load().tnml_comm_init_oneshot if oneshot else _lib.load().tnml_comm_init_local
+        if f(arr, len(states)) != 0:
+            raise TnmlError(_lib.load().tnml_last_error(None).decode() or "in-process communicator setup failed")
+
+    def collective_mode(self):
+        """0 none (one rank), 1 RCCL, 2 in-process staging buffer, 3 one-shot peer write"""
+        return self._L.tnml_collective_mode(self._h)
+
+    def allreduce_mode(self):
+        return ("none", "rccl", "in-process staging buffer", "one-shot peer write")[self.collective_mode()]
 
     @staticmethod
     def comm_unique_id() -> bytes:

@@ -88,6 +88,9 @@ int main(int argc, const char* argv[]) {
         const int device = (int)input.getInt("device", 0);                              // extension: first HIP ordinal
         const long ngpu = input.getInt("ngpu", 1);                                      // extension: GPUs (ranks) to shard the images over; 0 = all visible
         const bool share_device = input.getYesNo("share_device", false);                // extension: all ranks on `device` (in-process communicator; one-GPU boxes)
+        const std::string allreduce_kind = input.getString("allreduce", "rccl");        // extension: "oneshot" = peer-write all-gather + rank-ordered local sum (tnml_comm_init_oneshot)
+        const bool oneshot = allreduce_kind == "oneshot";
+        if (!oneshot && allreduce_kind != "rccl") die(nullptr, "allreduce must be rccl or oneshot");
         const std::string bond_log = input.getString("bond_log", "");                      // extension: a CSV line per bond update (machine-readable log for parity and bond updates/s)
         const bool pipeline = input.getYesNo("pipeline", true);                         // extension: enqueue bond k+1 before fetching the report of bond k (see the sweep loop)
         const std::string precision = input.getString("precision", "f64");              // extension: f64 | mixed | f32 | bf16x3 | bf16
@@ -186,7 +189,7 @@ int main(int argc, const char* argv[]) {
         const bool use_u8 = !train.reduced() && feature_scale == 1.;
         if (!use_u8) phi_all = all_features(train, false, feature_scale);
         unsigned char uid[128] = {0};
-        if (nranks > 1 && !share_device && tnml_comm_unique_id(uid) != 0) die(nullptr, "tnml_comm_unique_id");
+        if (nranks > 1 && !share_device && !oneshot && tnml_comm_unique_id(uid) != 0) die(nullptr, "tnml_comm_unique_id");
         std::vector<tnml_ctx*> all_ctx(nranks, nullptr);
 
         HostBarrier bar(nranks);
@@ -201,15 +204,15 @@ int main(int argc, const char* argv[]) {
             if (tnml_create(&ctx, &cfg) != 0) die(nullptr, "tnml_create");
             if (use_u8) CK(ctx, tnml_set_data_u8(ctx, train.pixels.data() + (size_t)lo[r] * N, train.labels.data() + lo[r]));   // TState ctor, :644-653
             else        CK(ctx, tnml_set_data_phi(ctx, phi_all.data() + (size_t)lo[r] * N * 2, train.labels.data() + lo[r]));
-            if (nranks > 1 && !share_device) CK(ctx, tnml_comm_init(ctx, uid));                // RCCL over xGMI, one rank per GPU
-            if (nranks > 1 && share_device) {                                               // in-process communicator on one GPU
+            if (nranks > 1 && !share_device && !oneshot) CK(ctx, tnml_comm_init(ctx, uid));    // RCCL over xGMI, one rank per GPU
+            if (nranks > 1 && (share_device || oneshot)) {                                  // in-process communicators: staging buffer on one GPU, or one-shot peer writes
                 all_ctx[r] = ctx;
                 bar.wait();
-                if (root && tnml_comm_init_local(all_ctx.data(), nranks) != 0) die(nullptr, "tnml_comm_init_local");
+                if (root && (oneshot ? tnml_comm_init_oneshot(all_ctx.data(), nranks) : tnml_comm_init_local(all_ctx.data(), nranks)) != 0) die(nullptr, "in-process communicator");
                 bar.wait();
             }
             upload(ctx, W);
-            if (nranks > 1) { int cnt = 0; CK(ctx, tnml_replica_check(ctx, &cnt)); if (root) std::printf("%s communicator of %d ranks, W replicas identical\n", share_device ? "in-process" : "RCCL", cnt); }
+            if (nranks > 1) { int cnt = 0; CK(ctx, tnml_replica_check(ctx, &cnt)); if (root) std::printf("%s communicator of %d ranks, W replicas identical\n", oneshot ? "one-shot peer-write" : (share_device ? "in-process" : "RCCL"), cnt); }
             if (root) { std::printf("Projecting training states..."); std::fflush(stdout); }   // :740
             CK(ctx, tnml_env_init(ctx));                                                    // :741
             if (root) { std::printf("done\n"); std::printf("Calling quadcost...\n"); }     // :744
