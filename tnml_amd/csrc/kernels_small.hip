@@ -275,8 +275,21 @@ __global__ __launch_bounds__(VB) void k_cg_resid2(const double* __restrict__ G, 
     const double ps = block_sum(pacc, sh);                 // partial |p|^2 of the next pass (k_cg_step2 sums them in block order)
     if (threadIdx.x == 0) { part_p[2 * blockIdx.x] = ps; part_p[2 * blockIdx.x + 1] = 0.; }
     double csp = 0.;                                       // workgroup 0: the cost partials of the output update, when they have not been reduced yet
-    if (blockIdx.x == 0 && cost_part && !merged)
-        for (int l = 0; l < TNML_NL; ++l) csp += sum_column(cost_part, ncp, l, sh);      // label by label, as the reduced tail would be added
+    if (blockIdx.x == 0 && cost_part && !merged) {
+        // wave w sums the columns of labels w, w + 4, w + 8 in the order of k_reduce_partials; the labels are then added in label order,
+        // as the reduced tail would be (one pass over the partial sums instead of ten workgroup-wide ones: 19 -> 6 us)
+        __syncthreads();
+        const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        for (int l = w; l < TNML_NL; l += VB / 64) {
+            double a = 0.;
+            for (int r = lane; r < ncp; r += 64) a += cost_part[(size_t)r * 12 + l];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
+            if (lane == 0) sh[l] = a;
+        }
+        __syncthreads();
+        for (int l = 0; l < TNML_NL; ++l) csp += sh[l];
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (!merged) {                                    // (merged: this pass's cost partials are summed over the ranks by the next all-reduce)
             double cs = 0.;
