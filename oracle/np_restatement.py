@@ -417,7 +417,7 @@ class NpSingle:
             rho = (rho + noise * drho).reshape(2 * mL, 2 * mL)               # C order: row index (a, s)
         else:                                                                # site c = b + 1 carries (t, r); the other site (a, s)
             rho = np.einsum('astr,asuq->truq', B, B)
-            if c < self.N:
+            if c < self.N - 1:                                              # single.h:655 as written: "ha == 2 && c < N-1"
                 E = self.E[c + 1]
                 T = np.einsum('nr,astr->nast', E, B)
                 w = np.einsum('nast,nasu->ntu', T, T)

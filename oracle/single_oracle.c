@@ -493,7 +493,7 @@ int sorc_noise_split(sorc* o, const double* B, int b, int ha, double noise, doub
     for (int j = 0; j < R; ++j) for (int i = 0; i < R; ++i) { double t = 0.; for (int y = 0; y < C; ++y) t += M[i + (size_t)R * y] * M[j + (size_t)R * y]; rho[i + (size_t)R * j] = t; }   /* :651-653 */
     const int c = ha == 1 ? b : b + 1;
     const int envsite = ha == 1 ? c - 1 : c + 1;
-    const int have_env = ha == 1 ? c > 1 : c < o->N;                  /* :658,663 */
+    const int have_env = ha == 1 ? c > 1 : c < o->N - 1;              /* :650,655 as written: "ha == 2 && c < N-1" */
     if (!have_env) {
         for (size_t k = 0; k < (size_t)R * R; ++k) drho[k] = (double)o->NT * rho[k];      /* dr = B for every image */
     } else {

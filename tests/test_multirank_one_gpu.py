@@ -325,3 +325,36 @@ def test_per_label_variant_on_two_ranks_with_and_without_noise(noise):
         assert a["truncerr"] == pytest.approx(c["truncerr"], rel=1e-3, abs=1e-12)
     for A0, A1 in zip(two[0][1], two[1][1]):
         assert np.array_equal(A0, A1)                              # replicas bit-identical
+
+
+def test_a_local_error_leaves_the_in_process_communicator_usable_and_a_failed_collective_does_not():
+    """tnml_fail aborts an in-process communicator only from inside an entry point that every rank calls in step (round-3 advisor
+    finding: a bad option name on one rank used to poison every later collective).  First half: rank 1 makes a benign mistake
+    (unknown option), then both ranks sweep and agree.  Second half: rank 1 fails INSIDE a collective entry point (a bond update
+    with half = 3); rank 0, already waiting in its all-reduce, must return an error within the configured comm_timeout_s
+    instead of hanging -- the failure is propagated by the abort, not by the timeout."""
+    import time
+    from tnml_amd.fixedl import TnmlError, mldmrg
+    N, NT, m = 8, 64, 6
+    pixels, labels, phi, W = make_problem(N, NT, m, 4)
+    args = (1, m, 1, 1e-10, 2, 1e-3, 1e-10)
+
+    def body(ts, r):
+        ts.set_option("comm_timeout_s", 60)
+        if r == 1:
+            with pytest.raises(TnmlError):
+                ts.set_option("no_such_option", 1)
+        ts.init()
+        reps = mldmrg(ts, *args, max_bonds=5)
+        ts.replica_check()
+        t0 = time.time()
+        with pytest.raises(TnmlError):
+            if r == 1:
+                ts.bond_update(3, 3, *args[1:])                # rejected by the argument check of a collective entry point
+            else:
+                ts.init()
+                mldmrg(ts, *args, max_bonds=2)                 # waits for rank 1 in its first all-reduce
+        return [x["cost"] for x in reps], time.time() - t0
+    two = _run_ranks(2, labels, phi, W, N, m, body)
+    assert two[0][0] == two[1][0]
+    assert two[0][1] < 30.0, "rank 0 was released by the time-out, not by the abort"

@@ -39,13 +39,14 @@ struct LocalComm {
     int refs = 0;
     // host barrier (generation counting)
     std::mutex mu; std::condition_variable cv; int waiting = 0; long bgen = 0;
+    int timeout_s = 120;                  // option comm_timeout_s (the longest wait of a rank for its peers)
     bool aborted = false;                 // a rank failed (or never arrived): every later collective fails at once instead of hanging
     bool barrier() {                      // false: the communicator is aborted
         std::unique_lock<std::mutex> lk(mu);
         if (aborted) return false;
         const long g = bgen;
         if (++waiting == n) { waiting = 0; ++bgen; cv.notify_all(); return true; }
-        const bool ok = cv.wait_for(lk, std::chrono::seconds(120), [&] { return bgen != g || aborted; });
+        const bool ok = cv.wait_for(lk, std::chrono::seconds(timeout_s), [&] { return bgen != g || aborted; });
         if (!ok || aborted) { aborted = true; cv.notify_all(); return false; }     // a peer left the protocol (error return on its side, or it never entered)
         return true;
     }
@@ -85,6 +86,7 @@ static int comm_init_inproc(tnml_ctx** ctxs, int n, int oneshot) {
     }
     LocalComm* lc = new LocalComm();
     lc->n = n; lc->device = ctxs[0]->cfg.device; lc->cap = cap; lc->refs = n; lc->oneshot = oneshot;
+    for (int r = 0; r < n; ++r) lc->timeout_s = std::min(lc->timeout_s, ctxs[r]->comm_timeout_s);
     lc->devs.resize(n);
     for (int r = 0; r < n; ++r) lc->devs[r] = ctxs[r]->cfg.device;
     auto fail = [&](tnml_ctx* c, const char* what) { for (int p = 0; p < 2; ++p) { if (lc->staging[p]) (void)hipFree(lc->staging[p]); for (double* q : lc->recv[p]) if (q) (void)hipFree(q); } delete lc; return tnml_fail(c, "%s: %s", who, what); };
@@ -176,3 +178,4 @@ int local_comm_exchange(tnml_ctx* c, double* buf, size_t count, int op) {
 }
 // a rank that fails outside a collective (tnml_fail in a bond update) tells its peers, so that they do not wait for it
 void local_comm_abort(tnml_ctx* c) { if (c->local) c->local->abort(); }
+void local_comm_set_timeout(tnml_ctx* c, int seconds) { if (c->local) { std::lock_guard<std::mutex> lk(c->local->mu); c->local->timeout_s = seconds; } }

@@ -131,7 +131,7 @@ __global__ void k_scale_all(double* __restrict__ x, size_t n, double f) {
 static int noise_add(tnml_ctx* c, const double* B_it, int b, int ha, int mL, int mR, double* G, int n) {
     hipStream_t st = c->stream;
     const int cs = ha == 1 ? b : b + 1, envsite = ha == 1 ? cs - 1 : cs + 1;
-    const bool have_env = ha == 1 ? cs > 1 : cs < c->N;              // single.h:658,663
+    const bool have_env = ha == 1 ? cs > 1 : cs < c->N - 1;          // single.h:650,655 as written: "ha == 2 && c < N-1" -- at c = N-1 the reference leaves the environment out
     if (!have_env) {                                                 // chain end: dr_n = B for every image, drho = NT rho
         hipLaunchKernelGGL(k_scale_all, dim3(nblk((size_t)n * n)), dim3(256), 0, st, G, (size_t)n * n, 1. + c->noise * (double)c->cfg.NT_total);
         HIPCK(c, hipGetLastError());

@@ -15,11 +15,13 @@ static std::string g_create_err;
 int tnml_fail(tnml_ctx* c, const char* fmt, ...) {
     char buf[512];
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
-    if (c) { c->err = buf; if (c->local) local_comm_abort(c); } else g_create_err = buf;   // (peers of an in-process communicator must not wait for a rank that has failed)
+    if (c) { c->err = buf; if (c->local && c->coll_depth > 0) local_comm_abort(c); } else g_create_err = buf;   // (inside a collective entry point the peers of an in-process communicator must not wait for a rank that has failed; an error of a local query leaves the communicator alone)
     return 1;
 }
 const char* tnml_last_error(const tnml_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 const char* tnml_last_warning(const tnml_ctx* c) { return c ? c->warn.c_str() : ""; }
+// Entry points every rank calls in step (they contain all-reduces) hold one of these: a failure inside aborts an in-process communicator.
+struct CollScope { tnml_ctx* c; explicit CollScope(tnml_ctx* c_) : c(c_) { ++c->coll_depth; } ~CollScope() { --c->coll_depth; } };
 
 // ---- profiling ------------------------------------------------------------------------------
 static hipEvent_t prof_event(tnml_ctx* c) {
@@ -89,6 +91,7 @@ int tnml_set_option(tnml_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "res_grid")) c->res_grid = value;
     else if (!strcmp(name, "res_pace")) c->res_pace = value;
     else if (!strcmp(name, "sytrd_exit")) c->sytrd_exit = value;
+    else if (!strcmp(name, "comm_timeout_s")) { if (value < 1) return tnml_fail(c, "comm_timeout_s must be >= 1"); c->comm_timeout_s = value; local_comm_set_timeout(c, value); }
     else if (!strcmp(name, "cg_method")) { if (value < 0 || value > 2 || (value >= 1 && !c->single())) return tnml_fail(c, "cg_method: 0 (conj) or, in TNML_MODE_SINGLE, 1 (fast_conj) / 2 (exact)"); c->cg_method = value; }
     else if (!strcmp(name, "debug_nudge_rank")) c->debug_nudge_rank = value;
     else if (!strcmp(name, "mc_spin_max")) c->mc_spin_max = value;
@@ -156,7 +159,8 @@ static inline int ru16(int x) { return (x + 15) / 16 * 16; }
 int64_t tnml_estimate_bytes(const tnml_config* cfg) {
     if (!cfg || cfg->N < 1 || cfg->NT_local < 1 || cfg->maxm < 1) return -1;
     const double NTp = (double)((cfg->NT_local + TNML_NTPAD - 1) / TNML_NTPAD * TNML_NTPAD);
-    const double m = cfg->maxm, Kmax = ru16(2 * cfg->maxm), n = 2. * m;
+    const bool bf = cfg->dtype == TNML_BF16 || cfg->dtype == TNML_BF16X3;
+    const double m = cfg->maxm, Kmax = bf ? (2 * cfg->maxm + 31) / 32 * 32 : ru16(2 * cfg->maxm), n = 2. * m;   // (as tnml_create pads it)
     const bool is64 = cfg->dtype == TNML_F64 || cfg->dtype == TNML_F64_E32;
     const double esz = is64 ? 8 : 4, eesz = cfg->dtype == TNML_F64 ? 8 : 4;
     const bool single = cfg->mode == TNML_MODE_SINGLE;
@@ -166,6 +170,8 @@ int64_t tnml_estimate_bytes(const tnml_config* cfg) {
     b += mcap * (4 + 6 * 8) + 128. * Kmax * Kmax * 4 * (is64 ? 2 : 1);    // Mf, vB vR vP [tail|G] tB tB2, split-K slabs
     b += 8. * (std::max(40. * m * m, TNML_NL * Kmax * (double)ru16(cfg->maxm)) + 3. * n * n + 7. * n * m + 2. * TNML_NL * m * m + 2. * m * m);   // split workspaces
     b += 8. * (cfg->N - 1 + TNML_NL) * 2. * m * m;                                            // W replica
+    if (2 * cfg->maxm > 240) b += (double)eigh_mc_xbuf_bytes();                               // exchange buffer of the multi-workgroup tridiagonalisation
+    if (single) b += 8. * (5. * m * NTp + 3. * NTp + 3. * m * m);                             // workspace of the noise split (allocated on first use with noise > 0)
     const double nslab = single ? (cfg->N / 10. + 2.) : (0.55 * cfg->N + 3.);
     b += nslab * TNML_NL * m * NTp * eesz;
     return (int64_t)b;
@@ -384,6 +390,8 @@ static int carry_deliver(tnml_ctx* c) {
     c->carry_slot = -1;
     HIPCK(c, hipMemcpyAsync(pend_host(c, slot) + TNML_CARRY, c->tail + TNML_CARRY, sizeof(double) * TNML_CARRYN, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipEventRecord(c->pend[slot].ev2, c->stream));
+    if (c->comm || c->local)                                          // delivered: the next packed all-reduce must not sum (and so scale by nranks) what is left here
+        HIPCK(c, hipMemsetAsync(c->tail + TNML_CARRY, 0, sizeof(double) * TNML_CARRYN, c->stream));
     return 0;
 }
 // the packed buffer [tail | G] of the current bond (n = elements of G)
@@ -420,6 +428,7 @@ static bool fingerprint_agrees(const double* sums8, int nranks) {
     return true;
 }
 int tnml_replica_check(tnml_ctx* c, int* nranks_in_comm) {
+    CollScope coll_(c);
     HIPCK(c, hipSetDevice(c->cfg.device));
     if (nranks_in_comm) *nranks_in_comm = 1;
     if (!c->comm && !c->local) return c->cfg.nranks == 1 ? 0 : tnml_fail(c, "tnml_replica_check: nranks > 1 but tnml_comm_init was not called");
@@ -644,6 +653,7 @@ int tnml_get_env(tnml_ctx* c, int j, double* E) {
 // W_n[l] = (prod_{j<c} phi_j*A_j) * (phi_c*A_c) * (prod_{j>c} phi_j*A_j) for every local image, with rolling
 // chain buffers borrowed from the environment pools (the training environments are left untouched).
 int tnml_classify(tnml_ctx* c, double* weights, int32_t* pred, int64_t count[TNML_NL], int64_t nincorrect[TNML_NL]) {
+    CollScope coll_(c);
     HIPCK(c, hipSetDevice(c->cfg.device));
     if (!c->data_set) return tnml_fail(c, "tnml_classify: image data not set");
     c->p_valid = false;
@@ -1075,6 +1085,7 @@ int tnml_forward(tnml_ctx* c, const double* B, double* P) {
     return 0;
 }
 int tnml_gradient(tnml_ctx* c, const double* B, double* G) {
+    CollScope coll_(c);
     HIPCK(c, hipSetDevice(c->cfg.device));
     c->p_valid = false;
     TCK(upload_bond(c, B));
@@ -1083,6 +1094,7 @@ int tnml_gradient(tnml_ctx* c, const double* B, double* G) {
 }
 // sum_n |p.v_n|^2 + lambda |p|^2 for a direction p (fixedL.cc:394-403), collective
 int tnml_pAp(tnml_ctx* c, const double* p, double lambda, double* pAp) {
+    CollScope coll_(c);
     HIPCK(c, hipSetDevice(c->cfg.device));
     c->p_valid = false;
     TCK(upload_bond(c, p));
@@ -1096,6 +1108,7 @@ int tnml_pAp(tnml_ctx* c, const double* p, double lambda, double* pAp) {
     return 0;
 }
 int tnml_quadcost(tnml_ctx* c, const double* B, double lambda, double* cost, double label_cost[TNML_NL], double* reg_cost, int64_t* ncorrect) {
+    CollScope coll_(c);
     HIPCK(c, hipSetDevice(c->cfg.device));
     c->p_valid = false;
     TCK(upload_bond(c, B));
@@ -1186,6 +1199,7 @@ int tnml_pinv(tnml_ctx* c, const double* V0, int r, int npass, double lambda, do
     return 0;
 }
 int tnml_exact(tnml_ctx* c, double* B, double lambda, double pcut) {   // single.h:117-160 on the bond chosen by tnml_set_bond
+    CollScope coll_(c);
     HIPCK(c, hipSetDevice(c->cfg.device));
     if (c->currb < 1) return tnml_fail(c, "tnml_exact: setBond has not been called");
     c->p_valid = false;
@@ -1203,6 +1217,7 @@ int tnml_set_option_real(tnml_ctx* c, const char* name, double value) {
     return tnml_fail(c, "tnml_set_option_real: unknown option %s", name);
 }
 int tnml_cgrad(tnml_ctx* c, double* B, int npass, double lambda, double cconv, tnml_cg_trace* trace) {
+    CollScope coll_(c);
     HIPCK(c, hipSetDevice(c->cfg.device));
     c->p_valid = false;
     TCK(upload_bond(c, B));
@@ -1212,6 +1227,7 @@ int tnml_cgrad(tnml_ctx* c, double* B, int npass, double lambda, double cconv, t
 }
 int tnml_svd_split(tnml_ctx* c, const double* B, int b, int ha, double cutoff, int maxm, int minm,
                    double* truncerr, int* newm, double* sv, int* nsv) {
+    CollScope coll_(c);
     HIPCK(c, hipSetDevice(c->cfg.device));
     if (b < 1 || b > c->N - 1 || (ha != 1 && ha != 2)) return tnml_fail(c, "tnml_svd_split: bad bond/half");
     c->p_valid = false;
@@ -1228,6 +1244,7 @@ int tnml_svd_split(tnml_ctx* c, const double* B, int b, int ha, double cutoff, i
 // caller may begin bond k+1 before ending bond k (at most two bond updates in flight): the wait of `end` then costs nothing
 // because `begin` of the next bond has already passed its own synchronisation point.
 int tnml_bond_update_begin(tnml_ctx* c, int b, int ha, const tnml_sweep_params* sp) {
+    CollScope coll_(c);
     HIPCK(c, hipSetDevice(c->cfg.device));
     if (ha != 1 && ha != 2) return tnml_fail(c, "tnml_bond_update: half must be 1 or 2");
     if (c->pend_count >= 2) return tnml_fail(c, "tnml_bond_update_begin: two bond updates are in flight, call tnml_bond_update_end first");
@@ -1308,6 +1325,7 @@ int tnml_bond_update_begin(tnml_ctx* c, int b, int ha, const tnml_sweep_params* 
     return 0;
 }
 int tnml_bond_update_end(tnml_ctx* c, tnml_bond_report* rep) {
+    CollScope coll_(c);
     if (c->pend_count < 1) return tnml_fail(c, "tnml_bond_update_end: no bond update in flight");
     const int slot = c->pend_tail;
     PendingReport& pr = c->pend[slot];

@@ -127,6 +127,8 @@ struct tnml_ctx {
     // recompute with its own forward GEMM + label dot.  p_valid marks P/dP as current; anything that changes W, the data or
     // P itself clears it (env TNML_REUSE_P=0 disables the shortcut).
     bool reuse_p = true, p_valid = false;
+    int coll_depth = 0;                  // >0 inside an entry point that every rank calls in step (tnml_fail then aborts an in-process communicator)
+    int comm_timeout_s = 120;            // option comm_timeout_s: how long a rank of an in-process communicator waits for its peers
     int opt_fg64_cfg = 0, opt_ldot_cfg = 0;   // kernel-instantiation overrides (0: chosen by the image count)
     void* Zp = nullptr;        // [maxm][NTp]
     float* Mf = nullptr;       // fp32 GEMM operand, M-layout, capacity 10*Kmax*Kmax (env shifts, F32 mode)
@@ -406,6 +408,7 @@ void local_comm_release(tnml_ctx* c);
 int local_comm_size(const tnml_ctx* c);
 int local_comm_mode(const tnml_ctx* c);     // 0 none, 2 staging buffer on one device, 3 one-shot peer write
 void local_comm_abort(tnml_ctx* c);
+void local_comm_set_timeout(tnml_ctx* c, int seconds);
 int local_comm_exchange(tnml_ctx* c, double* buf, size_t count, int op);   // 0 sum, 1 broadcast from rank 0
 
 // rank 0's values to every rank, in stream order (no-op without a communicator)
