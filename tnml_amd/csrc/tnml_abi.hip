@@ -843,7 +843,8 @@ static int grad_eval(tnml_ctx* c, bool from_P_update = false, bool outputs_curre
     if (p.kind != 2 && !fuse) TCK(launch_zprime(c, p.EX, (size_t)p.mO * c->NTp, wsrc, c->Zp, p.mO, c->NTp));
     if (fuse && c->grad_res >= 2 && c->env64() && !c->single() && p.Kp == 240 && p.Np == 240 && p.mI == 120 && p.mO == 120) {
         GradResArgs gr{(const double*)p.EI, (const double*)p.phiI, (const double*)p.phiO, (const double*)p.EX, (size_t)p.mO * c->NTp, (const double*)wsrc, c->NTp, c->NTp / 32};
-        TCK(launch_grad_res(c, gr, c->vG));
+        if (c->grad_res == 3) TCK(launch_grad_q(c, gr, c->vG));     // uniform waves, groups of four workgroups
+        else TCK(launch_grad_res(c, gr, c->vG));
     } else if (c->f64()) {
         Bgemm64Args g;
         g.EL = nullptr; g.EL_lstride = 0; g.dPz = nullptr; g.env64 = c->env64();

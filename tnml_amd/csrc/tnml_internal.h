@@ -173,7 +173,7 @@ struct tnml_ctx {
     void* mc_xbuf = nullptr;   // exchange buffer of the multi-workgroup tridiagonalisation (eigh_mc.hip), contexts with maxm > 120 only
     unsigned mc_epoch = 0;
     int mc_spin_max = -1;      // polls before a waiting thread of k_sytrd_mc gives up (-1: default; option "mc_spin_max", 0 in the fallback test)
-    bool attr_res = false, attr_gres = false;        // kernels_res.hip
+    bool attr_res = false, attr_gres = false, attr_gq = false;        // kernels_res.hip
     int res_pace = 0;                // pacing of the GEMM waves of k_fwd_res (0: default; option "res_pace")
     int fwd_res = 1;                 // forward pass on k_fwd_res (kernels_res.hip): 1 = from 7 680 images per rank on, 0 never, 2 always; option "fwd_res"
     int shift_res = 1;               // Label-carrying environment shift on k_shift_res (kernels_res.hip): 1 = from 7 680 images per rank on, 0 never, 2 always; option "shift_res"
@@ -343,6 +343,7 @@ struct GradResArgs {
     double* slab = nullptr;                           // split-K slabs [pairs][240][240] (set by the launcher)
 };
 int launch_grad_res(tnml_ctx* c, const GradResArgs& a, double* G);
+int launch_grad_q(tnml_ctx* c, const GradResArgs& a, double* G);      // ntiles is set by the launcher (16-image tiles)
 struct ShiftResArgs {
     const double* EI; size_t EI_lstride;              // Label-carrying input environment [L][120][NTp]
     const double* phiI;                               // features of the absorbed site [2][NTp]

@@ -134,6 +134,25 @@ int main(int argc, char** argv) {
         TRYG(0, 1, 0, "kernel alone, GEMM waves never pause:") TRYG(6, 2, 0, "pause 384 cycles every 8 MFMAs (default):") TRYG(4, 2, 0, "256 cycles every 8 MFMAs:") TRYG(6, 3, 0, "384 cycles every 12 MFMAs:")
         TRYG(4, 1, 0, "256 cycles every 4 MFMAs:") TRYG(8, 2, 0, "512 cycles every 8 MFMAs:") TRYG(8, 4, 0, "512 cycles every 16 MFMAs:")
         TRYG(0, 1, 1, "GEMM role alone (no environment loads):") TRYG(0, 1, 2, "streaming role alone (no MFMAs):")
+        // ---- k_grad_q (uniform waves, groups of four workgroups)
+        CK(hipMemset(G1, 0, (size_t)Kp * Np * 8));
+        if (launch_grad_q(c, gr, G1)) return 1;
+        CK(hipStreamSynchronize(c->stream)); CK(hipGetLastError());
+        CK(hipMemcpy(a.data(), G1, a.size() * 8, hipMemcpyDeviceToHost));
+        printf("k_grad_q: G max rel diff %.3e against k_bgemm64\n", maxrel(a, b2, a.size()));
+        launch_grad_q(c, gr, G1); CK(hipStreamSynchronize(c->stream));
+        CK(hipMemcpy(a2.data(), G1, a2.size() * 8, hipMemcpyDeviceToHost));
+        nd = 0; for (size_t i = 0; i < a2.size(); ++i) nd += a2[i] != a[i];
+        printf("         repeat run: %zu differing entries\n", nd);
+        const float t_q = time_it([&]() { launch_grad_q(c, gr, G1); });
+        printf("         k_grad_q + slab reduce %.1f us (%.1f TF on the algorithmic flops)\n", t_q * 1e3, gf / t_q);
+        {
+            const size_t ldsq = GQ_LDS_BYTES;
+            GradResArgs gq = gr; gq.ntiles = NTp / GQ_T;
+#define TRYQ(ABL, what) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_grad_q<ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq); \
+            const float t_ = time_it([&]() { hipLaunchKernelGGL((k_grad_q<ABL>), dim3(c->res_grid > 0 ? c->res_grid : 256), dim3(512), ldsq, c->stream, gq); }); printf("         %-64s %.1f us\n", what, t_ * 1e3); }
+            TRYQ(0, "k_grad_q alone:") TRYQ(1, "no DMA (LDS + MFMA only):") TRYQ(2, "no MFMAs (DMA + build only):") TRYQ(3, "no MFMAs, no Label-free pieces:") TRYQ(4, "no MFMAs, no Label-carrying pieces:") TRYQ(5, "DMA only (no build reads):")
+        }
     }
     return 0;
 }
