@@ -595,9 +595,14 @@ def main():
                          "frac": achieved_tf / peak,
                          "traffic": tr_fg, "traffic_source": src_fg,
                          "avg_launch_ms": avg_ms, "launches": n_fg, "flops_per_launch": flops_per_launch, "images_per_launch": img_fg,
-                         "note": ("k_fwd_fused = the feature GEMM (these flops) with the label dot of the previous 64-image tile running on four extra "
-                                  "waves of the same workgroup: its launch time replaces feature GEMM + label dot (kernel_ms_per_step.fwd_fused); "
-                                  "bytes streamed beside the flops: roofline_hbm") if fused else None},
+                         "note": (("k_fwd_res = the whole forward pass B*t.v in one launch: the feature GEMM (these flops; the bond matrix resident in the "
+                                   "registers of a pair of workgroups) with the label dot of the previous 32-image tile on four streaming waves of the "
+                                   "same workgroup"
+                                   if FWD_KERNEL[0] == "k_fwd_res" else
+                                   "k_fwd_fused = the feature GEMM (these flops) with the label dot of the previous 64-image tile running on four extra "
+                                   "waves of the same workgroup")
+                                  + ": its launch time replaces feature GEMM + label dot (kernel_ms_per_step.fwd_fused); "
+                                    "bytes streamed beside the flops: roofline_hbm") if fused else None},
             "roofline_step": {"bound": "mfma", "peak": peak, "unit": "TFLOP/s",
                               "achieved": exec_gf / ms_per_step, "frac": exec_gf / ms_per_step / peak,
                               "executed_gflop_per_step": exec_gf, "frac_executed": exec_gf / ms_per_step / peak,
