@@ -467,6 +467,39 @@ def test_test_set_accuracy_within_a_tenth_of_a_percent_on_10000_images(tmp_path)
     assert d <= 0.001 * NTEST + spread
 
 
+def _forward_with_fp32_stored_environments(phi, W, b, Bt):
+    """B*t.v of bond b for a direction Bt with the storage format of TNML_F64_E32 modelled exactly: features and every environment are
+    rounded to fp32 where the library stores them (once per shift, fixedL.cc:142-149,221-228), all arithmetic in fp64.
+    phi [NT][N][2]; W = the N site tensors [l][s][r]([L]) at the moment the bond is evaluated."""
+    r32 = lambda x: x.astype(np.float32).astype(np.float64)
+    f = r32(np.asarray(phi, dtype=np.float64))
+    NT, N, _ = f.shape
+    L = None
+    for j in range(1, b):                                             # left environments, built left to right by shiftE
+        M = np.einsum('ns,asr...->nar...', f[:, j - 1], W[j - 1])
+        if L is None:
+            L = M[:, 0]
+        else:
+            L = np.einsum('narl,na->nrl' if M.ndim == 4 else ('nar,nal->nrl' if L.ndim == 3 else 'nar,na->nr'), M, L)
+        L = r32(L)
+    R = None
+    for j in range(N, b + 1, -1):                                     # right environments, built right to left by init
+        M = np.einsum('ns,asr...->nar...', f[:, j - 1], W[j - 1])
+        if R is None:
+            R = M[:, :, 0]
+        else:
+            R = np.einsum('narl,nr->nal' if M.ndim == 4 else ('nar,nrl->nal' if R.ndim == 3 else 'nar,nr->na'), M, R)
+        R = r32(R)
+    fs, ft = f[:, b - 1], f[:, b]
+    L = np.ones((NT, 1)) if L is None else L                          # chain ends
+    R = np.ones((NT, 1)) if R is None else R
+    if Bt.ndim == 5:
+        return np.einsum('astrl,na,ns,nt,nr->nl', Bt, L, fs, ft, R, optimize=True)
+    if L.ndim == 3:
+        return np.einsum('astr,nal,ns,nt,nr->nl', Bt, L, fs, ft, R, optimize=True)
+    return np.einsum('astr,na,ns,nt,nrl->nl', Bt, L, fs, ft, R, optimize=True)
+
+
 @pytest.mark.gpu
 def test_c5_bond_updates_at_maxm_300_in_fp64_fp32_and_bf16():
     """BASELINE config 5 (maxm = 300: fp64 vs fp32 vs bf16 bond contraction) on the HIP kernels, bond update by bond update in
@@ -474,7 +507,18 @@ def test_c5_bond_updates_at_maxm_300_in_fp64_fp32_and_bf16():
     environment), 24 images (the oracle's dense t.v is 29 MB per image at this bond dimension).  Each arithmetic starts every bond
     update from the oracle's state.  The split is the 600 x 600 (6000 on the Label-on-B bonds) problem of eigh_mc.hip.
       f64      fp64 MFMA, fp64 storage                         gated: cost 1e-8, bond dimension and #correct exact
-      f64_e32  fp64 MFMA over fp32-stored environments         gated: cost 1e-5
+      f64_e32  fp64 MFMA over fp32-stored environments         gated against the storage format itself, not against a fitted number: the
+                                                               same evaluation in numpy with features and environments rounded to fp32
+                                                               once per shift and fp64 arithmetic (_forward_with_fp32_stored_environments)
+                                                               must agree with the HIP path to 1e-7 -- they differ in the fp64 summation
+                                                               order only, and a value that lands on the other side of an fp32 rounding
+                                                               boundary moves ONE entry of one environment by 6e-8 of itself (measured:
+                                                               4e-15).  What the format costs against fp64 on THIS chain (9 + 11 roundings
+                                                               through m = 300 sites) is that model's own deviation, 2.2e-7, and the HIP
+                                                               path must not exceed twice it; after-SVD cost 1e-6.
+                                                               (Round 3 measured 1.04e-5 here and widened its gate to fit: the shifts of
+                                                               this mode ran on the fp32 matrix pipe with fp32 accumulation -- the model
+                                                               exposed it; they run on the fp64 pipe and round once, on the store, now.)
       f32      v_mfma_f32_16x16x4_f32                          interior bonds gated at 1e-3
       bf16x3   v_mfma_f32_16x16x32_bf16, operands hi + lo      forward map gated at 1e-4 (the kernel's operand layout), costs reported
       bf16     v_mfma_f32_16x16x32_bf16                        forward map gated at 3e-2, costs reported (report-don't-gate)
@@ -498,11 +542,12 @@ def test_c5_bond_updates_at_maxm_300_in_fp64_fp32_and_bf16():
         Bt = B0 + 0.05 * np.abs(B0).max() * rng.standard_normal(B0.shape)       # a direction for the single-evaluation check
         Pt = o.forward(Bt)
         before = (o.get_site(b).copy(), o.get_site(b + 1).copy())
+        Pt32 = _forward_with_fp32_stored_environments(phi, o.get_mps(), b, Bt)
         B, tr = o.cgrad(B0, npass, lam, cconv)
         newm, te, _ = o.svd_split(B, b, 1, cutoff, m, minm)
         C, lc, cr, nc = o.quadcost(o.bond_tensor(b), lam)
         o.shiftE(b, True)
-        ref.append(dict(b=b, Bt=Bt, Pt=Pt, before=before, after=(o.get_site(b).copy(), o.get_site(b + 1).copy()), newm=newm, te=te, C=C, nc=nc,
+        ref.append(dict(b=b, Bt=Bt, Pt=Pt, Pt32=Pt32, before=before, after=(o.get_site(b).copy(), o.get_site(b + 1).copy()), newm=newm, te=te, C=C, nc=nc,
                         cg=tr["cost"]))
     rows = []
     for dtype in ("f64", "f64_e32", "f32", "bf16x3", "bf16"):
@@ -513,12 +558,16 @@ def test_c5_bond_updates_at_maxm_300_in_fp64_fp32_and_bf16():
             ts.shiftE(bb, True)
         worst = {"interior": 0.0, "label_on_B": 0.0}
         fwd = 0.0
+        fwd_model = 0.0
         dm = dn = 0
         for r0 in ref:
             b = r0["b"]
             ts.set_site(b, r0["before"][0]); ts.set_site(b + 1, r0["before"][1])
             ts.setBond(b)
-            fwd = max(fwd, _rel(ts.forward(r0["Bt"]), r0["Pt"]))
+            Pg = ts.forward(r0["Bt"])
+            fwd = max(fwd, _rel(Pg, r0["Pt"]))
+            if dtype == "f64_e32":
+                fwd_model = max(fwd_model, _rel(Pg, r0["Pt32"]))
             r = ts.bond_update(b, 1, m, minm, cutoff, npass, lam, cconv)
             kind = "label_on_B" if r["label_on_B"] else "interior"
             worst[kind] = max(worst[kind], abs(r["cost"] / r0["C"] - 1))
@@ -530,14 +579,19 @@ def test_c5_bond_updates_at_maxm_300_in_fp64_fp32_and_bf16():
             ts.shiftE(b, True)
         stats = ts.svd_stats()
         rows.append((dtype, fwd, worst["interior"], worst["label_on_B"], dm, dn, stats["fallbacks"]))
+        if dtype == "f64_e32":
+            e32_model = fwd_model
         ts.close()
     print("\nC5 (maxm = 300) lockstep, 4 bond updates per arithmetic: max rel. error of one forward evaluation | of the after-SVD cost, interior bonds | "
           "Label-on-B bonds | bond-dimension mismatches | #correct differences | eigensolver fallbacks")
     for rw in rows:
         print("  %-8s %.2e | %.2e | %.2e | %d | %d | %d" % rw)
+    predicted = max(_rel(r0["Pt32"], r0["Pt"]) for r0 in ref)
+    print("  fp32 storage modelled in numpy: deviation from fp64 %.2e (the format's cost on this chain) | HIP f64_e32 against the model %.2e" % (predicted, e32_model))
     by = {r[0]: r for r in rows}
+    assert e32_model < 1e-7 and by["f64_e32"][1] < 2 * predicted
     assert by["f64"][1] < 1e-11 and max(by["f64"][2], by["f64"][3]) < 1e-8 and by["f64"][4] == 0 and by["f64"][5] == 0 and by["f64"][6] == 0
-    assert by["f64_e32"][1] < 5e-5 and max(by["f64_e32"][2], by["f64_e32"][3]) < 1e-5 and by["f64_e32"][4] == 0
+    assert max(by["f64_e32"][2], by["f64_e32"][3]) < 1e-6 and by["f64_e32"][4] == 0
     assert by["f32"][1] < 1e-4 and by["f32"][2] < 1e-3
     assert by["bf16x3"][1] < 1e-4                                              # a wrong operand layout would give O(1)
     assert by["bf16"][1] < 3e-2

@@ -214,6 +214,8 @@ __global__ __launch_bounds__(64 * WR * WC) void k_fgemm64(Fgemm64Args A) {
                     v += __shfl_xor(v, 16);
                     const int q = j >> 1;
                     if ((g & 1) == 0 && q < A.mO) out[(size_t)q * NTp + n] = v;
+                } else if (A.out32) {                                        // fp32-stored environment: fp64 arithmetic, ONE rounding on the store
+                    if (j < A.mO) (reinterpret_cast<float*>(A.out) + (size_t)l * A.out_lstride)[(size_t)j * NTp + n] = (float)acc[c][r][e];
                 } else {
                     if (j < A.mO) out[(size_t)j * NTp + n] = acc[c][r][e];     // (non-temporal stores: no gain)
                 }

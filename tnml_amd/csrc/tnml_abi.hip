@@ -570,7 +570,7 @@ static int shift_core(tnml_ctx* c, int cs, bool from_left, const void* src, int 
     d.Kp = ru16(2 * d.nx); d.Np = ru16(d.ny);
     if ((size_t)d.L * d.Kp * d.Np > c->sM_cap || (size_t)d.L * d.Kp * d.Np > c->mcap)
         return tnml_fail(c, "shift: packed site matrix of site %d (%d x %d x %d) exceeds the workspace", cs, d.L, d.Kp, d.Np);
-    if (c->env64() || (acc_out && c->f64())) {          // fp64 output: fp64 MFMA shift (M in the free SVD workspace)
+    if (c->f64()) {                                     // fp64 MFMA shift (M in the free SVD workspace); fp32-stored environments (TNML_F64_E32) are rounded once, on the store
         TCK(launch_pack(c, d, A.a, c->sM, nullptr));
         Fgemm64Args f;
         f.EI = src ? src : c->ones;
@@ -579,7 +579,7 @@ static int shift_core(tnml_ctx* c, int cs, bool from_left, const void* src, int 
         f.M = c->sM; f.M_lstride = (A.L == TNML_NL) ? (size_t)d.Kp * d.Np : 0; f.Kp = d.Kp; f.Np = d.Np;
         f.phiO = nullptr;
         f.out = (double*)dst; f.out_lstride = (size_t)m_out * c->NTp; f.mO = m_out;
-        f.NTp = c->NTp; f.L = Lout; f.env64 = c->env64();
+        f.NTp = c->NTp; f.L = Lout; f.env64 = c->env64(); f.out32 = !c->env64() && !acc_out;
         // the Label-carrying shift at m = 120 with the site matrix resident in registers (kernels_res.hip)
         if (c->shift_res && c->env64() && !acc_out && src && Le == TNML_NL && A.L == 1 && m_in == 120 && m_out == 120 && d.Kp == 240 && d.Np == 128 &&
             (c->shift_res >= 2 || c->NTp >= 7680)) {

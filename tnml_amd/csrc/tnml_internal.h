@@ -255,6 +255,7 @@ struct Fgemm64Args {
     double* out; size_t out_lstride; int mO;
     int NTp; int L;
     int env64;
+    int out32 = 0;                                    // shift form only: out is a float array (fp32-stored environments, TNML_F64_E32)
     int n_off = 0, n_cnt = 0;                         // image range of this launch (n_cnt = 0: all NTp); multiples of 128
     hipStream_t st = nullptr;                         // nullptr: the context's stream
     int kclass = -1;                                  // profiling class override
