@@ -5,6 +5,7 @@
 #include "../../tnml_amd/csrc/kernels_fused.hip"
 #include "../../tnml_amd/csrc/kernels_stream.hip"
 #include "../../tnml_amd/csrc/kernels_gemm.hip"
+#include "k_grad_h.inc"       // the fourth gradient form (not in the library): tools/probe/attic/k_grad_h_attempt.hip.txt + ablation switches
 #include <cstdarg>
 #include <cstdlib>
 #include <vector>
@@ -152,6 +153,25 @@ int main(int argc, char** argv) {
 #define TRYQ(ABL, what) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_grad_q<ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq); \
             const float t_ = time_it([&]() { hipLaunchKernelGGL((k_grad_q<ABL>), dim3(c->res_grid > 0 ? c->res_grid : 256), dim3(512), ldsq, c->stream, gq); }); printf("         %-64s %.1f us\n", what, t_ * 1e3); }
             TRYQ(0, "k_grad_q alone:") TRYQ(1, "no DMA (LDS + MFMA only):") TRYQ(2, "no MFMAs (DMA + build only):") TRYQ(3, "no MFMAs, no Label-free pieces:") TRYQ(4, "no MFMAs, no Label-carrying pieces:") TRYQ(5, "DMA only (no build reads):")
+        }
+        {   // ---- k_grad_h (probe only): k_grad_q's GEMM waves without a single VMEM instruction + four mover waves
+            const size_t ldsh = GH_LDS_BYTES;
+            GradResArgs gh = gr; gh.ntiles = NTp / 32; gh.slab = (double*)c->slab;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_grad_h<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsh);
+            auto run_h = [&]() { hipLaunchKernelGGL((k_grad_h<0>), dim3(256), dim3(768), ldsh, c->stream, gh); launch_slab_reduce64(c, (const double*)c->slab, G1, (size_t)Kp * Np, 64); };
+            CK(hipMemset(G1, 0, (size_t)Kp * Np * 8));
+            run_h(); CK(hipStreamSynchronize(c->stream)); CK(hipGetLastError());
+            CK(hipMemcpy(a.data(), G1, a.size() * 8, hipMemcpyDeviceToHost));
+            printf("k_grad_h: G max rel diff %.3e against k_bgemm64\n", maxrel(a, b2, a.size()));
+            run_h(); CK(hipStreamSynchronize(c->stream));
+            CK(hipMemcpy(a2.data(), G1, a2.size() * 8, hipMemcpyDeviceToHost));
+            nd = 0; for (size_t i = 0; i < a2.size(); ++i) nd += a2[i] != a[i];
+            printf("         repeat run: %zu differing entries\n", nd);
+            printf("         k_grad_h + slab reduce %.1f us\n", time_it(run_h) * 1e3);
+#define TRYH(ABL, what) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_grad_h<ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsh); \
+            const float t_ = time_it([&]() { hipLaunchKernelGGL((k_grad_h<ABL>), dim3(c->res_grid > 0 ? c->res_grid : 256), dim3(768), ldsh, c->stream, gh); }); printf("         %-64s %.1f us\n", what, t_ * 1e3); }
+            TRYH(0, "k_grad_h alone:") TRYH(1, "no loads (LDS + MFMA only; the operands are zeros):") TRYH(10, "no loads, LDS filled with full-mantissa numbers:") TRYH(2, "no MFMAs (movers + DMA + build):")
+            TRYH(6, "movers do not write to LDS:") TRYH(7, "no DMA pieces (movers' ring on):") TRYH(8, "ring off (DMA pieces on):")
         }
     }
     return 0;
