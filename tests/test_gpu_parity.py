@@ -1524,11 +1524,18 @@ def test_split_at_every_size_between_the_one_workgroup_kernel_and_the_cluster_li
     ts.setBond(b)
     rng = np.random.default_rng(m)
     Bn = rng.standard_normal((m, 2, 2, m)) * np.logspace(0, -9, 2 * m)[rng.permutation(2 * m)].reshape(m, 2, 1, 1)   # graded rows: a spectrum over 9 decades
-    mg, teg, svg = ts.svd_split(Bn, b, 1, 1e-12, m, m)
+    ref = (lambda U, S, Vt: (U[:, :m] * S[:m]) @ Vt[:m])(*np.linalg.svd(Bn.reshape(2 * m, 2 * m)))
     sv = np.linalg.svd(Bn.reshape(2 * m, 2 * m), compute_uv=False)
-    assert mg == m
-    np.testing.assert_allclose(svg[:m], sv[:m], rtol=1e-7, atol=1e-9 * sv[0])
-    assert _relmax(ts.bond_tensor(b).reshape(2 * m, 2 * m), (lambda U, S, Vt: (U[:, :m] * S[:m]) @ Vt[:m])(*np.linalg.svd(Bn.reshape(2 * m, 2 * m)))) < 1e-7
+    # above 128 kept columns the Cholesky QR of the basis is a block Gram-Schmidt over <= 128-column blocks (2 blocks up to 256, 3 above);
+    # bgs_chol = 0 is the stock dpotrf + dtrsm it replaced -- both at the sizes either side of a block-count switch
+    for bgs in ((1, 0) if m in (129, 256, 257, 300) else (1,)):
+        ts.set_option("bgs_chol", bgs)
+        mg, teg, svg = ts.svd_split(Bn, b, 1, 1e-12, m, m)
+        assert mg == m
+        np.testing.assert_allclose(svg[:m], sv[:m], rtol=1e-7, atol=1e-9 * sv[0])
+        assert _relmax(ts.bond_tensor(b).reshape(2 * m, 2 * m), ref) < 1e-7
+        Ab = ts.get_site(b).reshape(2 * m, m)                       # the left factor is an isometry
+        assert np.abs(Ab.T @ Ab - np.eye(m)).max() < 1e-11, bgs
     assert ts.svd_stats()["fallbacks"] == 0
     ts.close()
 

@@ -84,6 +84,15 @@ __global__ void k_potrf_flags(const int* __restrict__ info, double* __restrict__
     if (threadIdx.x == 0) { flag[0] = info[0] != 0 ? 1. : 0.; flag[1] = 1.; }
 }
 
+// flags of the blocks of the block Gram-Schmidt -> the two flags of the Cholesky QR (any block failed / any block factored)
+__global__ void k_flags_any(const double* __restrict__ fl, int nb, double* __restrict__ flag) {
+    if (threadIdx.x == 0) {
+        double f0 = 0., f1 = 0.;
+        for (int k = 0; k < nb; ++k) { if (fl[2 * k] != 0.) f0 = 1.; if (fl[2 * k + 1] != 0.) f1 = 1.; }
+        flag[0] = f0; flag[1] = f1;
+    }
+}
+
 // the workgroup cluster's status word -> a double that can be summed over the ranks (1 = this rank's cluster gave up)
 __global__ void k_mc_flag(const unsigned long long* __restrict__ status, double* __restrict__ out) {
     if (threadIdx.x == 0) out[0] = status[0] != 0ull ? 1. : 0.;
@@ -219,7 +228,6 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
         // Z (already "largest first") -> U = H_0 H_1 ... Z for all mk candidate columns, queued BEFORE the eigenvalues go to
         // the host, so that the truncation decision costs no idle gap on the device; the kept columns are the first m.
         TCK(eigh_backtransform(c, c->sV, c->sTau, n, c->sC, n, Q0, n, mk));
-        RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, mk, mk, n, &one, Q0, n, Q0, n, &zero, c->sS, mk));
         // The Gram matrix of a bond tensor spans 12+ decades (the common mode of the images dominates), so most of the kept
         // eigenvalues sit within a few 100 eps*|T| of each other: inverse iteration returns the right invariant subspace for
         // them but not orthogonal vectors (80 % of the bond updates of a sweep).  Any orthonormal basis of that subspace is
@@ -228,10 +236,40 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
         // second synchronisation.
         const double* Qin;
         if (mk <= TNML_CHOL_MAXM) {                       // one-workgroup kernel; returns R = I straight away when Q0 is orthonormal to 5e-7
+            RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, mk, mk, n, &one, Q0, n, Q0, n, &zero, c->sS, mk));
             TCK(eigh_chol_rinv(c, c->sS, mk, c->sCm, dv + 1));              // writes both flags
             RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, n, mk, mk, &one, Q0, n, c->sCm, mk, &zero, c->sG, n));   // the Gram matrix is consumed by now
             Qin = c->sG;
-        } else {                                          // larger bases (maxm > 128): rocSOLVER dpotrf + rocBLAS dtrsm, in place
+        } else if (c->bgs_chol && mk <= 3 * TNML_CHOL_MAXM) {
+            // larger bases (128 < mk <= 384; BASELINE config 5 keeps 300 columns): block Gram-Schmidt over column blocks of <= 128 with the
+            // one-workgroup Cholesky kernel inside a block.  Block k is projected against the finished blocks before it -- twice
+            // (classical Gram-Schmidt loses what the first pass leaves of a cluster that straddles a block boundary; the second pass
+            // removes it) -- then Q_k <- Q_k R_k^-1 with Q_k^T Q_k = R_k^T R_k.  Everything is a small GEMM or the 26-110 us kernel:
+            // 0.69 ms of stock dpotrf (three potf2 panels) + dtrsm become ~0.4 ms at mk = 300.  The polish step and its check below are
+            // the same for every path, so a basis this does not fix still ends in the rocSOLVER fallback.
+            const int nb = (mk + TNML_CHOL_MAXM - 1) / TNML_CHOL_MAXM, wb = (mk + nb - 1) / nb;
+            double* Cw = c->sCm;                            // coefficients against the finished columns (c0 x w)
+            double* Rk = c->sCm + (size_t)(mk - wb) * wb;   // R_k^-1 (w x w); (mk - wb) wb + wb^2 <= maxm^2
+            double* fl = c->sScr;                           // two flags per block (the eigen stages are done with the scratch)
+            const double mone = -1.0;
+            HIPCK(c, hipMemsetAsync(fl, 0, sizeof(double) * 2 * nb, st));        // (a failing block writes its first flag only)
+            for (int k = 0, c0 = 0; k < nb; ++k) {
+                const int w = std::min(wb, mk - c0);
+                double* Qk = Q0 + (size_t)c0 * n;
+                if (c0 > 0)
+                    for (int pass = 0; pass < 2; ++pass) {
+                        RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, c0, w, n, &one, c->sG, n, Qk, n, &zero, Cw, c0));
+                        RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, n, w, c0, &mone, c->sG, n, Cw, c0, &one, Qk, n));
+                    }
+                RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, w, w, n, &one, Qk, n, Qk, n, &zero, c->sS, w));
+                TCK(eigh_chol_rinv(c, c->sS, w, Rk, fl + 2 * k));
+                RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, n, w, w, &one, Qk, n, Rk, w, &zero, c->sG + (size_t)c0 * n, n));
+                c0 += w;
+            }
+            hipLaunchKernelGGL(k_flags_any, dim3(1), dim3(64), 0, st, (const double*)fl, nb, dv + 1);
+            Qin = c->sG;
+        } else {                                          // rocSOLVER dpotrf + rocBLAS dtrsm, in place (option bgs_chol = 0, or more than 384 columns)
+            RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, mk, mk, n, &one, Q0, n, Q0, n, &zero, c->sS, mk));
             RBCK(c, rocsolver_dpotrf(c->blas, rocblas_fill_upper, mk, c->sS, mk, c->sInfo));
             hipLaunchKernelGGL(k_potrf_flags, dim3(1), dim3(64), 0, st, (const int*)c->sInfo, dv + 1);
             RBCK(c, rocblas_dtrsm(c->blas, rocblas_side_right, rocblas_fill_upper, rocblas_operation_none, rocblas_diagonal_non_unit, n, mk, &one, c->sS, mk, Q0, n));

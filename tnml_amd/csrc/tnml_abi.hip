@@ -91,6 +91,7 @@ int tnml_set_option(tnml_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "res_grid")) c->res_grid = value;
     else if (!strcmp(name, "res_pace")) c->res_pace = value;
     else if (!strcmp(name, "sytrd_exit")) c->sytrd_exit = value;
+    else if (!strcmp(name, "bgs_chol")) c->bgs_chol = value != 0;
     else if (!strcmp(name, "comm_timeout_s")) { if (value < 1) return tnml_fail(c, "comm_timeout_s must be >= 1"); c->comm_timeout_s = value; local_comm_set_timeout(c, value); }
     else if (!strcmp(name, "cg_method")) { if (value < 0 || value > 2 || (value >= 1 && !c->single())) return tnml_fail(c, "cg_method: 0 (conj) or, in TNML_MODE_SINGLE, 1 (fast_conj) / 2 (exact)"); c->cg_method = value; }
     else if (!strcmp(name, "debug_nudge_rank")) c->debug_nudge_rank = value;
@@ -238,6 +239,7 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     if (const char* e = getenv("TNML_GRAD_RES")) c->grad_res = atoi(e);
     if (const char* e = getenv("TNML_SHIFT_RES")) c->shift_res = atoi(e);
     if (const char* e = getenv("TNML_RES_PACE")) c->res_pace = atoi(e);
+    if (const char* e = getenv("TNML_BGS_CHOL")) c->bgs_chol = atoi(e) != 0;
     if (rocblas_create_handle(&c->blas) != rocblas_status_success) return bail(tnml_fail(c, "rocblas_create_handle failed"));
     rocblas_set_stream(c->blas, c->stream);
     // replicas of W must stay bit-identical over the ranks: no atomics-based split-K inside rocBLAS

@@ -127,6 +127,7 @@ struct tnml_ctx {
     // recompute with its own forward GEMM + label dot.  p_valid marks P/dP as current; anything that changes W, the data or
     // P itself clears it (env TNML_REUSE_P=0 disables the shortcut).
     bool reuse_p = true, p_valid = false;
+    int bgs_chol = 1;                    // option bgs_chol: block Gram-Schmidt Cholesky QR for 128 < kept columns <= 384 (0: rocSOLVER dpotrf + dtrsm)
     int coll_depth = 0;                  // >0 inside an entry point that every rank calls in step (tnml_fail then aborts an in-process communicator)
     int comm_timeout_s = 120;            // option comm_timeout_s: how long a rank of an in-process communicator waits for its peers
     int opt_fg64_cfg = 0, opt_ldot_cfg = 0;   // kernel-instantiation overrides (0: chosen by the image count)
