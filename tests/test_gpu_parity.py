@@ -1557,3 +1557,29 @@ def test_bond_dimension_above_120_splits_on_the_workgroup_cluster(m, NT):
     assert mg == mo
     np.testing.assert_allclose(svg[:mg], svo[:mo], rtol=1e-7, atol=1e-8 * svo[0])
     assert _relmax(ts.bond_tensor(10), o.bond_tensor(10)) < 1e-8
+
+
+@pytest.mark.parametrize("dtype,gate_on,gate_off", [("bf16x3", 2e-4, 2e-5), ("bf16", 5e-2, 5e-3)])
+def test_gradient_gemm_on_the_bf16_pipe(dtype, gate_on, gate_off):
+    """dP*dag(t.v) (fixedL.cc:379,418) in the bf16 study modes (BASELINE config 5: bf16 MFMA bond contraction): k_bgemm_bf16 rounds both
+    operands of the gradient GEMM to bf16 (plain: 8 mantissa bits; hi + lo: ~16) and accumulates in fp32; with option bf16_grad = 0
+    the fp32 kernel of round 3 runs instead.  All three bond kinds; the gates are the operand precision (a wrong fragment layout gives
+    O(1)); the residuals dP that weight the sum come from the mode's own forward pass, so the fp32 kernel's result carries that error too."""
+    ts, o = _pair(N=12, NT=300, m=24, dtype=dtype)
+    at = 1
+    for b, kind in ((3, "Label on RE"), (6, "Label on B"), (9, "Label on LE")):
+        for bb in range(at, b):
+            ts.shiftE(bb, True); o.shiftE(bb, True)
+        at = b
+        ts.setBond(b); o.set_bond(b)
+        B = o.bond_tensor(b)
+        Go = o.gradient(B)
+        ts.set_option("bf16_grad", 1)
+        e_on = _relmax(ts.gradient(B), Go)
+        ts.set_option("bf16_grad", 0)
+        e_off = _relmax(ts.gradient(B), Go)
+        print(dtype, kind, "gradient error with the bf16 kernel %.2e, with the fp32 kernel %.2e" % (e_on, e_off))
+        assert e_on < gate_on, kind
+        assert e_off < gate_off, kind                      # the fp32 gradient kernel; its weights dP come from the mode's forward pass (bf16: 1e-3)
+        assert e_on != e_off, kind                         # the two kernels really are different code paths
+    ts.close()

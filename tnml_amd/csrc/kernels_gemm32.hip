@@ -1,6 +1,7 @@
 // kernels_gemm32.hip -- the reduced-precision study modes of the two image-proportional GEMMs (TNML_F32, TNML_BF16, TNML_BF16X3;
 // BASELINE config 5's "bf16 MFMA bond contraction vs fp32"): k_fgemm (feature GEMM / environment shift on v_mfma_f32_16x16x4_f32),
-// k_fgemm_bf16 (forward feature GEMM on v_mfma_f32_16x16x32_bf16, plain and hi + lo split), k_bgemm (gradient GEMM, fp32 MFMA).
+// k_fgemm_bf16 (forward feature GEMM on v_mfma_f32_16x16x32_bf16, plain and hi + lo split), k_bgemm (gradient GEMM, fp32 MFMA),
+// k_bgemm_bf16 (gradient GEMM on the bf16 pipe).
 // The default arithmetic (fp64 MFMA) lives in kernels_gemm.hip; the algebra and the tile maps are the same.
 #include "tnml_internal.h"
 
@@ -341,6 +342,106 @@ __global__ __launch_bounds__(64 * WR * WC) void k_bgemm(BgemmKArgs K) {
         }
 }
 
+// k_bgemm_bf16 -- the gradient GEMM dP*dag(t.v) (fixedL.cc:379,418) on the bf16 matrix pipe (TNML_BF16 / TNML_BF16X3): k_bgemm's tiling,
+// split-K slabs and C-fragment map; both operands are formed in fp32 (X_n = EI_n (x) phiI_n, Z_n phiO_n w_n), rounded to bf16 (SPLIT: hi + lo
+// with three MFMAs per product, small terms first) while they are staged, fp32 accumulation.  The reduction index is the image, which is
+// already the contiguous index of both operands in memory: an A / B fragment is 8 consecutive images of one row (k = 8 (lane >> 4) + 0..7),
+// one 32-image chunk is ONE MFMA step per tile.  With k_fgemm_bf16 this puts the whole bond contraction of the bf16 modes on the bf16 pipe.
+template <int RT, int CT, int WR, int WC, int SPLIT>
+__global__ __launch_bounds__(64 * WR * WC) void k_bgemm_bf16(BgemmKArgs K) {
+    constexpr int T = 64 * WR * WC, BMr = 16 * RT * WR, BNc = 16 * CT * WC, KTn = 32, KS = KTn + 8;     // KS: row stride in bf16 elements (80 bytes)
+    constexpr int NP = SPLIT ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) unsigned short lds[NP * (BMr + BNc) * KS];
+    unsigned short* As = lds;                               // [NP][BMr][KS]
+    unsigned short* Bs = lds + NP * BMr * KS;               // [NP][BNc][KS]
+    const BgemmArgs& A = K.a;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid / WC, wc = wid % WC;
+    const int i0 = blockIdx.x * BMr, j0 = blockIdx.y * BNc;
+    const int split = blockIdx.z % K.nsplit, l = blockIdx.z / K.nsplit;
+    const int NTp = A.NTp;
+    const int nbeg = split * K.imgs_per_split;
+    const int nend = min(nbeg + K.imgs_per_split, NTp);
+    const float* w = A.w ? A.w + (size_t)l * A.w_lstride : nullptr;
+
+    f32x4 acc[RT][CT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto put4 = [&](unsigned short* dst, unsigned short* dst_lo, float4 v) {          // four consecutive images of one row
+        const float x[4] = {v.x, v.y, v.z, v.w};
+        unsigned short h[4], lo[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { h[q] = f2bf(x[q]); if (SPLIT) lo[q] = f2bf(x[q] - bf2f(h[q])); }
+        *reinterpret_cast<uint2*>(dst) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+        if (SPLIT) *reinterpret_cast<uint2*>(dst_lo) = make_uint2((unsigned)lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2] | ((unsigned)lo[3] << 16));
+    };
+    for (int nb = nbeg; nb < nend; nb += KTn) {
+        for (int idx = tid; idx < (BMr / 2) * (KTn / 4); idx += T) {
+            const int ar = idx / (KTn / 4), c4 = idx % (KTn / 4);
+            const int a = i0 / 2 + ar, n = nb + c4 * 4;
+            float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a < A.mI) e = *reinterpret_cast<const float4*>(A.EI + (size_t)a * NTp + n);
+            const float4 p0 = *reinterpret_cast<const float4*>(A.phiI + n);
+            const float4 p1 = *reinterpret_cast<const float4*>(A.phiI + NTp + n);
+            put4(&As[(2 * ar) * KS + c4 * 4], &As[BMr * KS + (2 * ar) * KS + c4 * 4], mul4(e, p0));
+            put4(&As[(2 * ar + 1) * KS + c4 * 4], &As[BMr * KS + (2 * ar + 1) * KS + c4 * 4], mul4(e, p1));
+        }
+        for (int idx = tid; idx < (BNc / 2) * (KTn / 4); idx += T) {
+            const int qr = idx / (KTn / 4), c4 = idx % (KTn / 4);
+            const int q = j0 / 2 + qr, n = nb + c4 * 4;
+            float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < A.mO) z = *reinterpret_cast<const float4*>(A.Zq + (size_t)q * NTp + n);
+            if (w) z = mul4(z, *reinterpret_cast<const float4*>(w + n));
+            const float4 p0 = *reinterpret_cast<const float4*>(A.phiO + n);
+            const float4 p1 = *reinterpret_cast<const float4*>(A.phiO + NTp + n);
+            put4(&Bs[(2 * qr) * KS + c4 * 4], &Bs[BNc * KS + (2 * qr) * KS + c4 * 4], mul4(z, p0));
+            put4(&Bs[(2 * qr + 1) * KS + c4 * 4], &Bs[BNc * KS + (2 * qr + 1) * KS + c4 * 4], mul4(z, p1));
+        }
+        __syncthreads();
+        {
+            const int ko = 8 * (lane >> 4);
+            bf16x8 ah[RT], bh[CT], al[SPLIT ? RT : 1], bl[SPLIT ? CT : 1];
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                ah[r] = *reinterpret_cast<const bf16x8*>(&As[((wr * RT + r) * 16 + (lane & 15)) * KS + ko]);
+                if (SPLIT) al[r] = *reinterpret_cast<const bf16x8*>(&As[BMr * KS + ((wr * RT + r) * 16 + (lane & 15)) * KS + ko]);
+            }
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                bh[c] = *reinterpret_cast<const bf16x8*>(&Bs[((wc * CT + c) * 16 + (lane & 15)) * KS + ko]);
+                if (SPLIT) bl[c] = *reinterpret_cast<const bf16x8*>(&Bs[BNc * KS + ((wc * CT + c) * 16 + (lane & 15)) * KS + ko]);
+            }
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    if (SPLIT) {
+                        acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[r], bh[c], acc[r][c], 0, 0, 0);
+                        acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[r], bl[c], acc[r][c], 0, 0, 0);
+                    }
+                    acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[r], bh[c], acc[r][c], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+    float* slab = K.slab + ((size_t)split * A.L + l) * A.Kp * A.Np;
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const int j = j0 + (wc * CT + c) * 16 + (lane & 15);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = i0 + (wr * RT + r) * 16 + (lane >> 4) * 4 + e;
+                if (i < A.Kp && j < A.Np) slab[(size_t)i * A.Np + j] = acc[r][c][e];
+            }
+        }
+}
+
 __global__ void k_slab_reduce(const float* __restrict__ slab, double* __restrict__ G, size_t n, int nsplit) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -367,7 +468,9 @@ static int bgemm_go(tnml_ctx* c, const BgemmArgs& a, double* G) {
     {
         ProfScope ps(c, KC_BGEMM);
         dim3 grid((a.Kp + BMr - 1) / BMr, (a.Np + BNc - 1) / BNc, nsplit * a.L);
-        hipLaunchKernelGGL((k_bgemm<RT, CT, WR, WC>), grid, dim3(64 * WR * WC), 0, c->stream, K);
+        if (a.bf16 == 2)      hipLaunchKernelGGL((k_bgemm_bf16<RT, CT, WR, WC, 1>), grid, dim3(64 * WR * WC), 0, c->stream, K);
+        else if (a.bf16 == 1) hipLaunchKernelGGL((k_bgemm_bf16<RT, CT, WR, WC, 0>), grid, dim3(64 * WR * WC), 0, c->stream, K);
+        else                  hipLaunchKernelGGL((k_bgemm<RT, CT, WR, WC>), grid, dim3(64 * WR * WC), 0, c->stream, K);
     }
     {
         ProfScope ps(c, KC_SLABRED);

@@ -92,6 +92,7 @@ int tnml_set_option(tnml_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "res_pace")) c->res_pace = value;
     else if (!strcmp(name, "sytrd_exit")) c->sytrd_exit = value;
     else if (!strcmp(name, "bgs_chol")) c->bgs_chol = value != 0;
+    else if (!strcmp(name, "bf16_grad")) c->bf16_grad = value != 0;
     else if (!strcmp(name, "comm_timeout_s")) { if (value < 1) return tnml_fail(c, "comm_timeout_s must be >= 1"); c->comm_timeout_s = value; local_comm_set_timeout(c, value); }
     else if (!strcmp(name, "cg_method")) { if (value < 0 || value > 2 || (value >= 1 && !c->single())) return tnml_fail(c, "cg_method: 0 (conj) or, in TNML_MODE_SINGLE, 1 (fast_conj) / 2 (exact)"); c->cg_method = value; }
     else if (!strcmp(name, "debug_nudge_rank")) c->debug_nudge_rank = value;
@@ -859,7 +860,7 @@ static int grad_eval(tnml_ctx* c, bool from_P_update = false, bool outputs_curre
     } else {
         BgemmArgs g;
         g.EI = (const float*)p.EI; g.mI = p.mI; g.phiI = (const float*)p.phiI; g.phiO = (const float*)p.phiO; g.mO = p.mO;
-        g.Kp = p.Kp; g.Np = p.Np; g.NTp = c->NTp; g.L = p.LB;
+        g.Kp = p.Kp; g.Np = p.Np; g.NTp = c->NTp; g.L = p.LB; g.bf16 = c->bf16() && c->bf16_grad ? c->bf16() : 0;
         if (p.kind == 2) { g.Zq = (const float*)p.EX; g.w = (const float*)wsrc; g.w_lstride = c->NTp; }
         else             { g.Zq = (const float*)c->Zp; g.w = nullptr; g.w_lstride = 0; }
         TCK(launch_bgemm(c, g, c->vG));

@@ -127,6 +127,7 @@ struct tnml_ctx {
     // recompute with its own forward GEMM + label dot.  p_valid marks P/dP as current; anything that changes W, the data or
     // P itself clears it (env TNML_REUSE_P=0 disables the shortcut).
     bool reuse_p = true, p_valid = false;
+    int bf16_grad = 1;                   // option bf16_grad: in the bf16 modes the gradient GEMM runs on the bf16 pipe too (0: the fp32 kernel, as through round 3)
     int bgs_chol = 1;                    // option bgs_chol: block Gram-Schmidt Cholesky QR for 128 < kept columns <= 384 (0: rocSOLVER dpotrf + dtrsm)
     int coll_depth = 0;                  // >0 inside an entry point that every rank calls in step (tnml_fail then aborts an in-process communicator)
     int comm_timeout_s = 120;            // option comm_timeout_s: how long a rank of an in-process communicator waits for its peers
@@ -243,6 +244,7 @@ struct BgemmArgs {
     const float* Zq; int mO; const float* phiO;      // B operand rows: w[n]*phiO[t][n]*Zq[q][n]
     const float* w; size_t w_lstride;                // per-image weight [L][NTp] or null
     int Kp, Np, NTp, L;
+    int bf16 = 0;                                    // 1 / 2: operands rounded to bf16 (plain / hi + lo) on v_mfma_f32_16x16x32_bf16 (TNML_BF16, TNML_BF16X3)
 };
 // writes split-K partial slabs then reduces them (fixed order, fp64) into G[L][Kp][Np]
 int launch_bgemm(tnml_ctx* c, const BgemmArgs& a, double* G);
