@@ -46,9 +46,10 @@ typedef struct tnml_ctx tnml_ctx;
                  sweep follows the fp64 trajectory only loosely (DESIGN.md "fp32 environments").
    TNML_F32      v_mfma_f32_16x16x4_f32, exact-fp32 arithmetic -- 2x the MFMA rate, for the tolerance study only:
                  the reference's CG is not reproducible in fp32 (DESIGN.md "why fp64 MFMA").
-   TNML_BF16     as TNML_F32 (fp32 storage, fp32 CG/label dot/gradient GEMM) with the forward feature GEMM of B*t.v on
-                 v_mfma_f32_16x16x32_bf16: operands rounded to bf16 while staging, fp32 accumulation (BASELINE config 5's
-                 "bf16 MFMA bond contraction"; report-don't-gate)
+   TNML_BF16     as TNML_F32 (fp32 storage, fp32 CG / label dot / shifts) with the two image-proportional GEMMs of the bond
+                 contraction -- the feature GEMM of B*t.v and the gradient GEMM dP*dag(t.v) -- on v_mfma_f32_16x16x32_bf16:
+                 operands rounded to bf16 while staging, fp32 accumulation (BASELINE config 5's "bf16 MFMA bond
+                 contraction"; report-don't-gate).  Option bf16_grad = 0 keeps the gradient GEMM on the fp32 kernel.
    TNML_BF16X3   the same with every operand split hi + lo (x = bf16(x) + bf16(x - bf16(x))) and three bf16 MFMAs per product
                  (hi*hi + hi*lo + lo*hi): ~16 mantissa bits */
 enum { TNML_F32 = 0, TNML_F64_E32 = 1, TNML_F64 = 2, TNML_BF16 = 3, TNML_BF16X3 = 4 };
