@@ -13,7 +13,7 @@ f=sys.argv[1]
 try:
     d=json.load(open("gpurun_out/final/%s.json"%f))
     k=d["kernel_ms_per_step"]
-    print(f, "%.1f/s %.3f ms lit %s | rf %.3f hbm %.3f step_exec %.3f alg %.3f | grad %.3f svd %.3f |" % (d["value"], d["ms_per_step"], d["value_literal_order"] and round(d["value_literal_order"],1), d["roofline"]["frac"], (d["roofline_hbm"] or {}).get("frac",0), d["roofline_step"]["frac_executed"], d["roofline_step"]["frac_algorithmic"], d["gradient_phase_ms"], d["svd_ms"]), {a:round(b,3) for a,b in k.items()}, d.get("cpu_baseline",{}).get("value"), d["device_gb"])
+    print(f, "%.1f/s %.3f ms lit %s | rf %.3f hbm %.3f step_exec %.3f alg %.3f | grad %.3f svd %.3f |" % (d["value"], d["ms_per_step"], d["value_literal_order"] and round(d["value_literal_order"],1), d["roofline"]["frac"], (d["roofline_hbm"] or {}).get("frac",0), d["roofline_step"]["frac_executed"], d["roofline_step"]["algorithmic_gflop_per_step"] / d["ms_per_step"] / 78.6, d["gradient_phase_ms"], d["svd_ms"]), {a:round(b,3) for a,b in k.items()}, d.get("cpu_baseline",{}).get("value"), d["device_gb"])
 except Exception as e: print(f, "failed", e)
 PY
 done
