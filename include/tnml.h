@@ -175,6 +175,12 @@ int tnml_set_bond(tnml_ctx* ctx, int b);               /* selects env buffers; t
 int tnml_shift_env(tnml_ctx* ctx, int b, int from_left);
 int tnml_env_dims(tnml_ctx* ctx, int j, int* m, int* has_label);
 int tnml_get_env(tnml_ctx* ctx, int j, double* E);     /* [NT_local][m(*10)], for parity tests */
+/* The host tier of the environments (the reference's Nbatch / proj_images spill, fixedL.cc:115-120,153,177-178,216,231, with host
+   memory in the place of its disk files).  tnml_set_option(ctx, "env_budget_mb", MB) caps the environment slabs held on the device
+   (0, the default: no cap -- everything stays in HBM); an environment that does not fit is copied to host memory, farthest from
+   the current bond first, and copied back when setBond / shiftE needs it.  Results do not depend on the budget.  Also taken when
+   hipMalloc of a new slab fails.  tnml_env_stats: copies to the host / back so far, slabs on the device, bytes currently on the host. */
+int tnml_env_stats(tnml_ctx* ctx, int64_t* spills, int64_t* fetches, int64_t* slabs_on_device, int64_t* host_bytes);
 
 /* ---- bond tensor oB = W.A(b)*W.A(b+1)  (fixedL.cc:494,527,745) --------------------------- */
 int tnml_bond_dims(tnml_ctx* ctx, int b, int* mL, int* mR, int* label_on_B);

@@ -1583,3 +1583,46 @@ def test_gradient_gemm_on_the_bf16_pipe(dtype, gate_on, gate_off):
         assert e_off < gate_off, kind                      # the fp32 gradient kernel; its weights dP come from the mode's forward pass (bf16: 1e-3)
         assert e_on != e_off, kind                         # the two kernels really are different code paths
     ts.close()
+
+
+def test_environments_spill_to_host_memory_and_the_sweep_does_not_notice():
+    """the host tier of the environments (the reference's Nbatch / proj_images spill, fixedL.cc:115-120,153,177-178,216,231): with
+    env_budget_mb the environment slabs on the device are capped, slabs farthest from the current bond are copied to host memory and
+    copied back when setBond / shiftE needs them.  Two sweeps under a budget of FOUR slabs (the chain needs more than twice that without one) give
+    bit-identical costs, bond dimensions and site tensors; every environment -- resident or spilled -- still equals the oracle's; the
+    test-set pass (its chain buffers come from the same slabs) and a second context without a budget agree."""
+    from tnml_amd.fixedl import TrainStates, mldmrg
+    from conftest import make_problem
+    N, NT, m = 24, 300, 12
+    pixels, labels, phi, W = make_problem(N, NT, m, 11, pixel_boost=200.0)
+    args = (2, m, m // 2, 1e-10, 3, 1e-3, 1e-10)
+
+    def run(budget_slabs):
+        ts = TrainStates(labels, N, m, phi=phi)
+        if budget_slabs:
+            ts.set_option("env_budget_mb", 2)                   # 2 MiB = 4.27 slabs of 10 x 12 x 512 doubles: at most four on the device
+        ts.set_mps(W)
+        ts.init()
+        reps = mldmrg(ts, *args)
+        envs = {}
+        for j in range(1, N + 1):
+            try:
+                envs[j] = ts.env(j)
+            except Exception:                                   # sites whose environment was never built
+                pass
+        acc = ts.classify()
+        out = dict(cost=[r["cost"] for r in reps], newm=[r["newm"] for r in reps], W=[ts.get_site(j) for j in range(1, N + 1)],
+                   envs=envs, acc=acc, stats=ts.env_stats(), dev=ts.device_bytes())
+        ts.close()
+        return out
+    free, tight = run(0), run(3)
+    assert free["stats"]["spills"] == 0 and free["stats"]["slabs"] >= 8
+    assert tight["stats"]["slabs"] <= 4 and tight["stats"]["spills"] > 20 and tight["stats"]["fetches"] > 20
+    assert tight["dev"] < free["dev"]
+    assert tight["cost"] == free["cost"] and tight["newm"] == free["newm"]
+    for a, b in zip(tight["W"], free["W"]):
+        assert np.array_equal(a, b)
+    assert tight["envs"].keys() == free["envs"].keys()
+    for j in free["envs"]:
+        assert np.array_equal(tight["envs"][j], free["envs"][j]), j
+    assert np.array_equal(tight["acc"][0], free["acc"][0]) and np.array_equal(tight["acc"][1], free["acc"][1])

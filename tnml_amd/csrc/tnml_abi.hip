@@ -93,6 +93,7 @@ int tnml_set_option(tnml_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "sytrd_exit")) c->sytrd_exit = value;
     else if (!strcmp(name, "bgs_chol")) c->bgs_chol = value != 0;
     else if (!strcmp(name, "bf16_grad")) c->bf16_grad = value != 0;
+    else if (!strcmp(name, "env_budget_mb")) { if (value < 0) return tnml_fail(c, "env_budget_mb must be >= 0"); c->env_budget_bytes = (long)value << 20; }
     else if (!strcmp(name, "comm_timeout_s")) { if (value < 1) return tnml_fail(c, "comm_timeout_s must be >= 1"); c->comm_timeout_s = value; local_comm_set_timeout(c, value); }
     else if (!strcmp(name, "cg_method")) { if (value < 0 || value > 2 || (value >= 1 && !c->single())) return tnml_fail(c, "cg_method: 0 (conj) or, in TNML_MODE_SINGLE, 1 (fast_conj) / 2 (exact)"); c->cg_method = value; }
     else if (!strcmp(name, "debug_nudge_rank")) c->debug_nudge_rank = value;
@@ -345,6 +346,7 @@ int tnml_destroy(tnml_ctx* c) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& s : c->W) if (s.a) (void)hipFree(s.a);
     for (auto& sl : c->slabs) if (sl.base) (void)hipFree(sl.base);
+    for (auto& e : c->env) if (e.host) { if (e.host_pinned) (void)hipHostFree(e.host); else free(e.host); }
     if (c->h_scal) (void)hipHostFree(c->h_scal);
     if (c->blas) rocblas_destroy_handle(c->blas);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -530,30 +532,105 @@ static int check_W(tnml_ctx* c) {
 
 // ---- environments -------------------------------------------------------------------------------
 static void slot_release(tnml_ctx* c, EnvSlot& e) {
+    e.on_host = false;                                   // (a spilled copy of an environment that is being rebuilt is stale)
     if (!e.ptr) return;
     c->slabs[e.slab].mask &= (e.unit < 0) ? 0u : ~(1u << e.unit);
     e.ptr = nullptr; e.slab = e.unit = -1;
 }
+// The host tier.  With option env_budget_mb the environment slabs on the device are capped; when a new slab would exceed the cap (or
+// hipMalloc fails) a whole slab is evicted: the one whose environments lie farthest from the current bond -- in a sweep those are
+// needed last -- and none of which is an operand of the operation in flight.  Copies run on the compute stream (in order with the
+// kernels that wrote / will read the data); pinned host buffers when the host grants them, pageable ones otherwise.
+static bool env_is_protected(const tnml_ctx* c, int j) { for (int k = 0; k < 4; ++k) if (c->env_protect[k] == j) return true; return false; }
+static int env_spill(tnml_ctx* c, int j) {
+    EnvSlot& e = c->env[j];
+    const size_t bytes = (size_t)e.L * e.m * c->NTp * c->eesz();
+    if (e.host_cap < bytes) {
+        if (e.host) { if (e.host_pinned) (void)hipHostFree(e.host); else free(e.host); e.host = nullptr; e.host_cap = 0; }
+        void* hp = nullptr;
+        if (hipHostMalloc(&hp, bytes, hipHostMallocDefault) == hipSuccess) { e.host = (char*)hp; e.host_pinned = true; }
+        else { (void)hipGetLastError(); e.host = (char*)malloc(bytes); e.host_pinned = false; }
+        if (!e.host) return tnml_fail(c, "environment spill: no host memory for %zu bytes (site %d)", bytes, j);
+        e.host_cap = bytes;
+    }
+    HIPCK(c, hipMemcpyAsync(e.host, e.ptr, bytes, hipMemcpyDeviceToHost, c->stream));
+    if (!e.host_pinned) HIPCK(c, hipStreamSynchronize(c->stream));
+    c->slabs[e.slab].mask &= (e.unit < 0) ? 0u : ~(1u << e.unit);
+    e.ptr = nullptr; e.slab = e.unit = -1; e.on_host = true;
+    c->env_spills += 1;
+    return 0;
+}
+static int env_evict_slab(tnml_ctx* c) {                // frees one whole slab; 1 = nothing could be evicted
+    const int pos = c->currb > 0 ? c->currb : 1;
+    int best = -1, best_d = -1;
+    for (size_t k = 0; k < c->slabs.size(); ++k) {
+        if (!c->slabs[k].mask) continue;
+        int dmin = 1 << 30; bool ok = true, any = false;
+        for (int j = 1; j <= c->N; ++j) {
+            const EnvSlot& e = c->env[j];
+            if (!e.ptr || e.slab != (int)k) continue;
+            any = true;
+            if (env_is_protected(c, j)) { ok = false; break; }
+            const int d = j > pos ? j - pos : pos - j;
+            if (d < dmin) dmin = d;
+        }
+        if (!ok || !any) continue;                      // (slabs that hold classify's chain buffers have no environment: never evicted)
+        if (dmin > best_d) { best_d = dmin; best = (int)k; }
+    }
+    if (best < 0) return 1;
+    for (int j = 1; j <= c->N; ++j) if (c->env[j].ptr && c->env[j].slab == best) TCK(env_spill(c, j));
+    return 0;
+}
 static int slot_acquire(tnml_ctx* c, EnvSlot& e, int m, int L) {
     slot_release(c, e);
     const unsigned FULL = (1u << TNML_NL) - 1;
-    int pick = -1;
-    if (L != TNML_NL) for (size_t k = 0; k < c->slabs.size(); ++k) if (c->slabs[k].mask && c->slabs[k].mask != FULL) { pick = (int)k; break; }   // fill split slabs first
-    if (pick < 0) for (size_t k = 0; k < c->slabs.size(); ++k) if (!c->slabs[k].mask) { pick = (int)k; break; }
-    if (pick < 0) {
-        EnvSlab sl;
-        TCK(dmalloc(c, &sl.base, c->big_elems * c->eesz()));
-        c->slabs.push_back(sl); pick = (int)c->slabs.size() - 1;
+    const size_t slab_bytes = c->big_elems * c->eesz();
+    for (;;) {
+        int pick = -1;
+        if (L != TNML_NL) for (size_t k = 0; k < c->slabs.size(); ++k) if (c->slabs[k].mask && c->slabs[k].mask != FULL) { pick = (int)k; break; }   // fill split slabs first
+        if (pick < 0) for (size_t k = 0; k < c->slabs.size(); ++k) if (!c->slabs[k].mask) { pick = (int)k; break; }
+        if (pick < 0) {
+            const bool capped = c->env_budget_bytes > 0 && (c->slabs.size() + 1) * slab_bytes > (size_t)c->env_budget_bytes;
+            EnvSlab sl;
+            if (!capped && hipMalloc((void**)&sl.base, slab_bytes) == hipSuccess) {
+                c->bytes += (int64_t)slab_bytes;
+                c->slabs.push_back(sl); pick = (int)c->slabs.size() - 1;
+            } else {
+                if (!capped) (void)hipGetLastError();
+                if (env_evict_slab(c) != 0)
+                    return tnml_fail(c, capped ? "environment memory: the budget of %ld MB holds no slab that could be evicted (%zu slabs of %zu MB; every one holds an operand of the operation in flight)"
+                                               : "environment memory: hipMalloc failed and no slab could be evicted (env_budget %ld MB, %zu slabs of %zu MB)",
+                                     c->env_budget_bytes >> 20, c->slabs.size(), slab_bytes >> 20);
+                continue;
+            }
+        }
+        EnvSlab& sl = c->slabs[pick];
+        e.slab = pick; e.m = m; e.L = L;
+        if (L == TNML_NL) { e.unit = -1; sl.mask = FULL; e.ptr = sl.base; }
+        else {
+            int u = 0; while (sl.mask & (1u << u)) ++u;
+            e.unit = u; sl.mask |= 1u << u; e.ptr = sl.base + (size_t)u * c->small_elems * c->eesz();
+        }
+        return 0;
     }
-    EnvSlab& sl = c->slabs[pick];
-    e.slab = pick; e.m = m; e.L = L;
-    if (L == TNML_NL) { e.unit = -1; sl.mask = FULL; e.ptr = sl.base; }
-    else {
-        int u = 0; while (sl.mask & (1u << u)) ++u;
-        e.unit = u; sl.mask |= 1u << u; e.ptr = sl.base + (size_t)u * c->small_elems * c->eesz();
-    }
+}
+// the environment of site j back on the device (no-op when it is there)
+static int env_ensure(tnml_ctx* c, int j) {
+    EnvSlot& e = c->env[j];
+    if (!e.on_host) return 0;
+    const int m = e.m, L = e.L;
+    const size_t bytes = (size_t)L * m * c->NTp * c->eesz();
+    TCK(slot_acquire(c, e, m, L));                       // (clears on_host; the host copy stays valid until the copy below has read it)
+    HIPCK(c, hipMemcpyAsync(e.ptr, e.host, bytes, hipMemcpyHostToDevice, c->stream));
+    if (!e.host_pinned) HIPCK(c, hipStreamSynchronize(c->stream));
+    c->env_fetches += 1;
     return 0;
 }
+struct EnvProtect {                                     // the operands of one operation: resident and not evictable while it is set up
+    tnml_ctx* c; int keep[4];
+    EnvProtect(tnml_ctx* c_, int a, int b = 0, int d = 0, int e = 0) : c(c_) { for (int k = 0; k < 4; ++k) keep[k] = c->env_protect[k]; c->env_protect[0] = a; c->env_protect[1] = b; c->env_protect[2] = d; c->env_protect[3] = e; }
+    ~EnvProtect() { for (int k = 0; k < 4; ++k) c->env_protect[k] = keep[k]; }
+};
 static int env_alloc(tnml_ctx* c, int j, int m, int L) { return slot_acquire(c, c->env[j], m, L); }
 static const void* phi_site(const tnml_ctx* c, int j) { return (const char*)c->phi + (size_t)(j - 1) * 2 * c->NTp * c->eesz(); }
 
@@ -606,7 +683,10 @@ static int shift_core(tnml_ctx* c, int cs, bool from_left, const void* src, int 
 static int shift_site(tnml_ctx* c, int cs, int ps, bool from_left) {
     const SiteT& A = c->W[cs];
     const bool has_prev = ps >= 1 && ps <= c->N;
-    if (has_prev && !c->env[ps].ptr) return tnml_fail(c, "shift: environment of site %d missing", ps);
+    if (has_prev && !c->env[ps].built()) return tnml_fail(c, "shift: environment of site %d missing", ps);
+    // the source, the destination and the two environments of the bond in flight (its plan holds their addresses) stay on the device
+    EnvProtect keep(c, has_prev ? ps : 0, cs, c->currb > 0 ? c->currb - 1 : 0, c->currb > 0 ? c->currb + 2 : 0);
+    if (has_prev) TCK(env_ensure(c, ps));
     const int m_in = from_left ? A.ml : A.mr, m_out = from_left ? A.mr : A.ml;
     const int Le = has_prev ? c->env[ps].L : 1;
     if (has_prev && c->env[ps].m != m_in) return tnml_fail(c, "shift: env dim %d != site dim %d at site %d", c->env[ps].m, m_in, cs);
@@ -631,13 +711,24 @@ int tnml_shift_env(tnml_ctx* c, int b, int from_left) {   // TrainStates::shiftE
     TCK(shift_site(c, cs, (prevc >= 1 && prevc <= c->N) ? prevc : 0, from_left != 0));
     return 0;
 }
+int tnml_env_stats(tnml_ctx* c, int64_t* spills, int64_t* fetches, int64_t* slabs_on_device, int64_t* host_bytes) {
+    if (spills) *spills = c->env_spills;
+    if (fetches) *fetches = c->env_fetches;
+    if (slabs_on_device) *slabs_on_device = (int64_t)c->slabs.size();
+    if (host_bytes) { int64_t hb = 0; for (const auto& e : c->env) if (e.on_host) hb += (int64_t)e.L * e.m * c->NTp * (int64_t)c->eesz(); *host_bytes = hb; }
+    return 0;
+}
 int tnml_env_dims(tnml_ctx* c, int j, int* m, int* has_label) {
-    if (j < 1 || j > c->N || !c->env[j].ptr) return tnml_fail(c, "tnml_env_dims: environment of site %d not built", j);
+    if (j < 1 || j > c->N || !c->env[j].built()) return tnml_fail(c, "tnml_env_dims: environment of site %d not built", j);
     *m = c->env[j].m; *has_label = c->env[j].L == TNML_NL;
     return 0;
 }
 int tnml_get_env(tnml_ctx* c, int j, double* E) {
-    if (j < 1 || j > c->N || !c->env[j].ptr) return tnml_fail(c, "tnml_get_env: environment of site %d not built", j);
+    if (j < 1 || j > c->N || !c->env[j].built()) return tnml_fail(c, "tnml_get_env: environment of site %d not built", j);
+    {
+        EnvProtect keep(c, j, c->currb > 0 ? c->currb - 1 : 0, c->currb > 0 ? c->currb + 2 : 0);
+        TCK(env_ensure(c, j));
+    }
     const EnvSlot& e = c->env[j];
     const size_t ne = (size_t)e.L * e.m * c->NTp;
     std::vector<char> h(ne * c->eesz());
@@ -659,6 +750,7 @@ int tnml_classify(tnml_ctx* c, double* weights, int32_t* pred, int64_t count[TNM
     CollScope coll_(c);
     HIPCK(c, hipSetDevice(c->cfg.device));
     if (!c->data_set) return tnml_fail(c, "tnml_classify: image data not set");
+    EnvProtect keep(c, c->currb > 0 ? c->currb - 1 : 0, c->currb > 0 ? c->currb + 2 : 0);      // the chain buffers below may evict, but not the operands of the bond that is set
     c->p_valid = false;
     TCK(check_W(c));
     EnvSlot buf[3];
@@ -734,8 +826,14 @@ int tnml_set_bond(tnml_ctx* c, int b) {
     TCK(check_W(c));
     const int lc = b - 1, rc = b + 2;                         // :164-165
     const bool useL = lc > 0, useR = rc < c->N + 1;           // :166-167
-    if (useL && !c->env[lc].ptr) return tnml_fail(c, "setBond: left environment (site %d) missing", lc);
-    if (useR && !c->env[rc].ptr) return tnml_fail(c, "setBond: right environment (site %d) missing", rc);
+    if (useL && !c->env[lc].built()) return tnml_fail(c, "setBond: left environment (site %d) missing", lc);
+    if (useR && !c->env[rc].built()) return tnml_fail(c, "setBond: right environment (site %d) missing", rc);
+    {
+        EnvProtect keep(c, useL ? lc : 0, useR ? rc : 0);
+        c->currb = b;                                         // (eviction keeps what is nearest to the bond that is being set)
+        if (useL) TCK(env_ensure(c, lc));
+        if (useR) TCK(env_ensure(c, rc));
+    }
     BondPlan p;
     p.b = b; p.mL = c->W[b].ml; p.mR = c->W[b + 1].mr;
     if ((useL ? c->env[lc].m : 1) != p.mL || (useR ? c->env[rc].m : 1) != p.mR) return tnml_fail(c, "setBond: env dims do not match W at bond %d", b);

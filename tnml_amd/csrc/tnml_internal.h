@@ -38,9 +38,14 @@ static const char* const kclass_names[KC_COUNT] = {
     "small_gemm", "svd", "allreduce", "p_update", "fwd_fused", "fwd_res"};
 
 struct EnvSlot {
-    void* ptr = nullptr;    // [L][m][NTp], fp32 or fp64 elements (tnml_ctx::env64)
+    void* ptr = nullptr;    // [L][m][NTp], fp32 or fp64 elements (tnml_ctx::env64); null while the environment is spilled to the host
     int m = 0, L = 0;
     int slab = -1, unit = -1;   // where it lives (unit -1: the whole slab, a Label-carrying environment)
+    // host tier (option env_budget_mb; the reference's Nbatch / proj_images spill, fixedL.cc:115-120,153,177-178,216,231, with host memory
+    // in the place of its disk files): an environment that has been evicted lives in `host` until something needs it again
+    char* host = nullptr; size_t host_cap = 0; bool host_pinned = false;
+    bool on_host = false;
+    bool built() const { return ptr != nullptr || on_host; }
 };
 // Environment memory: slabs of one Label-carrying environment ([10][maxm][NTp]); a Label-free environment takes
 // one tenth of a slab.  During a sweep the mix of the two kinds changes from ~half/half at the chain ends to
@@ -127,6 +132,9 @@ struct tnml_ctx {
     // recompute with its own forward GEMM + label dot.  p_valid marks P/dP as current; anything that changes W, the data or
     // P itself clears it (env TNML_REUSE_P=0 disables the shortcut).
     bool reuse_p = true, p_valid = false;
+    long env_budget_bytes = 0;           // option env_budget_mb: cap on the environment slabs held on the device (0: none); beyond it environments spill to host memory
+    int env_protect[4] = {0, 0, 0, 0};   // sites whose environments must stay on the device (the operands of the operation in flight)
+    long env_spills = 0, env_fetches = 0;
     int bf16_grad = 1;                   // option bf16_grad: in the bf16 modes the gradient GEMM runs on the bf16 pipe too (0: the fp32 kernel, as through round 3)
     int bgs_chol = 1;                    // option bgs_chol: block Gram-Schmidt Cholesky QR for 128 < kept columns <= 384 (0: rocSOLVER dpotrf + dtrsm)
     int coll_depth = 0;                  // >0 inside an entry point that every rank calls in step (tnml_fail then aborts an in-process communicator)

@@ -180,6 +180,12 @@ class TrainStates:
     def shiftE(self, b, from_left):
         self._ck(self._L.tnml_shift_env(self._h, b, int(bool(from_left))))
 
+    def env_stats(self):
+        """host tier of the environments (option env_budget_mb): copies to the host / back, slabs on the device, bytes on the host"""
+        v = [C.c_int64() for _ in range(4)]
+        self._ck(self._L.tnml_env_stats(self._h, *[C.byref(x) for x in v]))
+        return dict(spills=v[0].value, fetches=v[1].value, slabs=v[2].value, host_bytes=v[3].value)
+
     def env(self, j):
         m, hl = C.c_int(), C.c_int()
         self._ck(self._L.tnml_env_dims(self._h, j, m, hl))

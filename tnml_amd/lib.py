@@ -27,7 +27,7 @@ EXPORTS = [
     "tnml_shard_bounds", "tnml_profile_enable", "tnml_profile_select", "tnml_profile_count", "tnml_profile_get",
     "tnml_profile_reset", "tnml_synchronize", "tnml_device_bytes", "tnml_svd_stats", "tnml_classify", "tnml_replica_check",
     "tnml_estimate_bytes", "tnml_device_memory", "tnml_plan_maxm", "tnml_set_option", "tnml_comm_init_local", "tnml_comm_init_oneshot", "tnml_collective_mode", "tnml_bond_update_begin", "tnml_bond_update_end", "tnml_replica_repairs", "tnml_pAp", "tnml_collective_stats", "tnml_last_warning",
-    "tnml_exact", "tnml_set_option_real", "tnml_pinv",
+    "tnml_exact", "tnml_set_option_real", "tnml_pinv", "tnml_env_stats",
 ]
 
 
@@ -85,6 +85,7 @@ def load():
     L.tnml_shift_env.argtypes = [vp, C.c_int, C.c_int]
     L.tnml_env_dims.argtypes = [vp, C.c_int, ip, ip]
     L.tnml_get_env.argtypes = [vp, C.c_int, dp]
+    L.tnml_env_stats.argtypes = [vp] + [C.POINTER(C.c_int64)] * 4
     L.tnml_bond_dims.argtypes = [vp, C.c_int, ip, ip, ip]
     L.tnml_bond_tensor.argtypes = [vp, C.c_int, dp]
     L.tnml_forward.argtypes = [vp, dp, dp]
