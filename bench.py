@@ -264,6 +264,8 @@ def main():
                     "(centre_bond_ms) and the SURVEY.md 8(d) workload (value_8d)")
     ap.add_argument("--plain", action="store_true", help="main window + breakdown steps only (no literal-order, unfused-forward, centre-bond or 8(d) "
                     "measurements): what the profiler runs of tools/*.sh use, so that the last bond updates of the run are ordinary ones")
+    ap.add_argument("--env-budget-gb", type=float, default=0.0, help="cap on the environment slabs held in HBM; what does not fit spills to host memory "
+                    "(tnml_set_option env_budget_mb; 0: everything resident, the headline configuration)")
     ap.add_argument("--dry-run", action="store_true", help="control plane only (launcher, rendezvous, shard bounds, max-over-ranks clock): no GPU work")
     args = ap.parse_args()
     if args.steps is None:
@@ -328,6 +330,8 @@ def main():
         uid = [TrainStates.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         ts.comm_init(uid[0])
+    if args.env_budget_gb > 0:
+        ts.set_option("env_budget_mb", int(args.env_budget_gb * 1024))
     ts.set_mps(W)
     if world > 1:
         comm_ranks = ts.replica_check()                          # ncclCommCount == world and bit-identical W replicas
@@ -633,6 +637,7 @@ def main():
                                    "timed on the bonds FOLLOWING the main window (not like for like with `value`: the split is cheaper there)") if elapsed_lit else None,
             "env_init_s": t_init,
             "device_gb": ts.device_bytes() / 1e9,
+            "env_host_tier": None if args.env_budget_gb <= 0 else dict(budget_gb=args.env_budget_gb, **ts.env_stats()),
             "last_cost_per_image": timed[-1]["cost"] / NT if timed else None,
             "svd_stats": ts.svd_stats(),
             "replica_repairs": ts.replica_repairs(),

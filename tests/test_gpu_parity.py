@@ -1597,10 +1597,11 @@ def test_environments_spill_to_host_memory_and_the_sweep_does_not_notice():
     pixels, labels, phi, W = make_problem(N, NT, m, 11, pixel_boost=200.0)
     args = (2, m, m // 2, 1e-10, 3, 1e-3, 1e-10)
 
-    def run(budget_slabs):
+    def run(budget_slabs, async_copies=1):
         ts = TrainStates(labels, N, m, phi=phi)
         if budget_slabs:
             ts.set_option("env_budget_mb", 2)                   # 2 MiB = 4.27 slabs of 10 x 12 x 512 doubles: at most four on the device
+            ts.set_option("env_async", async_copies)            # 1: evictions and look-ahead copies on a second stream beside the bond update; 0: on the compute stream
         ts.set_mps(W)
         ts.init()
         reps = mldmrg(ts, *args)
@@ -1615,14 +1616,43 @@ def test_environments_spill_to_host_memory_and_the_sweep_does_not_notice():
                    envs=envs, acc=acc, stats=ts.env_stats(), dev=ts.device_bytes())
         ts.close()
         return out
-    free, tight = run(0), run(3)
+    free = run(0)
     assert free["stats"]["spills"] == 0 and free["stats"]["slabs"] >= 8
-    assert tight["stats"]["slabs"] <= 4 and tight["stats"]["spills"] > 20 and tight["stats"]["fetches"] > 20
-    assert tight["dev"] < free["dev"]
-    assert tight["cost"] == free["cost"] and tight["newm"] == free["newm"]
-    for a, b in zip(tight["W"], free["W"]):
-        assert np.array_equal(a, b)
-    assert tight["envs"].keys() == free["envs"].keys()
-    for j in free["envs"]:
-        assert np.array_equal(tight["envs"][j], free["envs"][j]), j
-    assert np.array_equal(tight["acc"][0], free["acc"][0]) and np.array_equal(tight["acc"][1], free["acc"][1])
+    for async_copies in (1, 0):
+        tight = run(4, async_copies)
+        assert tight["stats"]["slabs"] <= 4 and tight["stats"]["spills"] > 20 and tight["stats"]["fetches"] > 20, async_copies
+        assert tight["dev"] < free["dev"]
+        assert tight["cost"] == free["cost"] and tight["newm"] == free["newm"], async_copies
+        for a, b in zip(tight["W"], free["W"]):
+            assert np.array_equal(a, b)
+        assert tight["envs"].keys() == free["envs"].keys()
+        for j in free["envs"]:
+            assert np.array_equal(tight["envs"][j], free["envs"][j]), (j, async_copies)
+        assert np.array_equal(tight["acc"][0], free["acc"][0]) and np.array_equal(tight["acc"][1], free["acc"][1])
+
+
+def test_fixedl_driver_with_an_environment_budget_prints_the_same_log(tmp_path):
+    """`env_budget_gb` of the C++ driver (the reference keeps what does not fit in its `proj_images` files, fixedL.cc:115-120; here
+    host memory): a 25-site chain under a budget of one MiB = eight of the ~16 slabs it needs -- every cost line identical to the run
+    with everything resident."""
+    import os
+    import re
+    import subprocess
+    from tnml_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    N, per_label = 25, 20                                      # (idx images are rows x cols: 5 x 5)
+    labels = synth.synthetic_labels(10 * per_label, seed=4, per_label=per_label)
+    pixels = np.clip(synth.synthetic_images(N, labels, seed=4).astype(np.int32) * 3, 0, 255).astype(np.uint8)
+    data = str(tmp_path / "data")
+    synth.write_idx(data, pixels, labels)
+    logs = []
+    for budget in ("", "env_budget_gb = 0.001\n"):
+        wd = tmp_path / ("run_budget" if budget else "run_resident")      # (a second run in the same directory would resume from the first one's W)
+        wd.mkdir()
+        inp = wd / "input"
+        inp.write_text("input\n{\ndatadir = %s\nNtrain = %d\nNsweep = 2\ncutoff = 1E-10\nmaxm = 6\nminm = 3\nninitial = 3\nlambda = 1E-3\nNpass = 3\nseed = 5\n"
+                       "feature_scale = 255\n%s}\n" % (data, per_label, budget))
+        run = subprocess.run([os.path.join(root, "tnml_amd", "fixedL"), str(inp)], capture_output=True, text=True, cwd=wd, timeout=300)
+        assert run.returncode == 0, run.stdout[-1500:] + run.stderr[-1500:]
+        logs.append(re.findall(r"--> After SVD, Cost = ([0-9.eE+-]+)", run.stdout))
+    assert len(logs[0]) == 2 * 2 * (N - 1) and logs[0] == logs[1]

@@ -93,6 +93,7 @@ int tnml_set_option(tnml_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "sytrd_exit")) c->sytrd_exit = value;
     else if (!strcmp(name, "bgs_chol")) c->bgs_chol = value != 0;
     else if (!strcmp(name, "bf16_grad")) c->bf16_grad = value != 0;
+    else if (!strcmp(name, "env_async")) c->env_async = value != 0;
     else if (!strcmp(name, "env_budget_mb")) { if (value < 0) return tnml_fail(c, "env_budget_mb must be >= 0"); c->env_budget_bytes = (long)value << 20; }
     else if (!strcmp(name, "comm_timeout_s")) { if (value < 1) return tnml_fail(c, "comm_timeout_s must be >= 1"); c->comm_timeout_s = value; local_comm_set_timeout(c, value); }
     else if (!strcmp(name, "cg_method")) { if (value < 0 || value > 2 || (value >= 1 && !c->single())) return tnml_fail(c, "cg_method: 0 (conj) or, in TNML_MODE_SINGLE, 1 (fast_conj) / 2 (exact)"); c->cg_method = value; }
@@ -103,7 +104,7 @@ int tnml_set_option(tnml_ctx* c, const char* name, int value) {
     else return tnml_fail(c, "tnml_set_option: unknown option %s", name);
     return 0;
 }
-int tnml_synchronize(tnml_ctx* c) { HIPCK(c, hipStreamSynchronize(c->stream)); return 0; }
+int tnml_synchronize(tnml_ctx* c) { HIPCK(c, hipStreamSynchronize(c->stream)); if (c->copy_stream) HIPCK(c, hipStreamSynchronize(c->copy_stream)); return 0; }
 int64_t tnml_device_bytes(tnml_ctx* c) { return c->bytes; }
 int64_t tnml_replica_repairs(tnml_ctx* c) { return c->replica_repairs; }
 int tnml_svd_stats(tnml_ctx* c, int64_t* fallbacks, int64_t* cluster_repairs, double* d0, double* d1) {
@@ -346,7 +347,10 @@ int tnml_destroy(tnml_ctx* c) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& s : c->W) if (s.a) (void)hipFree(s.a);
     for (auto& sl : c->slabs) if (sl.base) (void)hipFree(sl.base);
-    for (auto& e : c->env) if (e.host) { if (e.host_pinned) (void)hipHostFree(e.host); else free(e.host); }
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    if (c->ev_compute) (void)hipEventDestroy(c->ev_compute);
+    for (auto& e : c->env) { if (e.host) { if (e.host_pinned) (void)hipHostFree(e.host); else free(e.host); } if (e.ev) (void)hipEventDestroy(e.ev); }
+    for (auto& sl : c->slabs) if (sl.ev) (void)hipEventDestroy(sl.ev);
     if (c->h_scal) (void)hipHostFree(c->h_scal);
     if (c->blas) rocblas_destroy_handle(c->blas);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -534,6 +538,12 @@ static int check_W(tnml_ctx* c) {
 static void slot_release(tnml_ctx* c, EnvSlot& e) {
     e.on_host = false;                                   // (a spilled copy of an environment that is being rebuilt is stale)
     if (!e.ptr) return;
+    if (e.ev_pending) {                                  // a prefetch of the value that is being replaced is still in flight: the unit's next user must not overtake it
+        EnvSlab& sl = c->slabs[e.slab];
+        if (!sl.ev) (void)hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming);
+        (void)hipEventRecord(sl.ev, c->copy_stream);
+        sl.ev_pending = true; e.ev_pending = false;
+    }
     c->slabs[e.slab].mask &= (e.unit < 0) ? 0u : ~(1u << e.unit);
     e.ptr = nullptr; e.slab = e.unit = -1;
 }
@@ -542,20 +552,45 @@ static void slot_release(tnml_ctx* c, EnvSlot& e) {
 // needed last -- and none of which is an operand of the operation in flight.  Copies run on the compute stream (in order with the
 // kernels that wrote / will read the data); pinned host buffers when the host grants them, pageable ones otherwise.
 static bool env_is_protected(const tnml_ctx* c, int j) { for (int k = 0; k < 4; ++k) if (c->env_protect[k] == j) return true; return false; }
+static int env_copy_stream(tnml_ctx* c) {
+    if (c->copy_stream) return 0;
+    HIPCK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    HIPCK(c, hipEventCreateWithFlags(&c->ev_compute, hipEventDisableTiming));
+    return 0;
+}
+static int env_host_buffer(tnml_ctx* c, EnvSlot& e, size_t bytes, int j) {
+    if (e.host_cap >= bytes) return 0;
+    if (e.host) { if (e.host_pinned) (void)hipHostFree(e.host); else free(e.host); e.host = nullptr; e.host_cap = 0; }
+    void* hp = nullptr;
+    if (hipHostMalloc(&hp, bytes, hipHostMallocDefault) == hipSuccess) { e.host = (char*)hp; e.host_pinned = true; }
+    else { (void)hipGetLastError(); e.host = (char*)malloc(bytes); e.host_pinned = false; }
+    if (!e.host) return tnml_fail(c, "environment spill: no host memory for %zu bytes (site %d)", bytes, j);
+    e.host_cap = bytes;
+    return 0;
+}
+// environment j -> host.  Asynchronous form (pinned buffer, option env_async): the copy runs on the copy stream once everything the
+// compute stream holds so far has finished, and the slab remembers the event that marks its end; whoever takes a unit of that slab
+// next waits for it.  Otherwise: on the compute stream, in order.
 static int env_spill(tnml_ctx* c, int j) {
     EnvSlot& e = c->env[j];
     const size_t bytes = (size_t)e.L * e.m * c->NTp * c->eesz();
-    if (e.host_cap < bytes) {
-        if (e.host) { if (e.host_pinned) (void)hipHostFree(e.host); else free(e.host); e.host = nullptr; e.host_cap = 0; }
-        void* hp = nullptr;
-        if (hipHostMalloc(&hp, bytes, hipHostMallocDefault) == hipSuccess) { e.host = (char*)hp; e.host_pinned = true; }
-        else { (void)hipGetLastError(); e.host = (char*)malloc(bytes); e.host_pinned = false; }
-        if (!e.host) return tnml_fail(c, "environment spill: no host memory for %zu bytes (site %d)", bytes, j);
-        e.host_cap = bytes;
+    TCK(env_host_buffer(c, e, bytes, j));
+    EnvSlab& sl = c->slabs[e.slab];
+    if (c->env_async && e.host_pinned) {
+        TCK(env_copy_stream(c));
+        HIPCK(c, hipEventRecord(c->ev_compute, c->stream));
+        HIPCK(c, hipStreamWaitEvent(c->copy_stream, c->ev_compute, 0));
+        HIPCK(c, hipMemcpyAsync(e.host, e.ptr, bytes, hipMemcpyDeviceToHost, c->copy_stream));
+        if (!sl.ev) HIPCK(c, hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+        HIPCK(c, hipEventRecord(sl.ev, c->copy_stream));
+        sl.ev_pending = true;
+    } else {
+        if (e.ev_pending) { HIPCK(c, hipStreamWaitEvent(c->stream, e.ev, 0)); }
+        HIPCK(c, hipMemcpyAsync(e.host, e.ptr, bytes, hipMemcpyDeviceToHost, c->stream));
+        if (!e.host_pinned) HIPCK(c, hipStreamSynchronize(c->stream));
     }
-    HIPCK(c, hipMemcpyAsync(e.host, e.ptr, bytes, hipMemcpyDeviceToHost, c->stream));
-    if (!e.host_pinned) HIPCK(c, hipStreamSynchronize(c->stream));
-    c->slabs[e.slab].mask &= (e.unit < 0) ? 0u : ~(1u << e.unit);
+    e.ev_pending = false;                               // (a copy back that was still in flight is ordered before this one: same stream, or waited for above)
+    sl.mask &= (e.unit < 0) ? 0u : ~(1u << e.unit);
     e.ptr = nullptr; e.slab = e.unit = -1; e.on_host = true;
     c->env_spills += 1;
     return 0;
@@ -581,8 +616,10 @@ static int env_evict_slab(tnml_ctx* c) {                // frees one whole slab;
     for (int j = 1; j <= c->N; ++j) if (c->env[j].ptr && c->env[j].slab == best) TCK(env_spill(c, j));
     return 0;
 }
-static int slot_acquire(tnml_ctx* c, EnvSlot& e, int m, int L) {
+// consumer: the stream whose work will touch the new unit first (it waits for a copy to the host that may still be reading the slab)
+static int slot_acquire(tnml_ctx* c, EnvSlot& e, int m, int L, hipStream_t consumer = nullptr) {
     slot_release(c, e);
+    if (!consumer) consumer = c->stream;
     const unsigned FULL = (1u << TNML_NL) - 1;
     const size_t slab_bytes = c->big_elems * c->eesz();
     for (;;) {
@@ -605,6 +642,7 @@ static int slot_acquire(tnml_ctx* c, EnvSlot& e, int m, int L) {
             }
         }
         EnvSlab& sl = c->slabs[pick];
+        if (sl.ev_pending) HIPCK(c, hipStreamWaitEvent(consumer, sl.ev, 0));
         e.slab = pick; e.m = m; e.L = L;
         if (L == TNML_NL) { e.unit = -1; sl.mask = FULL; e.ptr = sl.base; }
         else {
@@ -614,16 +652,31 @@ static int slot_acquire(tnml_ctx* c, EnvSlot& e, int m, int L) {
         return 0;
     }
 }
-// the environment of site j back on the device (no-op when it is there)
-static int env_ensure(tnml_ctx* c, int j) {
+// host -> device for environment j, started now; the compute stream is made to wait for it by env_ensure
+static int env_fetch(tnml_ctx* c, int j) {
     EnvSlot& e = c->env[j];
-    if (!e.on_host) return 0;
     const int m = e.m, L = e.L;
     const size_t bytes = (size_t)L * m * c->NTp * c->eesz();
-    TCK(slot_acquire(c, e, m, L));                       // (clears on_host; the host copy stays valid until the copy below has read it)
-    HIPCK(c, hipMemcpyAsync(e.ptr, e.host, bytes, hipMemcpyHostToDevice, c->stream));
-    if (!e.host_pinned) HIPCK(c, hipStreamSynchronize(c->stream));
+    const bool async = c->env_async && e.host_pinned;
+    if (async) TCK(env_copy_stream(c));
+    TCK(slot_acquire(c, e, m, L, async ? c->copy_stream : c->stream));     // (clears on_host; the host copy stays valid until the copy below has read it)
+    if (async) {
+        HIPCK(c, hipMemcpyAsync(e.ptr, e.host, bytes, hipMemcpyHostToDevice, c->copy_stream));
+        if (!e.ev) HIPCK(c, hipEventCreateWithFlags(&e.ev, hipEventDisableTiming));
+        HIPCK(c, hipEventRecord(e.ev, c->copy_stream));
+        e.ev_pending = true;
+    } else {
+        HIPCK(c, hipMemcpyAsync(e.ptr, e.host, bytes, hipMemcpyHostToDevice, c->stream));
+        if (!e.host_pinned) HIPCK(c, hipStreamSynchronize(c->stream));
+    }
     c->env_fetches += 1;
+    return 0;
+}
+// the environment of site j on the device and visible to the compute stream (no-op when it is there)
+static int env_ensure(tnml_ctx* c, int j) {
+    EnvSlot& e = c->env[j];
+    if (e.on_host) TCK(env_fetch(c, j));
+    if (e.ev_pending) { HIPCK(c, hipStreamWaitEvent(c->stream, e.ev, 0)); e.ev_pending = false; }
     return 0;
 }
 struct EnvProtect {                                     // the operands of one operation: resident and not evictable while it is set up
@@ -632,6 +685,20 @@ struct EnvProtect {                                     // the operands of one o
     ~EnvProtect() { for (int k = 0; k < 4; ++k) c->env_protect[k] = keep[k]; }
 };
 static int env_alloc(tnml_ctx* c, int j, int m, int L) { return slot_acquire(c, c->env[j], m, L); }
+// Host tier, beside the bond update that is about to be enqueued: the environment the NEXT bond of the sweep will need is started on
+// its way back (half 1 moves right: bond b + 1 reads the right environment of site b + 3; half 2 moves left: site b - 2), and one slab
+// is kept free for the environment shiftE will build at the end of this bond update -- its eviction, if one is needed, then runs beside
+// this bond update's kernels instead of in front of the shift.
+static int env_lookahead(tnml_ctx* c, int b, int ha) {
+    const int next = ha == 1 ? b + 3 : b - 2;
+    EnvProtect keep(c, b - 1 > 0 ? b - 1 : 0, b + 2 <= c->N ? b + 2 : 0, (next >= 1 && next <= c->N) ? next : 0);
+    if (next >= 1 && next <= c->N && c->env[next].on_host) { TCK(env_fetch(c, next)); c->env_prefetches += 1; }
+    bool free_slab = false;
+    for (const auto& sl : c->slabs) if (!sl.mask) { free_slab = true; break; }
+    const size_t slab_bytes = c->big_elems * c->eesz();
+    if (!free_slab && (c->slabs.size() + 1) * slab_bytes > (size_t)c->env_budget_bytes) (void)env_evict_slab(c);     // (nothing evictable: the shift will say so if it matters)
+    return 0;
+}
 static const void* phi_site(const tnml_ctx* c, int j) { return (const char*)c->phi + (size_t)(j - 1) * 2 * c->NTp * c->eesz(); }
 
 // dst = src*(t.A(cs)*W.A(cs)) (fixedL.cc:142-149,221-228); src == nullptr: chain end.  dst is an environment
@@ -1355,6 +1422,7 @@ int tnml_bond_update_begin(tnml_ctx* c, int b, int ha, const tnml_sweep_params* 
     tnml_bond_report* rep = &pr.rep;
     memset(rep, 0, sizeof *rep);
     TCK(tnml_set_bond(c, b));                                         // :488
+    if (c->env_budget_bytes > 0 && c->env_async) TCK(env_lookahead(c, b, ha));
     const BondPlan p = c->plan;
     const size_t ne = (size_t)p.mL * 4 * p.mR * p.LB;
     rep->bond = b; rep->half = ha; rep->c = (ha == 1) ? b : b + 1;    // :482

@@ -45,6 +45,7 @@ struct EnvSlot {
     // in the place of its disk files): an environment that has been evicted lives in `host` until something needs it again
     char* host = nullptr; size_t host_cap = 0; bool host_pinned = false;
     bool on_host = false;
+    hipEvent_t ev = nullptr; bool ev_pending = false;   // a copy back from the host is in flight on the copy stream: the compute stream waits for ev before it touches ptr
     bool built() const { return ptr != nullptr || on_host; }
 };
 // Environment memory: slabs of one Label-carrying environment ([10][maxm][NTp]); a Label-free environment takes
@@ -54,6 +55,7 @@ struct EnvSlot {
 struct EnvSlab {
     char* base = nullptr;
     unsigned mask = 0;      // bit k: unit k in use
+    hipEvent_t ev = nullptr; bool ev_pending = false;   // a former tenant is still being copied to the host (copy stream): whoever takes a unit of this slab waits for ev first
 };
 
 struct SiteT {
@@ -134,7 +136,10 @@ struct tnml_ctx {
     bool reuse_p = true, p_valid = false;
     long env_budget_bytes = 0;           // option env_budget_mb: cap on the environment slabs held on the device (0: none); beyond it environments spill to host memory
     int env_protect[4] = {0, 0, 0, 0};   // sites whose environments must stay on the device (the operands of the operation in flight)
-    long env_spills = 0, env_fetches = 0;
+    long env_spills = 0, env_fetches = 0, env_prefetches = 0;
+    hipStream_t copy_stream = nullptr;   // host tier: evictions and prefetches run beside the compute stream
+    hipEvent_t ev_compute = nullptr;     // "everything enqueued on the compute stream so far" (recorded before an eviction starts)
+    int env_async = 1;                   // option env_async: 0 = every copy of the host tier on the compute stream (the simple form)
     int bf16_grad = 1;                   // option bf16_grad: in the bf16 modes the gradient GEMM runs on the bf16 pipe too (0: the fp32 kernel, as through round 3)
     int bgs_chol = 1;                    // option bgs_chol: block Gram-Schmidt Cholesky QR for 128 < kept columns <= 384 (0: rocSOLVER dpotrf + dtrsm)
     int coll_depth = 0;                  // >0 inside an entry point that every rank calls in step (tnml_fail then aborts an in-process communicator)

@@ -92,6 +92,7 @@ int main(int argc, const char* argv[]) {
         const bool oneshot = allreduce_kind == "oneshot";
         if (!oneshot && allreduce_kind != "rccl") die(nullptr, "allreduce must be rccl or oneshot");
         const std::string bond_log = input.getString("bond_log", "");                      // extension: a CSV line per bond update (machine-readable log for parity and bond updates/s)
+        const double env_budget_gb = input.getReal("env_budget_gb", 0.);                    // extension: cap on the environments held in HBM, the rest lives in host memory (the reference's Nbatch / proj_images spill); 0 = all resident
         const bool pipeline = input.getYesNo("pipeline", true);                         // extension: enqueue bond k+1 before fetching the report of bond k (see the sweep loop)
         const std::string precision = input.getString("precision", "f64");              // extension: f64 | mixed | f32 | bf16x3 | bf16
         const long imglen = input.getInt("imglen", 0);                                   // extension: 0 = keep the file's size
@@ -178,7 +179,8 @@ int main(int argc, const char* argv[]) {
             int64_t freeb = 0, totb = 0;
             if (tnml_device_memory(pc.device, &freeb, &totb) != 0) die(nullptr, "tnml_device_memory");
             if (share_device) freeb /= nranks;
-            ctx_maxm = std::min(ctx_maxm, tnml_plan_maxm(&pc, ctx_maxm, wm, (int64_t)(0.97 * (double)freeb)));
+            // (with a host tier the environments need not fit: only what an N-site MPS can reach bounds maxm then)
+            ctx_maxm = std::min(ctx_maxm, tnml_plan_maxm(&pc, ctx_maxm, wm, env_budget_gb > 0. ? (int64_t)0 : (int64_t)(0.97 * (double)freeb)));
         }
         ctx_maxm = std::max(ctx_maxm, wm);
         if (ctx_maxm < maxm)
@@ -202,6 +204,7 @@ int main(int argc, const char* argv[]) {
             cfg.maxm = ctx_maxm; cfg.dtype = dtype; cfg.svd_backend = TNML_SVD_SYEVD;
             tnml_ctx* ctx = nullptr;
             if (tnml_create(&ctx, &cfg) != 0) die(nullptr, "tnml_create");
+            if (env_budget_gb > 0.) CK(ctx, tnml_set_option(ctx, "env_budget_mb", (int)(env_budget_gb * 1024.)));
             if (use_u8) CK(ctx, tnml_set_data_u8(ctx, train.pixels.data() + (size_t)lo[r] * N, train.labels.data() + lo[r]));   // TState ctor, :644-653
             else        CK(ctx, tnml_set_data_phi(ctx, phi_all.data() + (size_t)lo[r] * N * 2, train.labels.data() + lo[r]));
             if (nranks > 1 && !share_device && !oneshot) CK(ctx, tnml_comm_init(ctx, uid));    // RCCL over xGMI, one rank per GPU
