@@ -358,3 +358,44 @@ def test_a_local_error_leaves_the_in_process_communicator_usable_and_a_failed_co
     two = _run_ranks(2, labels, phi, W, N, m, body)
     assert two[0][0] == two[1][0]
     assert two[0][1] < 30.0, "rank 0 was released by the time-out, not by the abort"
+
+
+def test_ranks_with_an_environment_budget_keep_their_replicas_and_their_results():
+    """the host tier of the environments (option env_budget_mb) under the collective path: two ranks on one GPU, each with its own budget of
+    one MiB -- every rank evicts and fetches on its own second stream while the all-reduces go on; costs, bond dimensions and site tensors
+    are bit-identical to the same two ranks with everything resident, and both ranks really spilled.  The per-label variant (label extent
+    1: ten environments share a slab) under a budget, on one rank, against its resident run."""
+    from tnml_amd.fixedl import TrainStates, mldmrg
+    N, NT, m = 25, 180, 6
+    pixels, labels, phi, W = make_problem(N, NT, m, 5, pixel_boost=200.0)
+    args = (1, m, m // 2, 1e-10, 3, 1e-3, 1e-10)
+
+    def body(budget):
+        def run(ts, r):
+            if budget:
+                ts.set_option("env_budget_mb", 1)                # 8 slabs of 10 x 6 x 256 doubles
+            ts.init()
+            reps = mldmrg(ts, *args, pipelined=True)
+            ts.replica_check()
+            return dict(cost=[x["cost"] for x in reps], newm=[x["newm"] for x in reps], W=ts.get_mps(), st=ts.env_stats())
+        return run
+    tight = _run_ranks(2, labels, phi, W, N, m, body(True))
+    free = _run_ranks(2, labels, phi, W, N, m, body(False))
+    for r in range(2):
+        assert tight[r]["st"]["spills"] > 10 and tight[r]["st"]["fetches"] > 5 and free[r]["st"]["spills"] == 0
+        assert tight[r]["cost"] == free[r]["cost"] == tight[0]["cost"] and tight[r]["newm"] == free[r]["newm"]
+        assert all(np.array_equal(a, b) for a, b in zip(tight[r]["W"], free[r]["W"]))
+    # per-label variant
+    Ws = [A[..., 0] if A.ndim == 4 else A for A in W]
+    out = []
+    for budget in (0, 1):
+        ts = TrainStates(labels, N, m, phi=phi, single_label=3)
+        if budget:
+            ts.set_option("env_budget_mb", budget)
+        ts.set_mps(Ws)
+        ts.init()
+        reps = mldmrg(ts, 2, m, m // 2, 1e-10, 3, 1e-3, 1e-10)
+        out.append(([x["cost"] for x in reps], ts.env_stats()))
+        ts.close()
+    assert out[0][0] == out[1][0]
+    assert out[0][1]["spills"] == 0
