@@ -4,8 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef double f64x4 __attribute__((ext_vector_type(4)));
-template <int NMM, int CH, int VALU_ON>
-__global__ __launch_bounds__(768) void k(long long* out, double* sink, int iters) {
+template <int NMM, int CH, int VALU_ON, int NV = 4>
+__global__ __launch_bounds__(1024) void k(long long* out, double* sink, int iters) {
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (wid < 8) {
         if (wid >= NMM) return;
@@ -24,7 +24,7 @@ __global__ __launch_bounds__(768) void k(long long* out, double* sink, int iters
         if (s == 1.2345) sink[0] = s;
         if (lane == 0 && blockIdx.x == 0 && wid == 0) out[4] = t1 - t0;
     } else {
-        if (!VALU_ON) return;
+        if (!VALU_ON || wid >= 8 + NV) return;
         double d[10];
         for (int i = 0; i < 10; ++i) d[i] = lane + i;
         const double dm = 1.0000001;
@@ -37,13 +37,13 @@ __global__ __launch_bounds__(768) void k(long long* out, double* sink, int iters
         const long long t1 = clock64();
         double s = 0; for (int i = 0; i < 10; ++i) s += d[i];
         if (s == 1.2345) sink[1] = s;
-        if (lane == 0 && blockIdx.x == 0) out[wid - 8] = t1 - t0;
+        if (lane == 0 && blockIdx.x == 0 && wid < 12) out[wid - 8] = t1 - t0;
     }
 }
-template <int NMM, int CH, int VALU_ON> static void run(const char* tag, long long* d, double* sink) {
+template <int NMM, int CH, int VALU_ON, int NV = 4> static void run(const char* tag, long long* d, double* sink) {
     const int iters = 2000;
     hipMemset(d, 0, 64);
-    hipLaunchKernelGGL((k<NMM, CH, VALU_ON>), dim3(256), dim3(768), 0, 0, d, sink, iters); hipDeviceSynchronize();
+    hipLaunchKernelGGL((k<NMM, CH, VALU_ON, NV>), dim3(256), dim3(NV > 4 ? 1024 : 768), 0, 0, d, sink, iters); hipDeviceSynchronize();
     long long h[5]; hipMemcpy(h, d, 40, hipMemcpyDeviceToHost);
     printf("%-78s %8.1f ticks per 10 FMAs | %6.2f ticks per MFMA of wave 0\n", tag, (double)h[0] / iters, (double)h[4] / (iters * 64.0));
 }
@@ -57,5 +57,7 @@ int main() {
     run<4, 1, 1>("1 MFMA wave per SIMD (1 chain: dependent MFMAs) + VALU waves", d, sink);
     run<8, 1, 1>("2 MFMA waves per SIMD (1 chain each) + VALU waves", d, sink);
     run<0, 1, 1>("no MFMA waves, VALU waves alone", d, sink);
+    run<8, 2, 1, 8>("2 MFMA waves per SIMD + TWO VALU waves per SIMD (1024 lanes)", d, sink);
+    run<4, 4, 1, 8>("1 MFMA wave per SIMD + TWO VALU waves per SIMD", d, sink);
     return 0;
 }
