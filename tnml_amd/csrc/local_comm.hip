@@ -123,6 +123,7 @@ static int comm_init_inproc(tnml_ctx** ctxs, int n, int oneshot) {
     }
     lc->gen.assign(n, 0);
     for (int r = 0; r < n; ++r) ctxs[r]->local = lc;
+    (void)hipSetDevice(ctxs[0]->cfg.device);             // (the calling thread -- rank 0's -- gets its own device back; every entry point sets it anyway)
     return 0;
 }
 int tnml_comm_init_local(tnml_ctx** ctxs, int n) { return comm_init_inproc(ctxs, n, 0); }
