@@ -238,8 +238,7 @@ def test_fused_forward_kernel_matches_the_oracle(NT, kernel):
     workgroups (fused_fwd = 4) every workgroup runs several rounds.  k_fwd_res (the bond matrix resident in the registers of a
     pair of workgroups, kernels_res.hip; option "fwd_res") + k_pfinish: 300 images = 16 tiles of 32 on 8 pairs (two rounds + fill
     and drain), 1100 images = 40 tiles on 16 pairs (ragged: 3 rounds on half of the pairs, 2 on the others), 2100 images = 72 tiles
-    on 8 pairs (res_grid caps the grid: 9 rounds each; the gradient GEMMs of that case run k_grad_q, groups of four workgroups with
-    uniform waves: 144 tiles of 16 images on 8 groups).  Forward map, gradient, cost / #correct, the CG (its pAp passes use the |P|^2 mode) and a bond update, for
+    on 8 pairs (res_grid caps the grid: 9 rounds each).  Forward map, gradient, cost / #correct, the CG (its pAp passes use the |P|^2 mode) and a bond update, for
     both bond kinds the kernels serve."""
     from oracle import pyoracle
     from tnml_amd.fixedl import TrainStates
@@ -253,7 +252,6 @@ def test_fused_forward_kernel_matches_the_oracle(NT, kernel):
     else:
         ts.set_option("fwd_res", 2)
         ts.set_option("shift_res", 2)                      # k_shift_res builds the Label-carrying environments of init / shiftE (checked below)
-        ts.set_option("grad_res", 3 if NT == 2100 else 2)  # k_grad_res / k_grad_q (accumulators resident; off by default) take the gradient GEMMs of this run
         ts.set_option("res_grid", 32 if NT == 1100 else 16)
     ts.set_mps(W)
     ts.init()

@@ -91,6 +91,9 @@ __global__ __launch_bounds__(512) void k_sytrd_v3(TriArgs T) {
         dg = wave_sum(dg);
         if (lane == 0) s_red[24 + wid] = dg;
     }
+    // every load of the prologue has landed before the chain starts: on gfx9 stores count in vmcnt too, and a wait the compiler places
+    // in the loop for a register of the prologue would, from the second step on, wait for the reflector stores of the step before
+    __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0)
     __syncthreads();
     double t0 = 0.;
 #pragma unroll
@@ -635,7 +638,7 @@ __global__ __launch_bounds__(64) void k_tridiag_invit(TeigArgs T) {
 }
 
 // scratch: TEIG_SCRATCH_DOUBLES doubles
-int eigh_tridiag_eig(tnml_ctx* c, const double* D, const double* E, int n, double* W, int mk, double* Z, int ldz, double* scratch) {
+int eigh_tridiag_eig_v1(tnml_ctx* c, const double* D, const double* E, int n, double* W, int mk, double* Z, int ldz, double* scratch) {
     if (n > TEIG_MAXN || mk > n) return tnml_fail(c, "eigh_tridiag_eig: n=%d mk=%d exceed %d", n, mk, TEIG_MAXN);
     int* is = (int*)(scratch + 2 * TEIG_MAXN);
     TeigArgs t{D, E, n, W, mk, Z, ldz, scratch, scratch + TEIG_MAXN, is, is + TEIG_MAXN, is + 2 * TEIG_MAXN};

@@ -261,463 +261,6 @@ __global__ __launch_bounds__(768) void k_fwd_res(FwdResArgs A) {
 }
 
 // ==========================================================================================================================
-// k_grad_res -- dP*dag(t.v) (fixedL.cc:379,418) with the OUTPUT resident: G[2a+s][2q+t] = sum_n E_n[a] phiI_n[s] phiO_n[t] Z_n[q],
-// Z_n[q] = sum_l EL_n[l][q] w_n[l].  A pair of workgroups owns all 240 x 240 accumulators (half = output links q of 64 half ..):
-// GEMM wave w keeps the 128 x 32 block (a padded to 128) x (q tiles 2 (w & 1), +1) of the site-index combination (s, t) = w >> 1
-// in 128 VGPRs for the whole launch and the pair walks its 32-image tiles; the k_bgemm64 this replaces re-reads the Label-free
-// environment once per 64-column tile (4x) and alternates staging and MFMA phases between barriers.  Operands: E rows raw (LDS-DMA,
-// one 256-byte row per piece into 272-byte padded rows -- the MFMA operand reads run ACROSS rows, so unpadded rows would be
-// 16-way bank conflicts), Z rows built by the streaming waves (ring of asm loads as in k_fwd_res), the two site features
-// multiplied into the Z fragment by the GEMM wave itself (2 VALU per 32 MFMAs, in its own instruction stream).
-// Round j: streaming waves build Z(j) and stage E(j), phi(j), w(j+1); GEMM waves accumulate tile j-1.  One barrier per round.
-// ==========================================================================================================================
-#define GR_ES 34                                   // padded row length (doubles) of the E and Z tiles
-#define GR_EROWS 128
-#define GR_LDS_DOUBLES (2 * GR_EROWS * GR_ES + 2 * 64 * GR_ES + 2 * 4 * FR_TI + 2 * 12 * FR_TI)
-
-template <int PS, int PK, int ABL>
-__global__ __launch_bounds__(768) void k_grad_res(GradResArgs A) {
-    extern __shared__ __attribute__((aligned(16))) double gr_lds[];
-    double* Es = gr_lds;                               // [2][128][34]
-    double* Zs = Es + 2 * GR_EROWS * GR_ES;            // [2][64][34]
-    double* Ps = Zs + 2 * 64 * GR_ES;                  // [2][4][32]: phiI[0..1], phiO[0..1]
-    double* Ws = Ps + 2 * 4 * FR_TI;                   // [2][12][32]: the per-image weights (10 rows used)
-    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x;
-    const int half = (b >> 3) & 1, pair = (b & 7) + 8 * (b >> 4), npairs = gridDim.x >> 1;
-    const int NTp = A.NTp;
-    const int nq = half ? 56 : 64;
-    const int niter = (A.ntiles - pair + npairs - 1) / npairs;      // >= 1
-    for (int i = tid; i < GR_LDS_DOUBLES; i += 768) gr_lds[i] = 0.;      // padding rows (E rows 120.., Z rows nq..) stay zero
-    __syncthreads();
-
-    if (wid < 8) {
-        // ---------------- GEMM role ----------------
-        const int w = wid, st = w >> 1, qt0 = 2 * (w & 1);
-        f64x4r acc[8][2];
-#pragma unroll
-        for (int rt = 0; rt < 8; ++rt) { acc[rt][0] = f64x4r{0., 0., 0., 0.}; acc[rt][1] = f64x4r{0., 0., 0., 0.}; }
-        fr_barrier();                                  // prologue
-        for (int it = 0; it <= niter; ++it) {
-            if (it >= 1 && ABL != 2) {
-                const int buf = (it - 1) & 1;
-                int ln = lane;
-                asm volatile("" : "+v"(ln));
-                const int g = ln >> 4, i = ln & 15;
-                const double* Eb = Es + buf * GR_EROWS * GR_ES + i * GR_ES + 2 * g;          // + rt * 16 rows + 8 kp
-                const double* Zb = Zs + buf * 64 * GR_ES + (16 * qt0 + i) * GR_ES + 2 * g;   // q tile qt0; qt0 + 1 is 16 rows on
-                const double* Pb = Ps + buf * 4 * FR_TI + 2 * g;
-#pragma unroll
-                for (int kp = 0; kp < 4; ++kp) {
-                    // lane group g owns images 8 kp + 2 g, + 1 of both operands (a permutation of the reduction index)
-                    const double2 fi = *reinterpret_cast<const double2*>(Pb + (st >> 1) * FR_TI + 8 * kp);
-                    const double2 fo = *reinterpret_cast<const double2*>(Pb + (2 + (st & 1)) * FR_TI + 8 * kp);
-                    double2 z0 = *reinterpret_cast<const double2*>(Zb + 8 * kp);
-                    double2 z1 = *reinterpret_cast<const double2*>(Zb + 16 * GR_ES + 8 * kp);
-                    double2 a0 = *reinterpret_cast<const double2*>(Eb + 8 * kp);
-                    double2 a1 = *reinterpret_cast<const double2*>(Eb + 16 * GR_ES + 8 * kp);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-                    const double fx = fi.x * fo.x, fy = fi.y * fo.y;
-                    z0.x *= fx; z0.y *= fy; z1.x *= fx; z1.y *= fy;
-#pragma unroll
-                    for (int rt = 0; rt < 8; ++rt) {
-                        const double2 ac = a0;
-                        a0 = a1;
-                        if (rt + 2 < 8) { a1 = *reinterpret_cast<const double2*>(Eb + (rt + 2) * 16 * GR_ES + 8 * kp); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
-                        acc[rt][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac.x, z0.x, acc[rt][0], 0, 0, 0);
-                        acc[rt][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac.x, z1.x, acc[rt][1], 0, 0, 0);
-                        acc[rt][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac.y, z0.y, acc[rt][0], 0, 0, 0);
-                        acc[rt][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac.y, z1.y, acc[rt][1], 0, 0, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                        if (PS > 0 && rt % PK == PK - 1) { __builtin_amdgcn_s_sleep(PS); __builtin_amdgcn_sched_barrier(0); }
-                    }
-                }
-            }
-            fr_barrier();
-        }
-        // lane (g, i) holds rows a = 16 rt + g + 4 e, output link q = 64 half + 16 (qt0 + c) + i: G[2 a + s][2 q + t]
-        const int g = lane >> 4, i = lane & 15;
-        double* slab = A.slab + (size_t)pair * 240 * 240;
-#pragma unroll
-        for (int rt = 0; rt < 8; ++rt)
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int a = 16 * rt + g + 4 * e, ql = 16 * (qt0 + c) + i;
-                    if (a < 120 && ql < nq) slab[(size_t)(2 * a + (st >> 1)) * 240 + 2 * (64 * half + ql) + (st & 1)] = acc[rt][c][e];
-                }
-    } else {
-        // ---------------- streaming role ----------------
-        __builtin_amdgcn_s_setprio(3);
-        const int sw = wid - 8;
-        const int img = lane & 31, qs = lane >> 5;
-        const int nk = nq >> 3;
-        const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)gr_lds));
-        // LDS-DMA pieces of a round (31 per wave, the same number on every wave: the counted waits below rely on it):
-        //   30 rows of the Label-free environment, one 256-byte row per piece (4 bytes per lane) into its padded row;
-        //   wave 8, 9, 10: 4 rows each of the NEXT tile's weights (16 bytes per lane); wave 11: the four feature rows
-        // (uniform 64-bit base in SGPRs + a 32-bit lane offset: no VALU instruction per piece)
-        const unsigned l4 = (unsigned)lane * 4u;
-        const unsigned c16 = (unsigned)(((size_t)(lane >> 4) * NTp + 2 * (lane & 15)) * sizeof(double));       // row lane >> 4 of a 4-row piece
-        const int wrow = 4 * sw + (lane >> 4);                                    // weights: rows 10, 11 (wave 10) read rows 8, 9 again
-        const unsigned w16 = (unsigned)(((size_t)(wrow < TNML_NL ? wrow : wrow - 2) * NTp + 2 * (lane & 15)) * sizeof(double));
-        const double* const ph0 = A.phiI < A.phiO ? A.phiI : A.phiO;
-        const unsigned poff = (unsigned)((((lane >> 4) < 2 ? A.phiI : A.phiO) - ph0 + (size_t)((lane >> 4) & 1) * NTp + 2 * (lane & 15)) * sizeof(double));
-        (void)c16;
-        auto dma4 = [&](const double* base, unsigned voff, unsigned dst) {
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff), "s"(dst), "s"(base) : "memory");
-        };
-        auto dma16 = [&](const double* base, unsigned voff, unsigned dst) {
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff), "s"(dst), "s"(base) : "memory");
-        };
-        const unsigned wsb = lds0 + (unsigned)((2 * GR_EROWS * GR_ES + 2 * 64 * GR_ES + 2 * 4 * FR_TI) * sizeof(double));     // Ws
-        const unsigned psb = lds0 + (unsigned)((2 * GR_EROWS * GR_ES + 2 * 64 * GR_ES) * sizeof(double));                     // Ps
-        // E(tile) -> Es[buf], phi(tile) -> Ps[buf] (wave 11), w(wtile) -> Ws[wbuf] (waves 8..10)
-        auto stage = [&](int tile, int buf, int wtile, int wbuf) {
-            const double* src = A.EI + (size_t)sw * NTp + (size_t)tile * FR_TI;                 // row sw, then every 4th
-            unsigned dst = lds0 + (unsigned)((buf * GR_EROWS * GR_ES + sw * GR_ES) * sizeof(double));
-#pragma unroll 1
-            for (int r = 0; r < 30; ++r) { dma4(src, l4, __builtin_amdgcn_readfirstlane(dst)); src += (size_t)4 * NTp; dst += 4 * GR_ES * sizeof(double); }
-            if (sw < 3) dma16(A.w + (size_t)wtile * FR_TI, w16, wsb + (unsigned)((wbuf * 12 * FR_TI + 4 * sw * FR_TI) * sizeof(double)));
-            else        dma16(ph0 + (size_t)tile * FR_TI, poff, psb + (unsigned)(buf * 4 * FR_TI * sizeof(double)));
-        };
-        const double* ELw = A.EL + (size_t)(64 * half + 2 * sw) * NTp;
-        const unsigned eoff = (unsigned)(((size_t)qs * NTp + img) * sizeof(double));
-        const unsigned zoff = (unsigned)((2 * sw + qs) * GR_ES + img);                // lane part of a Z write (doubles)
-        const size_t k7 = nk > 7 ? (size_t)56 * NTp : 0;
-        double ea[TNML_NL], eb[TNML_NL], ec[TNML_NL], ed[TNML_NL];
-        auto s_load = [&](int tile, size_t rowoff, double (&e)[TNML_NL]) {
-#pragma unroll
-            for (int l = 0; l < TNML_NL; ++l) {
-                const double* bp = ELw + (size_t)tile * FR_TI + (size_t)l * A.EL_lstride + rowoff;
-                if (ABL == 1) e[l] = 1.0;
-                else asm volatile("global_load_dwordx2 %0, %1, %2 nt" : "=v"(e[l]) : "v"(eoff), "s"(bp) : "memory");
-            }
-        };
-#define GR_WAIT(N, e) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6]), "+v"(e[7]), "+v"(e[8]), "+v"(e[9]) :: "memory")
-        // Z of a tile (its rows 0..3 are in the ring) -> Zb; requests rows 0..3 of tile `ntile`; mid(): the round's 31 DMA pieces
-        auto z_build = [&](int tile, int ntile, const double* Wb, double* Zb, auto&& mid) {
-            double wv[TNML_NL];
-#pragma unroll
-            for (int l = 0; l < TNML_NL; ++l) wv[l] = Wb[l * FR_TI + img];
-            auto s_use = [&](int k, const double (&e)[TNML_NL], bool on) {
-                double z = e[0] * wv[0];
-#pragma unroll
-                for (int l = 1; l < TNML_NL; ++l) z = fma(e[l], wv[l], z);
-                if (on) Zb[8 * k * GR_ES + zoff] = z;
-                asm volatile("" : "+v"(z) :: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            GR_WAIT(30, ea); s_use(0, ea, true); s_load(tile, (size_t)32 * NTp, ea);
-            GR_WAIT(30, eb); s_use(1, eb, true); s_load(tile, (size_t)40 * NTp, eb);
-            GR_WAIT(30, ec); s_use(2, ec, true); s_load(tile, (size_t)48 * NTp, ec);
-            GR_WAIT(30, ed); s_use(3, ed, true); s_load(tile, k7, ed);
-            mid();
-            // behind row 4: rows 5..7 (30) + 31 pieces
-            GR_WAIT(61, ea); s_use(4, ea, true); s_load(ntile, 0, ea);
-            GR_WAIT(61, eb); s_use(5, eb, true); s_load(ntile, (size_t)8 * NTp, eb);
-            GR_WAIT(61, ec); s_use(6, ec, true); s_load(ntile, (size_t)16 * NTp, ec);
-            GR_WAIT(61, ed); s_use(7, ed, nk > 7); s_load(ntile, (size_t)24 * NTp, ed);
-        };
-        // prologue: the first tile's weights; open the ring
-        if (sw < 3) dma16(A.w + (size_t)pair * FR_TI, w16, wsb + (unsigned)(4 * sw * FR_TI * sizeof(double)));
-        s_load(pair, 0, ea); s_load(pair, (size_t)8 * NTp, eb); s_load(pair, (size_t)16 * NTp, ec); s_load(pair, (size_t)24 * NTp, ed);
-        asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
-        fr_barrier();
-        for (int it = 0; it < niter; ++it) {
-            const int tile = pair + it * npairs;
-            const int ntile = it + 1 < niter ? tile + npairs : tile;
-            z_build(tile, ntile, Ws + (it & 1) * 12 * FR_TI, Zs + (it & 1) * 64 * GR_ES, [&]() { stage(tile, it & 1, ntile, (it + 1) & 1); });
-            asm volatile("s_waitcnt vmcnt(40)" ::: "memory");    // all but the 40 row loads just requested: this round's pieces have landed
-            fr_barrier();
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        fr_barrier();                                            // the GEMM waves' last round
-#undef GR_WAIT
-    }
-}
-
-// sum of nsplit slabs, 4 lanes per element (each a quarter of the slabs, in order), then the four parts in order: the same fixed
-// association on every launch; 4x the loads in flight of k_slab_reduce64 for the 128 slabs of k_grad_res (40 -> 11 us)
-__global__ __launch_bounds__(256) void k_slab_reduce_wide(const double* __restrict__ slab, double* __restrict__ G, size_t n, int nsplit) {
-    __shared__ double sh[256];
-    const int part = threadIdx.x >> 6, e = threadIdx.x & 63;
-    const size_t i = (size_t)blockIdx.x * 64 + e;
-    const int per = (nsplit + 3) / 4, k0 = part * per, k1 = min(nsplit, k0 + per);
-    double s = 0.;
-    if (i < n) {
-#pragma unroll 8
-        for (int k = k0; k < k1; ++k) s += slab[(size_t)k * n + i];
-    }
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    if (part == 0 && i < n) G[i] = ((sh[e] + sh[64 + e]) + sh[128 + e]) + sh[192 + e];
-}
-
-template <int PS, int PK>
-static int grad_res_go(tnml_ctx* c, const GradResArgs& a, int grid) {
-    const size_t lds = sizeof(double) * GR_LDS_DOUBLES;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_grad_res<PS, PK, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return tnml_fail(c, "grad_res: cannot reserve %zu bytes of LDS", lds);
-    ProfScope ps(c, KC_BGEMM);
-    hipLaunchKernelGGL((k_grad_res<PS, PK, 0>), dim3(grid), dim3(768), lds, c->stream, a);
-    return 0;
-}
-// G (M-layout [240][240]) = sum over the images; split-K slabs of the workgroup pairs reduced in a fixed order
-int launch_grad_res(tnml_ctx* c, const GradResArgs& a_in, double* G) {
-    GradResArgs a = a_in;
-    if (a.NTp % 256) return tnml_fail(c, "grad_res: image count not a multiple of 256");
-    if ((size_t)TNML_NL * a.EL_lstride * sizeof(double) >= ((size_t)1 << 32)) return tnml_fail(c, "grad_res: environment larger than 4 GB (32-bit lane offsets)");
-    if (!c->cu_count) { hipDeviceProp_t pr; c->cu_count = hipGetDeviceProperties(&pr, c->cfg.device) == hipSuccess ? pr.multiProcessorCount : 256; }
-    int grid = c->cu_count / 16 * 16;
-    if (c->res_grid > 0 && c->res_grid < grid) grid = c->res_grid / 16 * 16;
-    if (grid < 16) grid = 16;
-    while (grid > 16 && (grid / 2) > a.ntiles) grid -= 16;
-    const size_t n = (size_t)240 * 240;
-    while (grid > 16 && (size_t)(grid / 2) * n * sizeof(double) > c->slab_bytes) grid -= 16;
-    if ((size_t)(grid / 2) * n * sizeof(double) > c->slab_bytes) return tnml_fail(c, "grad_res: slab workspace too small");
-    a.slab = (double*)c->slab;
-    switch (c->res_pace) {
-        case 1:  TCK((grad_res_go<0, 1>(c, a, grid))); break;
-        case 2:  TCK((grad_res_go<4, 2>(c, a, grid))); break;
-        case 3:  TCK((grad_res_go<6, 3>(c, a, grid))); break;
-        case 4:  TCK((grad_res_go<4, 1>(c, a, grid))); break;
-        default: TCK((grad_res_go<6, 2>(c, a, grid))); break;
-    }
-    {
-        ProfScope ps(c, KC_SLABRED);
-        launch_slab_reduce64(c, (const double*)c->slab, G, n, grid / 2);
-    }
-    HIPCK(c, hipGetLastError());
-    return 0;
-}
-
-// ==========================================================================================================================
-// k_grad_q -- dP*dag(t.v) with UNIFORM waves: every operand reaches LDS by LDS-DMA (no load lands in a VGPR, no wave that only
-// streams), so nothing but MFMAs, LDS fragment reads and a handful of FMAs runs beside the matrix pipe -- the form that carries
-// k_shift_res to 83 % of the fp64 MFMA peak.  What made the gradient different is Z_n[q] = sum_l EL_n[l][q] w_n[l]: 10 FMAs per
-// element on the 577 MB stream, which k_bgemm64 does between its MFMA phases and k_grad_res in starved streaming waves.  Here the
-// Label-carrying rows of a tile are DMA'd to LDS and every wave builds 1/8 of the NEXT tile's Z (one element per lane: 10 + 10
-// ds_read_b64, 10 FMAs) inside its own MFMA stream.  LDS capacity sets the shape: a GROUP of four workgroups (on one XCD: the
-// Label-free rows they share come from its L2) owns all 240 x 240 accumulators, workgroup h the output links q in [30 h, 30 h + 30),
-// and the group walks 16-image tiles:  3 x 37.5 KB Label-carrying rows (two rounds of flight) + 2 x 15 KB Label-free rows + Z + w, phi.
-// Wave w: (s, t) = w >> 1, rows a in [64 (w & 1), +64), both q tiles: acc[4][2] = 64 VGPRs.
-// LDS rows are 128 bytes (16 images); the MFMA operand reads run ACROSS rows, so the 16-byte units of a row are XOR-swizzled with
-// (row >> 1) & 7 -- on the global side of the DMA (each lane names its own source address), the LDS side stays linear.
-// Round r: DMA E(r), EL(r+2), w/phi(r+2); build Z(r); accumulate tile r-1.  One barrier per round; vmcnt(6) at its end leaves the six
-// youngest pieces (EL(r+2), w/phi(r+2)) in flight.  Deterministic; slabs [group][240][240] reduced in a fixed order.
-// ==========================================================================================================================
-#define GQ_T 16
-#define GQ_NQ 30
-#define GQ_EL_D (TNML_NL * GQ_NQ * GQ_T)           // 4800 doubles = 37.5 KB
-#define GQ_E_D (120 * GQ_T)
-#define GQ_Z_D (32 * GQ_T)
-#define GQ_WP_D (14 * GQ_T)                        // w[0..9], phiI[0..1], phiO[0..1]
-#define GQ_LDS_DOUBLES (3 * GQ_EL_D + 2 * GQ_E_D + 2 * GQ_Z_D + 4 * GQ_WP_D)
-#define GQ_LDS_BYTES (GQ_LDS_DOUBLES * sizeof(double) + 256)   // + the dump area of the L2 prefetch pieces
-
-template <int ABL>
-__global__ __launch_bounds__(512) void k_grad_q(GradResArgs A) {
-    extern __shared__ __attribute__((aligned(16))) double gq_lds[];
-    double* ELs = gq_lds;                              // [3][300][16]
-    double* Es = ELs + 3 * GQ_EL_D;                    // [2][120][16]  (rows 120..127 of the last a tile read on into what follows: discarded output rows)
-    double* Zs = Es + 2 * GQ_E_D;                      // [2][32][16]   (rows 30, 31 stay zero)
-    double* WPs = Zs + 2 * GQ_Z_D;                     // [4][14][16]
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x;
-    const int h = (b >> 3) & 3, group = (b & 7) + 8 * (b >> 5), ngroups = gridDim.x >> 2;
-    const int NTp = A.NTp;
-    const int niter = (A.ntiles - group + ngroups - 1) / ngroups;      // >= 1
-    for (int i = tid; i < GQ_LDS_DOUBLES; i += 512) gq_lds[i] = 0.;
-    __syncthreads();
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)gq_lds));
-    auto dma16 = [&](const double* base, unsigned voff, unsigned dst) {
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff), "s"(dst), "s"(base) : "memory");
-    };
-    auto dma16nt = [&](const double* base, unsigned voff, unsigned dst) {
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 nt\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff), "s"(dst), "s"(base) : "memory");
-    };
-    auto dma16v = [&](const double* ptr, unsigned dst) {
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(ptr), "s"(dst) : "memory");
-    };
-    // ---- the eight DMA pieces of a wave and round (a piece = 8 rows of 128 bytes = 64 lanes x 16 bytes, LDS side linear) ----
-    const int prow = lane >> 3, pu = lane & 7;
-    unsigned el_off[5], el_dst[5]; bool el_on[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        int p = w + 8 * k;
-        if (p >= 38) p -= 38;                                         // pieces 38, 39 repeat 0, 1 (every wave issues the same number)
-        const int r = 8 * p + prow;
-        el_on[k] = r < TNML_NL * GQ_NQ;
-        const int rr = el_on[k] ? r : 0, l = rr / GQ_NQ, q = rr - l * GQ_NQ;
-        el_off[k] = (unsigned)(((size_t)l * A.EL_lstride + (size_t)(GQ_NQ * h + q) * NTp + 2 * (pu ^ ((q >> 1) & 7))) * sizeof(double));
-        el_dst[k] = (unsigned)(p * 1024);
-    }
-    unsigned e_off[2], e_dst[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        int p = w + 8 * k;
-        if (p >= 15) p -= 15;
-        const int a = 8 * p + prow;
-        e_off[k] = (unsigned)(((size_t)a * NTp + 2 * (pu ^ ((a >> 1) & 7))) * sizeof(double));
-        e_dst[k] = (unsigned)(p * 1024);
-    }
-    const int wp_p = w & 1, wp_row = 8 * wp_p + prow;
-    const bool wp_on = wp_row < 14;
-    const double* wp_ptr = wp_row < TNML_NL ? A.w + (size_t)wp_row * NTp : (wp_row < 12 ? A.phiI + (size_t)(wp_row - 10) * NTp : A.phiO + (size_t)((wp_on ? wp_row : 12) - 12) * NTp);
-    wp_ptr += 2 * pu;
-    const unsigned elb = lds0, eb0 = lds0 + (unsigned)(3 * GQ_EL_D * sizeof(double)), wpb = lds0 + (unsigned)((3 * GQ_EL_D + 2 * GQ_E_D + 2 * GQ_Z_D) * sizeof(double));
-    auto tile_n0 = [&](int j) { return (size_t)(group + (j < niter ? j : niter - 1) * ngroups) * GQ_T; };    // past the end: the last tile again (never used)
-    auto issue_el = [&](int j) {                                      // EL(j), w/phi(j): 6 pieces
-        const size_t n0 = tile_n0(j);
-        const unsigned dstb = elb + (unsigned)((j % 3) * GQ_EL_D * sizeof(double));
-#pragma unroll
-        for (int k = 0; k < 5; ++k) if (el_on[k] && ABL != 1 && ABL != 4) dma16nt(A.EL + n0, el_off[k], dstb + el_dst[k]);
-        if (wp_on && ABL != 1) dma16v(wp_ptr + n0, wpb + (unsigned)(((j & 3) * GQ_WP_D) * sizeof(double) + wp_p * 1024));
-    };
-    auto issue_e = [&](int j) {                                       // E(j): 2 pieces
-        const size_t n0 = tile_n0(j);
-        const unsigned dstb = eb0 + (unsigned)((j & 1) * GQ_E_D * sizeof(double));
-#pragma unroll
-        for (int k = 0; k < 2; ++k) if (ABL != 1 && ABL != 3) dma16(A.EI + n0, e_off[k], dstb + e_dst[k]);
-    };
-    // E(j) -> L2 two rounds before its DMA (one 4-byte piece per 128-byte row into a dump area): the DMA of E has one round of flight
-    const unsigned dumpb = lds0 + (unsigned)(GQ_LDS_DOUBLES * sizeof(double));
-    const unsigned pf_off = (unsigned)((size_t)(15 * w + (lane < 15 ? lane : 0)) * NTp * sizeof(double));
-    auto prefetch_e = [&](int j) {
-        unsigned keep;
-        const double* base = A.EI + tile_n0(j);
-        if (lane < 15 && ABL != 1 && ABL != 3)
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(pf_off), "s"(dumpb), "s"(base) : "memory");
-    };
-    const int st = w >> 1, ah = w & 1;
-    f64x4r acc[4][2];
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt) { acc[rt][0] = f64x4r{0., 0., 0., 0.}; acc[rt][1] = f64x4r{0., 0., 0., 0.}; }
-    issue_el(0); issue_el(1); prefetch_e(0); prefetch_e(1);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    fr_barrier();
-    // Round 0 accumulates the zero-initialised buffers and round niter builds a tile nobody reads: no branch inside a round.
-    for (int r = 0; r <= niter; ++r) {
-        issue_e(r);
-        issue_el(r + 2);
-        prefetch_e(r + 2);
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-        const int g = ln >> 4, i = ln & 15;
-        const int qb = 4 * w + g;                                      // build: Z(r)[q = 4 w + g][image i]  (q = 30, 31: rows nobody's output uses)
-        const int zsw = 2 * ((i >> 1) ^ ((qb >> 1) & 7)) + (i & 1);
-        const double* elp = ELs + (r % 3) * GQ_EL_D + qb * GQ_T + zsw;
-        const double* wpp = WPs + (r & 3) * GQ_WP_D + i;
-        const int jb = (r + 1) & 1;                                    // accumulate tile r - 1
-        const int sw8 = (i >> 1) & 7;
-        const double* Eb = Es + jb * GQ_E_D + (64 * ah + i) * GQ_T;
-        const double* Zb = Zs + jb * GQ_Z_D + i * GQ_T;
-        const double* Pb = WPs + ((r + 3) & 3) * GQ_WP_D;
-        double ev[TNML_NL], wv[TNML_NL];
-        double2 fi[2], fo[2], z0[2], z1[2], av[2][4];
-        auto frag = [&](int kp, int rt) {
-            const int u = 4 * kp + g;                                  // lane group g owns images 8 kp + 2 g, + 1 of both operands
-            av[kp][rt] = *reinterpret_cast<const double2*>(Eb + 16 * rt * GQ_T + 2 * (u ^ sw8));
-        };
-        auto frag_z = [&](int kp) {
-            const int u = 4 * kp + g;
-            fi[kp] = *reinterpret_cast<const double2*>(Pb + (10 + (st >> 1)) * GQ_T + 2 * u);
-            fo[kp] = *reinterpret_cast<const double2*>(Pb + (12 + (st & 1)) * GQ_T + 2 * u);
-            z0[kp] = *reinterpret_cast<const double2*>(Zb + 2 * (u ^ sw8));
-            z1[kp] = *reinterpret_cast<const double2*>(Zb + 16 * GQ_T + 2 * (u ^ sw8));
-        };
-        auto scale = [&](int kp) {
-            const double fx = fi[kp].x * fo[kp].x, fy = fi[kp].y * fo[kp].y;
-            z0[kp].x *= fx; z0[kp].y *= fy; z1[kp].x *= fx; z1[kp].y *= fy;
-        };
-        auto mm = [&](int kp, int rt) {
-            if (ABL == 2 || ABL >= 3) return;
-            acc[rt][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kp][rt].x, z0[kp].x, acc[rt][0], 0, 0, 0);
-            acc[rt][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kp][rt].x, z1[kp].x, acc[rt][1], 0, 0, 0);
-            acc[rt][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kp][rt].y, z0[kp].y, acc[rt][0], 0, 0, 0);
-            acc[rt][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kp][rt].y, z1[kp].y, acc[rt][1], 0, 0, 0);
-        };
-        auto bread = [&](int l0, int l1) {
-#pragma unroll
-            for (int l = l0; l < l1; ++l) { if (ABL == 5) { ev[l] = 1.; wv[l] = 1.; } else { ev[l] = elp[l * GQ_NQ * GQ_T]; wv[l] = wpp[l * GQ_T]; } }
-        };
-#define GQ_SB() __builtin_amdgcn_sched_barrier(0)
-        // issue order of a round, pinned block by block: the first half's fragments; its MFMAs with the build's reads and the second
-        // half's fragments behind them; the second half's MFMAs with the build's FMAs behind them
-        frag_z(0); frag(0, 0); frag(0, 1); frag(0, 2); frag(0, 3); GQ_SB();
-        scale(0); GQ_SB();
-        mm(0, 0); bread(0, 3); GQ_SB();
-        mm(0, 1); bread(3, 6); GQ_SB();
-        mm(0, 2); bread(6, 8); frag_z(1); GQ_SB();
-        mm(0, 3); bread(8, 10); frag(1, 0); frag(1, 1); frag(1, 2); frag(1, 3); GQ_SB();
-        scale(1); GQ_SB();
-        double z = ev[0] * wv[0];
-        mm(1, 0); z = fma(ev[1], wv[1], z); z = fma(ev[2], wv[2], z); GQ_SB();
-        mm(1, 1); z = fma(ev[3], wv[3], z); z = fma(ev[4], wv[4], z); z = fma(ev[5], wv[5], z); GQ_SB();
-        mm(1, 2); z = fma(ev[6], wv[6], z); z = fma(ev[7], wv[7], z); GQ_SB();
-        mm(1, 3); z = fma(ev[8], wv[8], z); z = fma(ev[9], wv[9], z); GQ_SB();
-#undef GQ_SB
-        Zs[(r & 1) * GQ_Z_D + qb * GQ_T + zsw] = z;
-        if (ABL == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if (ABL == 4) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-        fr_barrier();
-    }
-    // lane (g, i) holds rows a = 64 ah + 16 rt + g + 4 e, output link q = 30 h + 16 c + i: G[2 a + s][2 q + t]
-    {
-        const int g = lane >> 4, i = lane & 15;
-        double* slab = A.slab + (size_t)group * 240 * 240;
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int a = 64 * ah + 16 * rt + g + 4 * e, ql = 16 * c + i;
-                    if (a < 120 && ql < GQ_NQ) slab[(size_t)(2 * a + (st >> 1)) * 240 + 2 * (GQ_NQ * h + ql) + (st & 1)] = acc[rt][c][e];
-                }
-    }
-}
-
-int launch_grad_q(tnml_ctx* c, const GradResArgs& a_in, double* G) {
-    GradResArgs a = a_in;
-    if (a.NTp % 256) return tnml_fail(c, "grad_q: image count not a multiple of 256");
-    if ((size_t)TNML_NL * a.EL_lstride * sizeof(double) >= ((size_t)1 << 32)) return tnml_fail(c, "grad_q: environment larger than 4 GB (32-bit lane offsets)");
-    if (!c->cu_count) { hipDeviceProp_t pr; c->cu_count = hipGetDeviceProperties(&pr, c->cfg.device) == hipSuccess ? pr.multiProcessorCount : 256; }
-    a.ntiles = a.NTp / GQ_T;
-    int grid = c->cu_count / 32 * 32;
-    if (c->res_grid > 0 && c->res_grid < grid) grid = c->res_grid / 32 * 32;
-    if (grid < 32) grid = 32;
-    const size_t n = (size_t)240 * 240;
-    while (grid > 32 && ((grid / 4) > a.ntiles || (size_t)(grid / 4) * n * sizeof(double) > c->slab_bytes)) grid -= 32;
-    if ((size_t)(grid / 4) * n * sizeof(double) > c->slab_bytes) return tnml_fail(c, "grad_q: slab workspace too small");
-    a.slab = (double*)c->slab;
-    const size_t lds = GQ_LDS_BYTES;
-    if (!c->attr_gq) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_grad_q<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return tnml_fail(c, "grad_q: cannot reserve %zu bytes of LDS", lds);
-        c->attr_gq = true;
-    }
-    {
-        ProfScope ps(c, KC_BGEMM);
-        hipLaunchKernelGGL(k_grad_q<0>, dim3(grid), dim3(512), lds, c->stream, a);
-    }
-    {
-        ProfScope ps(c, KC_SLABRED);
-        launch_slab_reduce64(c, (const double*)c->slab, G, n, grid / 4);
-    }
-    HIPCK(c, hipGetLastError());
-    return 0;
-}
-
-// ==========================================================================================================================
 // k_shift_res -- the Label-carrying environment shift (TrainStates::shiftE / init, fixedL.cc:142-149,221-228), m = 120:
 //   E'[l][y][n] = sum_{a,s} E[l][a][n] phi[s][n] A[a,s,y]  =  phi[0] (E M_even) + phi[1] (E M_odd),  M = the packed site matrix [240][128].
 // M (245 KB) fits the registers of ONE workgroup: 8 waves, wave w keeps column tile w (120 VGPRs) for the whole launch and the

@@ -318,9 +318,8 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
         HIPCK(c, hipStreamSynchronize(st));
     }
     if (own_eig) { hd[0] = h[n]; hd[1] = h[n + 1]; hd[2] = h[n + 2]; }
-    if (const char* pe = getenv("TNML_SVD_PRINT")) {                           // debugging aid: the spectrum of one call
-        static int calls = 0;
-        if (calls++ == atoi(pe)) { fprintf(stderr, "svd_spectrum n=%d:", n); for (int g = 0; g < n; ++g) fprintf(stderr, " %.3e", h[n - 1 - g]); fprintf(stderr, "\n"); }
+    if (c->svd_print >= 0) {                                                   // debugging aid (option svd_print = k): the spectrum of the k-th split of this context
+        if (c->svd_calls++ == c->svd_print) { fprintf(stderr, "svd_spectrum n=%d:", n); for (int g = 0; g < n; ++g) fprintf(stderr, " %.3e", h[n - 1 - g]); fprintf(stderr, "\n"); }
     }
     std::vector<double> p(n), sig(n);
     for (int g = 0; g < n; ++g) { double lam = h[n - 1 - g]; if (!(lam > 0.)) lam = 0.; p[g] = lam; sig[g] = std::sqrt(lam); }
@@ -335,7 +334,7 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
     const SigmaRef d_sig{evals, n, 0}, d_isig{evals, n, 1}, no_scale{nullptr, 0, 0};   // sigma_g / 1/sigma_g of the kept columns, computed where they are used
 
     if (own_eig) {
-        if (const char* pe = getenv("TNML_SVD_PRINT")) if (atoi(pe) < 0) {
+        if (c->svd_print == -1) {                                                  // debugging aid (option svd_print = -1): the check values of every split
             double nref = -1.;
             (void)hipMemcpy(&nref, c->sTau + (n - 1), sizeof(double), hipMemcpyDeviceToHost);
             fprintf(stderr, "svd_check n=%d mk=%d dev=%.2e cholfail=%g factored=%g dev_in=%.2e reflectors=%g\n", n, mk, hd[0], hd[1], hd[2], h[n + 3], nref);
@@ -343,8 +342,9 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
         c->svd_last_dev0 = hd[0]; c->svd_last_dev1 = 0.75 * hd[0] * hd[0];      // Newton-Schulz: error -> 3/4 error^2
         const bool ok = hd[0] < 1e-6 && hd[1] == 0.;                             // the polish step leaves 3/4 d^2 < 1e-12
         if (hd[2] != 0.) c->svd_cholqr += 1;
-        if (!ok) if (const char* dump = getenv("TNML_SVD_DUMP")) {               // debugging aid: the offending tridiagonal problem
-            static int dumped = 0;
+        if (!ok && !c->svd_dump.empty()) {                                       // debugging aid (TNML_SVD_DUMP at tnml_create): the offending tridiagonal problem
+            const char* dump = c->svd_dump.c_str();
+            int& dumped = c->svd_dumped;
             if (dumped < 4) {
                 std::vector<double> hb((size_t)3 * n + (size_t)n * mk + 2);
                 hb[0] = n; hb[1] = mk;

@@ -86,7 +86,6 @@ int tnml_set_option(tnml_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "fused_fwd")) c->fused_fwd = value;
     else if (!strcmp(name, "fold_reduce")) c->fold_reduce = value != 0;
     else if (!strcmp(name, "fwd_res")) c->fwd_res = value;
-    else if (!strcmp(name, "grad_res")) c->grad_res = value;
     else if (!strcmp(name, "shift_res")) c->shift_res = value;
     else if (!strcmp(name, "res_grid")) c->res_grid = value;
     else if (!strcmp(name, "res_pace")) c->res_pace = value;
@@ -99,6 +98,7 @@ int tnml_set_option(tnml_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "cg_method")) { if (value < 0 || value > 2 || (value >= 1 && !c->single())) return tnml_fail(c, "cg_method: 0 (conj) or, in TNML_MODE_SINGLE, 1 (fast_conj) / 2 (exact)"); c->cg_method = value; }
     else if (!strcmp(name, "debug_nudge_rank")) c->debug_nudge_rank = value;
     else if (!strcmp(name, "mc_spin_max")) c->mc_spin_max = value;
+    else if (!strcmp(name, "svd_print")) { c->svd_print = value; c->svd_calls = 0; }
     else if (!strcmp(name, "fg64_cfg")) c->opt_fg64_cfg = value;
     else if (!strcmp(name, "ldot_cfg")) c->opt_ldot_cfg = value;
     else return tnml_fail(c, "tnml_set_option: unknown option %s", name);
@@ -239,7 +239,6 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(tnml_fail(c, "hipStreamCreate failed"));
     if (const char* e = getenv("TNML_FUSED_FWD")) c->fused_fwd = atoi(e);
     if (const char* e = getenv("TNML_FWD_RES")) c->fwd_res = atoi(e);
-    if (const char* e = getenv("TNML_GRAD_RES")) c->grad_res = atoi(e);
     if (const char* e = getenv("TNML_SHIFT_RES")) c->shift_res = atoi(e);
     if (const char* e = getenv("TNML_RES_PACE")) c->res_pace = atoi(e);
     if (const char* e = getenv("TNML_BGS_CHOL")) c->bgs_chol = atoi(e) != 0;
@@ -316,6 +315,8 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
         if (hipMemsetAsync(c->mc_xbuf, 0, eigh_mc_xbuf_bytes(), c->stream) != hipSuccess) return bail(tnml_fail(c, "memset failed"));
     }
     if (const char* e = getenv("TNML_SVD_BACKEND")) c->cfg.svd_backend = atoi(e);
+    if (const char* e = getenv("TNML_SVD_PRINT")) c->svd_print = atoi(e);
+    if (const char* e = getenv("TNML_SVD_DUMP")) c->svd_dump = e;
     for (int k = 0; k < 2; ++k)
         if (hipEventCreateWithFlags(&c->pend[k].ev, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->pend[k].ev2, hipEventDisableTiming) != hipSuccess)
             return bail(tnml_fail(c, "hipEventCreate failed"));
@@ -1009,11 +1010,7 @@ static int grad_eval(tnml_ctx* c, bool from_P_update = false, bool outputs_curre
     const void* wsrc = weights_pp ? c->Pp : c->dP;           // the per-image weights of the sum
     const bool fuse = c->f64() && c->fuse_z && p.kind != 2;
     if (p.kind != 2 && !fuse) TCK(launch_zprime(c, p.EX, (size_t)p.mO * c->NTp, wsrc, c->Zp, p.mO, c->NTp));
-    if (fuse && c->grad_res >= 2 && c->env64() && !c->single() && p.Kp == 240 && p.Np == 240 && p.mI == 120 && p.mO == 120) {
-        GradResArgs gr{(const double*)p.EI, (const double*)p.phiI, (const double*)p.phiO, (const double*)p.EX, (size_t)p.mO * c->NTp, (const double*)wsrc, c->NTp, c->NTp / 32};
-        if (c->grad_res == 3) TCK(launch_grad_q(c, gr, c->vG));     // uniform waves, groups of four workgroups
-        else TCK(launch_grad_res(c, gr, c->vG));
-    } else if (c->f64()) {
+    if (c->f64()) {
         Bgemm64Args g;
         g.EL = nullptr; g.EL_lstride = 0; g.dPz = nullptr; g.env64 = c->env64();
         g.EI = p.EI; g.mI = p.mI; g.phiI = p.phiI; g.phiO = p.phiO; g.mO = p.mO;

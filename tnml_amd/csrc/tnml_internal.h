@@ -188,11 +188,10 @@ struct tnml_ctx {
     void* mc_xbuf = nullptr;   // exchange buffer of the multi-workgroup tridiagonalisation (eigh_mc.hip), contexts with maxm > 120 only
     unsigned mc_epoch = 0;
     int mc_spin_max = -1;      // polls before a waiting thread of k_sytrd_mc gives up (-1: default; option "mc_spin_max", 0 in the fallback test)
-    bool attr_res = false, attr_gres = false, attr_gq = false;        // kernels_res.hip
+    bool attr_res = false;           // kernels_res.hip
     int res_pace = 0;                // pacing of the GEMM waves of k_fwd_res (0: default; option "res_pace")
     int fwd_res = 1;                 // forward pass on k_fwd_res (kernels_res.hip): 1 = from 7 680 images per rank on, 0 never, 2 always; option "fwd_res"
     int shift_res = 1;               // Label-carrying environment shift on k_shift_res (kernels_res.hip): 1 = from 7 680 images per rank on, 0 never, 2 always; option "shift_res"
-    int grad_res = 0;                // gradient GEMM on k_grad_res (kernels_res.hip): 0 never (default: no faster than k_bgemm64 yet), 2 always; option "grad_res"
     int res_grid = 0;                // test knob: workgroups of the resident-operand kernels (0: one per CU)
     unsigned* counters = nullptr;    // [16] device: arrival counters of the "last workgroup reduces" kernels (zero between launches)
     double* Ppart = nullptr;         // [2][10][NTp]: per-half outputs of k_fwd_res
@@ -200,6 +199,8 @@ struct tnml_ctx {
     int cu_count = 0;
     double svd_last_dev0 = 0., svd_last_dev1 = 0.;   // max|Q^T Q - I| before the 1st / 2nd polish step of the last split
     long svd_fallbacks = 0, svd_cholqr = 0;
+    int svd_print = -2, svd_calls = 0, svd_dumped = 0;   // debugging aids of the split, read once in tnml_create (TNML_SVD_PRINT, TNML_SVD_DUMP) / option "svd_print"
+    std::string svd_dump;
     double last_bnorm = 0.;         // |B| of the last quadcost
     int* sInfo = nullptr;
     unsigned long long* fprint = nullptr;   // [2] device: fingerprint of replicated tensors (and its complement)
@@ -351,16 +352,6 @@ struct PfinishArgs {
     double* out; int only_sum;                        // [12] sums over all images (only_sum: slot 11 alone)
 };
 int launch_pfinish(tnml_ctx* c, const PfinishArgs& a);
-struct GradResArgs {
-    const double* EI; const double* phiI;             // Label-free environment [120][NTp], its site features [2][NTp]
-    const double* phiO;                               // output-site features [2][NTp]
-    const double* EL; size_t EL_lstride;              // Label-carrying environment [10][120][NTp]
-    const double* w;                                  // per-image weights [10][NTp] (dP, or p.v of the pAp pass)
-    int NTp, ntiles;                                  // ntiles = NTp / 32
-    double* slab = nullptr;                           // split-K slabs [pairs][240][240] (set by the launcher)
-};
-int launch_grad_res(tnml_ctx* c, const GradResArgs& a, double* G);
-int launch_grad_q(tnml_ctx* c, const GradResArgs& a, double* G);      // ntiles is set by the launcher (16-image tiles)
 struct ShiftResArgs {
     const double* EI; size_t EI_lstride;              // Label-carrying input environment [L][120][NTp]
     const double* phiI;                               // features of the absorbed site [2][NTp]
@@ -407,7 +398,8 @@ int launch_fingerprint_pieces(tnml_ctx* c, const unsigned long long* acc, double
 
 // ---- eigh.hip -----------------------------------------------------------------------------
 int eigh_tridiagonalize(tnml_ctx* c, const double* A, int n, double* D, double* E, double* tau, double* V, double psd_tol = 0.);   // tau: n doubles, tau[n-1] = number of reflectors
-int eigh_tridiag_eig(tnml_ctx* c, const double* D, const double* E, int n, double* W, int mk, double* Z, int ldz, double* scratch);
+int eigh_tridiag_eig(tnml_ctx* c, const double* D, const double* E, int n, double* W, int mk, double* Z, int ldz, double* scratch);      // eigh_tri.hip
+int eigh_tridiag_eig_v1(tnml_ctx* c, const double* D, const double* E, int n, double* W, int mk, double* Z, int ldz, double* scratch);   // round-4 kernels (eigh.hip), kept for the A/B probe
 int eigh_ns_matrix(tnml_ctx* c, const double* S, double* Cm, int m, double* dev);
 int eigh_chol_rinv(tnml_ctx* c, const double* S, int m, double* Rinv, double* flag);   // m <= 128
 #define TNML_CHOL_MAXM 128

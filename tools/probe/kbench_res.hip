@@ -5,6 +5,7 @@
 #include "../../tnml_amd/csrc/kernels_fused.hip"
 #include "../../tnml_amd/csrc/kernels_stream.hip"
 #include "../../tnml_amd/csrc/kernels_gemm.hip"
+#include "k_grad_res_q.inc"   // the two resident-accumulator gradient forms of round 4 (out of the library since round 5)
 #include "k_grad_h.inc"       // the fourth gradient form (not in the library): tools/probe/attic/k_grad_h_attempt.hip.txt + ablation switches
 #include <cstdarg>
 #include <cstdlib>
