@@ -709,14 +709,14 @@ int eigh_ns_matrix(tnml_ctx* c, const double* S, double* Cm, int m, double* dev)
 // ==========================================================================================
 #define CQ_T 8
 #define CQ_NT 16
-__global__ __launch_bounds__(256) void k_chol_rinv_blocked(const double* __restrict__ S, int m, double* __restrict__ Rinv, double* __restrict__ flag, int all_panels) {
+__global__ __launch_bounds__(256) void k_chol_rinv_blocked(const double* __restrict__ S, int m, double* __restrict__ Rinv, double* __restrict__ flag, int all_panels, int zero_prev) {
     __shared__ __attribute__((aligned(16))) double s_li[CQ_T * CQ_T];            // L_pp^-1, row major, zeros above the diagonal
     __shared__ __attribute__((aligned(16))) double Pl[CQ_NT * CQ_T * CQ_T];      // L_ip rows: [row][k]
     __shared__ __attribute__((aligned(16))) double Px[CQ_T * CQ_NT * CQ_T];      // X_p* : [k][column]
     __shared__ int s_fail;
     const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
     const int nt = (m + CQ_T - 1) / CQ_T;
-    if (tid == 0) s_fail = 0;
+    if (tid == 0) { s_fail = 0; if (zero_prev) flag[-1] = 0.; }      // flag[-1]: the deviation slot of the polish step that follows (an atomic max)
     double a[CQ_T][CQ_T];
 #pragma unroll
     for (int r = 0; r < CQ_T; ++r)
@@ -918,9 +918,9 @@ __global__ __launch_bounds__(256) void k_chol_rinv_blocked(const double* __restr
         }
     if (tid == 0) { flag[0] = 0.; flag[1] = 1.; }          // flag[1]: a factorisation was needed
 }
-int eigh_chol_rinv(tnml_ctx* c, const double* S, int m, double* Rinv, double* flag) {
+int eigh_chol_rinv(tnml_ctx* c, const double* S, int m, double* Rinv, double* flag, int zero_prev) {
     if (m > CQ_T * CQ_NT) return tnml_fail(c, "eigh_chol_rinv: m=%d exceeds %d", m, CQ_T * CQ_NT);
-    hipLaunchKernelGGL(k_chol_rinv_blocked, dim3(1), dim3(256), 0, c->stream, S, m, Rinv, flag, 0);
+    hipLaunchKernelGGL(k_chol_rinv_blocked, dim3(1), dim3(256), 0, c->stream, S, m, Rinv, flag, 0, zero_prev);
     HIPCK(c, hipGetLastError());
     return 0;
 }

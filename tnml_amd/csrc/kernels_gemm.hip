@@ -525,7 +525,8 @@ static int bgemm64_go(tnml_ctx* c, const Bgemm64Args& a, double* G, int default_
         if (a.env64) hipLaunchKernelGGL((k_bgemm64<RT, CT, WR, WC, FUSE, double>), grid, dim3(64 * WR * WC), 0, c->stream, K);
         else         hipLaunchKernelGGL((k_bgemm64<RT, CT, WR, WC, FUSE, float>), grid, dim3(64 * WR * WC), 0, c->stream, K);
     }
-    {
+    if (c->defer_slab) c->slab_pending = nsplit;              // the CG vector kernel that consumes G sums the slabs itself (same order: same bits)
+    else {
         ProfScope ps(c, KC_SLABRED);
         hipLaunchKernelGGL(k_slab_reduce64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const double*)c->slab, G, n, nsplit);
     }

@@ -100,7 +100,7 @@ int launch_bond_form(tnml_ctx* c, const SiteT& A1, const SiteT& A2, double* B) {
     if (k >= 16 && (A1.L == 1 || A2.L == 1)) {
         const double one = 1.0, zero = 0.0;
         rocblas_status st;
-        if (A1.L == 1) st = dgemm_strips(c->blas, rocblas_operation_none, rocblas_operation_none, nl, nr * A2.L, k, A1.a, nl, A2.a, k, B, nl, 2);
+        if (A1.L == 1) return split_gemm(c, false, false, nl, nr * A2.L, k, A1.a, nl, A2.a, k, B, nl, 2);      // k_dgemm_small (kernels_sgemm.hip) unless option small_gemm = 0
         else           st = rocblas_dgemm_strided_batched(c->blas, rocblas_operation_none, rocblas_operation_none, nl, nr, k, &one, A1.a, nl, (rocblas_stride)nl * k,
                                                          A2.a, k, 0, &zero, B, nl, (rocblas_stride)nl * nr, A1.L);
         if (st != rocblas_status_success) return tnml_fail(c, "bond_form: rocblas dgemm failed (%d)", (int)st);
@@ -163,13 +163,27 @@ static __device__ __forceinline__ double sum_column(const double* __restrict__ p
 }
 
 // r = G - lambda*B (fixedL.cc:385-386); p = r (:388); partial |r|^2
-__global__ __launch_bounds__(VB) void k_cg_init1(const double* __restrict__ G, const double* __restrict__ B, double* __restrict__ R,
-                                                double* __restrict__ Pv, size_t n, double lambda, double* __restrict__ part) {
+// slab != nullptr (one rank): G = the sum of the nsplit split-K slabs the gradient GEMM left, in k_slab_reduce64's order -- the reduction
+// launch of its own is folded in here.  set_flags: workgroup 0 also does what k_cg_init2 did besides the sum (clears the trace and the
+// convergence flags); |r|^2 itself is then summed from `part` by the first k_cg_step2.
+__global__ __launch_bounds__(VB) void k_cg_init1(double* __restrict__ G, const double* __restrict__ B, double* __restrict__ R,
+                                                double* __restrict__ Pv, size_t n, double lambda, double* __restrict__ part,
+                                                const double* __restrict__ slab, int nsplit, double* __restrict__ scal, int set_flags) {
     __shared__ double sh[VB];
+    if (set_flags && blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < 4 * TNML_MAX_PASS; i += VB) scal[SC_N + i] = 0.;
+        if (threadIdx.x == 0) { scal[SC_CONV] = 0.; scal[SC_CONVP] = 0.; scal[SC_NPASS] = 0.; }
+    }
     size_t lo, hi; slice(n, &lo, &hi);
     double acc = 0.;
     for (size_t i = lo + threadIdx.x; i < hi; i += VB) {
-        double r = G[i];
+        double r;
+        if (slab) {
+            double g = 0.;
+#pragma unroll 8
+            for (int k = 0; k < nsplit; ++k) g += slab[(size_t)k * n + i];
+            G[i] = g; r = g;
+        } else r = G[i];
         if (lambda != 0.) r = r - lambda * B[i];
         R[i] = r; Pv[i] = r;
         acc += r * r;
@@ -198,10 +212,15 @@ __global__ __launch_bounds__(VB) void k_norm1(const double* __restrict__ x, cons
     if (threadIdx.x == 0) { part[2 * blockIdx.x] = s0; part[2 * blockIdx.x + 1] = s1; }
 }
 // pAp = sum_n|p v_n|^2 + lambda|p|^2 (:402-403); a = |r|^2/pAp (:405); B = B + a p (:406)
+// Workgroups [0, nbv) update B.  With U.P != nullptr the launch carries nbu more workgroups that apply the SAME step to the model
+// outputs, P <- P + a (p*t.v) (the fast CG's k_pupdate, a launch of its own before round 5): every workgroup derives a from the same
+// partial sums in the same order, so both halves use identical bits.
+struct StepUpd { double* P; const double* Pp; double* dP; const int* label; int NTp; double* partials; int nl, target; };
 __global__ __launch_bounds__(VB) void k_cg_step2(double* __restrict__ B, const double* __restrict__ Pv, size_t n, double lambda,
                                                 const double* __restrict__ tail, const double* __restrict__ part, int nb,
                                                 double* __restrict__ scal, int rr_in, double* __restrict__ trace, int pass, int merged,
-                                                const double* __restrict__ pp_part, int npp) {
+                                                const double* __restrict__ pp_part, int npp,
+                                                const double* __restrict__ rr_part, int nbv, StepUpd U) {
     // merged CG: the cost partials of the PREVIOUS pass's update (fixedL.cc:419,427-428) came with this pass's all-reduce
     if (merged && pass > 1 && blockIdx.x == 0 && threadIdx.x == 0 && scal[SC_CONVP + (pass & 1)] == 0.) {   // (slot of pass - 2: not converged before the previous pass)
         double cs = 0.;
@@ -211,30 +230,55 @@ __global__ __launch_bounds__(VB) void k_cg_step2(double* __restrict__ B, const d
     }
     if (scal[SC_CONVP + ((pass - 1) & 1)] != 0.) return;   // |r| < cconv was hit in an earlier pass (fixedL.cc:432-436)
     __shared__ double sh[VB];
+    // |r|^2: left in scal by k_cg_resid2 / k_cg_init2, or (pass 1 without k_cg_init2) still as k_cg_init1's partial sums
+    double rr, unused;
+    if (rr_part) sum_partials(rr_part, nb, &rr, &unused, sh); else rr = scal[rr_in];
     // |p|^2: p = r in pass 1 (fixedL.cc:388), afterwards the partial sums left by k_cg_resid2 when it formed p = r + beta p
-    double pn2, unused;
-    if (pass == 1) pn2 = scal[rr_in]; else sum_partials(part, nb, &pn2, &unused, sh);
+    double pn2;
+    if (pass == 1) pn2 = rr; else sum_partials(part, nb, &pn2, &unused, sh);
     // sum_n |p.v_n|^2: reduced already (tail), or still as the per-block partial sums of the pAp pass (column 11)
     const double pp = pp_part ? sum_column(pp_part, npp, 11, sh) : tail[SC_PP];
     const double pAp = pp + lambda * pn2;
-    const double a = scal[rr_in] / pAp;
-    size_t lo, hi; slice(n, &lo, &hi);
-    for (size_t i = lo + threadIdx.x; i < hi; i += VB) B[i] = B[i] + a * Pv[i];
+    const double a = rr / pAp;
+    if ((int)blockIdx.x >= nbv) {                          // output update: two units of LD_IMGS images per workgroup
+        __shared__ double s_part[(VB / 64) * 12];
+        const int half = threadIdx.x / LD_IMGS;
+        const int unit = ((int)blockIdx.x - nbv) * (VB / LD_IMGS) + half;
+        pupdate_unit<double>(U.P, U.Pp, U.dP, U.label, U.NTp, a, U.partials, U.nl, U.target, s_part + half * (LD_IMGS / 64) * 12, (int)threadIdx.x % LD_IMGS, unit);
+        return;
+    }
+    // slice over the nbv vector workgroups (gridDim.x may be larger)
+    {
+        const size_t per = (n + nbv - 1) / nbv;
+        size_t lo = per * blockIdx.x, hi = lo + per; if (hi > n) hi = n; if (lo > n) lo = n;
+        for (size_t i = lo + threadIdx.x; i < hi; i += VB) B[i] = B[i] + a * Pv[i];
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         scal[SC_PNORM2] = pn2; scal[SC_PAP] = pAp; scal[SC_ALPHA] = a; scal[SC_NPASS] = (double)pass;
+        if (rr_part) scal[rr_in] = rr;                     // k_cg_resid2 reads it
         trace[4 * (pass - 1) + 0] = pAp; trace[4 * (pass - 1) + 1] = a;
     }
 }
 // partial |nr|^2 with nr = G - lambda B, and |B|^2
 // merged (R, Pv given): G holds A p = sum_n (p.v_n) v_n and nr = r - a (A p + lambda p) with a = scal[SC_ALPHA] (single.h:378-379 structure)
-__global__ __launch_bounds__(VB) void k_cg_resid1(const double* __restrict__ G, const double* __restrict__ B, size_t n, double lambda,
-                                                 double* __restrict__ part, const double* __restrict__ R, const double* __restrict__ Pv, const double* __restrict__ scal) {
+// slab != nullptr (one rank, literal order): G is first formed as the ordered sum of the gradient GEMM's split-K slabs (the
+// k_slab_reduce64 launch folded in)
+__global__ __launch_bounds__(VB) void k_cg_resid1(double* __restrict__ G, const double* __restrict__ B, size_t n, double lambda,
+                                                 double* __restrict__ part, const double* __restrict__ R, const double* __restrict__ Pv, const double* __restrict__ scal,
+                                                 const double* __restrict__ slab, int nsplit, int pass) {
+    if (slab && scal[SC_CONVP + ((pass - 1) & 1)] != 0.) return;   // converged: k_cg_resid2 will not read G or the partials (the separate reduction launch used to run regardless)
     __shared__ double sh[VB];
     size_t lo, hi; slice(n, &lo, &hi);
     double an = 0., ab = 0.;
     const double a = R ? scal[SC_ALPHA] : 0.;
     for (size_t i = lo + threadIdx.x; i < hi; i += VB) {
         double nr;
+        if (slab) {
+            double g = 0.;
+#pragma unroll 8
+            for (int k = 0; k < nsplit; ++k) g += slab[(size_t)k * n + i];
+            G[i] = g;
+        }
         if (R) { double t = G[i]; if (lambda != 0.) t = t + lambda * Pv[i]; nr = R[i] - a * t; }
         else { nr = G[i]; if (lambda != 0.) nr = nr - lambda * B[i]; }
         an += nr * nr; ab += B[i] * B[i];
@@ -331,7 +375,12 @@ __global__ __launch_bounds__(VB) void k_diffnorm1(const double* __restrict__ x, 
     if (threadIdx.x == 0) { part[2 * blockIdx.x] = s0; part[2 * blockIdx.x + 1] = s1; }
 }
 
-static inline int vec_blocks(size_t n) { size_t b = (n + 1023) / 1024; if (b > VNB_MAX) b = VNB_MAX; if (b < 1) b = 1; return (int)b; }
+// Workgroups of the CG vector kernels.  Large vectors (config 3: 57 600 elements): one element per lane, up to VNB_MAX workgroups --
+// the kernels that fold the split-K slab reduction read nsplit values per element and need the width.  Small vectors keep the
+// partition of rounds 1-4 (1024 elements per workgroup): nothing to gain there, and the partition IS the summation order of
+// |r|^2, |p|^2, |B|^2 -- the free-running CLI test on the reference's badly conditioned feature map amplifies a change of it
+// (tests/test_gpu_parity.py::test_fixedl_cli_driver_end_to_end) exactly as it amplifies the oracle's own thread count.
+static inline int vec_blocks(size_t n) { const size_t per = n >= 16384 ? VB : 1024; size_t b = (n + per - 1) / per; if (b > VNB_MAX) b = VNB_MAX; if (b < 1) b = 1; return (int)b; }
 
 // the |r|^2 of the previous evaluation lives in scal[SC_RR + (c->rr_slot)], alternating between two
 // slots so that phase-2 workgroups never read a slot another workgroup is writing
@@ -339,15 +388,31 @@ int launch_cg_init(tnml_ctx* c, size_t n, double lambda, double cconv0) {
     ProfScope ps(c, KC_VEC);
     const int nb = vec_blocks(n);
     c->rr_slot = 0;
-    hipLaunchKernelGGL(k_cg_init1, dim3(nb), dim3(VB), 0, c->stream, c->vG, c->vB, c->vR, c->vP, n, lambda, c->vpart);
-    hipLaunchKernelGGL(k_cg_init2, dim3(1), dim3(VB), 0, c->stream, c->vpart, nb, c->scal, (int)SC_RR, cconv0);
+    // one rank (the slabs of the gradient GEMM are still unreduced: cgrad_device's fold path): the slab sum and, without the entry
+    // check of the per-label variant, everything k_cg_init2 did are folded into k_cg_init1; |r|^2 is summed by the first k_cg_step2
+    const double* slab = c->slab_pending > 0 ? (const double*)c->slab : nullptr;
+    const int nsplit = c->slab_pending;
+    c->slab_pending = 0;
+    c->rr_from_part = cconv0 < 0. && slab != nullptr;
+    hipLaunchKernelGGL(k_cg_init1, dim3(nb), dim3(VB), 0, c->stream, c->vG, c->vB, c->vR, c->vP, n, lambda, c->vpart, slab, nsplit, c->scal, c->rr_from_part ? 1 : 0);
+    if (!c->rr_from_part) hipLaunchKernelGGL(k_cg_init2, dim3(1), dim3(VB), 0, c->stream, c->vpart, nb, c->scal, (int)SC_RR, cconv0);
     HIPCK(c, hipGetLastError());
     return 0;
 }
-int launch_cg_step(tnml_ctx* c, size_t n, double lambda, int pass, bool merged, const double* pp_part, int npp) {
+// with_update (one rank, f64, literal pass order): the launch also applies the step to the model outputs (P, dP and the cost partials of
+// the new B -> c->partials2), what launch_pupdate did in a launch of its own
+int launch_cg_step(tnml_ctx* c, size_t n, double lambda, int pass, bool merged, const double* pp_part, int npp, bool with_update) {
     ProfScope ps(c, KC_VEC);
     const int nb = vec_blocks(n);
-    hipLaunchKernelGGL(k_cg_step2, dim3(nb), dim3(VB), 0, c->stream, c->vB, c->vP, n, lambda, c->tail, c->vpart + 512, nb, c->scal, SC_RR + c->rr_slot, c->cgtrace, pass, merged ? 1 : 0, pp_part, npp);
+    StepUpd U{nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, 0};
+    int nbu = 0;
+    if (with_update) {
+        U = StepUpd{(double*)c->P, (const double*)c->Pp, (double*)c->dP, c->label, c->NTp, c->partials2, c->nl(), c->target()};
+        nbu = c->NTp / VB;
+        c->part_n = c->NTp / LD_IMGS;
+    }
+    const double* rr_part = (pass == 1 && c->rr_from_part) ? (const double*)c->vpart : nullptr;
+    hipLaunchKernelGGL(k_cg_step2, dim3(nb + nbu), dim3(VB), 0, c->stream, c->vB, c->vP, n, lambda, c->tail, c->vpart + 512, nb, c->scal, SC_RR + c->rr_slot, c->cgtrace, pass, merged ? 1 : 0, pp_part, npp, rr_part, nb, U);
     HIPCK(c, hipGetLastError());
     return 0;
 }
@@ -355,7 +420,10 @@ int launch_cg_resid(tnml_ctx* c, size_t n, double lambda, double cconv, int pass
     ProfScope ps(c, KC_VEC);
     const int nb = vec_blocks(n);
     const int in = SC_RR + c->rr_slot, out = SC_RR + (c->rr_slot ^ 1);
-    hipLaunchKernelGGL(k_cg_resid1, dim3(nb), dim3(VB), 0, c->stream, c->vG, c->vB, n, lambda, c->vpart, merged ? (const double*)c->vR : (const double*)nullptr, (const double*)c->vP, (const double*)c->scal);
+    const double* slab = c->slab_pending > 0 ? (const double*)c->slab : nullptr;
+    const int nsplit = c->slab_pending;
+    c->slab_pending = 0;
+    hipLaunchKernelGGL(k_cg_resid1, dim3(nb), dim3(VB), 0, c->stream, c->vG, c->vB, n, lambda, c->vpart, merged ? (const double*)c->vR : (const double*)nullptr, (const double*)c->vP, (const double*)c->scal, slab, nsplit, pass);
     hipLaunchKernelGGL(k_cg_resid2, dim3(nb), dim3(VB), 0, c->stream, c->vG, c->vB, c->vR, c->vP, n, lambda, cconv, c->tail, c->vpart, nb, c->scal, in, out, c->cgtrace, pass, c->vpart + 512, merged ? 1 : 0, cost_part, ncp);
     c->rr_slot ^= 1;
     HIPCK(c, hipGetLastError());

@@ -10,7 +10,6 @@
 // k_features : TState ctor (fixedL.cc:28-47) with phi of :637-642 from raw bytes.
 #include "tnml_internal.h"
 
-#define LD_IMGS 128     // images per workgroup (2 per lane)
 
 template <typename T> struct vec2;
 template <> struct vec2<float> { typedef float2 type; };
@@ -26,36 +25,6 @@ static __device__ __forceinline__ float2 load2_nt(const float* p) {
     const f2v t = __builtin_nontemporal_load(reinterpret_cast<const f2v*>(p));
     return make_float2(t.x, t.y);
 }
-
-// Workgroup partial sums [12]: cost bucket of every label (0..9), number correct (10), plain sum (11, the
-// <p|A|p> mode).  Called by whole waves (all 64 lanes active): a fixed DPP tree inside the wave, lane 0
-// leaves the wave's 12 values in s_part[wave][12]; after a barrier sum_wave_partials adds the waves in
-// order -> deterministic for a given launch shape.  (The serial 128-entry LDS walk this replaces
-// was a third of k_pupdate.)
-static __device__ __forceinline__ void wave_bucket_partials(double val, int lab, int cor, bool pap, double* s_part, int wave, int lane) {
-    if (pap) {
-        const double s = wave_sum(val);
-        if (lane < 12) s_part[wave * 12 + lane] = lane == 11 ? s : 0.;
-        return;
-    }
-    double mine = 0.;
-#pragma unroll
-    for (int t = 0; t < TNML_NL; ++t) {
-        const double s = wave_sum(lab == t ? val : 0.);
-        if (lane == t) mine = s;
-    }
-    const double sc = wave_sum((double)cor);
-    if (lane == 10) mine = sc;
-    if (lane < 12) s_part[wave * 12 + lane] = mine;
-}
-static __device__ __forceinline__ void sum_wave_partials(const double* s_part, int nwaves, double* out, int tid) {
-    if (tid < 12) {
-        double s = 0.;
-        for (int w = 0; w < nwaves; ++w) s += s_part[w * 12 + tid];
-        out[tid] = s;
-    }
-}
-
 
 // TA: element type of the label-carrying operand, TB: of the label-free one, TC: arithmetic type
 // IPL: images per lane.  2 (128 images per workgroup, 16-byte loads) is the streaming configuration; 1 with more
@@ -266,28 +235,7 @@ __global__ __launch_bounds__(LD_IMGS) void k_pupdate(T* __restrict__ P, const T*
                                                     double* __restrict__ partials, int nl, int target) {
     if (conv[0] != 0.) return;                             // CG already converged: P must stay as it is
     __shared__ double s_part[(LD_IMGS / 64) * 12];
-    const int tid = threadIdx.x;
-    const int ni = blockIdx.x * LD_IMGS + tid;
-    const T a = (T)alpha[0];
-    const int lab = label[ni];
-    T val = 0; T best = 0; int arg = 0; T p0 = 0;
-#pragma unroll
-    for (int l = 0; l < TNML_NL; ++l) {
-        if (l < nl) {
-            const T p = fma(a, Pp[(size_t)l * NTp + ni], P[(size_t)l * NTp + ni]);
-            P[(size_t)l * NTp + ni] = p;
-            const T tgt = target < 0 ? (l == lab ? (T)1 : (T)0) : (lab == target ? (T)1 : (T)0);
-            const T d = (lab >= 0) ? (tgt - p) : (T)0;
-            dP[(size_t)l * NTp + ni] = d;
-            val = fma(d, d, val);
-            const T wgt = fabs(p);
-            if (l == 0) { best = wgt; p0 = p; } else if (wgt > best) { best = wgt; arg = l; }
-        }
-    }
-    const int cor = target < 0 ? ((lab >= 0 && arg == lab) ? 1 : 0) : ((lab >= 0 && ((p0 > (T)0.5) == (lab == target))) ? 1 : 0);
-    wave_bucket_partials((double)val, lab, cor, false, s_part, tid >> 6, tid & 63);
-    __syncthreads();
-    sum_wave_partials(s_part, LD_IMGS / 64, partials + (size_t)blockIdx.x * 12, tid);
+    pupdate_unit<T>(P, Pp, dP, label, NTp, (T)alpha[0], partials, nl, target, s_part, threadIdx.x, blockIdx.x);
 }
 
 int launch_pupdate(tnml_ctx* c, const double* alpha_dev, double* scal_out, bool reduce) {

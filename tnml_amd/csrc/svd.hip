@@ -81,7 +81,7 @@ __global__ void k_scale_cols(double* __restrict__ X, size_t rows, int m, SigmaRe
 
 // rocsolver_dpotrf's info -> flags of the Cholesky QR: flag[0] = the factorisation failed (a pivot was not positive), flag[1] = a factorisation ran
 __global__ void k_potrf_flags(const int* __restrict__ info, double* __restrict__ flag) {
-    if (threadIdx.x == 0) { flag[0] = info[0] != 0 ? 1. : 0.; flag[1] = 1.; }
+    if (threadIdx.x == 0) { flag[0] = info[0] != 0 ? 1. : 0.; flag[1] = 1.; flag[-1] = 0.; }      // flag[-1]: the polish step's deviation slot (an atomic max)
 }
 
 // flags of the blocks of the block Gram-Schmidt -> the two flags of the Cholesky QR (any block failed / any block factored)
@@ -89,13 +89,26 @@ __global__ void k_flags_any(const double* __restrict__ fl, int nb, double* __res
     if (threadIdx.x == 0) {
         double f0 = 0., f1 = 0.;
         for (int k = 0; k < nb; ++k) { if (fl[2 * k] != 0.) f0 = 1.; if (fl[2 * k + 1] != 0.) f1 = 1.; }
-        flag[0] = f0; flag[1] = f1;
+        flag[0] = f0; flag[1] = f1; flag[-1] = 0.;              // flag[-1]: the polish step's deviation slot (an atomic max)
     }
 }
 
 // the workgroup cluster's status word -> a double that can be summed over the ranks (1 = this rank's cluster gave up)
 __global__ void k_mc_flag(const unsigned long long* __restrict__ status, double* __restrict__ out) {
     if (threadIdx.x == 0) out[0] = status[0] != 0ull ? 1. : 0.;
+}
+
+// C = op(A) op(B) at the sizes of the split: k_dgemm_small (kernels_sgemm.hip) up to 4e7 multiply-adds, rocBLAS as
+// `strips` column strips beyond (the Label-on-B bonds reduce over 2400: 133 us as one call, 17 us as 8 strips) or with option small_gemm = 0
+int split_gemm(tnml_ctx* c, bool ta, bool tb, int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* C, int ldc, int strips) {
+    if (c->small_gemm && K <= 1024 && (double)M * N * K <= 4.0e7) {   // (tools/probe/probe_sgemm.hip: 8.7-9.9 us against 19 at 240^3, 17 against 25 at 300 x 300 x 600; loses from ~6e7 on)
+        SmallGemmArgs g{A, lda, B, ldb, C, ldc, M, N, K, ta ? 1 : 0, tb ? 1 : 0};
+        return launch_dgemm_small(c, g);
+    }
+    const rocblas_status st = dgemm_strips(c->blas, ta ? rocblas_operation_transpose : rocblas_operation_none, tb ? rocblas_operation_transpose : rocblas_operation_none,
+                                           M, N, K, A, lda, B, ldb, C, ldc, strips);
+    if (st != rocblas_status_success) return tnml_fail(c, "split_gemm: rocblas dgemm failed (%d)", (int)st);
+    return 0;
 }
 
 #define RBCK(c, expr) do { rocblas_status s_ = (expr); if (s_ != rocblas_status_success) return tnml_fail((c), "%s failed: rocblas status %d (%s:%d)", #expr, (int)s_, __FILE__, __LINE__); } while (0)
@@ -199,8 +212,8 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
     }
     const double one = 1.0, zero = 0.0;
     const int gstrips = (left ? nr : nl) >= 1024 ? 8 : 4;     // the Label-on-B bonds reduce over 2400: 133 us as one call, 17 us as 8 strips
-    if (left) RBCK(c, dgemm_strips(c->blas, rocblas_operation_none, rocblas_operation_transpose, nl, nl, nr, M, nl, M, nl, c->sG, nl, gstrips));
-    else      RBCK(c, dgemm_strips(c->blas, rocblas_operation_transpose, rocblas_operation_none, nr, nr, nl, M, nl, M, nl, c->sG, nr, gstrips));
+    if (left) TCK(split_gemm(c, false, true, nl, nl, nr, M, nl, M, nl, c->sG, nl, gstrips));
+    else      TCK(split_gemm(c, true, false, nr, nr, nl, M, nl, M, nl, c->sG, nr, gstrips));
     if (dm) TCK(noise_add(c, B_it, b, ha, mL, mR, c->sG, n));           // rho += noise * drho (single.h:654-665)
     // eigen-decomposition of rho.  backend 0 (default): in-house Householder tridiagonalisation (one workgroup up to n = 240,
     // eigh.hip; a cluster of workgroups up to n = 640, eigh_mc.hip) + in-house bisection / inverse iteration + back
@@ -236,9 +249,9 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
         // second synchronisation.
         const double* Qin;
         if (mk <= TNML_CHOL_MAXM) {                       // one-workgroup kernel; returns R = I straight away when Q0 is orthonormal to 5e-7
-            RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, mk, mk, n, &one, Q0, n, Q0, n, &zero, c->sS, mk));
-            TCK(eigh_chol_rinv(c, c->sS, mk, c->sCm, dv + 1));              // writes both flags
-            RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, n, mk, mk, &one, Q0, n, c->sCm, mk, &zero, c->sG, n));   // the Gram matrix is consumed by now
+            TCK(split_gemm(c, true, false, mk, mk, n, Q0, n, Q0, n, c->sS, mk, 1));
+            TCK(eigh_chol_rinv(c, c->sS, mk, c->sCm, dv + 1, 1));           // writes both flags, clears dv[0] for the polish step's atomic max
+            TCK(split_gemm(c, false, false, n, mk, mk, Q0, n, c->sCm, mk, c->sG, n, 1));   // the Gram matrix is consumed by now
             Qin = c->sG;
         } else if (c->bgs_chol && mk <= 3 * TNML_CHOL_MAXM) {
             // larger bases (128 < mk <= 384; BASELINE config 5 keeps 300 columns): block Gram-Schmidt over column blocks of <= 128 with the
@@ -275,13 +288,18 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
             RBCK(c, rocblas_dtrsm(c->blas, rocblas_side_right, rocblas_fill_upper, rocblas_operation_none, rocblas_diagonal_non_unit, n, mk, &one, c->sS, mk, Q0, n));
             Qin = Q0;
         }
-        RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_transpose, rocblas_operation_none, mk, mk, n, &one, Qin, n, Qin, n, &zero, c->sS, mk));
+        TCK(split_gemm(c, true, false, mk, mk, n, Qin, n, Qin, n, c->sS, mk, 1));
         // Newton-Schulz step Q <- Q (1.5 I - 0.5 Q^T Q); d = max|Q^T Q - I| before the step is checked on the host (after it: ~0.75 d^2)
-        TCK(eigh_ns_matrix(c, c->sS, c->sCm, mk, dv));
         // the kept basis lands where it is needed: straight in the site tensor when that is its final place
         direct_left = left && !labL && mk <= c->maxm;
         if (direct_left) Q = Sl.a;
-        RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, n, mk, mk, &one, Qin, n, c->sCm, mk, &zero, Q, n));
+        if (c->small_gemm) {                              // the factor 1.5 I - 0.5 S is formed while the product loads S; d by an atomic max into dv[0]
+            SmallGemmArgs g{Qin, n, c->sS, mk, Q, n, n, mk, mk, 0, 0, 1, dv};
+            TCK(launch_dgemm_small(c, g));
+        } else {
+            TCK(eigh_ns_matrix(c, c->sS, c->sCm, mk, dv));
+            RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, n, mk, mk, &one, Qin, n, c->sCm, mk, &zero, Q, n));
+        }
     }
     // eigenvalues -> host: the truncation decision (ITensor truncate()) fixes the new bond dimension.  With more than
     // one rank the decision is made collective: every rank decides on rank 0's eigenvalues (and rank 0's orthogonality
@@ -308,8 +326,8 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
         // split with the stock solver: Gram matrix again (sG may have served as workspace), dsyevd, eigenvalues to the host.
         c->svd_fallbacks += 1;
         HIPCK(c, hipMemsetAsync(const_cast<void*>(static_cast<const void*>(static_cast<const char*>(eigh_mc_status_ptr(c->mc_xbuf)) - 8)), 0, 16, st));
-        if (left) RBCK(c, dgemm_strips(c->blas, rocblas_operation_none, rocblas_operation_transpose, nl, nl, nr, M, nl, M, nl, c->sG, nl, gstrips));
-        else      RBCK(c, dgemm_strips(c->blas, rocblas_operation_transpose, rocblas_operation_none, nr, nr, nl, M, nl, M, nl, c->sG, nr, gstrips));
+        if (left) TCK(split_gemm(c, false, true, nl, nl, nr, M, nl, M, nl, c->sG, nl, gstrips));
+        else      TCK(split_gemm(c, true, false, nr, nr, nl, M, nl, M, nl, c->sG, nr, gstrips));
         if (dm) TCK(noise_add(c, B_it, b, ha, mL, mR, c->sG, n));
         RBCK(c, rocsolver_dsyevd(c->blas, rocblas_evect_original, rocblas_fill_upper, n, c->sG, n, c->sD, c->sE, c->sInfo));
         evals = c->sD; own_eig = false; stock = true; Q = c->sF; direct_left = false;
@@ -376,7 +394,7 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
     double* Aright = Sr.a;                 // right factor (m x nr), ld = m  == A_{b+1}[g][t][be](,[l])
     if (left) {
         // Q = U_m
-        RBCK(c, dgemm_strips(c->blas, rocblas_operation_transpose, rocblas_operation_none, m, nr, nl, Q, nl, M, nl, Aright, m, 2));   // U^T M = S V^T
+        TCK(split_gemm(c, true, false, m, nr, nl, Q, nl, M, nl, Aright, m, 2));   // U^T M = S V^T
         if (Q != Aleft) HIPCK(c, hipMemcpyAsync(Aleft, Q, sizeof(double) * (size_t)nl * m, hipMemcpyDeviceToDevice, st));
         if (ha == 2) {   // orthonormal factor goes right: V^T = S^-1 U^T M ; left gets U S
             hipLaunchKernelGGL(k_scale_rows, dim3(nblk((size_t)m * nr)), dim3(256), 0, st, Aright, m, (size_t)nr, d_isig);
@@ -384,7 +402,7 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
         }
     } else {
         // Q = V_m
-        RBCK(c, dgemm_strips(c->blas, rocblas_operation_none, rocblas_operation_none, nl, m, nr, M, nl, Q, nr, Aleft, nl, 2));        // M V = U S
+        TCK(split_gemm(c, false, false, nl, m, nr, M, nl, Q, nr, Aleft, nl, 2));        // M V = U S
         if (ha == 2) {
             hipLaunchKernelGGL(k_transpose_scale, dim3(nblk((size_t)nr * m)), dim3(256), 0, st, Q, Aright, nr, m, no_scale);
         } else {         // orthonormal factor goes left: U = M V S^-1 ; right gets S V^T

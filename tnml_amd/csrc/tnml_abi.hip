@@ -91,6 +91,7 @@ int tnml_set_option(tnml_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "res_pace")) c->res_pace = value;
     else if (!strcmp(name, "sytrd_exit")) c->sytrd_exit = value;
     else if (!strcmp(name, "bgs_chol")) c->bgs_chol = value != 0;
+    else if (!strcmp(name, "small_gemm")) c->small_gemm = value != 0;
     else if (!strcmp(name, "bf16_grad")) c->bf16_grad = value != 0;
     else if (!strcmp(name, "env_async")) c->env_async = value != 0;
     else if (!strcmp(name, "env_budget_mb")) { if (value < 0) return tnml_fail(c, "env_budget_mb must be >= 0"); c->env_budget_bytes = (long)value << 20; }
@@ -242,6 +243,7 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     if (const char* e = getenv("TNML_SHIFT_RES")) c->shift_res = atoi(e);
     if (const char* e = getenv("TNML_RES_PACE")) c->res_pace = atoi(e);
     if (const char* e = getenv("TNML_BGS_CHOL")) c->bgs_chol = atoi(e) != 0;
+    if (const char* e = getenv("TNML_SMALL_GEMM")) c->small_gemm = atoi(e) != 0;
     if (rocblas_create_handle(&c->blas) != rocblas_status_success) return bail(tnml_fail(c, "rocblas_create_handle failed"));
     rocblas_set_stream(c->blas, c->stream);
     // replicas of W must stay bit-identical over the ranks: no atomics-based split-K inside rocBLAS
@@ -275,6 +277,7 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     if ((rc = dmalloc(c, &c->Mf, c->mcap))) return bail(rc);
     if ((rc = dmalloc(c, (char**)&c->slab, c->slab_bytes))) return bail(rc);
     if ((rc = dmalloc(c, &c->partials, (size_t)c->partial_cap * 12))) return bail(rc);
+    if ((rc = dmalloc(c, &c->partials2, (size_t)c->partial_cap * 12))) return bail(rc);
     if ((rc = dmalloc(c, &c->counters, 16))) return bail(rc);
     if (hipMemsetAsync(c->counters, 0, 16 * sizeof(unsigned), c->stream) != hipSuccess) return bail(tnml_fail(c, "memset failed"));
     if (cfg->dtype == TNML_F64 && cfg->mode == TNML_MODE_FIXEDL && c->maxm >= 120 && (rc = dmalloc(c, &c->Ppart, (size_t)2 * TNML_NL * NTp))) return bail(rc);   // k_fwd_res
@@ -343,7 +346,7 @@ int tnml_destroy(tnml_ctx* c) {
     for (int k = 0; k < 2; ++k) { if (c->pend[k].ev) (void)hipEventDestroy(c->pend[k].ev); if (c->pend[k].ev2) (void)hipEventDestroy(c->pend[k].ev2); }
     for (auto& p : c->prof_pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     for (auto e : c->prof_free) (void)hipEventDestroy(e);
-    void* ptrs[] = {c->phi, c->label, c->ones, c->U, c->P, c->dP, c->Pp, c->Zp, c->Mf, c->slab, c->partials, c->vB, c->vR, c->vP,
+    void* ptrs[] = {c->phi, c->label, c->ones, c->U, c->P, c->dP, c->Pp, c->Zp, c->Mf, c->slab, c->partials, c->partials2, c->vB, c->vR, c->vP,
                     c->arbuf, c->locals, c->scal, c->vpart, c->counters, c->Ppart, c->tB, c->tB2, c->sM, c->sG, c->sD, c->sE, c->sF, c->sInfo, c->sE2, c->sTau, c->sV, c->sC, c->sW, c->sScr, c->sS, c->sCm, c->sQ1, c->sDev, c->mc_xbuf, c->fprint, c->noise_ws};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& s : c->W) if (s.a) (void)hipFree(s.a);
@@ -1000,12 +1003,12 @@ static int forward_pass(tnml_ctx* c, const double* vec, int mode, double* tail, 
 // G = sum_n dP_n*dag(t.v) over all ranks for the bond tensor in vB; cost partials ride in the tail.
 // weights_pp: the image sum A p = sum_n (p.v_n) v_n instead, weights p.v_n as left in Pp by the pAp pass (fast_conj of the per-label
 // variant, single.h:347-379, and the merged CG of every variant); the tail is left as it is
-static int grad_eval(tnml_ctx* c, bool from_P_update = false, bool outputs_current = false, bool weights_pp = false, bool reduce = true, bool fold = false) {
+static int grad_eval(tnml_ctx* c, bool from_P_update = false, bool outputs_current = false, bool weights_pp = false, bool reduce = true, bool fold = false, bool p_updated = false) {
     const BondPlan& p = c->plan;
     const size_t n = p.msize();
     if (weights_pp) {}
     else if (outputs_current)    { if (!c->tail_zeroed) HIPCK(c, hipMemsetAsync(c->tail, 0, sizeof(double) * TNML_NSCAL_AR, c->stream)); }   // P/dP already hold B*t.v and the residuals (the pack kernel of tnml_bond_update has cleared the tail)
-    else if (from_P_update) TCK(launch_pupdate(c, c->scal + SC_ALPHA, c->tail, !fold));   // P += a (p*t.v): no GEMM
+    else if (from_P_update) { if (!p_updated) TCK(launch_pupdate(c, c->scal + SC_ALPHA, c->tail, !fold)); }   // P += a (p*t.v): no GEMM (p_updated: the CG step kernel has done it)
     else                    TCK(forward_pass(c, c->vB, LD_MODE_COST, c->tail, c->fast_cg)); // keeps P when fast CG is on
     const void* wsrc = weights_pp ? c->Pp : c->dP;           // the per-image weights of the sum
     const bool fuse = c->f64() && c->fuse_z && p.kind != 2;
@@ -1057,24 +1060,34 @@ static int cgrad_device(tnml_ctx* c, int npass, double lambda, double cconv, boo
     // one rank, literal pass order: the per-block partial sums of a pAp pass / an output update are summed by the CG step kernel that
     // consumes them (k_cg_step2: sum |p.v|^2, k_cg_resid2: the cost of the trace) -- seven k_reduce_partials launches less per bond update
     const bool fold = c->fold_reduce && !(c->comm || c->local) && !merged && !fastc && c->fast_cg;
-    TCK(grad_eval(c, false, outputs_current));           // :374-385
-    TCK(launch_cg_init(c, n, lambda, c->single() ? cconv : -1.));   // :386-388 (single.h:200-208 with the entry check)
-    for (int pass = 1; pass <= npass; ++pass) {          // :389
+    // one rank, fp64: the slab reduction of every gradient GEMM is folded into the CG vector kernel that consumes G, the output update
+    // P <- P + a (p*t.v) rides in the CG step kernel, and k_cg_init2's work is split between its neighbours (round 5: eight launches less)
+    c->defer_slab = fold && c->f64();
+    const bool step_updates = fold && c->f64();
+    int rc = grad_eval(c, false, outputs_current);       // :374-385
+    if (!rc) rc = launch_cg_init(c, n, lambda, c->single() ? cconv : -1.);   // :386-388 (single.h:200-208 with the entry check)
+    for (int pass = 1; !rc && pass <= npass; ++pass) {   // :389
         c->cg_pass = pass;
-        TCK(forward_pass(c, c->vP, LD_MODE_PAP, c->tail, c->fast_cg || fastc, !fold));   // :394-401 (keeps p*t.v for the fast update)
-        if (merged && pass < npass) TCK(grad_eval(c, false, false, true));        // A p, all-reduced with the tail
-        else if (!fold) TCK(allreduce(c, c->tail, TNML_NSCAL_AR));                 // :402
-        TCK(launch_cg_step(c, n, lambda, pass, merged, fold ? c->partials : nullptr, c->part_n)); // :403-407
-        if (pass == npass) break;                        // :409
+        rc = forward_pass(c, c->vP, LD_MODE_PAP, c->tail, c->fast_cg || fastc, !fold);   // :394-401 (keeps p*t.v for the fast update)
+        if (rc) break;
+        if (merged && pass < npass) rc = grad_eval(c, false, false, true);        // A p, all-reduced with the tail
+        else if (!fold) rc = allreduce(c, c->tail, TNML_NSCAL_AR);                 // :402
+        if (rc) break;
+        const bool upd = step_updates && pass < npass;
+        const int npp = c->part_n;                       // rows of the pAp pass's partial sums (the update below re-sets part_n)
+        rc = launch_cg_step(c, n, lambda, pass, merged, fold ? c->partials : nullptr, npp, upd); // :403-407
+        if (rc || pass == npass) break;                  // :409
         if (merged) {
-            TCK(launch_pupdate(c, c->scal + SC_ALPHA, c->tail));                  // P, dP and the cost partials of the new B (:414-420, without the GEMM)
+            rc = launch_pupdate(c, c->scal + SC_ALPHA, c->tail);                  // P, dP and the cost partials of the new B (:414-420, without the GEMM)
         } else if (fastc) {                              // single.h:347-379: A p from the p.v of this pass, residual by recurrence
-            TCK(grad_eval(c, false, false, true));
-            TCK(launch_cg_fast_resid0(c, n, pass));
-        } else TCK(grad_eval(c, c->fast_cg, false, false, true, fold));           // :412-421
-        TCK(launch_cg_resid(c, n, lambda, cconv, pass, merged, fold ? c->partials : nullptr, c->part_n)); // :422-428, :432-436, :442
+            rc = grad_eval(c, false, false, true);
+            if (!rc) rc = launch_cg_fast_resid0(c, n, pass);
+        } else rc = grad_eval(c, c->fast_cg, false, false, true, fold, upd);      // :412-421
+        if (rc) break;
+        rc = launch_cg_resid(c, n, lambda, cconv, pass, merged, fold ? (upd ? c->partials2 : c->partials) : nullptr, c->part_n); // :422-428, :432-436, :442
     }
-    return 0;
+    c->defer_slab = false; c->slab_pending = 0;
+    return rc;
 }
 // the CG's device scalars and per-pass trace: enqueue the copies, parse after any later synchronisation of the stream
 static int cgrad_trace_enqueue(tnml_ctx* c) {

@@ -141,6 +141,7 @@ struct tnml_ctx {
     hipEvent_t ev_compute = nullptr;     // "everything enqueued on the compute stream so far" (recorded before an eviction starts)
     int env_async = 1;                   // option env_async: 0 = every copy of the host tier on the compute stream (the simple form)
     int bf16_grad = 1;                   // option bf16_grad: in the bf16 modes the gradient GEMM runs on the bf16 pipe too (0: the fp32 kernel, as through round 3)
+    int small_gemm = 1;                  // option small_gemm: the split's products on k_dgemm_small (0: rocBLAS, as through round 4)
     int bgs_chol = 1;                    // option bgs_chol: block Gram-Schmidt Cholesky QR for 128 < kept columns <= 384 (0: rocSOLVER dpotrf + dtrsm)
     int coll_depth = 0;                  // >0 inside an entry point that every rank calls in step (tnml_fail then aborts an in-process communicator)
     int comm_timeout_s = 120;            // option comm_timeout_s: how long a rank of an in-process communicator waits for its peers
@@ -158,6 +159,10 @@ struct tnml_ctx {
     size_t esz() const { return f64() ? 8 : 4; }
     size_t eesz() const { return env64() ? 8 : 4; }
     double* partials = nullptr;  // [nblk][16]
+    double* partials2 = nullptr; // second set: the output update that rides in k_cg_step2 writes here while the launch still reads the pAp pass's partials
+    bool defer_slab = false;     // the gradient GEMM leaves its split-K slabs unreduced: the CG vector kernel that consumes G sums them (one rank; set inside cgrad_device only)
+    int slab_pending = 0;        // > 0: c->slab holds that many unreduced slabs of the last gradient GEMM
+    bool rr_from_part = false;   // |r|^2 of the CG's start is still in k_cg_init1's partial sums (no k_cg_init2 launch)
     int partial_cap = 0;
     int part_n = 0;              // rows of `partials` the last forward pass / output update wrote
     bool fold_reduce = true;     // one rank: the CG step kernels sum those rows themselves (no k_reduce_partials launch inside a CG pass); option "fold_reduce"
@@ -385,7 +390,7 @@ int launch_cvt(tnml_ctx* c, const double* src, float* dst, size_t n);
 int launch_bond_form(tnml_ctx* c, const SiteT& A1, const SiteT& A2, double* B);            // B = A1*A2, ITensor layout
 // CG vector algebra on device scalars (single-block kernels)
 int launch_cg_init(tnml_ctx* c, size_t n, double lambda, double cconv0);   // cconv0 < 0: no entry check          // r = G - lambda B ; p = r ; RR = |r|^2
-int launch_cg_step(tnml_ctx* c, size_t n, double lambda, int pass, bool merged = false, const double* pp_part = nullptr, int npp = 0);   // pp_part: column 11 of the pAp pass's per-block partial sums, not reduced yet          // pAp, alpha, B += alpha p (merged: also the cost of the previous pass)
+int launch_cg_step(tnml_ctx* c, size_t n, double lambda, int pass, bool merged = false, const double* pp_part = nullptr, int npp = 0, bool with_update = false);   // pp_part: column 11 of the pAp pass's per-block partial sums, not reduced yet          // pAp, alpha, B += alpha p (merged: also the cost of the previous pass)
 int launch_cg_resid(tnml_ctx* c, size_t n, double lambda, double cconv, int pass, bool merged = false, const double* cost_part = nullptr, int ncp = 0);   // merged: G holds A p, residual by recurrence
 int launch_cg_fast_resid0(tnml_ctx* c, size_t n, int pass);      // fast_conj: G <- r - a*G before launch_cg_resid   // nr, beta, r, cost, conv, p
 int launch_sqnorm(tnml_ctx* c, const double* x, size_t n, double* out);    // out[0] = |x|^2
@@ -396,12 +401,22 @@ int launch_nudge(tnml_ctx* c, double* p);
 int launch_fingerprint(tnml_ctx* c, const double* x, size_t n, unsigned long long salt, unsigned long long* acc, bool reset);
 int launch_fingerprint_pieces(tnml_ctx* c, const unsigned long long* acc, double* out8);   // 16-bit pieces p_i and p_i^2 of the 64-bit fingerprint: sums over ranks stay exact
 
+// ---- kernels_sgemm.hip: the few-hundred-square fp64 products of the split, one wave per output tile ----
+struct SmallGemmArgs {
+    const double* A; int lda; const double* B; int ldb; double* C; int ldc;     // column-major; C = op(A) op(B), M x N, reduction length K
+    int M, N, K; int ta, tb;
+    int bmode = 0; double* dev = nullptr;      // bmode 1: op(B) = 1.5 I - 0.5 B (B symmetric, K == N), dev[0] = max |B - I| (atomic max: zero it first)
+};
+int launch_dgemm_small(tnml_ctx* c, const SmallGemmArgs& a);
+// C = op(A) op(B) at the sizes of the split: the in-house kernel up to 4e7 multiply-adds, rocBLAS (as `strips` column strips) beyond
+int split_gemm(tnml_ctx* c, bool ta, bool tb, int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* C, int ldc, int strips);
+
 // ---- eigh.hip -----------------------------------------------------------------------------
 int eigh_tridiagonalize(tnml_ctx* c, const double* A, int n, double* D, double* E, double* tau, double* V, double psd_tol = 0.);   // tau: n doubles, tau[n-1] = number of reflectors
 int eigh_tridiag_eig(tnml_ctx* c, const double* D, const double* E, int n, double* W, int mk, double* Z, int ldz, double* scratch);      // eigh_tri.hip
 int eigh_tridiag_eig_v1(tnml_ctx* c, const double* D, const double* E, int n, double* W, int mk, double* Z, int ldz, double* scratch);   // round-4 kernels (eigh.hip), kept for the A/B probe
 int eigh_ns_matrix(tnml_ctx* c, const double* S, double* Cm, int m, double* dev);
-int eigh_chol_rinv(tnml_ctx* c, const double* S, int m, double* Rinv, double* flag);   // m <= 128
+int eigh_chol_rinv(tnml_ctx* c, const double* S, int m, double* Rinv, double* flag, int zero_prev = 0);   // m <= 128; zero_prev: also clears flag[-1]
 #define TNML_CHOL_MAXM 128
 #define TEIG_SCRATCH_DOUBLES 4096        // eigh_tridiag_eig scratch
 // ---- eigh_mc.hip: tridiagonalisation on a cluster of workgroups, 240 < n <= 640
@@ -460,4 +475,63 @@ static __device__ __forceinline__ double wave_sum(double x) {
     return __hiloint2double(hi, lo);
 }
 
+// Workgroup partial sums [12]: cost bucket of every label (0..9), number correct (10), plain sum (11, the
+// <p|A|p> mode).  Called by whole waves (all 64 lanes active): a fixed DPP tree inside the wave, lane 0
+// leaves the wave's 12 values in s_part[wave][12]; after a barrier sum_wave_partials adds the waves in
+// order -> deterministic for a given launch shape.  (The serial 128-entry LDS walk this replaces
+// was a third of k_pupdate.)
+static __device__ __forceinline__ void wave_bucket_partials(double val, int lab, int cor, bool pap, double* s_part, int wave, int lane) {
+    if (pap) {
+        const double s = wave_sum(val);
+        if (lane < 12) s_part[wave * 12 + lane] = lane == 11 ? s : 0.;
+        return;
+    }
+    double mine = 0.;
+#pragma unroll
+    for (int t = 0; t < TNML_NL; ++t) {
+        const double s = wave_sum(lab == t ? val : 0.);
+        if (lane == t) mine = s;
+    }
+    const double sc = wave_sum((double)cor);
+    if (lane == 10) mine = sc;
+    if (lane < 12) s_part[wave * 12 + lane] = mine;
+}
+static __device__ __forceinline__ void sum_wave_partials(const double* s_part, int nwaves, double* out, int tid) {
+    if (tid < 12) {
+        double s = 0.;
+        for (int w = 0; w < nwaves; ++w) s += s_part[w * 12 + tid];
+        out[tid] = s;
+    }
+}
 
+
+
+// Fast CG (tnml_ctx::fast_cg): B*t.v is linear in B, so after B <- B + a p the model outputs are P <- P + a (p*t.v) with p*t.v
+// already computed by the pAp pass (the idea of the reference's own single.h:290-398 fast_cgrad).  Recomputes dP, the per-label
+// cost partials and the argmax count of one unit of LD_IMGS images (two waves; tid = lane within the unit) -> partials[unit][12].
+// Used by k_pupdate (kernels_stream.hip) and by the update half of k_cg_step2 (kernels_small.hip).
+#define LD_IMGS 128     // images per unit
+template <typename T>
+static __device__ __forceinline__ void pupdate_unit(T* __restrict__ P, const T* __restrict__ Pp, T* __restrict__ dP, const int* __restrict__ label, int NTp,
+                                                    T a, double* __restrict__ partials, int nl, int target, double* s_part, int tid, int unit) {
+    const int ni = unit * LD_IMGS + tid;
+    const int lab = label[ni];
+    T val = 0; T best = 0; int arg = 0; T p0 = 0;
+#pragma unroll
+    for (int l = 0; l < TNML_NL; ++l) {
+        if (l < nl) {
+            const T p = fma(a, Pp[(size_t)l * NTp + ni], P[(size_t)l * NTp + ni]);
+            P[(size_t)l * NTp + ni] = p;
+            const T tgt = target < 0 ? (l == lab ? (T)1 : (T)0) : (lab == target ? (T)1 : (T)0);
+            const T d = (lab >= 0) ? (tgt - p) : (T)0;
+            dP[(size_t)l * NTp + ni] = d;
+            val = fma(d, d, val);
+            const T wgt = fabs(p);
+            if (l == 0) { best = wgt; p0 = p; } else if (wgt > best) { best = wgt; arg = l; }
+        }
+    }
+    const int cor = target < 0 ? ((lab >= 0 && arg == lab) ? 1 : 0) : ((lab >= 0 && ((p0 > (T)0.5) == (lab == target))) ? 1 : 0);
+    wave_bucket_partials((double)val, lab, cor, false, s_part, tid >> 6, tid & 63);
+    __syncthreads();
+    sum_wave_partials(s_part, LD_IMGS / 64, partials + (size_t)unit * 12, tid);
+}
