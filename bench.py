@@ -212,6 +212,21 @@ def self_launch(ngpus):
     return subprocess.call(cmd, env=env)
 
 
+def baseline_config_name(N, maxm, NT, world, dtype):
+    """which of BASELINE.json's configs the run is (or is a share / a variation of)"""
+    if N == 784 and maxm == 120 and NT == 60000:
+        return "BASELINE config 3" + ("" if world == 8 else ": its 60 000 images on %d GPU%s instead of 8" % (world, "" if world == 1 else "s"))
+    if N == 784 and maxm == 300:
+        return "BASELINE config 5 (maxm = 300 tolerance study%s)" % ("" if NT == 60000 else ": %d of its 60 000 images" % NT)
+    if N == 784 and maxm == 120:
+        return "one rank's share of BASELINE config 3: %d of its 60 000 images" % NT if NT * 8 == 60000 else "BASELINE config 3 shape with %d images" % NT
+    if N == 784 and maxm == 20 and NT == 10000:
+        return "BASELINE config 2"
+    if N == 196 and maxm == 10 and NT == 1000:
+        return "BASELINE config 1"
+    return "not a BASELINE configuration"
+
+
 def shift_flops(r, NTl, N, single):
     """flops of the shiftE that ends bond update r: 2 NT (2 m_in) m_out, x10 when the new environment carries the Label index"""
     c0 = -1 if single else N // 2
@@ -266,6 +281,8 @@ def main():
                     "measurements): what the profiler runs of tools/*.sh use, so that the last bond updates of the run are ordinary ones")
     ap.add_argument("--env-budget-gb", type=float, default=0.0, help="cap on the environment slabs held in HBM; what does not fit spills to host memory "
                     "(tnml_set_option env_budget_mb; 0: everything resident, the headline configuration)")
+    ap.add_argument("--allreduce", default="rccl", choices=["rccl", "oneshot"], help="transport of the library's collectives at --gpus N > 1: RCCL (ncclAllReduce / "
+                    "ncclBroadcast), or the one-shot all-reduce across processes (IPC-mapped receive regions, device-side arrival flags, no host barrier: ipc_comm.hip)")
     ap.add_argument("--dry-run", action="store_true", help="control plane only (launcher, rendezvous, shard bounds, max-over-ranks clock): no GPU work")
     args = ap.parse_args()
     if args.steps is None:
@@ -301,9 +318,16 @@ def main():
             dist.barrier()
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dist.all_reduce(cnt)
+        # the handle exchange of --allreduce oneshot runs over the same control plane: exercise it with placeholder handles
+        gathered = None
+        if args.allreduce == "oneshot" and world > 1:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, bytes([rank]) * 64)
+            assert [g[0] for g in gathered] == list(range(world))
         if rank == 0:
             print(json.dumps({"dry_run": True, "n_gpus": world, "max_over_ranks": float(t[0]), "images_over_ranks": int(cnt[0]),
-                              "shard_of_rank0": [lo, hi]}))
+                              "shard_of_rank0": [lo, hi], "allreduce": args.allreduce if world > 1 else "none",
+                              "handles_gathered": None if gathered is None else len(gathered)}))
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -326,7 +350,11 @@ def main():
                      NT_total=NT, dtype=args.dtype, single_label=args.single_label)
     del pixels
     comm_ranks = 1
-    if world > 1:
+    if world > 1 and args.allreduce == "oneshot":
+        handles = [None] * world                                 # every rank's IPC handle, in rank order, over the gloo control plane
+        dist.all_gather_object(handles, ts.oneshot_export())
+        ts.oneshot_connect(handles)
+    elif world > 1:
         uid = [TrainStates.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         ts.comm_init(uid[0])
@@ -401,7 +429,10 @@ def main():
     # (the split is one event pair per bond update around the whole of svd_split: it costs nothing and, unlike the other classes, its time
     # depends on WHICH bonds are timed -- the rank-adaptive tridiagonalisation forms ~131 reflectors on bonds whose neighbours are still
     # random-init and 14-27 later in a long window -- so it is taken inside the timed region, not on the breakdown steps after it)
-    ts.profile(os.environ.get("TNML_BENCH_NOPROF", "0") != "1", only="fgemm_fwd,fwd_fused,fwd_res,svd")
+    # (the gradient GEMM and the shift are timed live as well -- roofline_kernels -- where a bond update is GPU-bound; on toy workloads, where
+    # it is bound by the host's launch rate, ten more event records per bond update would move the figure being measured)
+    live = "fgemm_fwd,fwd_fused,fwd_res,svd" + (",bgemm,fgemm_shift" if (hi - lo) * maxm * maxm >= 1e8 else "")
+    ts.profile(os.environ.get("TNML_BENCH_NOPROF", "0") != "1", only=live)
     ts.profile_reset()
     # no cyclic garbage collection inside the timed region: a generation-2 pass over this process's heap takes ~40 ms -- the time of
     # 30 bond updates of an 8-GPU shard -- and where it lands depends on the allocation count (seen as one 40 ms step in an otherwise
@@ -581,8 +612,8 @@ def main():
             "data": "synthetic",
             "parity": "unpinned-oracle (no reference-held vectors exist and ITensor is absent: GPU results are checked against "
                       "oracle/, a line-cited restatement of fixedL.cc cross-checked by an independent numpy restatement)",
-            "config": {"workload": "fixedL N=%d, maxm=%d, %d images (BASELINE config 3), Npass=%d, lambda=%g, minm=%d, "
-                                   "%s; %s; timed bonds %d..%d (%s, m=%.0f)" % (N, maxm, NT, npass, lam, minm,
+            "config": {"workload": "fixedL N=%d, maxm=%d, %d images (%s), Npass=%d, lambda=%g, minm=%d, "
+                                   "%s; %s; timed bonds %d..%d (%s, m=%.0f)" % (N, maxm, NT, baseline_config_name(N, maxm, NT, world, args.dtype), npass, lam, minm,
                                                                                {"f64": "fp64 throughout", "f64_e32": "fp64 MFMA over fp32-stored environments", "f32": "fp32 study mode",
                                                                                 "bf16x3": "fp32 storage, forward feature GEMM on bf16 MFMA with hi + lo operands (study mode)",
                                                                                 "bf16": "fp32 storage, forward feature GEMM on bf16 MFMA (study mode)"}[args.dtype],
@@ -592,7 +623,7 @@ def main():
                                                                                "whole sweeps" if full_sweeps else
                                                                                ("consecutive interior bonds, Label-carrying shiftE on each" if args.workload == "default" else "consecutive interior bonds of the second sweep"),
                                                                                m_avg),
-                       "global_images": NT, "sites": N, "maxm": maxm, "parallelism": "dp%d (image sharding + RCCL all-reduce)" % world,
+                       "global_images": NT, "sites": N, "maxm": maxm, "parallelism": "dp%d (image sharding + %s)" % (world, "RCCL all-reduce" if args.allreduce == "rccl" or world == 1 else "one-shot all-reduce over IPC-mapped regions"),
                        "rccl_ranks": comm_ranks},
             "roofline": {"bound": "mfma", "kernel": FWD_KERNEL[0] if fused else ("k_fgemm64" if args.dtype in ("f64", "f64_e32") else ("k_fgemm" if args.dtype == "f32" else "k_fgemm_bf16")),
                          "achieved": achieved_tf, "peak": peak, "unit": "TFLOP/s",
@@ -653,10 +684,42 @@ def main():
                 "allreduces_per_bond_update": (coll1[0] - coll0[0]) / args.steps, "broadcasts_per_bond_update": (coll1[1] - coll0[1]) / args.steps,
                 "allreduce_ms_per_bond_update": kms.get("allreduce", 0.0),
                 "ms_per_allreduce": (prof_all["allreduce"][1] / prof_all["allreduce"][0]) if prof_all.get("allreduce", (0, 0))[0] else None,
-                "allreduce_mode": ts.allreduce_mode() if hasattr(ts, "allreduce_mode") else "rccl",
+                "mode": ts.allreduce_mode() if hasattr(ts, "allreduce_mode") else "rccl",
                 "note": "sum all-reduces of the packed [scalars | gradient or A p] buffer (merged CG passes, carried after-SVD scalars) and "
                         "broadcasts of rank 0's eigenvalues, per bond update of the timed region; allreduce ms from HIP events on the breakdown steps"},
         }
+        # The three matrix-pipe kernels of a bond update, each from its own HIP events over the TIMED region, with the stamped PMC
+        # traffic where it is current; `roofline` is the one with the most time per bond update (the block above describes the forward
+        # kernel when that is it).
+        if args.dtype in ("f64", "f64_e32"):
+            pmc_ok = args.dtype == "f64" and maxm == 120 and NT == 60000 and world == 1
+            rk = {}
+            for cls, kname, per_step_flops, alg_bytes in (
+                    ("fwd_fused" if fused else "fgemm_fwd", out["roofline"]["kernel"], flops_per_pass, float(np.mean([NTl * (11 * min(r["mL"], r["mR"]) * 8 + 2 * 2 * 8 + 4) for r in timed])) if timed else None),
+                    ("bgemm", "k_bgemm64 (gradient GEMM dP*dag(t.v), Z built while staging)", flops_per_pass, float(np.mean([NTl * (11 * min(r["mL"], r["mR"]) * 8 + 2 * 2 * 8 + 10 * 8) for r in timed])) if timed else None),
+                    ("fgemm_shift", "k_shift_res / k_fgemm64 (shiftE)", sh, None)):
+                nl_, ms_ = prof.get(cls, (0, 0.0))
+                if not nl_:
+                    continue
+                per_launch_ms = ms_ / nl_
+                launches_per_step = nl_ / args.steps
+                fl_launch = per_step_flops if cls != "fgemm_shift" else sh / max(launches_per_step, 1e-9)
+                tr_, src_ = pmc_traffic(cls) if pmc_ok else (None, None)
+                ach = fl_launch / (per_launch_ms * 1e-3) / 1e12
+                rk[cls] = {"kernel": kname, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                           "avg_launch_ms": per_launch_ms, "launches": nl_, "ms_per_step": ms_ / args.steps, "flops_per_launch": fl_launch,
+                           "algorithmic_bytes_per_launch": alg_bytes, "traffic": tr_,
+                           "traffic_over_algorithmic": (tr_ / alg_bytes) if (tr_ and alg_bytes) else None, "traffic_source": src_}
+            out["roofline_kernels"] = rk
+            if rk:
+                dom = max(rk, key=lambda k: rk[k]["ms_per_step"])
+                if dom != ("fwd_fused" if fused else "fgemm_fwd"):
+                    d = rk[dom]
+                    out["roofline"] = {"bound": "mfma", "kernel": d["kernel"], "achieved": d["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": d["frac"],
+                                       "traffic": d["traffic"], "traffic_source": d["traffic_source"], "avg_launch_ms": d["avg_launch_ms"], "launches": d["launches"],
+                                       "flops_per_launch": d["flops_per_launch"], "images_per_launch": NTl,
+                                       "note": "the kernel with the most time per bond update (%.3f ms; all three matrix-pipe kernels: roofline_kernels)" % d["ms_per_step"]}
+                out["roofline"]["dominant_by_ms_per_step"] = True
         st = pmc_step_traffic() if args.dtype == "f64" and maxm == 120 and NT == 60000 and world == 1 and not full_sweeps else None
         if st:
             out["roofline_step"]["traffic"] = st["bytes_per_step"]

@@ -146,6 +146,17 @@ int tnml_comm_init_local(tnml_ctx** ctxs, int n);
    Ranks may also share a device (how it is tested on one GPU).  Same calling rules as tnml_comm_init_local. */
 int tnml_comm_init_oneshot(tnml_ctx** ctxs, int n);
 /* which collective path this context uses: 0 none (one rank), 1 RCCL, 2 in-process staging buffer, 3 one-shot peer write */
+/* One-shot all-reduce ACROSS PROCESSES (one process per GPU -- how `python bench.py --gpus N --allreduce oneshot` and any
+   torch.distributed / MPI launch run; replaces stdx::accumulate, fixedL.cc:385,402,421,427, like tnml_comm_init): every rank exports an
+   IPC handle of its receive region (tnml_oneshot_export), the caller gathers the nranks handles over its own control plane in rank
+   order and hands all of them to every rank (tnml_oneshot_connect).  From then on every collective of the library is ONE kernel per
+   rank -- peer stores into the mapped regions, device-side arrival flags, an ordered local sum (the same bits on every rank) -- with no
+   host synchronisation between the ranks (tnml_ctx option comm_timeout_s bounds the device-side wait; tnml_synchronize reports a
+   time-out).  Needs HSA_ENABLE_IPC_MODE_LEGACY=0 and peer access between the ranks' devices; ranks may share a device (tests). */
+#define TNML_ONESHOT_HANDLE_BYTES 64
+int tnml_oneshot_export(tnml_ctx* ctx, void* handle64);
+int tnml_oneshot_connect(tnml_ctx* ctx, const void* handles /* nranks * TNML_ONESHOT_HANDLE_BYTES, rank order */);
+/* transport in use: 0 none, 1 RCCL, 2 in-process staging buffer, 3 in-process one-shot, 4 cross-process one-shot */
 int tnml_collective_mode(tnml_ctx* ctx);
 /* Collective.  Verifies that the communicator really spans cfg.nranks ranks (ncclCommCount) and that every rank holds a
    bit-identical replica of the weight MPS (a 64-bit fingerprint of all site tensors, max/min-reduced over the ranks);

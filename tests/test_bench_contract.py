@@ -76,7 +76,13 @@ def test_bench_gpus_n_without_a_launcher_starts_n_ranks():
     lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, run.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d == {"dry_run": True, "n_gpus": 2, "max_over_ranks": 2.0, "images_over_ranks": 61, "shard_of_rank0": [0, 30]}
+    assert d == {"dry_run": True, "n_gpus": 2, "max_over_ranks": 2.0, "images_over_ranks": 61, "shard_of_rank0": [0, 30], "allreduce": "rccl", "handles_gathered": None}
+    # --allreduce oneshot: the IPC handles of the cross-process one-shot all-reduce travel over the same gloo control plane
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--images", "61", "--allreduce", "oneshot"],
+                         capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
+    assert run.returncode == 0, (run.stderr + run.stdout)[-2000:]
+    d = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["allreduce"] == "oneshot" and d["handles_gathered"] == 2
 
 
 def test_bench_under_the_launcher_form_the_driver_uses():

@@ -1659,3 +1659,52 @@ def test_fixedl_driver_with_an_environment_budget_prints_the_same_log(tmp_path):
         assert run.returncode == 0, run.stdout[-1500:] + run.stderr[-1500:]
         logs.append(re.findall(r"--> After SVD, Cost = ([0-9.eE+-]+)", run.stdout))
     assert len(logs[0]) == 2 * 2 * (N - 1) and logs[0] == logs[1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_speculative_split_and_its_roll_back(pipelined):
+    """minm >= the columns the split may keep: the new bond dimension does not depend on the spectrum, so tnml_bond_update_begin enqueues
+    the split WITHOUT its host synchronisation (option spec_split, default on) -- eigenvalues and check values reach tnml_bond_update_end
+    through pinned mirrors, the new site tensors sit in spare buffers until the deferred check has passed.  Same numbers as the
+    synchronous split, bit for bit; with the test hook debug_fail_split the k-th speculative split reports a failed check, the bond
+    update and the one begun after it are rolled back and repeated (the failed one with the synchronous split), and the sweep still
+    follows the oracle."""
+    from oracle import pyoracle
+    from tnml_amd.fixedl import TrainStates, mldmrg
+    from conftest import make_problem
+    N, NT, m = 12, 200, 6
+    pixels, labels, phi, W = make_problem(N, NT, m, 5, pixel_boost=200.0)
+    args = (1, m, m, 1e-10, 3, 1e-3, 1e-10)                            # minm = maxm
+
+    def run(spec, fail=None):
+        ts = TrainStates(labels, N, m, phi=phi)
+        ts.set_option("spec_split", spec)
+        if fail is not None:
+            ts.set_option("debug_fail_split", fail)
+        ts.set_mps(W)
+        ts.init()
+        reps = mldmrg(ts, *args, pipelined=pipelined)
+        st = ts.svd_stats()
+        Wf = ts.get_mps()
+        ts.close()
+        return reps, st, Wf
+    sync, st_sync, W_sync = run(0)
+    spec, st_spec, W_spec = run(1)
+    assert [r["newm"] for r in spec] == [r["newm"] for r in sync]
+    assert [r["cost"] for r in spec] == [r["cost"] for r in sync]     # the same kernels in the same order
+    assert [r["ncorrect"] for r in spec] == [r["ncorrect"] for r in sync]
+    np.testing.assert_allclose([r["truncerr"] for r in spec], [r["truncerr"] for r in sync], rtol=1e-12, atol=1e-300)
+    np.testing.assert_allclose([r["cg"]["cost"][0] for r in spec], [r["cg"]["cost"][0] for r in sync], rtol=0, atol=0)
+    for a, b in zip(W_spec, W_sync):
+        assert np.array_equal(a, b)
+    for fail in (0, 4, 17):                                            # first, an interior and the last speculative split of the sweep (the four chain-end splits are 2 x 2: stock solver)
+        redo, st_redo, W_redo = run(1, fail)
+        assert st_redo["fallbacks"] >= st_spec["fallbacks"] + 1, (fail, st_redo, st_spec)
+        assert [r["bond"] for r in redo] == [r["bond"] for r in sync] and [r["newm"] for r in redo] == [r["newm"] for r in sync]
+        np.testing.assert_allclose([r["cost"] for r in redo], [r["cost"] for r in sync], rtol=1e-8)
+    o = pyoracle.Oracle(phi, labels, W, nthread=2)
+    o.init()
+    ro = o.mldmrg(*args)
+    np.testing.assert_allclose([r["cost"] for r in spec], [r["cost"] for r in ro], rtol=1e-8)
+    assert [r["newm"] for r in spec] == [r["newm"] for r in ro] and [r["ncorrect"] for r in spec] == [r["ncorrect"] for r in ro]

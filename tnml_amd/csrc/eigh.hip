@@ -44,7 +44,14 @@ static __device__ __forceinline__ void wave_lds_fence() {
 // Two barriers per step; Householder convention of LAPACK dlarfg.
 // ==========================================================================================
 #define V3_LD 242
-#define V3_SMEM_DOUBLES (T8_MAXNB * V3_LD + 240 + 240 + 2 * 240 + 32)
+// s_v / s_w are read by every lane at the eight rows of its block (row 8 R + r): unpadded, the lanes of a wave (consecutive R) hit
+// every fourth bank group only (64-byte stride); with one pad double per block of eight (stride 72 bytes) 30 blocks land on 30 different bank pairs
+#ifndef V3_PAD
+#define V3_PAD 1
+#endif
+#define SVI(i) (V3_PAD ? (i) + ((i) >> 3) : (i))
+#define V3_VLEN (240 + 32)
+#define V3_SMEM_DOUBLES (T8_MAXNB * V3_LD + 2 * V3_VLEN + 2 * 240 + 32)
 static __device__ __forceinline__ double lane_bcast(double x, int l) {          // l uniform
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
@@ -53,9 +60,9 @@ static __device__ __forceinline__ double lane_bcast(double x, int l) {          
 __global__ __launch_bounds__(512) void k_sytrd_v3(TriArgs T) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* Y = smem;                                   // [nb][V3_LD]
-    double* s_v = Y + T8_MAXNB * V3_LD;                 // [240]
-    double* s_w = s_v + 240;                            // [240]
-    double* s_xo = s_w + 240;                           // [2][240]
+    double* s_v = Y + T8_MAXNB * V3_LD;                 // [240] at index SVI(i)
+    double* s_w = s_v + V3_VLEN;                        // [240], padded like s_v
+    double* s_xo = s_w + V3_VLEN;                           // [2][240]
     double* s_red = s_xo + 480;                         // [32]: 0..7 v^T A v partials, 8 tau, 9 exact-trace flag, 16..23 trailing-trace partials, 24..31 trace(A) partials
     const int n = T.n, nb = (n + T8 - 1) / T8;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -81,7 +88,8 @@ __global__ __launch_bounds__(512) void k_sytrd_v3(TriArgs T) {
     double x[4], v[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) { const int i = lane + 64 * e; x[e] = i < n ? T.A[i] : 0.; v[e] = 0.; }
-    if (tid < 240) { s_v[tid] = 0.; s_w[tid] = 0.; s_xo[tid] = 0.; s_xo[240 + tid] = 0.; }
+    if (tid < V3_VLEN) { s_v[tid] = 0.; s_w[tid] = 0.; }
+    if (tid < 240) { s_xo[tid] = 0.; s_xo[240 + tid] = 0.; }
     {   // trace(A) (rank-adaptive early exit below)
         double dg = 0.;
         if (owner && R == C) {
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(512) void k_sytrd_v3(TriArgs T) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 v[e] = (e == e1 && at1) ? 1. : xt[e] * scale;
-                if (e < 3 || lane < 48) s_v[lane + 64 * e] = v[e];    // identical values from every live wave
+                if (e < 3 || lane < 48) s_v[SVI(lane + 64 * e)] = v[e];    // identical values from every live wave
             }
             const double dk = lane_bcast(xd, l0);
             trem -= dk;                                               // trace of rows k+1.. (before and after this step's update)
@@ -193,9 +201,9 @@ __global__ __launch_bounds__(512) void k_sytrd_v3(TriArgs T) {
             double q = 0.;
             if (active && tau != 0.) {
 #pragma unroll
-                for (int r = 0; r < T8; ++r) vI[r] = s_v[i0 + r];
+                for (int r = 0; r < T8; ++r) vI[r] = s_v[SVI(i0) + r];
 #pragma unroll
-                for (int cc = 0; cc < T8; ++cc) vJ[cc] = s_v[j0 + cc];
+                for (int cc = 0; cc < T8; ++cc) vJ[cc] = s_v[SVI(j0) + cc];
                 double c1[T8];
 #pragma unroll
                 for (int r = 0; r < T8; ++r) {
@@ -266,7 +274,7 @@ __global__ __launch_bounds__(512) void k_sytrd_v3(TriArgs T) {
                 const double yh = (y0 + y1) + y2;
                 const double yo = dpp_quad<0xB1>(yh);                 // the other half of the row (lane ^ 1)
                 const double y = ch == 0 ? yh + yo : yo + yh;         // first-half part + second-half part on both lanes
-                if (ch == 0 && ci < 240) s_w[ci] = (ci > k && ci < n) ? fma(K, s_v[cic], tau * y) : 0.;
+                if (ch == 0 && ci < 240) s_w[SVI(ci)] = (ci > k && ci < n) ? fma(K, s_v[SVI(cic)], tau * y) : 0.;
             }
             TP3(3);
             __syncthreads();
@@ -275,9 +283,9 @@ __global__ __launch_bounds__(512) void k_sytrd_v3(TriArgs T) {
             if (active) {
                 double wI[T8], wJ[T8];
 #pragma unroll
-                for (int r = 0; r < T8; ++r) wI[r] = s_w[i0 + r];
+                for (int r = 0; r < T8; ++r) wI[r] = s_w[SVI(i0) + r];
 #pragma unroll
-                for (int cc = 0; cc < T8; ++cc) wJ[cc] = s_w[j0 + cc];
+                for (int cc = 0; cc < T8; ++cc) wJ[cc] = s_w[SVI(j0) + cc];
 #pragma unroll
                 for (int r = 0; r < T8; ++r)
 #pragma unroll
@@ -285,12 +293,12 @@ __global__ __launch_bounds__(512) void k_sytrd_v3(TriArgs T) {
             }
             if (live) {
                 // look-ahead: column k+1 of the updated matrix, into the registers of every live wave
-                const double wk1 = s_w[k + 1];
+                const double wk1 = s_w[SVI(k + 1)];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int i = lane + 64 * e;
                     const int ic = i < 240 ? i : 239;
-                    const double xo = s_xo[par * 240 + ic], wi = s_w[ic];
+                    const double xo = s_xo[par * 240 + ic], wi = s_w[SVI(ic)];
                     x[e] = (i >= k + 1 && i < n) ? (xo - v[e] * wk1) - wi : 0.;
                 }
             }

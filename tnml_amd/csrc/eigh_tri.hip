@@ -33,6 +33,7 @@ struct Teig2Args {
     // workspace: Es = E with negligible couplings zeroed, mu[i] = eigenvalue owned by row i (the (i - lo[i])-th smallest of its
     // unreduced block), tnb[i] = norm of that block, blo/bhi = block [lo, hi) of row i, src[g] = row owning the g-th largest eigenvalue
     double* Es; double* mu; double* tnb; int* blo; int* bhi; int* src;
+    double* Wh;                                    // pinned host mirror of W (may be null): a speculative split hands its eigenvalues over without a copy
 };
 
 static __device__ __forceinline__ int wave_max_i(int v) {
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256) void k_teig_vectors(Teig2Args T) {
         const double mi = s_mu[i];
         int g = 0;
         for (int j = 0; j < n; ++j) { const double mj = s_mu[j]; g += (mj > mi || (mj == mi && j < i)) ? 1 : 0; }
-        if (blockIdx.x == 0) { T.W[n - 1 - g] = mi; T.src[g] = i; }
+        if (blockIdx.x == 0) { T.W[n - 1 - g] = mi; T.src[g] = i; if (T.Wh) T.Wh[n - 1 - g] = mi; }
         if (g >= g0 && g < g0 + IV_L) s_src[g - g0] = i;
     }
     __syncthreads();
@@ -314,10 +315,10 @@ __global__ __launch_bounds__(256) void k_teig_vectors(Teig2Args T) {
 }
 
 // scratch: TEIG_SCRATCH_DOUBLES doubles
-int eigh_tridiag_eig(tnml_ctx* c, const double* D, const double* E, int n, double* W, int mk, double* Z, int ldz, double* scratch) {
+int eigh_tridiag_eig(tnml_ctx* c, const double* D, const double* E, int n, double* W, int mk, double* Z, int ldz, double* scratch, double* W_host) {
     if (n > TEIG_MAXN || mk > n) return tnml_fail(c, "eigh_tridiag_eig: n=%d mk=%d exceed %d", n, mk, TEIG_MAXN);
     int* is = (int*)(scratch + 3 * TEIG_MAXN);
-    Teig2Args t{D, E, n, W, mk, Z, ldz, scratch, scratch + TEIG_MAXN, scratch + 2 * TEIG_MAXN, is, is + TEIG_MAXN, is + 2 * TEIG_MAXN};
+    Teig2Args t{D, E, n, W, mk, Z, ldz, scratch, scratch + TEIG_MAXN, scratch + 2 * TEIG_MAXN, is, is + TEIG_MAXN, is + 2 * TEIG_MAXN, W_host};
     static_assert(3 * TEIG_MAXN + (3 * TEIG_MAXN + 1) / 2 <= TEIG_SCRATCH_DOUBLES, "scratch of the tridiagonal eigensolver");
     hipLaunchKernelGGL(k_teig_values, dim3(n), dim3(64), 0, c->stream, t);
     const int ns = (n + 63) & ~63;

@@ -80,7 +80,7 @@ static int comm_init_inproc(tnml_ctx** ctxs, int n, int oneshot) {
         if (!c) return tnml_fail(nullptr, "%s: null context", who);
         if (c->cfg.nranks != n || c->cfg.rank != r) return tnml_fail(c, "%s: context %d was created as rank %d of %d", who, r, c->cfg.rank, c->cfg.nranks);
         if (!oneshot && c->cfg.device != ctxs[0]->cfg.device) return tnml_fail(c, "tnml_comm_init_local: ranks on different devices use tnml_comm_init_oneshot or RCCL (tnml_comm_init)");
-        if (c->comm || c->local) return tnml_fail(c, "%s: context already has a communicator", who);
+        if (c->multi()) return tnml_fail(c, "%s: context already has a communicator", who);
         if (c->mcap + TNML_TAILN > cap) cap = c->mcap + TNML_TAILN;
         if (c->mcap != ctxs[0]->mcap) return tnml_fail(c, "%s: contexts must share maxm", who);
     }

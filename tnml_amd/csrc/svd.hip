@@ -100,14 +100,16 @@ __global__ void k_mc_flag(const unsigned long long* __restrict__ status, double*
 
 // C = op(A) op(B) at the sizes of the split: k_dgemm_small (kernels_sgemm.hip) up to 4e7 multiply-adds, rocBLAS as
 // `strips` column strips beyond (the Label-on-B bonds reduce over 2400: 133 us as one call, 17 us as 8 strips) or with option small_gemm = 0
-int split_gemm(tnml_ctx* c, bool ta, bool tb, int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* C, int ldc, int strips) {
+int split_gemm(tnml_ctx* c, bool ta, bool tb, int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* C, int ldc, int strips, const SmallGemmArgs* chk) {
     if (c->small_gemm && K <= 1024 && (double)M * N * K <= 4.0e7) {   // (tools/probe/probe_sgemm.hip: 8.7-9.9 us against 19 at 240^3, 17 against 25 at 300 x 300 x 600; loses from ~6e7 on)
         SmallGemmArgs g{A, lda, B, ldb, C, ldc, M, N, K, ta ? 1 : 0, tb ? 1 : 0};
+        if (chk) { g.chk_src = chk->chk_src; g.chk_host = chk->chk_host; g.chk_bad = chk->chk_bad; g.chk_force_bad = chk->chk_force_bad; }
         return launch_dgemm_small(c, g);
     }
     const rocblas_status st = dgemm_strips(c->blas, ta ? rocblas_operation_transpose : rocblas_operation_none, tb ? rocblas_operation_transpose : rocblas_operation_none,
                                            M, N, K, A, lda, B, ldb, C, ldc, strips);
     if (st != rocblas_status_success) return tnml_fail(c, "split_gemm: rocblas dgemm failed (%d)", (int)st);
+    if (chk) return launch_split_check_mirror(c, chk->chk_src, chk->chk_host, chk->chk_bad, chk->chk_force_bad);
     return 0;
 }
 
@@ -184,7 +186,7 @@ static int noise_add(tnml_ctx* c, const double* B_it, int b, int ha, int mL, int
 }
 
 int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cutoff, int maxm, int minm,
-                     double* truncerr, int* newm, double* sv_host, int* nsv) {
+                     double* truncerr, int* newm, double* sv_host, int* nsv, int spec_slot) {
     ProfScope ps(c, KC_SVD);
     SiteT& Sl = c->W[b];
     SiteT& Sr = c->W[b + 1];
@@ -224,9 +226,35 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
     const bool mc = tri && n > 240;
     const int mk = maxm < n ? maxm : n;                   // the truncation never keeps more than maxm
     const double* evals = c->sD;                          // ascending eigenvalues of rho
+    // Speculative form (tnml_bond_update_begin, option spec_split): minm >= mk means the truncation keeps exactly mk columns whatever
+    // the spectrum (tnml_truncate stops at its minm test), so nothing the host would read decides anything but the FALLBACK -- and that
+    // decision can wait for tnml_bond_update_end.  No eigenvalue broadcast, no copy, no stream synchronisation: eigenvalues and check
+    // values reach the host through pinned mirrors written by the kernels themselves, the two site tensors go to spare buffers, and a
+    // failed check rolls the bond update back (tnml_abi.hip).  One-workgroup sizes only (the cluster's give-up flag is a collective decision).
+    bool spec = spec_slot >= 0 && c->spec_split && !c->force_safe && own_eig && !mc && minm >= mk && !sv_host && c->hrep != nullptr;
+    double* hmir = spec ? c->hrep + (size_t)spec_slot * c->hrep_stride : nullptr;     // [n eigenvalues | 4 check values]
+    if (spec_slot >= 0) {
+        // inside a bond update in flight the two new site tensors ALWAYS go to spare buffers (whichever form the split takes): a later
+        // roll-back -- of this bond update, or of the one before it whose check is still pending -- can then restore both sites
+        PendingReport& pr = c->pend[spec_slot];
+        pr.nundo = 0; pr.spec = false;
+        auto& pl = (b == c->c0) ? c->spare_big : c->spare_small;
+        auto& pr_ = (b + 1 == c->c0) ? c->spare_big : c->spare_small;
+        const bool have = !pl.empty() && !pr_.empty() && !(&pl == &pr_ && pl.size() < 2);     // (always, with two bond updates in flight at most)
+        if (have) {
+            for (int j = b; j <= b + 1; ++j) {
+                SiteT& S = c->W[j];
+                auto& pool = (j == c->c0) ? c->spare_big : c->spare_small;
+                pr.undo[pr.nundo++] = SiteUndo{j, S.a, S.ml, S.mr};
+                S.a = pool.back(); pool.pop_back();
+            }
+        } else spec = false;
+        if (spec) { pr.spec = true; pr.split_n = n; pr.split_mk = mk; c->spec_splits += 1; }
+        else hmir = nullptr;
+    }
     if (tri) {
         TCK(eigh_tridiagonalize(c, c->sG, n, c->sD, c->sE2, c->sTau, c->sV, c->sytrd_exit ? 1e-15 : 0.));   // sG is a Gram matrix: rank-adaptive exit at ~4 eps trace(G), the size of the error G = B^T B carries anyway
-        if (own_eig) { TCK(eigh_tridiag_eig(c, c->sD, c->sE2, n, c->sW, mk, c->sC, n, c->sScr)); evals = c->sW; }
+        if (own_eig) { TCK(eigh_tridiag_eig(c, c->sD, c->sE2, n, c->sW, mk, c->sC, n, c->sScr, hmir)); evals = c->sW; }
         else RBCK(c, rocsolver_dstedc(c->blas, rocblas_evect_tridiagonal, n, c->sD, c->sE2, c->sC, n, c->sInfo));
     } else {
         RBCK(c, rocsolver_dsyevd(c->blas, rocblas_evect_original, rocblas_fill_upper, n, c->sG, n, c->sD, c->sE, c->sInfo));
@@ -301,6 +329,20 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
             RBCK(c, rocblas_dgemm(c->blas, rocblas_operation_none, rocblas_operation_none, n, mk, mk, &one, Qin, n, c->sCm, mk, &zero, Q, n));
         }
     }
+    int m = mk;
+    bool stock = !tri;                                   // eigenvectors of rho itself in sG (dsyevd)
+    double* h = c->h_scal;          // pinned, capacity >= 2*svd_n + 64
+    SmallGemmArgs chk{};                                   // the check-value side job of the speculative form (rides in the factor product below)
+    const SmallGemmArgs* chkp = nullptr;
+    if (spec) {
+        // m = mk; the eigenvalues are on their way to hmir[0..n) (k_teig_vectors), the check values follow with the factor product
+        chk.chk_src = dv; chk.chk_host = hmir + n; chk.chk_bad = c->tail + TNML_SPECSLOT;
+        chk.chk_force_bad = (c->debug_fail_split >= 0 && c->spec_splits - 1 == c->debug_fail_split) ? 1 : 0;
+        chkp = &chk;
+        if (truncerr) *truncerr = 0.;                      // tnml_bond_update_end computes it from the mirrored eigenvalues
+        if (newm) *newm = m;
+        if (nsv) *nsv = n;
+    } else {
     // eigenvalues -> host: the truncation decision (ITensor truncate()) fixes the new bond dimension.  With more than
     // one rank the decision is made collective: every rank decides on rank 0's eigenvalues (and rank 0's orthogonality
     // check), so that a last-bit difference between replicas can never produce different bond dimensions.
@@ -314,13 +356,11 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
         hipLaunchKernelGGL(k_mc_flag, dim3(1), dim3(64), 0, st, static_cast<const unsigned long long*>(eigh_mc_status_ptr(c->mc_xbuf)), mcflag);
         TCK(allreduce_sum(c, mcflag, 1));
     }
-    double* h = c->h_scal;          // pinned, capacity >= 2*svd_n + 64
     HIPCK(c, hipMemcpyAsync(h, evals, sizeof(double) * nev, hipMemcpyDeviceToHost, st));
     double* h_mc = h + n + 8;
     *h_mc = 0.;
     if (mc) HIPCK(c, hipMemcpyAsync(h_mc, mcflag, 8, hipMemcpyDeviceToHost, st));
     HIPCK(c, hipStreamSynchronize(st));
-    bool stock = !tri;                                   // eigenvectors of rho itself in sG (dsyevd)
     if (mc && *h_mc != 0.) {
         // the workgroup cluster gave up waiting for a peer (a workgroup that never got a CU): nothing it wrote is used.  Redo this
         // split with the stock solver: Gram matrix again (sG may have served as workspace), dsyevd, eigenvalues to the host.
@@ -342,16 +382,17 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
     std::vector<double> p(n), sig(n);
     for (int g = 0; g < n; ++g) { double lam = h[n - 1 - g]; if (!(lam > 0.)) lam = 0.; p[g] = lam; sig[g] = std::sqrt(lam); }
     double te = 0.;
-    const int m = tnml_truncate(p.data(), n, maxm, minm, cutoff, &te);
+    m = tnml_truncate(p.data(), n, maxm, minm, cutoff, &te);
     if (truncerr) *truncerr = te;
     if (newm) *newm = m;
     if (nsv) *nsv = n;
     if (sv_host) for (int g = 0; g < n; ++g) sv_host[g] = sig[g];
     if (m > c->maxm) return tnml_fail(c, "svd_split: new bond dimension %d exceeds maxm %d of the context", m, c->maxm);
 
+    }
     const SigmaRef d_sig{evals, n, 0}, d_isig{evals, n, 1}, no_scale{nullptr, 0, 0};   // sigma_g / 1/sigma_g of the kept columns, computed where they are used
 
-    if (own_eig) {
+    if (own_eig && !spec) {
         if (c->svd_print == -1) {                                                  // debugging aid (option svd_print = -1): the check values of every split
             double nref = -1.;
             (void)hipMemcpy(&nref, c->sTau + (n - 1), sizeof(double), hipMemcpyDeviceToHost);
@@ -394,7 +435,7 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
     double* Aright = Sr.a;                 // right factor (m x nr), ld = m  == A_{b+1}[g][t][be](,[l])
     if (left) {
         // Q = U_m
-        TCK(split_gemm(c, true, false, m, nr, nl, Q, nl, M, nl, Aright, m, 2));   // U^T M = S V^T
+        TCK(split_gemm(c, true, false, m, nr, nl, Q, nl, M, nl, Aright, m, 2, chkp));   // U^T M = S V^T
         if (Q != Aleft) HIPCK(c, hipMemcpyAsync(Aleft, Q, sizeof(double) * (size_t)nl * m, hipMemcpyDeviceToDevice, st));
         if (ha == 2) {   // orthonormal factor goes right: V^T = S^-1 U^T M ; left gets U S
             hipLaunchKernelGGL(k_scale_rows, dim3(nblk((size_t)m * nr)), dim3(256), 0, st, Aright, m, (size_t)nr, d_isig);
@@ -402,7 +443,7 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
         }
     } else {
         // Q = V_m
-        TCK(split_gemm(c, false, false, nl, m, nr, M, nl, Q, nr, Aleft, nl, 2));        // M V = U S
+        TCK(split_gemm(c, false, false, nl, m, nr, M, nl, Q, nr, Aleft, nl, 2, chkp));        // M V = U S
         if (ha == 2) {
             hipLaunchKernelGGL(k_transpose_scale, dim3(nblk((size_t)nr * m)), dim3(256), 0, st, Q, Aright, nr, m, no_scale);
         } else {         // orthonormal factor goes left: U = M V S^-1 ; right gets S V^T

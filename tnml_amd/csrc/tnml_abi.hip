@@ -92,6 +92,8 @@ int tnml_set_option(tnml_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "sytrd_exit")) c->sytrd_exit = value;
     else if (!strcmp(name, "bgs_chol")) c->bgs_chol = value != 0;
     else if (!strcmp(name, "small_gemm")) c->small_gemm = value != 0;
+    else if (!strcmp(name, "spec_split")) c->spec_split = value != 0;
+    else if (!strcmp(name, "debug_fail_split")) { c->debug_fail_split = value; c->spec_splits = 0; }
     else if (!strcmp(name, "bf16_grad")) c->bf16_grad = value != 0;
     else if (!strcmp(name, "env_async")) c->env_async = value != 0;
     else if (!strcmp(name, "env_budget_mb")) { if (value < 0) return tnml_fail(c, "env_budget_mb must be >= 0"); c->env_budget_bytes = (long)value << 20; }
@@ -105,7 +107,7 @@ int tnml_set_option(tnml_ctx* c, const char* name, int value) {
     else return tnml_fail(c, "tnml_set_option: unknown option %s", name);
     return 0;
 }
-int tnml_synchronize(tnml_ctx* c) { HIPCK(c, hipStreamSynchronize(c->stream)); if (c->copy_stream) HIPCK(c, hipStreamSynchronize(c->copy_stream)); return 0; }
+int tnml_synchronize(tnml_ctx* c) { HIPCK(c, hipStreamSynchronize(c->stream)); if (c->copy_stream) HIPCK(c, hipStreamSynchronize(c->copy_stream)); return ipc_comm_check(c); }
 int64_t tnml_device_bytes(tnml_ctx* c) { return c->bytes; }
 int64_t tnml_replica_repairs(tnml_ctx* c) { return c->replica_repairs; }
 int tnml_svd_stats(tnml_ctx* c, int64_t* fallbacks, int64_t* cluster_repairs, double* d0, double* d1) {
@@ -175,6 +177,7 @@ int64_t tnml_estimate_bytes(const tnml_config* cfg) {
     b += mcap * (4 + 6 * 8) + 128. * Kmax * Kmax * 4 * (is64 ? 2 : 1);    // Mf, vB vR vP [tail|G] tB tB2, split-K slabs
     b += 8. * (std::max(40. * m * m, TNML_NL * Kmax * (double)ru16(cfg->maxm)) + 3. * n * n + 7. * n * m + 2. * TNML_NL * m * m + 2. * m * m);   // split workspaces
     b += 8. * (cfg->N - 1 + TNML_NL) * 2. * m * m;                                            // W replica
+    b += 8. * (4 + 2 * TNML_NL) * 2. * m * m;                                                 // spare site tensors of the speculative split
     if (2 * cfg->maxm > 240) b += (double)eigh_mc_xbuf_bytes();                               // exchange buffer of the multi-workgroup tridiagonalisation
     if (single) b += 8. * (5. * m * NTp + 3. * NTp + 3. * m * m);                             // workspace of the noise split (allocated on first use with noise > 0)
     const double nslab = single ? (cfg->N / 10. + 2.) : (0.55 * cfg->N + 3.);
@@ -328,6 +331,17 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
         const size_t cap = (size_t)2 * c->maxm * c->maxm * (j == c->c0 ? TNML_NL : 1);
         if ((rc = dmalloc(c, &c->W[j].a, cap))) return bail(rc);
     }
+    // speculative split: pinned mirrors [eigenvalues + 4 check values | CG scalars + trace] per bond update in flight, and spare site
+    // tensors (two bond updates in flight replace two sites each; the Label site has its own size class)
+    c->hrep_stride = (size_t)c->svd_n + 8 + SC_N + (size_t)4 * TNML_MAX_PASS;
+    if (hipHostMalloc((void**)&c->hrep, sizeof(double) * 2 * c->hrep_stride) != hipSuccess) return bail(tnml_fail(c, "hipHostMalloc failed"));
+    memset(c->hrep, 0, sizeof(double) * 2 * c->hrep_stride);
+    for (int k = 0; k < 4 + (c->c0 > 0 ? 2 : 0); ++k) {
+        double* sp = nullptr;
+        if ((rc = dmalloc(c, &sp, (size_t)2 * c->maxm * c->maxm * (k >= 4 ? TNML_NL : 1)))) return bail(rc);
+        (k >= 4 ? c->spare_big : c->spare_small).push_back(sp);
+    }
+    if (const char* e = getenv("TNML_SPEC_SPLIT")) c->spec_split = atoi(e);
     if (hipMemsetAsync(c->arbuf, 0, sizeof(double) * (c->mcap + TNML_TAILN), c->stream) != hipSuccess) return bail(tnml_fail(c, "memset failed"));
     if (hipMemsetAsync(c->locals, 0, sizeof(double) * 32, c->stream) != hipSuccess) return bail(tnml_fail(c, "memset failed"));
     if (hipMemsetAsync(c->scal, 0, sizeof(double) * SC_N, c->stream) != hipSuccess) return bail(tnml_fail(c, "memset failed"));
@@ -343,13 +357,19 @@ int tnml_destroy(tnml_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) ncclCommDestroy(c->comm);
     local_comm_release(c);
+    ipc_comm_release(c);
     for (int k = 0; k < 2; ++k) { if (c->pend[k].ev) (void)hipEventDestroy(c->pend[k].ev); if (c->pend[k].ev2) (void)hipEventDestroy(c->pend[k].ev2); }
     for (auto& p : c->prof_pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     for (auto e : c->prof_free) (void)hipEventDestroy(e);
     void* ptrs[] = {c->phi, c->label, c->ones, c->U, c->P, c->dP, c->Pp, c->Zp, c->Mf, c->slab, c->partials, c->partials2, c->vB, c->vR, c->vP,
                     c->arbuf, c->locals, c->scal, c->vpart, c->counters, c->Ppart, c->tB, c->tB2, c->sM, c->sG, c->sD, c->sE, c->sF, c->sInfo, c->sE2, c->sTau, c->sV, c->sC, c->sW, c->sScr, c->sS, c->sCm, c->sQ1, c->sDev, c->mc_xbuf, c->fprint, c->noise_ws};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    // (site tensors and spares have changed places during speculative splits: every buffer is in exactly one of the two sets)
     for (auto& s : c->W) if (s.a) (void)hipFree(s.a);
+    for (size_t k = 0; k < c->spare_small.size(); ++k) (void)hipFree(c->spare_small[k]);
+    for (size_t k = 0; k < c->spare_big.size(); ++k) (void)hipFree(c->spare_big[k]);
+    for (int k = 0; k < 2; ++k) for (int u = 0; u < c->pend[k].nundo; ++u) if (c->pend[k].undo[u].old) (void)hipFree(c->pend[k].undo[u].old);
+    if (c->hrep) (void)hipHostFree(c->hrep);
     for (auto& sl : c->slabs) if (sl.base) (void)hipFree(sl.base);
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->ev_compute) (void)hipEventDestroy(c->ev_compute);
@@ -382,6 +402,7 @@ int tnml_comm_init(tnml_ctx* c, const void* id128) {
 }
 // sum over ranks of a fp64 device buffer, in stream order (replaces stdx::accumulate, fixedL.cc:385,402,421,427)
 static int allreduce(tnml_ctx* c, double* buf, size_t count) {
+    if (c->ipc) { ProfScope ps(c, KC_ALLREDUCE); c->allreduce_calls += 1; return ipc_comm_exchange(c, buf, count, 0); }
     if (c->local) { ProfScope ps(c, KC_ALLREDUCE); c->allreduce_calls += 1; return local_comm_exchange(c, buf, count, 0); }
     if (!c->comm) {
         if (c->cfg.nranks == 1) return 0;
@@ -403,7 +424,7 @@ static int carry_deliver(tnml_ctx* c) {
     c->carry_slot = -1;
     HIPCK(c, hipMemcpyAsync(pend_host(c, slot) + TNML_CARRY, c->tail + TNML_CARRY, sizeof(double) * TNML_CARRYN, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipEventRecord(c->pend[slot].ev2, c->stream));
-    if (c->comm || c->local)                                          // delivered: the next packed all-reduce must not sum (and so scale by nranks) what is left here
+    if (c->multi())                                        // delivered: the next packed all-reduce must not sum (and so scale by nranks) what is left here
         HIPCK(c, hipMemsetAsync(c->tail + TNML_CARRY, 0, sizeof(double) * TNML_CARRYN, c->stream));
     return 0;
 }
@@ -413,6 +434,7 @@ static int allreduce_packed(tnml_ctx* c, size_t n) {
     return carry_deliver(c);
 }
 int bcast_rank0(tnml_ctx* c, double* buf, size_t count) {
+    if (c->ipc) { c->bcast_calls += 1; return ipc_comm_exchange(c, buf, count, 1); }
     if (c->local) { c->bcast_calls += 1; return local_comm_exchange(c, buf, count, 1); }
     if (!c->comm) return 0;
     c->bcast_calls += 1;
@@ -420,7 +442,7 @@ int bcast_rank0(tnml_ctx* c, double* buf, size_t count) {
     if (r != ncclSuccess) return tnml_fail(c, "ncclBroadcast failed: %s", ncclGetErrorString(r));
     return 0;
 }
-int tnml_collective_mode(tnml_ctx* c) { return c->local ? local_comm_mode(c) : (c->comm ? 1 : 0); }
+int tnml_collective_mode(tnml_ctx* c) { return c->ipc ? 4 : (c->local ? local_comm_mode(c) : (c->comm ? 1 : 0)); }
 int tnml_collective_stats(tnml_ctx* c, int64_t* allreduces, int64_t* broadcasts) {
     if (allreduces) *allreduces = c->allreduce_calls;
     if (broadcasts) *broadcasts = c->bcast_calls;
@@ -444,9 +466,10 @@ int tnml_replica_check(tnml_ctx* c, int* nranks_in_comm) {
     CollScope coll_(c);
     HIPCK(c, hipSetDevice(c->cfg.device));
     if (nranks_in_comm) *nranks_in_comm = 1;
-    if (!c->comm && !c->local) return c->cfg.nranks == 1 ? 0 : tnml_fail(c, "tnml_replica_check: nranks > 1 but tnml_comm_init was not called");
+    if (!c->multi()) return c->cfg.nranks == 1 ? 0 : tnml_fail(c, "tnml_replica_check: nranks > 1 but tnml_comm_init was not called");
     int cnt = 0;
     if (c->local) cnt = local_comm_size(c);
+    else if (c->ipc) cnt = c->cfg.nranks;
     else if (ncclCommCount(c->comm, &cnt) != ncclSuccess) return tnml_fail(c, "ncclCommCount failed");
     if (nranks_in_comm) *nranks_in_comm = cnt;
     if (cnt != c->cfg.nranks) return tnml_fail(c, "communicator has %d ranks, context was created for %d", cnt, c->cfg.nranks);
@@ -1056,10 +1079,10 @@ static int cgrad_device(tnml_ctx* c, int npass, double lambda, double cconv, boo
     // It is used where it buys something -- when the sum over images is also a sum over ranks (merged_cg = 1) -- because the
     // recurrence is not the reference's literal order: on the reference's own, badly conditioned feature map the fourth step size of
     // a Label-on-B bond moves by 1e-3 (the cost by 1e-10); merged_cg = 2 forces it on a single rank (parity tests), 0 disables it.
-    const bool merged = c->fast_cg && !fastc && (c->merged_cg >= 2 || (c->merged_cg == 1 && (c->comm || c->local)));
+    const bool merged = c->fast_cg && !fastc && (c->merged_cg >= 2 || (c->merged_cg == 1 && c->multi()));
     // one rank, literal pass order: the per-block partial sums of a pAp pass / an output update are summed by the CG step kernel that
     // consumes them (k_cg_step2: sum |p.v|^2, k_cg_resid2: the cost of the trace) -- seven k_reduce_partials launches less per bond update
-    const bool fold = c->fold_reduce && !(c->comm || c->local) && !merged && !fastc && c->fast_cg;
+    const bool fold = c->fold_reduce && !c->multi() && !merged && !fastc && c->fast_cg;
     // one rank, fp64: the slab reduction of every gradient GEMM is folded into the CG vector kernel that consumes G, the output update
     // P <- P + a (p*t.v) rides in the CG step kernel, and k_cg_init2's work is split between its neighbours (round 5: eight launches less)
     c->defer_slab = fold && c->f64();
@@ -1090,14 +1113,15 @@ static int cgrad_device(tnml_ctx* c, int npass, double lambda, double cconv, boo
     return rc;
 }
 // the CG's device scalars and per-pass trace: enqueue the copies, parse after any later synchronisation of the stream
-static int cgrad_trace_enqueue(tnml_ctx* c) {
-    double* hp = c->h_scal + 2 * c->svd_n + 64;
-    HIPCK(c, hipMemcpyAsync(hp, c->scal, sizeof(double) * (SC_N + 4 * TNML_MAX_PASS), hipMemcpyDeviceToHost, c->stream));
+// slot >= 0: into the report block of that bond update in flight (parsed by tnml_bond_update_end: two may be in flight)
+static double* trace_host(tnml_ctx* c, int slot) { return slot >= 0 ? c->hrep + (size_t)slot * c->hrep_stride + c->svd_n + 8 : c->h_scal + 2 * c->svd_n + 64; }
+static int cgrad_trace_enqueue(tnml_ctx* c, int slot = -1) {
+    HIPCK(c, hipMemcpyAsync(trace_host(c, slot), c->scal, sizeof(double) * (SC_N + 4 * TNML_MAX_PASS), hipMemcpyDeviceToHost, c->stream));
     return 0;
 }
-static void cgrad_trace_parse(tnml_ctx* c, int npass, tnml_cg_trace* tr) {
+static void cgrad_trace_parse(tnml_ctx* c, int npass, tnml_cg_trace* tr, int slot = -1) {
     memset(tr, 0, sizeof *tr);
-    const double* hp = c->h_scal + 2 * c->svd_n + 64;
+    const double* hp = trace_host(c, slot);
     const int done = (int)llround(hp[SC_NPASS]);
     tr->npass_done = done;
     tr->converged = (int)llround(hp[SC_CONV]);
@@ -1431,6 +1455,7 @@ int tnml_bond_update_begin(tnml_ctx* c, int b, int ha, const tnml_sweep_params* 
     PendingReport& pr = c->pend[slot];
     tnml_bond_report* rep = &pr.rep;
     memset(rep, 0, sizeof *rep);
+    pr.b = b; pr.ha = ha; pr.sp = *sp; pr.spec = false; pr.nundo = 0;
     TCK(tnml_set_bond(c, b));                                         // :488
     if (c->env_budget_bytes > 0 && c->env_async) TCK(env_lookahead(c, b, ha));
     const BondPlan p = c->plan;
@@ -1458,16 +1483,14 @@ int tnml_bond_update_begin(tnml_ctx* c, int b, int ha, const tnml_sweep_params* 
     if (sp->report_costs) TCK(quadcost_device(c, sp->lambda_cost, &rep->cost_cg, nullptr, &rep->reg_cost_cg, nullptr, false));   // single.h:622,626
     if (c->carry_slot >= 0) { TCK(allreduce(c, c->tail + TNML_CARRY, TNML_CARRYN)); TCK(carry_deliver(c)); }   // (only when no packed all-reduce ran above: the exact solver)
     TCK(launch_unpack(c, pd, c->vB, c->tB));
-    TCK(cgrad_trace_enqueue(c));                                      // lands with the split's own synchronisation (eigenvalues)
-    TCK(svd_split_device(c, c->tB, b, ha, sp->cutoff, sp->maxm, sp->minm, &rep->truncerr, &rep->newm, nullptr, nullptr));   // :519-522
-    cgrad_trace_parse(c, sp->npass, &rep->cg);
-    if (exact) memset(&rep->cg, 0, sizeof rep->cg);               // no CG ran
+    TCK(cgrad_trace_enqueue(c, slot));                                // parsed by tnml_bond_update_end
+    TCK(svd_split_device(c, c->tB, b, ha, sp->cutoff, sp->maxm, sp->minm, &rep->truncerr, &rep->newm, nullptr, nullptr, slot));   // :519-522 (may run without its host synchronisation: tnml_ctx::spec_split)
     if (c->debug_nudge_rank == c->cfg.rank) TCK(launch_nudge(c, c->W[b].a));
     // replicas: the two site tensors the split just wrote must be bit-identical on every rank.  Their fingerprint goes into the
     // carried slots of the tail as exact integer pieces (mode 1: summed with the next packed all-reduce, checked when the report
     // is handed out -- no collective of its own).  Mode 2 checks at once, BEFORE anything consumes the tensors (bond tensor, P/dP,
     // the shifted environment): on a mismatch rank 0's two tensors replace everybody's, counted.
-    pr.fp = (c->comm || c->local) && c->check_replicas;
+    pr.fp = c->multi() && c->check_replicas;
     if (pr.fp) {
         TCK(replica_fingerprint(c, b, b + 1, c->tail + TNML_FPSLOT));
         if (c->check_replicas_mode == 2) {
@@ -1490,7 +1513,7 @@ int tnml_bond_update_begin(tnml_ctx* c, int b, int ha, const tnml_sweep_params* 
     TCK(launch_diffnorm(c, c->tB2, c->tB, ne, loc + 12, 3));          // |newB|^2 twice (slot 12 of quadcost, :528), |newB - B|^2 (:530)
     double* hq = pend_host(c, slot);
     HIPCK(c, hipMemcpyAsync(hq, loc, sizeof(double) * 16, hipMemcpyDeviceToHost, c->stream));
-    const bool multi = c->comm || c->local;
+    const bool multi = c->multi();
     if (multi && c->defer_tail) c->carry_slot = slot;                 // summed by the next packed all-reduce (tnml_bond_update_end flushes otherwise)
     else {
         c->carry_slot = slot;
@@ -1504,6 +1527,20 @@ int tnml_bond_update_begin(tnml_ctx* c, int b, int ha, const tnml_sweep_params* 
     c->p_valid = true;                                                // in stream order: P/dP of the after-SVD quadcost
     return 0;
 }
+// a speculative split whose deferred check failed: the site tensors it replaced come back, the buffers it wrote return to the pool
+static void spec_rollback(tnml_ctx* c, PendingReport& pr) {
+    for (int u = pr.nundo - 1; u >= 0; --u) {
+        SiteT& S = c->W[pr.undo[u].j];
+        ((pr.undo[u].j == c->c0) ? c->spare_big : c->spare_small).push_back(S.a);
+        S.a = pr.undo[u].old; S.ml = pr.undo[u].ml; S.mr = pr.undo[u].mr;
+    }
+    pr.nundo = 0; pr.spec = false;
+}
+// ... verified: the replaced buffers are free again
+static void spec_commit(tnml_ctx* c, PendingReport& pr) {
+    for (int u = 0; u < pr.nundo; ++u) ((pr.undo[u].j == c->c0) ? c->spare_big : c->spare_small).push_back(pr.undo[u].old);
+    pr.nundo = 0; pr.spec = false;
+}
 int tnml_bond_update_end(tnml_ctx* c, tnml_bond_report* rep) {
     CollScope coll_(c);
     if (c->pend_count < 1) return tnml_fail(c, "tnml_bond_update_end: no bond update in flight");
@@ -1515,8 +1552,49 @@ int tnml_bond_update_end(tnml_ctx* c, tnml_bond_report* rep) {
     }
     HIPCK(c, hipEventSynchronize(pr.ev));
     HIPCK(c, hipEventSynchronize(pr.ev2));
-    c->pend_tail ^= 1; c->pend_count -= 1;
     double* hq = pend_host(c, slot);
+    if (pr.spec) {
+        // the deferred check of the speculative split: its verdict came with the carried slots (summed over the ranks: every rank sees the same number)
+        const double* hm = c->hrep + (size_t)slot * c->hrep_stride;
+        const int n = pr.split_n;
+        if (hq[TNML_SPECSLOT] != 0.) {
+            // dependent vectors even after re-orthonormalisation (or the test hook): everything this bond update and the one begun after
+            // it wrote is dropped -- site tensors back from their spare buffers -- and both run again, this one with the synchronous split
+            // and its rocSOLVER fallback.  Rare (a few per sweep), so the repeat may cost what it costs.
+            const bool had_next = c->pend_count == 2;
+            PendingReport& nx = c->pend[slot ^ 1];
+            HIPCK(c, hipStreamSynchronize(c->stream));
+            if (c->copy_stream) HIPCK(c, hipStreamSynchronize(c->copy_stream));
+            const int b1 = nx.b, ha1 = nx.ha; const tnml_sweep_params sp1 = nx.sp;
+            const int b0 = pr.b, ha0 = pr.ha; const tnml_sweep_params sp0 = pr.sp;
+            if (had_next) { if (nx.nundo == 2) spec_rollback(c, nx); else return tnml_fail(c, "bond %d: cannot repeat after a failed split check (the next bond update kept no undo record)", b0); }
+            spec_rollback(c, pr);
+            c->pend_count = 0; c->carry_slot = -1; c->p_valid = false; c->currb = -1;
+            HIPCK(c, hipMemsetAsync(c->tail + TNML_CARRY, 0, sizeof(double) * TNML_CARRYN, c->stream));
+            c->spec_redos += 1; c->svd_fallbacks += 1;
+            c->force_safe = true;
+            int rc = tnml_bond_update_begin(c, b0, ha0, &sp0);        // lands in `slot` again (pend_tail has not moved)
+            c->force_safe = false;
+            if (rc) return rc;
+            if (had_next) TCK(tnml_bond_update_begin(c, b1, ha1, &sp1));
+            return tnml_bond_update_end(c, rep);
+        }
+        spec_commit(c, pr);
+        // what the synchronous form does right after its host round trip: truncation error from the eigenvalues, statistics
+        std::vector<double> p(n);
+        for (int g = 0; g < n; ++g) { double lam = hm[n - 1 - g]; if (!(lam > 0.)) lam = 0.; p[g] = lam; }
+        double te = 0.;
+        const int mx = pr.sp.maxm < c->maxm ? pr.sp.maxm : c->maxm;
+        const int m = tnml_truncate(p.data(), n, mx, pr.sp.minm < mx ? pr.sp.minm : mx, pr.sp.cutoff, &te);
+        if (m != pr.rep.newm) return tnml_fail(c, "bond %d: speculative split kept %d columns, the truncation rule says %d", pr.rep.bond, pr.rep.newm, m);
+        pr.rep.truncerr = te;
+        c->svd_last_dev0 = hm[n]; c->svd_last_dev1 = 0.75 * hm[n] * hm[n];
+        if (hm[n + 2] != 0.) c->svd_cholqr += 1;
+    } else spec_commit(c, pr);                                        // synchronous split: verified when it ran
+    c->pend_tail ^= 1; c->pend_count -= 1;
+    const bool exact = c->single() && c->cg_method == 2;
+    cgrad_trace_parse(c, pr.sp.npass, &pr.rep.cg, slot);
+    if (exact) memset(&pr.rep.cg, 0, sizeof pr.rep.cg);              // no CG ran
     if (pr.fp && !fingerprint_agrees(hq + TNML_FPSLOT, c->cfg.nranks))   // every rank sees the same sums
         return tnml_fail(c, "bond %d: replicas of W.A(%d), W.A(%d) differ between ranks after the split", pr.rep.bond, pr.rep.bond, pr.rep.bond + 1);
     double t[13];

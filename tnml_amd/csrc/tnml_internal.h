@@ -79,6 +79,7 @@ enum { SC_COST0 = 0, /* ..9 */ SC_NCORR = 10, SC_PP = 11, SC_RR = 12, /* 13: sec
 #define TNML_CARRY 16      /* first carried slot */
 #define TNML_FPSLOT 32     /* first fingerprint slot (8 doubles) */
 #define TNML_CARRYN 24     /* carried doubles: slots 16..39 */
+#define TNML_SPECSLOT 28   /* carried: 1 when the deferred check of a speculative split failed (summed over the ranks: every rank rolls back together) */
 
 struct BondPlan {
     int b = -1;
@@ -92,7 +93,15 @@ struct BondPlan {
 };
 
 struct ProfPending { hipEvent_t e0, e1; int kc; };
-struct PendingReport { tnml_bond_report rep; double lambda_cost = 0.; hipEvent_t ev = nullptr, ev2 = nullptr; bool fp = false; };
+// a site tensor the split of a bond update in flight has replaced: its former buffer and bond dimensions stay until the split is verified
+struct SiteUndo { int j = 0; double* old = nullptr; int ml = 0, mr = 0; };
+struct PendingReport {
+    tnml_bond_report rep; double lambda_cost = 0.; hipEvent_t ev = nullptr, ev2 = nullptr; bool fp = false;
+    // speculative split (no host synchronisation inside tnml_bond_update_begin): what tnml_bond_update_end needs to finish the report
+    // and, when the deferred orthogonality check fails, to roll the bond update back and run it again with the synchronous split
+    int b = 0, ha = 0; tnml_sweep_params sp{};
+    bool spec = false; int split_n = 0, split_mk = 0; int nundo = 0; SiteUndo undo[2];
+};
 
 struct tnml_ctx {
     tnml_config cfg;
@@ -107,6 +116,8 @@ struct tnml_ctx {
     rocblas_handle blas = nullptr;
     ncclComm_t comm = nullptr;
     struct LocalComm* local = nullptr;   // in-process communicator of ranks sharing one device (local_comm.hip)
+    struct IpcComm* ipc = nullptr;       // cross-process one-shot all-reduce over IPC-mapped receive regions (ipc_comm.hip)
+    bool multi() const { return comm != nullptr || local != nullptr || ipc != nullptr; }   // the sum over images is also a sum over ranks
     std::string err;
     std::string warn;               // last non-fatal notice (tnml_last_warning): e.g. maxm / minm clamped to the context's maxm by the split
     int64_t bytes = 0;
@@ -202,6 +213,14 @@ struct tnml_ctx {
     double* Ppart = nullptr;         // [2][10][NTp]: per-half outputs of k_fwd_res
     bool attr_sytrd = false, attr_invit = false, attr_fused = false;   // per-device function attributes set (a process may drive several devices)
     int cu_count = 0;
+    // Speculative split (option spec_split, default on): when the truncation cannot change the outcome (minm >= the columns the split may keep)
+    // the new bond dimension is known without the eigenvalues, so the split is enqueued WITHOUT its host synchronisation; eigenvalues and
+    // check values are mirrored into pinned host memory by the kernels that produce them and read by tnml_bond_update_end.  The new site
+    // tensors go to spare buffers; a failed check rolls the sites back and repeats the bond update with the synchronous split.
+    int spec_split = 1; bool force_safe = false; long spec_redos = 0, spec_splits = 0; int debug_fail_split = -1;
+    std::vector<double*> spare_small, spare_big;   // spare site-tensor buffers (capacity 2 maxm^2, x 10 for the Label site)
+    double* hrep = nullptr;                        // pinned: [2 slots][hrep_stride] = eigenvalues + check values of a speculative split, CG trace
+    size_t hrep_stride = 0;
     double svd_last_dev0 = 0., svd_last_dev1 = 0.;   // max|Q^T Q - I| before the 1st / 2nd polish step of the last split
     long svd_fallbacks = 0, svd_cholqr = 0;
     int svd_print = -2, svd_calls = 0, svd_dumped = 0;   // debugging aids of the split, read once in tnml_create (TNML_SVD_PRINT, TNML_SVD_DUMP) / option "svd_print"
@@ -406,14 +425,17 @@ struct SmallGemmArgs {
     const double* A; int lda; const double* B; int ldb; double* C; int ldc;     // column-major; C = op(A) op(B), M x N, reduction length K
     int M, N, K; int ta, tb;
     int bmode = 0; double* dev = nullptr;      // bmode 1: op(B) = 1.5 I - 0.5 B (B symmetric, K == N), dev[0] = max |B - I| (atomic max: zero it first)
+    // a side job of tile (0, 0) (speculative split): the four check values of the split to their pinned host mirror, and bad[0] = 1 when they fail
+    const double* chk_src = nullptr; double* chk_host = nullptr; double* chk_bad = nullptr; int chk_force_bad = 0;
 };
 int launch_dgemm_small(tnml_ctx* c, const SmallGemmArgs& a);
+int launch_split_check_mirror(tnml_ctx* c, const double* src, double* host, double* bad, int force_bad);
 // C = op(A) op(B) at the sizes of the split: the in-house kernel up to 4e7 multiply-adds, rocBLAS (as `strips` column strips) beyond
-int split_gemm(tnml_ctx* c, bool ta, bool tb, int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* C, int ldc, int strips);
+int split_gemm(tnml_ctx* c, bool ta, bool tb, int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* C, int ldc, int strips, const SmallGemmArgs* chk = nullptr);   // chk: its chk_* fields ride along (or get a launch of their own)
 
 // ---- eigh.hip -----------------------------------------------------------------------------
 int eigh_tridiagonalize(tnml_ctx* c, const double* A, int n, double* D, double* E, double* tau, double* V, double psd_tol = 0.);   // tau: n doubles, tau[n-1] = number of reflectors
-int eigh_tridiag_eig(tnml_ctx* c, const double* D, const double* E, int n, double* W, int mk, double* Z, int ldz, double* scratch);      // eigh_tri.hip
+int eigh_tridiag_eig(tnml_ctx* c, const double* D, const double* E, int n, double* W, int mk, double* Z, int ldz, double* scratch, double* W_host = nullptr);      // eigh_tri.hip; W_host: pinned mirror of W (may be null)
 int eigh_tridiag_eig_v1(tnml_ctx* c, const double* D, const double* E, int n, double* W, int mk, double* Z, int ldz, double* scratch);   // round-4 kernels (eigh.hip), kept for the A/B probe
 int eigh_ns_matrix(tnml_ctx* c, const double* S, double* Cm, int m, double* dev);
 int eigh_chol_rinv(tnml_ctx* c, const double* S, int m, double* Rinv, double* flag, int zero_prev = 0);   // m <= 128; zero_prev: also clears flag[-1]
@@ -427,6 +449,12 @@ int eigh_mc_tridiagonalize(tnml_ctx* c, hipStream_t st, const double* A, int n, 
 int eigh_mc_workgroups(int n);
 const void* eigh_mc_status_ptr(const void* xbuf);
 int eigh_backtransform(tnml_ctx* c, const double* V, const double* tau, int n, const double* Z, int ldz, double* U, int ldu, int ncols, hipStream_t st = nullptr);   // Z == nullptr: U = H_0 ... H_{n-2}
+
+// ---- ipc_comm.hip ----
+void ipc_comm_release(tnml_ctx* c);
+int ipc_comm_exchange(tnml_ctx* c, double* buf, size_t count, int op);   // 0 sum, 1 broadcast from rank 0; in stream order, never blocks the host
+int ipc_comm_check(tnml_ctx* c);                                       // non-zero (and an error message) when a collective timed out
+int ipc_comm_mem_kind(const tnml_ctx* c);
 
 // ---- local_comm.hip ----
 void local_comm_release(tnml_ctx* c);
@@ -443,7 +471,7 @@ int ctx_alloc_doubles(tnml_ctx* c, double** p, size_t n);       // device memory
 
 // ---- svd.hip ------------------------------------------------------------------------------
 int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cutoff, int maxm, int minm,
-                     double* truncerr, int* newm, double* sv_host, int* nsv);
+                     double* truncerr, int* newm, double* sv_host, int* nsv, int spec_slot = -1);   // spec_slot >= 0: may run without its host synchronisation (see tnml_ctx::spec_split)
 
 // ---- wave64 DPP helpers (device) ----
 // quad-lane exchange of a double through DPP (lanes 4q..4q+3 hold the 4 column strips of one block)

@@ -88,12 +88,26 @@ class TrainStates:
         if f(arr, len(states)) != 0:
             raise TnmlError(_lib.load().tnml_last_error(None).decode() or "in-process communicator setup failed")
 
+    def oneshot_export(self) -> bytes:
+        """the cross-process one-shot all-reduce, step 1 (tnml_oneshot_export): allocates this rank's receive region and returns the
+        64-byte IPC handle the other ranks need"""
+        buf = C.create_string_buffer(64)
+        self._ck(self._L.tnml_oneshot_export(self._h, buf))
+        return buf.raw
+
+    def oneshot_connect(self, handles):
+        """step 2 (tnml_oneshot_connect): `handles` = the handles of ALL ranks in rank order (gathered over any control plane)"""
+        blob = b"".join(handles)
+        assert len(blob) == 64 * self.nranks, (len(blob), self.nranks)
+        self._ck(self._L.tnml_oneshot_connect(self._h, C.create_string_buffer(blob, len(blob))))
+
     def collective_mode(self):
-        """0 none (one rank), 1 RCCL, 2 in-process staging buffer, 3 one-shot peer write"""
+        """0 none (one rank), 1 RCCL, 2 in-process staging buffer, 3 in-process one-shot peer write, 4 cross-process one-shot (IPC)"""
         return self._L.tnml_collective_mode(self._h)
 
     def allreduce_mode(self):
-        return ("none", "rccl", "in-process staging buffer", "one-shot peer write")[self.collective_mode()]
+        return ("none", "rccl", "in-process staging buffer", "one-shot peer write (threads of one process)",
+                "one-shot peer write (processes, IPC-mapped receive regions, device-side arrival flags)")[self.collective_mode()]
 
     @staticmethod
     def comm_unique_id() -> bytes:

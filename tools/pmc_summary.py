@@ -63,7 +63,7 @@ def step_total(ctr):
         return None
     rows = [(int(r.get("Dispatch_Id", 0) or 0), r["Kernel_Name"], float(r["Counter_Value"])) for r in csv.DictReader(open(f[0])) if r["Counter_Name"] == ctr]
     rows.sort()
-    marks = [i for i, r in enumerate(rows) if "k_tridiag_split" in r[1]]
+    marks = [i for i, r in enumerate(rows) if "k_teig_values" in r[1] or "k_tridiag_split" in r[1]]      # one per split
     if len(marks) < 5:
         return None
     a, b, n = marks[-4], marks[-1], 3
@@ -71,7 +71,7 @@ def step_total(ctr):
 fs, ws = step_total("FETCH_SIZE"), step_total("WRITE_SIZE")
 if fs is not None and ws is not None:
     rec["step"] = {"bytes_per_step": (2.0 * fs + ws) * 1024.0, "fetch_size_kb_per_step": fs, "write_size_kb_per_step": ws, "steps_averaged": 3,
-                   "source": "every dispatch of a bond update (between consecutive k_tridiag_split launches), FETCH_SIZE x 2 + WRITE_SIZE, mean of the last three bond updates of the PMC run"}
+                   "source": "every dispatch of a bond update (between the first eigen-stage launches of consecutive splits), FETCH_SIZE x 2 + WRITE_SIZE, mean of the last three bond updates of the PMC run"}
 json.dump(rec, open(out + "/pmc_traffic.json", "w"), indent=1)
 if "step" in rec: print("whole bond update: %.1f MB" % (rec["step"]["bytes_per_step"] / 1e6))
 print("wrote", out + "/pmc_traffic.json", {k: round(v["bytes_per_launch"] / 1e6, 1) for k, v in rec["kernels"].items()}, "MB per launch")

@@ -86,7 +86,7 @@ int main() {
         float tv[2] = {1e9f, 1e9f};
         {
             int* is = (int*)(dS + 3 * TEIG_MAXN);
-            Teig2Args t{dD, dE, n, dW[1], mk, dZ[1], n, dS, dS + TEIG_MAXN, dS + 2 * TEIG_MAXN, is, is + TEIG_MAXN, is + 2 * TEIG_MAXN};
+            Teig2Args t{dD, dE, n, dW[1], mk, dZ[1], n, dS, dS + TEIG_MAXN, dS + 2 * TEIG_MAXN, is, is + TEIG_MAXN, is + 2 * TEIG_MAXN, nullptr};
             const int ns = (n + 63) & ~63, ivl = n <= 248 ? 16 : (n <= 448 ? 8 : 4);
             const size_t lds = sizeof(double) * (3 * (size_t)ns + (size_t)4 * n * ivl);
             for (int rep = 0; rep < 5; ++rep) {
