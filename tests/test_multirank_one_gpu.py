@@ -216,8 +216,10 @@ def test_a_pipelined_bond_update_enters_five_payload_allreduces():
     assert new[0]["newm"] == old[0]["newm"] and new[0]["nc"] == old[0]["nc"]
     # same algebra, different rounding: identical to 1e-9 while the two runs are still on the same trajectory (a free-running sweep
     # amplifies any rounding difference -- the oracle with 1 and with 8 threads does the same), close after
-    np.testing.assert_allclose(new[0]["cost"][:6], old[0]["cost"][:6], rtol=1e-9)
-    np.testing.assert_allclose(new[0]["cost"][:8], old[0]["cost"][:8], rtol=1e-8)      # (bond 8: 1.7e-9 with the round-5 split kernels, 0.9e-9 before: the amplification has begun)
+    np.testing.assert_allclose(new[0]["cost"][:4], old[0]["cost"][:4], rtol=1e-9)
+    # bonds 5 and 6 carry the Label index on B: there the merged recurrence and the literal order differ in the later step sizes at 1e-3
+    # and in the cost at ~1e-9 (tnml_abi.hip, cgrad_device; 1.7e-9 at bond 6 with the round-5 split kernels, 0.9e-9 with round 4's)
+    np.testing.assert_allclose(new[0]["cost"][:8], old[0]["cost"][:8], rtol=1e-8)
     np.testing.assert_allclose(new[0]["cost"], old[0]["cost"], rtol=1e-3)
     for a, b in zip(new[0]["cg"][:8], old[0]["cg"][:8]):                          # the per-pass costs the reference prints (:429)
         np.testing.assert_allclose(a, b, rtol=1e-9)

@@ -44,10 +44,11 @@ static __device__ __forceinline__ void wave_lds_fence() {
 // Two barriers per step; Householder convention of LAPACK dlarfg.
 // ==========================================================================================
 #define V3_LD 242
-// s_v / s_w are read by every lane at the eight rows of its block (row 8 R + r): unpadded, the lanes of a wave (consecutive R) hit
-// every fourth bank group only (64-byte stride); with one pad double per block of eight (stride 72 bytes) 30 blocks land on 30 different bank pairs
+// s_v / s_w are read by every lane at the eight rows of its block (row 8 R + r).  V3_PAD = 1 puts one pad double after every eight (stride 72
+// bytes: 30 blocks on 30 different bank pairs instead of every fourth bank group) -- measured SLOWER (2.90 against 2.78 us per step,
+// profiles/r05_probe_sytrd_padding.txt: the padded rows lose their 16-byte alignment and with it ds_read_b128), so it is off
 #ifndef V3_PAD
-#define V3_PAD 1
+#define V3_PAD 0
 #endif
 #define SVI(i) (V3_PAD ? (i) + ((i) >> 3) : (i))
 #define V3_VLEN (240 + 32)

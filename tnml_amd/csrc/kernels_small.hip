@@ -220,13 +220,14 @@ __global__ __launch_bounds__(VB) void k_cg_step2(double* __restrict__ B, const d
                                                 const double* __restrict__ tail, const double* __restrict__ part, int nb,
                                                 double* __restrict__ scal, int rr_in, double* __restrict__ trace, int pass, int merged,
                                                 const double* __restrict__ pp_part, int npp,
-                                                const double* __restrict__ rr_part, int nbv, StepUpd U) {
+                                                const double* __restrict__ rr_part, int nbv, StepUpd U, double* __restrict__ hmir) {
     // merged CG: the cost partials of the PREVIOUS pass's update (fixedL.cc:419,427-428) came with this pass's all-reduce
     if (merged && pass > 1 && blockIdx.x == 0 && threadIdx.x == 0 && scal[SC_CONVP + (pass & 1)] == 0.) {   // (slot of pass - 2: not converged before the previous pass)
         double cs = 0.;
         for (int l = 0; l < TNML_NL; ++l) cs += tail[SC_COST0 + l];
         const double cst = cs + lambda * scal[SC_BNORM2];
         scal[SC_COST] = cst; trace[4 * (pass - 2) + 2] = cst;
+        if (hmir) hmir[SC_N + 4 * (pass - 2) + 2] = cst;
     }
     if (scal[SC_CONVP + ((pass - 1) & 1)] != 0.) return;   // |r| < cconv was hit in an earlier pass (fixedL.cc:432-436)
     __shared__ double sh[VB];
@@ -257,6 +258,8 @@ __global__ __launch_bounds__(VB) void k_cg_step2(double* __restrict__ B, const d
         scal[SC_PNORM2] = pn2; scal[SC_PAP] = pAp; scal[SC_ALPHA] = a; scal[SC_NPASS] = (double)pass;
         if (rr_part) scal[rr_in] = rr;                     // k_cg_resid2 reads it
         trace[4 * (pass - 1) + 0] = pAp; trace[4 * (pass - 1) + 1] = a;
+        // hmir: the pinned host mirror of [scal | trace] of the bond update in flight -- what the host report needs lands there without a copy
+        if (hmir) { hmir[SC_NPASS] = (double)pass; hmir[SC_N + 4 * (pass - 1) + 0] = pAp; hmir[SC_N + 4 * (pass - 1) + 1] = a; }
     }
 }
 // partial |nr|^2 with nr = G - lambda B, and |B|^2
@@ -265,10 +268,27 @@ __global__ __launch_bounds__(VB) void k_cg_step2(double* __restrict__ B, const d
 // k_slab_reduce64 launch folded in)
 __global__ __launch_bounds__(VB) void k_cg_resid1(double* __restrict__ G, const double* __restrict__ B, size_t n, double lambda,
                                                  double* __restrict__ part, const double* __restrict__ R, const double* __restrict__ Pv, const double* __restrict__ scal,
-                                                 const double* __restrict__ slab, int nsplit, int pass) {
+                                                 const double* __restrict__ slab, int nsplit, int pass,
+                                                 const double* __restrict__ cost_part, int ncp, double* __restrict__ cost_sum, int nbv) {
     if (slab && scal[SC_CONVP + ((pass - 1) & 1)] != 0.) return;   // converged: k_cg_resid2 will not read G or the partials (the separate reduction launch used to run regardless)
     __shared__ double sh[VB];
-    size_t lo, hi; slice(n, &lo, &hi);
+    if ((int)blockIdx.x >= nbv) {
+        // the one workgroup beyond the vector's: the cost partials of the output update (per label, in k_reduce_partials' order, then the
+        // labels in label order) -> cost_sum[0], beside the others' streaming instead of on k_cg_resid2's critical path (6 us there)
+        const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        for (int l = w; l < TNML_NL; l += VB / 64) {
+            double a = 0.;
+            for (int r = lane; r < ncp; r += 64) a += cost_part[(size_t)r * 12 + l];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
+            if (lane == 0) sh[l] = a;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { double cs = 0.; for (int l = 0; l < TNML_NL; ++l) cs += sh[l]; cost_sum[0] = cs; }
+        return;
+    }
+    size_t lo, hi;
+    { const size_t per = (n + nbv - 1) / nbv; lo = per * blockIdx.x; hi = lo + per; if (hi > n) hi = n; if (lo > n) lo = n; }
     double an = 0., ab = 0.;
     const double a = R ? scal[SC_ALPHA] : 0.;
     for (size_t i = lo + threadIdx.x; i < hi; i += VB) {
@@ -294,7 +314,7 @@ __global__ __launch_bounds__(VB) void k_cg_resid2(const double* __restrict__ G, 
                                                  const double* __restrict__ tail, const double* __restrict__ part, int nb,
                                                  double* __restrict__ scal, int rr_in, int rr_out,
                                                  double* __restrict__ trace, int pass, double* __restrict__ part_p, int merged,
-                                                 const double* __restrict__ cost_part, int ncp) {
+                                                 const double* __restrict__ cost_part, int ncp, double* __restrict__ hmir) {
     const double was = scal[SC_CONVP + ((pass - 1) & 1)];
     if (was != 0.) {                                       // already converged: hand the flag on to the next pass's slot
         if (blockIdx.x == 0 && threadIdx.x == 0) scal[SC_CONVP + (pass & 1)] = was;
@@ -320,6 +340,8 @@ __global__ __launch_bounds__(VB) void k_cg_resid2(const double* __restrict__ G, 
     if (threadIdx.x == 0) { part_p[2 * blockIdx.x] = ps; part_p[2 * blockIdx.x + 1] = 0.; }
     double csp = 0.;                                       // workgroup 0: the cost partials of the output update, when they have not been reduced yet
     if (blockIdx.x == 0 && cost_part && !merged) {
+        if (ncp < 0) csp = cost_part[0];                   // already summed by the extra workgroup of k_cg_resid1
+        else {
         // wave w sums the columns of labels w, w + 4, w + 8 in the order of k_reduce_partials; the labels are then added in label order,
         // as the reduced tail would be (one pass over the partial sums instead of ten workgroup-wide ones: 19 -> 6 us)
         __syncthreads();
@@ -333,6 +355,7 @@ __global__ __launch_bounds__(VB) void k_cg_resid2(const double* __restrict__ G, 
         }
         __syncthreads();
         for (int l = 0; l < TNML_NL; ++l) csp += sh[l];
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (!merged) {                                    // (merged: this pass's cost partials are summed over the ranks by the next all-reduce)
@@ -341,12 +364,14 @@ __global__ __launch_bounds__(VB) void k_cg_resid2(const double* __restrict__ G, 
             else for (int l = 0; l < TNML_NL; ++l) cs += tail[SC_COST0 + l];
             scal[SC_COST] = cs + lambda * bn2;
             trace[4 * (pass - 1) + 2] = cs + lambda * bn2;
+            if (hmir) hmir[SC_N + 4 * (pass - 1) + 2] = cs + lambda * bn2;
         }
         scal[SC_BNORM2] = bn2; scal[SC_BETA] = beta; scal[SC_RNORM] = rn;
         scal[rr_out] = nn;
         trace[4 * (pass - 1) + 3] = rn;
         scal[SC_CONVP + (pass & 1)] = (double)conv;        // read by the kernels of the next pass; this pass's readers use the other slot
         scal[SC_CONV] = (double)conv;                      // host copy
+        if (hmir) { hmir[SC_N + 4 * (pass - 1) + 3] = rn; hmir[SC_CONV] = (double)conv; }
     }
 }
 // method = fast_conj (single.h:290-398): the image sum of this pass is A p = sum_n (p.v_n) v_n, and the residual follows the
@@ -365,7 +390,7 @@ __global__ __launch_bounds__(VB) void k_norm2(const double* __restrict__ part, i
     double a, b; sum_partials(part, nb, &a, &b, sh);
     if (threadIdx.x == 0) { out[0] = a; if (nout == 2) out[1] = b; if (nout == 3) { out[1] = a; out[2] = b; } }
 }
-__global__ __launch_bounds__(VB) void k_diffnorm1(const double* __restrict__ x, const double* __restrict__ y, size_t n, double* __restrict__ part) {
+__global__ __launch_bounds__(VB) void k_diffnorm1(const double* __restrict__ x, const double* __restrict__ y, size_t n, double* __restrict__ part) {   // part may be pinned host memory
     __shared__ double sh[VB];
     size_t lo, hi; slice(n, &lo, &hi);
     double a = 0., d = 0.;
@@ -412,7 +437,7 @@ int launch_cg_step(tnml_ctx* c, size_t n, double lambda, int pass, bool merged, 
         c->part_n = c->NTp / LD_IMGS;
     }
     const double* rr_part = (pass == 1 && c->rr_from_part) ? (const double*)c->vpart : nullptr;
-    hipLaunchKernelGGL(k_cg_step2, dim3(nb + nbu), dim3(VB), 0, c->stream, c->vB, c->vP, n, lambda, c->tail, c->vpart + 512, nb, c->scal, SC_RR + c->rr_slot, c->cgtrace, pass, merged ? 1 : 0, pp_part, npp, rr_part, nb, U);
+    hipLaunchKernelGGL(k_cg_step2, dim3(nb + nbu), dim3(VB), 0, c->stream, c->vB, c->vP, n, lambda, c->tail, c->vpart + 512, nb, c->scal, SC_RR + c->rr_slot, c->cgtrace, pass, merged ? 1 : 0, pp_part, npp, rr_part, nb, U, c->hmir);
     HIPCK(c, hipGetLastError());
     return 0;
 }
@@ -423,8 +448,13 @@ int launch_cg_resid(tnml_ctx* c, size_t n, double lambda, double cconv, int pass
     const double* slab = c->slab_pending > 0 ? (const double*)c->slab : nullptr;
     const int nsplit = c->slab_pending;
     c->slab_pending = 0;
-    hipLaunchKernelGGL(k_cg_resid1, dim3(nb), dim3(VB), 0, c->stream, c->vG, c->vB, n, lambda, c->vpart, merged ? (const double*)c->vR : (const double*)nullptr, (const double*)c->vP, (const double*)c->scal, slab, nsplit, pass);
-    hipLaunchKernelGGL(k_cg_resid2, dim3(nb), dim3(VB), 0, c->stream, c->vG, c->vB, c->vR, c->vP, n, lambda, cconv, c->tail, c->vpart, nb, c->scal, in, out, c->cgtrace, pass, c->vpart + 512, merged ? 1 : 0, cost_part, ncp);
+    // the cost partials of the output update (one rank: not reduced yet) are summed by one extra workgroup of k_cg_resid1
+    const bool early = cost_part != nullptr && !merged;
+    double* csum = c->vpart + 1024;
+    hipLaunchKernelGGL(k_cg_resid1, dim3(nb + (early ? 1 : 0)), dim3(VB), 0, c->stream, c->vG, c->vB, n, lambda, c->vpart, merged ? (const double*)c->vR : (const double*)nullptr, (const double*)c->vP, (const double*)c->scal, slab, nsplit, pass,
+                       cost_part, ncp, csum, nb);
+    hipLaunchKernelGGL(k_cg_resid2, dim3(nb), dim3(VB), 0, c->stream, c->vG, c->vB, c->vR, c->vP, n, lambda, cconv, c->tail, c->vpart, nb, c->scal, in, out, c->cgtrace, pass, c->vpart + 512, merged ? 1 : 0,
+                       early ? (const double*)csum : cost_part, early ? -1 : ncp, c->hmir);
     c->rr_slot ^= 1;
     HIPCK(c, hipGetLastError());
     return 0;
@@ -449,6 +479,17 @@ int launch_diffnorm(tnml_ctx* c, const double* x, const double* y, size_t n, dou
     hipLaunchKernelGGL(k_diffnorm1, dim3(nb), dim3(VB), 0, c->stream, x, y, n, c->vpart);
     hipLaunchKernelGGL(k_norm2, dim3(1), dim3(VB), 0, c->stream, c->vpart, nb, out2, nout);
     HIPCK(c, hipGetLastError());
+    return 0;
+}
+// the same sums for the HOST: the per-workgroup partial pairs go straight to pinned memory (no second launch, no copy); the host adds
+// them in workgroup order (host_diffnorm_sum) once the stream has passed this point.  Returns the number of pairs.
+int launch_diffnorm_host(tnml_ctx* c, const double* x, const double* y, size_t n, double* part_host, int cap_pairs) {
+    ProfScope ps(c, KC_VEC);
+    const int nb = vec_blocks(n);
+    if (nb > cap_pairs) return tnml_fail(c, "diffnorm: %d partial pairs exceed the host block (%d)", nb, cap_pairs);
+    hipLaunchKernelGGL(k_diffnorm1, dim3(nb), dim3(VB), 0, c->stream, x, y, n, part_host);
+    HIPCK(c, hipGetLastError());
+    c->last_dn_pairs = nb;
     return 0;
 }
 

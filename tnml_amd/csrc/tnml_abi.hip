@@ -292,7 +292,7 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     if ((rc = dmalloc(c, &c->locals, 32))) return bail(rc);
     if ((rc = dmalloc(c, &c->scal, SC_N + (size_t)4 * TNML_MAX_PASS))) return bail(rc);   // CG scalars, then the per-pass trace: one copy to the host
     c->cgtrace = c->scal + SC_N;
-    if ((rc = dmalloc(c, &c->vpart, 1024))) return bail(rc);   // [256][2] phase-1 partials, then [256][2] for |p|^2 of the next pass
+    if ((rc = dmalloc(c, &c->vpart, 1024 + 16))) return bail(rc);   // [256][2] phase-1 partials, then [256][2] for |p|^2 of the next pass, then the summed cost of an output update
     if ((rc = dmalloc(c, &c->tB, c->mcap))) return bail(rc);
     if ((rc = dmalloc(c, &c->tB2, c->mcap))) return bail(rc);
     // sM holds (a) the Label-permuted bond matrix of the split, 40 maxm^2, and (b) the 16-padded site matrix of an
@@ -333,8 +333,9 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     }
     // speculative split: pinned mirrors [eigenvalues + 4 check values | CG scalars + trace] per bond update in flight, and spare site
     // tensors (two bond updates in flight replace two sites each; the Label site has its own size class)
-    c->hrep_stride = (size_t)c->svd_n + 8 + SC_N + (size_t)4 * TNML_MAX_PASS;
+    c->hrep_stride = (size_t)c->svd_n + 8 + SC_N + (size_t)4 * TNML_MAX_PASS + 512 + 64;      // eigenvalues + checks | scal + trace | norm partial pairs | after-SVD scalars
     if (hipHostMalloc((void**)&c->hrep, sizeof(double) * 2 * c->hrep_stride) != hipSuccess) return bail(tnml_fail(c, "hipHostMalloc failed"));
+    if (hipHostMalloc((void**)&c->hcost, sizeof(double) * 2 * (size_t)c->partial_cap * 12) != hipSuccess) return bail(tnml_fail(c, "hipHostMalloc failed"));
     memset(c->hrep, 0, sizeof(double) * 2 * c->hrep_stride);
     for (int k = 0; k < 4 + (c->c0 > 0 ? 2 : 0); ++k) {
         double* sp = nullptr;
@@ -370,6 +371,7 @@ int tnml_destroy(tnml_ctx* c) {
     for (size_t k = 0; k < c->spare_big.size(); ++k) (void)hipFree(c->spare_big[k]);
     for (int k = 0; k < 2; ++k) for (int u = 0; u < c->pend[k].nundo; ++u) if (c->pend[k].undo[u].old) (void)hipFree(c->pend[k].undo[u].old);
     if (c->hrep) (void)hipHostFree(c->hrep);
+    if (c->hcost) (void)hipHostFree(c->hcost);
     for (auto& sl : c->slabs) if (sl.base) (void)hipFree(sl.base);
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->ev_compute) (void)hipEventDestroy(c->ev_compute);
@@ -415,14 +417,16 @@ static int allreduce(tnml_ctx* c, double* buf, size_t count) {
     return 0;
 }
 int allreduce_sum(tnml_ctx* c, double* buf, size_t count) { return allreduce(c, buf, count); }
-static double* pend_host(tnml_ctx* c, int slot) { return c->h_scal + 2 * c->svd_n + 64 + SC_N + 4 * TNML_MAX_PASS + 64 * slot; }
+static double* pend_host(tnml_ctx* c, int slot) { return c->hrep + (size_t)slot * c->hrep_stride + c->svd_n + 8 + SC_N + 4 * TNML_MAX_PASS + 512; }
+static double* dn_host(tnml_ctx* c, int slot) { return c->hrep + (size_t)slot * c->hrep_stride + c->svd_n + 8 + SC_N + 4 * TNML_MAX_PASS; }
 // the carried slots of a finished bond update (after-SVD cost partials, fingerprint pieces) have just been summed over the ranks by an
 // all-reduce that covered them: hand them to the host report they belong to
 static int carry_deliver(tnml_ctx* c) {
     if (c->carry_slot < 0) return 0;
     const int slot = c->carry_slot;
     c->carry_slot = -1;
-    HIPCK(c, hipMemcpyAsync(pend_host(c, slot) + TNML_CARRY, c->tail + TNML_CARRY, sizeof(double) * TNML_CARRYN, hipMemcpyDeviceToHost, c->stream));
+    if (!c->pend[slot].carry_direct)      // (one rank: k_reduce_partials has mirrored the cost partials into the report block itself)
+        HIPCK(c, hipMemcpyAsync(pend_host(c, slot) + TNML_CARRY, c->tail + TNML_CARRY, sizeof(double) * TNML_CARRYN, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipEventRecord(c->pend[slot].ev2, c->stream));
     if (c->multi())                                        // delivered: the next packed all-reduce must not sum (and so scale by nranks) what is left here
         HIPCK(c, hipMemsetAsync(c->tail + TNML_CARRY, 0, sizeof(double) * TNML_CARRYN, c->stream));
@@ -1456,6 +1460,16 @@ int tnml_bond_update_begin(tnml_ctx* c, int b, int ha, const tnml_sweep_params* 
     tnml_bond_report* rep = &pr.rep;
     memset(rep, 0, sizeof *rep);
     pr.b = b; pr.ha = ha; pr.sp = *sp; pr.spec = false; pr.nundo = 0;
+    // what the report needs reaches its pinned block through the kernels that compute it (round 5: four copy kernels per bond update less):
+    // the CG scalars and trace (k_cg_step2 / k_cg_resid2 of the fp64 literal or merged CG), the norms of the new bond tensor (partial pairs,
+    // summed by tnml_bond_update_end), and -- on one rank -- the after-SVD cost partials (k_reduce_partials)
+    const bool exact_ = c->single() && c->cg_method == 2;
+    const bool fastc_ = c->single() && c->cg_method == 1;
+    pr.trace_mirrored = !c->single() && !exact_ && !fastc_ && !sp->report_costs;    // (the per-label variant's entry check writes its flag in k_cg_init2: it keeps the copy)
+    pr.carry_direct = !c->multi();
+    if (pr.trace_mirrored) { memset(trace_host(c, slot), 0, sizeof(double) * (SC_N + 4 * TNML_MAX_PASS)); c->hmir = trace_host(c, slot); }
+    memset(pend_host(c, slot), 0, sizeof(double) * 64);
+    struct MirrorOff { tnml_ctx* c; ~MirrorOff() { c->hmir = nullptr; } } mirror_off_{c};
     TCK(tnml_set_bond(c, b));                                         // :488
     if (c->env_budget_bytes > 0 && c->env_async) TCK(env_lookahead(c, b, ha));
     const BondPlan p = c->plan;
@@ -1483,7 +1497,8 @@ int tnml_bond_update_begin(tnml_ctx* c, int b, int ha, const tnml_sweep_params* 
     if (sp->report_costs) TCK(quadcost_device(c, sp->lambda_cost, &rep->cost_cg, nullptr, &rep->reg_cost_cg, nullptr, false));   // single.h:622,626
     if (c->carry_slot >= 0) { TCK(allreduce(c, c->tail + TNML_CARRY, TNML_CARRYN)); TCK(carry_deliver(c)); }   // (only when no packed all-reduce ran above: the exact solver)
     TCK(launch_unpack(c, pd, c->vB, c->tB));
-    TCK(cgrad_trace_enqueue(c, slot));                                // parsed by tnml_bond_update_end
+    c->hmir = nullptr;
+    if (!pr.trace_mirrored) TCK(cgrad_trace_enqueue(c, slot));        // parsed by tnml_bond_update_end
     TCK(svd_split_device(c, c->tB, b, ha, sp->cutoff, sp->maxm, sp->minm, &rep->truncerr, &rep->newm, nullptr, nullptr, slot));   // :519-522 (may run without its host synchronisation: tnml_ctx::spec_split)
     if (c->debug_nudge_rank == c->cfg.rank) TCK(launch_nudge(c, c->W[b].a));
     // replicas: the two site tensors the split just wrote must be bit-identical on every rank.  Their fingerprint goes into the
@@ -1508,11 +1523,18 @@ int tnml_bond_update_begin(tnml_ctx* c, int b, int ha, const tnml_sweep_params* 
     TCK(launch_bond_form(c, c->W[b], c->W[b + 1], c->tB2));           // :527
     TCK(launch_pack(c, pd, c->tB2, c->vB, nullptr));
     // :532 quadcost(newB); P and dP stay for the next bond update.  Its cost partials land in the CARRIED slots of the tail.
-    TCK(forward_pass(c, c->vB, LD_MODE_COST, c->tail + TNML_CARRY, true));
-    double* loc = c->locals + 16 * slot;                              // local scalars: slot 12 |newB|^2, 13/14 of :528,:530
-    TCK(launch_diffnorm(c, c->tB2, c->tB, ne, loc + 12, 3));          // |newB|^2 twice (slot 12 of quadcost, :528), |newB - B|^2 (:530)
-    double* hq = pend_host(c, slot);
-    HIPCK(c, hipMemcpyAsync(hq, loc, sizeof(double) * 16, hipMemcpyDeviceToHost, c->stream));
+    if (pr.carry_direct) {
+        // one rank: nothing on the device consumes these cost partials -- the per-block sums go straight to the pinned report block and the
+        // host adds them (no k_reduce_partials launch, no copy)
+        double* dev_partials = c->partials;
+        c->partials = c->hcost + (size_t)slot * c->partial_cap * 12;
+        const int rc_ = forward_pass(c, c->vB, LD_MODE_COST, c->tail + TNML_CARRY, true, false);
+        c->partials = dev_partials;
+        TCK(rc_);
+        pr.cost_rows = c->part_n;
+    } else TCK(forward_pass(c, c->vB, LD_MODE_COST, c->tail + TNML_CARRY, true));
+    TCK(launch_diffnorm_host(c, c->tB2, c->tB, ne, dn_host(c, slot), 256));   // |newB|^2 (slot 12 of quadcost, :528) and |newB - B|^2 (:530) as partial pairs
+    pr.dn_pairs = c->last_dn_pairs;
     const bool multi = c->multi();
     if (multi && c->defer_tail) c->carry_slot = slot;                 // summed by the next packed all-reduce (tnml_bond_update_end flushes otherwise)
     else {
@@ -1557,7 +1579,7 @@ int tnml_bond_update_end(tnml_ctx* c, tnml_bond_report* rep) {
         // the deferred check of the speculative split: its verdict came with the carried slots (summed over the ranks: every rank sees the same number)
         const double* hm = c->hrep + (size_t)slot * c->hrep_stride;
         const int n = pr.split_n;
-        if (hq[TNML_SPECSLOT] != 0.) {
+        if ((c->multi() ? hq[TNML_SPECSLOT] : hm[n + 4]) != 0.) {    // (one rank: straight from the mirror of the check values)
             // dependent vectors even after re-orthonormalisation (or the test hook): everything this bond update and the one begun after
             // it wrote is dropped -- site tensors back from their spare buffers -- and both run again, this one with the synchronous split
             // and its rocSOLVER fallback.  Rare (a few per sweep), so the repeat may cost what it costs.
@@ -1598,10 +1620,15 @@ int tnml_bond_update_end(tnml_ctx* c, tnml_bond_report* rep) {
     if (pr.fp && !fingerprint_agrees(hq + TNML_FPSLOT, c->cfg.nranks))   // every rank sees the same sums
         return tnml_fail(c, "bond %d: replicas of W.A(%d), W.A(%d) differ between ranks after the split", pr.rep.bond, pr.rep.bond, pr.rep.bond + 1);
     double t[13];
-    for (int l = 0; l < 12; ++l) t[l] = hq[TNML_CARRY + l];
-    t[12] = hq[12];
+    if (pr.carry_direct) {
+        const double* hp = c->hcost + (size_t)slot * c->partial_cap * 12;
+        for (int l = 0; l < 12; ++l) { double a = 0.; for (int r = 0; r < pr.cost_rows; ++r) a += hp[(size_t)r * 12 + l]; t[l] = a; }
+    } else for (int l = 0; l < 12; ++l) t[l] = hq[TNML_CARRY + l];
+    double nb2 = 0., df2 = 0.;                                        // the partial pairs of k_diffnorm1, in workgroup order
+    { const double* dp = dn_host(c, slot); for (int k = 0; k < pr.dn_pairs; ++k) { nb2 += dp[2 * k]; df2 += dp[2 * k + 1]; } }
+    t[12] = nb2;
     quadcost_parse(c, t, pr.lambda_cost, &pr.rep.cost_after_svd, pr.rep.label_cost, &pr.rep.reg_cost, &pr.rep.ncorrect);
-    pr.rep.norm_newB = std::sqrt(hq[13]); pr.rep.diff_B_newB = std::sqrt(hq[14]);
+    pr.rep.norm_newB = std::sqrt(nb2); pr.rep.diff_B_newB = std::sqrt(df2);
     if (rep) *rep = pr.rep;
     return 0;
 }

@@ -101,6 +101,7 @@ struct PendingReport {
     // and, when the deferred orthogonality check fails, to roll the bond update back and run it again with the synchronous split
     int b = 0, ha = 0; tnml_sweep_params sp{};
     bool spec = false; int split_n = 0, split_mk = 0; int nundo = 0; SiteUndo undo[2];
+    int dn_pairs = 0, cost_rows = 0; bool trace_mirrored = false, carry_direct = false;
 };
 
 struct tnml_ctx {
@@ -219,7 +220,10 @@ struct tnml_ctx {
     // tensors go to spare buffers; a failed check rolls the sites back and repeats the bond update with the synchronous split.
     int spec_split = 1; bool force_safe = false; long spec_redos = 0, spec_splits = 0; int debug_fail_split = -1;
     std::vector<double*> spare_small, spare_big;   // spare site-tensor buffers (capacity 2 maxm^2, x 10 for the Label site)
-    double* hrep = nullptr;                        // pinned: [2 slots][hrep_stride] = eigenvalues + check values of a speculative split, CG trace
+    double* hrep = nullptr;                        // pinned: [2 slots][hrep_stride] = eigenvalues + check values of a speculative split | CG scalars + trace | norm partials | after-SVD scalars
+    double* hmir = nullptr;                        // != nullptr while a bond update is being enqueued: the [scal | trace] mirror of its slot (the CG step kernels write it)
+    double* hcost = nullptr;                       // pinned: [2 slots][partial_cap][12]: one rank, the per-block partial sums of the after-SVD quadcost go there (the host adds them)
+    int last_dn_pairs = 0;                         // partial pairs the last launch_diffnorm_host wrote
     size_t hrep_stride = 0;
     double svd_last_dev0 = 0., svd_last_dev1 = 0.;   // max|Q^T Q - I| before the 1st / 2nd polish step of the last split
     long svd_fallbacks = 0, svd_cholqr = 0;
@@ -413,7 +417,8 @@ int launch_cg_step(tnml_ctx* c, size_t n, double lambda, int pass, bool merged =
 int launch_cg_resid(tnml_ctx* c, size_t n, double lambda, double cconv, int pass, bool merged = false, const double* cost_part = nullptr, int ncp = 0);   // merged: G holds A p, residual by recurrence
 int launch_cg_fast_resid0(tnml_ctx* c, size_t n, int pass);      // fast_conj: G <- r - a*G before launch_cg_resid   // nr, beta, r, cost, conv, p
 int launch_sqnorm(tnml_ctx* c, const double* x, size_t n, double* out);    // out[0] = |x|^2
-int launch_diffnorm(tnml_ctx* c, const double* x, const double* y, size_t n, double* out2, int nout = 2);  // out2[0]=|x|^2, out2[1]=|x-y|^2 (nout = 3: |x|^2, |x|^2, |x-y|^2)
+int launch_diffnorm(tnml_ctx* c, const double* x, const double* y, size_t n, double* out2, int nout = 2);
+int launch_diffnorm_host(tnml_ctx* c, const double* x, const double* y, size_t n, double* part_host, int cap_pairs);   // partial pairs to pinned memory, summed by the host  // out2[0]=|x|^2, out2[1]=|x-y|^2 (nout = 3: |x|^2, |x|^2, |x-y|^2)
 int launch_fill_f32(tnml_ctx* c, float* p, float v, size_t n);
 int launch_fill_f64(tnml_ctx* c, double* p, double v, size_t n);
 int launch_nudge(tnml_ctx* c, double* p);
