@@ -337,15 +337,22 @@ __global__ __launch_bounds__(64) void k_backtransform(const double* __restrict__
 #pragma unroll
     for (int e = 0; e < NE; ++e) { const int i = lane + 64 * e; z[e] = i < n ? (Z ? Z[i + (size_t)ldz * c] : (i == c ? 1. : 0.)) : 0.; }   // Z == nullptr: the identity (forms H_0 ... H_{n-2} itself)
     const int nr = nrefp ? (int)nrefp[0] : n - 1;                      // reflectors 0 .. nr-1 exist (the tridiagonalisation may stop early)
-    for (int k0 = nr - 1; k0 >= 0; k0 -= PF) {
-        double v[PF][NE], t[PF];
+    // software pipeline over batches of PF reflectors: the loads of batch b + 1 are in flight while batch b's PF dependent updates run
+    // (round 5: each batch used to wait for its own loads -- one L2 round trip per batch on the critical path of every column)
+    double v[PF][NE], t[PF], vn[PF][NE], tn[PF];
+    auto fetch = [&](int k0, double (&vv)[PF][NE], double (&tt)[PF]) {
 #pragma unroll
         for (int q = 0; q < PF; ++q) {
             const int k = k0 - q;
-            t[q] = k >= 0 ? tau[k] : 0.;
+            tt[q] = k >= 0 ? tau[k] : 0.;
 #pragma unroll
-            for (int e = 0; e < NE; ++e) { const int i = lane + 64 * e; v[q][e] = (k >= 0 && i < n && i > k) ? V[i + (size_t)ldv * k] : 0.; }
+            for (int e = 0; e < NE; ++e) { const int i = lane + 64 * e; vv[q][e] = (k >= 0 && i < n && i > k) ? V[i + (size_t)ldv * k] : 0.; }
         }
+    };
+    if (nr > 0) fetch(nr - 1, v, t);
+    for (int k0 = nr - 1; k0 >= 0; k0 -= PF) {
+        const bool more = k0 - PF >= 0;
+        if (more) fetch(k0 - PF, vn, tn);
 #pragma unroll
         for (int q = 0; q < PF; ++q) {
             double dot = 0.;
@@ -355,6 +362,14 @@ __global__ __launch_bounds__(64) void k_backtransform(const double* __restrict__
             const double f = t[q] * dot;
 #pragma unroll
             for (int e = 0; e < NE; ++e) z[e] -= f * v[q][e];
+        }
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+                t[q] = tn[q];
+#pragma unroll
+                for (int e = 0; e < NE; ++e) v[q][e] = vn[q][e];
+            }
         }
     }
 #pragma unroll
@@ -389,288 +404,7 @@ int eigh_backtransform(tnml_ctx* c, const double* V, const double* tau, int n, c
     return 0;
 }
 
-// ==========================================================================================
-// Tridiagonal eigenproblem in one launch: all eigenvalues by Sturm bisection (one lane per eigenvalue),
-// then the eigenvectors of the `mk` largest by inverse iteration (one lane per vector, LAPACK
-// dlagtf/dlagts-style LU with partial pivoting, scratch in global memory laid out [k][lane] so that the
-// lanes' sequential sweeps stay coalesced).  The vectors are NOT re-orthogonalised against each other
-// here (that is what makes LAPACK's dstein sequential); the caller polishes them with Newton-Schulz
-// steps, verifies Z^T Z = I and falls back to rocSOLVER dstedc when the check fails.
-// Replaces rocSOLVER dstedc, whose ~140 tiny launches cost ~1.0 ms per bond split at n=240.
-// ==========================================================================================
-struct TeigArgs {
-    const double* D; const double* E; int n;      // tridiagonal (E has n-1 entries)
-    double* W;                                     // eigenvalues, ascending (out of k_tridiag_rank)
-    int mk; double* Z; int ldz;                    // out: eigenvectors of the mk largest (column g = g-th largest)
-    // splitting workspace (k_tridiag_split): Es = E with negligible couplings zeroed, mu[i] = eigenvalue owned by
-    // row i (the (i - lo[i])-th smallest of its unreduced block), blo/bhi = block [lo, hi) of row i, src[g] = row
-    // owning the g-th largest eigenvalue
-    double* Es; double* mu; int* blo; int* bhi; int* src;
-};
-
-// Split T into unreduced blocks at couplings |e_k| <= eps*||T|| (a normwise backward-stable perturbation, the
-// same size as the error of the Gram matrix itself).  A trained bond tensor is numerically rank deficient: its
-// Gram matrix has a graded spectrum whose tail sits below eps*lambda_max, and the tridiagonal form decouples
-// there.  Eigenvectors of different blocks have disjoint supports -- exactly orthogonal -- and inverse iteration
-// inside a block works at the block's own scale.  (Without the split the tail is one big cluster at the
-// resolution of inverse iteration, and its vectors come out far from orthogonal.)
-#define TEIG_MAXN 640
-__global__ __launch_bounds__(1024) void k_tridiag_split(TeigArgs T) {
-    __shared__ double s_red[1024];
-    __shared__ int s_cut[1025];
-    const int n = T.n, i = threadIdx.x;
-    double rs = 0.;
-    if (i < n) rs = fabs(T.D[i]) + (i > 0 ? fabs(T.E[i - 1]) : 0.) + (i < n - 1 ? fabs(T.E[i]) : 0.);
-    s_red[i] = rs;
-    __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) { if (i < s) s_red[i] = fmax(s_red[i], s_red[i + s]); __syncthreads(); }
-    const double thr = 2.220446049250313e-16 * s_red[0];
-    if (i < n) {
-        const bool cut = (i == n - 1) || !(fabs(T.E[i]) > thr);      // block ends after row i
-        s_cut[i] = cut ? 1 : 0;
-        T.Es[i] = cut ? 0. : T.E[i];
-    }
-    __syncthreads();
-    if (i < n) {
-        int lo = i; while (lo > 0 && !s_cut[lo - 1]) --lo;
-        int hi = i; while (!s_cut[hi]) ++hi;
-        T.blo[i] = lo; T.bhi[i] = hi + 1;
-    }
-}
-
-// Sturm count over rows [lo, hi): number of eigenvalues of that block < x = sign changes of the leading
-// principal minors.  Three-term recurrence on the block scaled to unit norm (s_de[j] = {d_j, e_{j-1}^2} / norm),
-// one FMA on the dependent path per step; magnitudes are renormalised every 4 steps (growth per step <= ~3,
-// decay per step >= ~1e-17, thresholds 1e+-100); a zero minor takes the sign opposite to its predecessor.
-static __device__ __forceinline__ int sturm_count(const double2* s_de, int lo, int hi, double x) {
-    double pm2 = 1., pm1 = s_de[lo].x - x;
-    int cnt = pm1 < 0. ? 1 : 0;
-    int j = lo + 1;
-    for (; j + 3 < hi; j += 4) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const double2 de = s_de[j + u];
-            double p = fma(de.x - x, pm1, -de.y * pm2);
-            if (p == 0.) p = pm1 < 0. ? 1e-300 : -1e-300;
-            cnt += ((__double2hiint(p) ^ __double2hiint(pm1)) >> 31) & 1;
-            pm2 = pm1; pm1 = p;
-        }
-        const double ap = fabs(pm1);
-        if (ap > 1e100) { pm1 *= 1e-100; pm2 *= 1e-100; }
-        else if (ap < 1e-100) { pm1 *= 1e100; pm2 *= 1e100; }
-    }
-    for (; j < hi; ++j) {
-        const double2 de = s_de[j];
-        double p = fma(de.x - x, pm1, -de.y * pm2);
-        if (p == 0.) p = pm1 < 0. ? 1e-300 : -1e-300;
-        cnt += ((__double2hiint(p) ^ __double2hiint(pm1)) >> 31) & 1;
-        pm2 = pm1; pm1 = p;
-    }
-    return cnt;
-}
-
-// eigenvalue owned by row i = the (i - lo)-th smallest of its block, by 65-section: one wave per eigenvalue,
-// every lane probes one interior point of the bracket per round, so the bracket shrinks 65x per round (9-10
-// rounds to fp64 resolution instead of 53 bisections).  The recurrence is a pure latency chain, so width is
-// free: one wave per row on as many CUs.
-__global__ __launch_bounds__(64) void k_tridiag_eigvals(TeigArgs T) {
-    __shared__ double2 s_de[TEIG_MAXN];
-    __shared__ double s_bounds[4];
-    const int lane = threadIdx.x;
-    const int i = blockIdx.x;
-    const int lo_r = T.blo[i], hi_r = T.bhi[i];
-    if (hi_r - lo_r == 1) { if (lane == 0) T.mu[i] = T.D[i]; return; }
-    {   // Gershgorin interval and norm of the block (lanes stride over its rows, then a wave reduction)
-        double gl = 1e300, gu = -1e300, tn = 0.;
-        for (int j = lo_r + lane; j < hi_r; j += 64) {
-            const double r = (j > lo_r ? fabs(T.Es[j - 1]) : 0.) + (j < hi_r - 1 ? fabs(T.Es[j]) : 0.);
-            gl = fmin(gl, T.D[j] - r); gu = fmax(gu, T.D[j] + r);
-            tn = fmax(tn, fabs(T.D[j]) + r);
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            gl = fmin(gl, __shfl_xor(gl, off)); gu = fmax(gu, __shfl_xor(gu, off)); tn = fmax(tn, __shfl_xor(tn, off));
-        }
-        if (!(tn > 0.)) tn = 1.;
-        const double pad = 2.2e-16 * tn * (hi_r - lo_r) + 1e-300;
-        if (lane == 0) { s_bounds[0] = (gl - pad) / tn; s_bounds[1] = (gu + pad) / tn; s_bounds[2] = tn; }
-    }
-    __syncthreads();
-    const double tn = s_bounds[2], itn = 1. / tn;
-    for (int k = lo_r + lane; k < hi_r; k += 64) {
-        const double e = k > lo_r ? T.Es[k - 1] * itn : 0.;
-        s_de[k] = make_double2(T.D[k] * itn, e * e);
-    }
-    __syncthreads();
-    const int li = i - lo_r;                                     // local eigenvalue index (ascending)
-    double lo = s_bounds[0], hi = s_bounds[1];
-    for (int it = 0; it < 16; ++it) {
-        const double w = hi - lo;
-        if (!(w > 4.4e-16 * (1. + fmax(fabs(lo), fabs(hi))))) break;
-        const double step = w * (1. / 65.);
-        const double x = lo + step * (lane + 1);
-        const bool below = sturm_count(s_de, lo_r, hi_r, x) > li;                // eigenvalue li is below x
-        const unsigned long long mask = __ballot(below);
-        const int p = mask ? __ffsll((long long)mask) - 1 : 64;                 // first probe above the eigenvalue
-        const double nlo = p > 0 ? lo + step * p : lo;
-        const double nhi = p < 64 ? lo + step * (p + 1) : hi;
-        if (!(nhi > nlo)) break;
-        lo = nlo; hi = nhi;
-    }
-    if (lane == 0) T.mu[i] = 0.5 * (lo + hi) * tn;
-}
-
-// global order: row i owns the g-th largest eigenvalue, g = #{j : mu_j > mu_i or (mu_j == mu_i and j < i)}
-__global__ __launch_bounds__(1024) void k_tridiag_rank(TeigArgs T) {
-    __shared__ double s_mu[1024];
-    const int n = T.n, i = threadIdx.x;
-    s_mu[i] = i < n ? T.mu[i] : 0.;
-    __syncthreads();
-    if (i >= n) return;
-    const double mi = s_mu[i];
-    int g = 0;
-    for (int j = 0; j < n; ++j) { const double mj = s_mu[j]; g += (mj > mi || (mj == mi && j < i)) ? 1 : 0; }
-    T.W[n - 1 - g] = mi;
-    T.src[g] = i;
-}
-
-// eigenvectors of the mk largest eigenvalues by inverse iteration inside the owning block; 16 vectors per
-// workgroup, their LU factors and iterates live in LDS as [array][k][lane]
-// IV_L: vectors per workgroup (16 up to n = 248; 8 / 4 for larger blocks, whose LU factors would not fit otherwise);
-// BIG: the interchange flags live in LDS bytes instead of four 64-bit registers
-template <int IV_L, bool BIG>
-__global__ __launch_bounds__(64) void k_tridiag_invit(TeigArgs T) {
-    extern __shared__ __attribute__((aligned(16))) double iv_lds[];
-    const int n = T.n, lane = threadIdx.x;
-    const int ns = (n + 63) & ~63;
-    double* s_d = iv_lds;                 // [n]
-    double* s_e = s_d + ns;               // [n]
-    double* a = s_e + ns;                 // U diagonal            [k][IV_L]
-    double* b = a + (size_t)n * IV_L;     // U first superdiagonal
-    double* c = b + (size_t)n * IV_L;     // L multipliers
-    double* d2 = c + (size_t)n * IV_L;    // U second superdiagonal
-    double* x = d2 + (size_t)n * IV_L;    // iterate
-    unsigned char* pvb = reinterpret_cast<unsigned char*>(x + (size_t)n * IV_L);   // BIG: interchange flags [k][IV_L]
-    for (int k = lane; k < n; k += 64) { s_d[k] = T.D[k]; s_e[k] = k < n - 1 ? T.Es[k] : 0.; }
-    __syncthreads();
-    const int g = blockIdx.x * IV_L + lane;           // g-th largest eigenvalue
-    if (lane >= IV_L || g >= T.mk) return;
-    const int row = T.src[g];
-    const int lo = T.blo[row], hi = T.bhi[row];       // the vector is supported on rows [lo, hi)
-    double* zc = T.Z + (size_t)T.ldz * g;
-    for (int k = 0; k < lo; ++k) zc[k] = 0.;
-    for (int k = hi; k < n; ++k) zc[k] = 0.;
-    if (hi - lo == 1) { zc[lo] = 1.; return; }
-    double tnorm = 0.;
-    for (int k = lo; k < hi; ++k) tnorm = fmax(tnorm, fabs(s_d[k]) + (k > lo ? fabs(s_e[k - 1]) : 0.) + (k < hi - 1 ? fabs(s_e[k]) : 0.));
-    const double lam = T.mu[row];
-    const double tiny = 2.2e-16 * tnorm + 1e-300;
-#define IX(k) ((k) * IV_L + lane)
-    // LAPACK dlagtf: (T - lam I) = P L U with partial pivoting; the rows are generated on the fly.
-    // Where the time of this kernel goes (tools/probe/probe_invit.hip, 131-row block): factorisation 45 us, reciprocal pivots 21 us,
-    // two sweeps 47 us of 131 -- the factorisation is one dependent chain per row, and in its straightforward form it holds two
-    // IEEE divisions on divergent branches (the lanes of a wave pivot differently).  Here the pivot choice is a select, the one
-    // multiplier of a row comes from v_rcp_f64 + two Newton steps, and the reciprocal pivot the solves need is formed in the same
-    // iteration, off the chain (no second pass over the block).
-    auto frcp = [](double x) {
-        if (!(fabs(x) > 1e-290 && fabs(x) < 1e290)) return 1. / x;    // out of the fast path's range: IEEE division
-        double y = __builtin_amdgcn_rcp(x);
-        double e = fma(-x, y, 1.0); y = fma(y, e, y);
-        e = fma(-x, y, 1.0); y = fma(y, e, y);
-        return y;
-    };
-    auto rpiv = [&](double pk) { if (fabs(pk) < tiny) pk = pk < 0. ? -tiny : tiny; return frcp(pk); };   // tiny pivots perturbed (dlagts job = -1 in spirit): the solves only multiply
-    unsigned long long pv0 = 0, pv1 = 0, pv2 = 0, pv3 = 0;   // interchange flags, n <= 256 (named: no dynamic register indexing)
-    double ak = s_d[lo] - lam, bk = s_e[lo];
-    double scale1 = fabs(ak) + fabs(bk);
-    for (int k = lo; k < hi - 1; ++k) {
-        const double ck = s_e[k];                       // sub-diagonal entry of row k+1
-        const double ak1 = s_d[k + 1] - lam;
-        const double bk1 = k < hi - 2 ? s_e[k + 1] : 0.;
-        const double scale2 = fabs(ck) + fabs(ak1) + fabs(bk1);
-        // dlagtf's test |c_k|/scale2 <= |a_k|/scale1, cross-multiplied (no divisions); c_k = 0: nothing to eliminate
-        const bool zero = ck == 0.;
-        const bool sw = !zero && !(fabs(ck) * scale1 <= fabs(ak) * scale2);       // interchange rows k, k+1
-        const double num = sw ? ak : ck, den = sw ? ck : ak;
-        const double mult = zero ? 0. : num * frcp(den);
-        const double piv = sw ? ck : ak;
-        b[IX(k)] = sw ? ak1 : bk; c[IX(k)] = mult; d2[IX(k)] = sw ? bk1 : 0.;
-        const double nak = (sw ? bk : ak1) - mult * (sw ? ak1 : bk);
-        const double nbk = sw ? -mult * bk1 : bk1;
-        if (BIG) pvb[IX(k)] = sw ? 1 : 0;
-        else {
-            const unsigned long long bit = sw ? 1ull << (k & 63) : 0ull; const int wq = k >> 6;
-            pv0 |= wq == 0 ? bit : 0ull; pv1 |= wq == 1 ? bit : 0ull; pv2 |= wq == 2 ? bit : 0ull; pv3 |= wq == 3 ? bit : 0ull;
-        }
-        a[IX(k)] = rpiv(piv);                           // reciprocal pivot
-        scale1 = scale2;
-        ak = nak; bk = nbk;
-    }
-    a[IX(hi - 1)] = rpiv(ak); b[IX(hi - 1)] = 0.; d2[IX(hi - 1)] = 0.;
-    d2[IX(hi - 2)] = 0.;
-    // start vector: deterministic pseudo-random entries in (-1, 1), different for every vector
-    unsigned int seed = 12345u + 7919u * (unsigned)g;
-    for (int k = lo; k < hi; ++k) { seed = seed * 1664525u + 1013904223u; x[IX(k)] = ((seed >> 8) * (1.0 / 8388608.0)) - 1.0; }
-    double xscale = 1.;                                     // max-norm scaling of the iterate, applied when the next pass reads it
-    for (int iter = 0; iter < 2; ++iter) {                 // the shift is exact to round-off: two sweeps suffice
-        // forward: apply (P L)^-1 (the interchange is a select: the lanes of a wave pivot differently)
-        double xk = x[IX(lo)] * xscale;
-        for (int k = lo; k < hi - 1; ++k) {
-            bool sw;
-            if (BIG) sw = pvb[IX(k)] != 0;
-            else {
-                const int wq = k >> 6;
-                const unsigned long long word = wq == 0 ? pv0 : wq == 1 ? pv1 : wq == 2 ? pv2 : pv3;
-                sw = (word >> (k & 63)) & 1;
-            }
-            const double xk1 = x[IX(k + 1)] * xscale, m = c[IX(k)];
-            const double keep = sw ? xk1 : xk, go = sw ? xk : xk1;
-            x[IX(k)] = keep;
-            xk = go - m * keep;
-        }
-        x[IX(hi - 1)] = xk;
-        // back substitution
-        double xn1 = 0., xn2 = 0., vmax = 0.;
-        for (int k = hi - 1; k >= lo; --k) {
-            const double t = (x[IX(k)] - b[IX(k)] * xn1 - d2[IX(k)] * xn2) * a[IX(k)];
-            x[IX(k)] = t;
-            xn2 = xn1; xn1 = t;
-            vmax = fmax(vmax, fabs(t));
-        }
-        xscale = vmax > 0. ? 1. / vmax : 1.;               // keeps the iterates in range
-    }
-    double nrm2 = 0.;
-    for (int k = lo; k < hi; ++k) { const double v = x[IX(k)] * xscale; nrm2 = fma(v, v, nrm2); }
-    const double inv = nrm2 > 0. ? 1. / sqrt(nrm2) : 0.;
-    for (int k = lo; k < hi; ++k) zc[k] = (x[IX(k)] * xscale) * inv;
-#undef IX
-}
-
-// scratch: TEIG_SCRATCH_DOUBLES doubles
-int eigh_tridiag_eig_v1(tnml_ctx* c, const double* D, const double* E, int n, double* W, int mk, double* Z, int ldz, double* scratch) {
-    if (n > TEIG_MAXN || mk > n) return tnml_fail(c, "eigh_tridiag_eig: n=%d mk=%d exceed %d", n, mk, TEIG_MAXN);
-    int* is = (int*)(scratch + 2 * TEIG_MAXN);
-    TeigArgs t{D, E, n, W, mk, Z, ldz, scratch, scratch + TEIG_MAXN, is, is + TEIG_MAXN, is + 2 * TEIG_MAXN};
-    hipLaunchKernelGGL(k_tridiag_split, dim3(1), dim3(1024), 0, c->stream, t);
-    hipLaunchKernelGGL(k_tridiag_eigvals, dim3(n), dim3(64), 0, c->stream, t);
-    hipLaunchKernelGGL(k_tridiag_rank, dim3(1), dim3(1024), 0, c->stream, t);
-    const int ns = (n + 63) & ~63;
-    const int ivl = n <= 248 ? 16 : (n <= 448 ? 8 : 4);        // (16 vectors of 249..256 rows would need 161-168 KB)
-    const size_t lds = sizeof(double) * (2 * (size_t)ns + (size_t)5 * n * ivl) + (ivl != 16 ? (size_t)n * ivl : 0);   // + the byte flags of the BIG instantiations
-    if (lds > 160 * 1024) return tnml_fail(c, "eigh_tridiag_eig: %zu bytes of LDS for n=%d", lds, n);
-    if (!c->attr_invit) {
-        (void)hipFuncSetAttribute((const void*)k_tridiag_invit<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)k_tridiag_invit<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)k_tridiag_invit<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        c->attr_invit = true;
-    }
-    const dim3 grid((mk + ivl - 1) / ivl);
-    if (ivl == 16)     hipLaunchKernelGGL((k_tridiag_invit<16, false>), grid, dim3(64), lds, c->stream, t);
-    else if (ivl == 8) hipLaunchKernelGGL((k_tridiag_invit<8, true>), grid, dim3(64), lds, c->stream, t);
-    else               hipLaunchKernelGGL((k_tridiag_invit<4, true>), grid, dim3(64), lds, c->stream, t);
-    HIPCK(c, hipGetLastError());
-    return 0;
-}
+// (the tridiagonal eigenproblem -- eigenvalues by multisection, eigenvectors by inverse iteration -- lives in eigh_tri.hip since round 5)
 
 // C = 1.5 I - 0.5 S (Newton-Schulz polish of a nearly orthonormal basis), dev[0] = max |S - I|
 // (one workgroup of 1024 lanes, a column per group of lanes: 14 independent loads per lane at m = 120 instead of a 57-deep chain)

@@ -253,7 +253,12 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
         else hmir = nullptr;
     }
     if (tri) {
-        TCK(eigh_tridiagonalize(c, c->sG, n, c->sD, c->sE2, c->sTau, c->sV, c->sytrd_exit ? 1e-15 : 0.));   // sG is a Gram matrix: rank-adaptive exit at ~4 eps trace(G), the size of the error G = B^T B carries anyway
+        // sG is a Gram matrix: rank-adaptive exit once the trailing block weighs less than the error G = B^T B carries anyway -- ~4 eps of
+        // the trace in the fp64 / fp32 modes; in the bf16 study modes the bond tensor itself carries the relative noise e of the bf16 operands of
+        // its gradient (2^-8 plain, ~2^-16 with hi + lo operands), eigenvalues of G below (e / 8)^2 trace(G) are that noise, and chasing them
+        // costs the whole chain (config 5, m = 300: 598 steps instead of ~330 -- the bf16 bond update was SLOWER than the fp32 one for it)
+        const double exit_tol = c->cfg.dtype == TNML_BF16 ? 2.4e-7 : (c->cfg.dtype == TNML_BF16X3 ? 3.6e-12 : 1e-15);
+        TCK(eigh_tridiagonalize(c, c->sG, n, c->sD, c->sE2, c->sTau, c->sV, c->sytrd_exit ? exit_tol : 0.));
         if (own_eig) { TCK(eigh_tridiag_eig(c, c->sD, c->sE2, n, c->sW, mk, c->sC, n, c->sScr, hmir)); evals = c->sW; }
         else RBCK(c, rocsolver_dstedc(c->blas, rocblas_evect_tridiagonal, n, c->sD, c->sE2, c->sC, n, c->sInfo));
     } else {

@@ -692,6 +692,10 @@ static int env_fetch(tnml_ctx* c, int j) {
     if (async) TCK(env_copy_stream(c));
     TCK(slot_acquire(c, e, m, L, async ? c->copy_stream : c->stream));     // (clears on_host; the host copy stays valid until the copy below has read it)
     if (async) {
+        // the unit may have been vacated by slot_release a moment ago (no event of its own): order the copy behind everything the compute
+        // stream has been given so far -- work that is normally long finished, so the overlap with the current bond update stays
+        HIPCK(c, hipEventRecord(c->ev_compute, c->stream));
+        HIPCK(c, hipStreamWaitEvent(c->copy_stream, c->ev_compute, 0));
         HIPCK(c, hipMemcpyAsync(e.ptr, e.host, bytes, hipMemcpyHostToDevice, c->copy_stream));
         if (!e.ev) HIPCK(c, hipEventCreateWithFlags(&e.ev, hipEventDisableTiming));
         HIPCK(c, hipEventRecord(e.ev, c->copy_stream));
@@ -760,7 +764,8 @@ static int shift_core(tnml_ctx* c, int cs, bool from_left, const void* src, int 
         f.NTp = c->NTp; f.L = Lout; f.env64 = c->env64(); f.out32 = !c->env64() && !acc_out;
         // the Label-carrying shift at m = 120 with the site matrix resident in registers (kernels_res.hip)
         if (c->shift_res && c->env64() && !acc_out && src && Le == TNML_NL && A.L == 1 && m_in == 120 && m_out == 120 && d.Kp == 240 && d.Np == 128 &&
-            (c->shift_res >= 2 || c->NTp >= 7680)) {
+            (c->shift_res >= 2 || c->NTp >= 7680) &&
+            (size_t)TNML_NL * m_in * c->NTp * sizeof(double) < ((size_t)1 << 32)) {      // (32-bit lane offsets: beyond ~447 000 images per rank the generic kernel takes over)
             ShiftResArgs sa{(const double*)src, (size_t)m_in * c->NTp, (const double*)phi_site(c, cs), c->sM, (double*)dst, (size_t)m_out * c->NTp, m_out, c->NTp, Lout};
             return launch_shift_res(c, sa);
         }
@@ -794,6 +799,7 @@ static int shift_site(tnml_ctx* c, int cs, int ps, bool from_left) {
 }
 
 int tnml_env_init(tnml_ctx* c) {       // TrainStates::init, fixedL.cc:122-157
+    CollScope coll_(c);                // every rank calls it in step: a rank that fails here (host tier out of memory) tells its peers at once
     HIPCK(c, hipSetDevice(c->cfg.device));
     if (!c->data_set) return tnml_fail(c, "tnml_env_init: training data not set");
     TCK(check_W(c));
@@ -802,6 +808,7 @@ int tnml_env_init(tnml_ctx* c) {       // TrainStates::init, fixedL.cc:122-157
     return tnml_set_bond(c, 1);                                                            // :156
 }
 int tnml_shift_env(tnml_ctx* c, int b, int from_left) {   // TrainStates::shiftE, fixedL.cc:192-233
+    CollScope coll_(c);
     HIPCK(c, hipSetDevice(c->cfg.device));
     if (b < 1 || b > c->N - 1) return tnml_fail(c, "tnml_shift_env: bond %d out of range", b);
     const int cs = from_left ? b : b + 1;              // :196
@@ -919,7 +926,14 @@ static PackDesc bond_pack_desc(const BondPlan& p) {
     d.Kp = p.Kp; d.Np = p.Np;
     return d;
 }
+static int set_bond_impl(tnml_ctx* c, int b);
 int tnml_set_bond(tnml_ctx* c, int b) {
+    CollScope coll_(c);
+    const int rc = set_bond_impl(c, b);
+    if (rc) { c->currb = -1; c->plan = BondPlan(); }          // no dangling environment pointers after a failed setBond: the next use has to set a bond again
+    return rc;
+}
+static int set_bond_impl(tnml_ctx* c, int b) {
     if (b < 1 || b > c->N - 1) return tnml_fail(c, "tnml_set_bond: bond %d out of range", b);
     TCK(check_W(c));
     const int lc = b - 1, rc = b + 2;                         // :164-165
@@ -995,7 +1009,8 @@ static int forward_pass(tnml_ctx* c, const double* vec, int mode, double* tail, 
         // the bond matrix resident in the registers of a pair of workgroups (kernels_res.hip): from 7 680 images per rank on (the 7 500-image
         // shard of an 8-GPU run: 0.162 ms per bond update against 0.250 for the feature GEMM + label dot pair, profiles/r04_shard7500_res_kernels.txt)
         if (c->fwd_res && c->Ppart && c->env64() && !c->single() && p.kind != 2 && p.Kp == 240 && p.Np == 240 && p.mI == 120 && p.mO == 120 &&
-            (c->fwd_res >= 2 || c->NTp >= 7680)) {
+            (c->fwd_res >= 2 || c->NTp >= 7680) &&
+            (size_t)TNML_NL * ustride * sizeof(double) < ((size_t)1 << 32)) {           // (32-bit lane offsets of k_fwd_res: larger shards fall through to the kernels below)
             FwdResArgs fr{(const double*)p.EI, (const double*)p.phiI, vec, (const double*)p.phiO, (const double*)p.EX, ustride, c->NTp, c->NTp / 32, c->Ppart};
             TCK(launch_fwd_res(c, fr));
             PfinishArgs pf{2, c->Ppart, nullptr, nullptr, nullptr, nullptr, c->label, c->NTp, (double*)a.P, (double*)a.dP, mode, c->partials, c->counters, tail, mode == LD_MODE_PAP ? 1 : 0};

@@ -441,7 +441,6 @@ int split_gemm(tnml_ctx* c, bool ta, bool tb, int M, int N, int K, const double*
 // ---- eigh.hip -----------------------------------------------------------------------------
 int eigh_tridiagonalize(tnml_ctx* c, const double* A, int n, double* D, double* E, double* tau, double* V, double psd_tol = 0.);   // tau: n doubles, tau[n-1] = number of reflectors
 int eigh_tridiag_eig(tnml_ctx* c, const double* D, const double* E, int n, double* W, int mk, double* Z, int ldz, double* scratch, double* W_host = nullptr);      // eigh_tri.hip; W_host: pinned mirror of W (may be null)
-int eigh_tridiag_eig_v1(tnml_ctx* c, const double* D, const double* E, int n, double* W, int mk, double* Z, int ldz, double* scratch);   // round-4 kernels (eigh.hip), kept for the A/B probe
 int eigh_ns_matrix(tnml_ctx* c, const double* S, double* Cm, int m, double* dev);
 int eigh_chol_rinv(tnml_ctx* c, const double* S, int m, double* Rinv, double* flag, int zero_prev = 0);   // m <= 128; zero_prev: also clears flag[-1]
 #define TNML_CHOL_MAXM 128
