@@ -697,7 +697,9 @@ def main():
             for cls, kname, per_step_flops, alg_bytes in (
                     ("fwd_fused" if fused else "fgemm_fwd", out["roofline"]["kernel"], flops_per_pass, float(np.mean([NTl * (11 * min(r["mL"], r["mR"]) * 8 + 2 * 2 * 8 + 4) for r in timed])) if timed else None),
                     ("bgemm", "k_bgemm64 (gradient GEMM dP*dag(t.v), Z built while staging)", flops_per_pass, float(np.mean([NTl * (11 * min(r["mL"], r["mR"]) * 8 + 2 * 2 * 8 + 10 * 8) for r in timed])) if timed else None),
-                    ("fgemm_shift", "k_shift_res / k_fgemm64 (shiftE)", sh, None)):
+                    ("fgemm_shift", "k_shift_res / k_fgemm64 (shiftE)", sh,
+                     float(np.mean([NTl * 8.0 * ((r["mL"] if r["half"] == 1 else r["mR"]) + r["newm"]) * (shift_flops(r, NTl, N, single) / (2.0 * NTl * 2 * (r["mL"] if r["half"] == 1 else r["mR"]) * r["newm"])) + NTl * 16.0
+                                    for r in timed])) if timed else None)):
                 nl_, ms_ = prof.get(cls, (0, 0.0))
                 if not nl_:
                     continue

@@ -337,22 +337,17 @@ __global__ __launch_bounds__(64) void k_backtransform(const double* __restrict__
 #pragma unroll
     for (int e = 0; e < NE; ++e) { const int i = lane + 64 * e; z[e] = i < n ? (Z ? Z[i + (size_t)ldz * c] : (i == c ? 1. : 0.)) : 0.; }   // Z == nullptr: the identity (forms H_0 ... H_{n-2} itself)
     const int nr = nrefp ? (int)nrefp[0] : n - 1;                      // reflectors 0 .. nr-1 exist (the tridiagonalisation may stop early)
-    // software pipeline over batches of PF reflectors: the loads of batch b + 1 are in flight while batch b's PF dependent updates run
-    // (round 5: each batch used to wait for its own loads -- one L2 round trip per batch on the critical path of every column)
-    double v[PF][NE], t[PF], vn[PF][NE], tn[PF];
-    auto fetch = [&](int k0, double (&vv)[PF][NE], double (&tt)[PF]) {
+    // (a software pipeline over the batches -- the loads of batch b + 1 in flight during batch b's updates -- measured SLOWER in round 5:
+    // 36.5 us against 29.6; the second register set costs more than the L2 round trip it hides)
+    for (int k0 = nr - 1; k0 >= 0; k0 -= PF) {
+        double v[PF][NE], t[PF];
 #pragma unroll
         for (int q = 0; q < PF; ++q) {
             const int k = k0 - q;
-            tt[q] = k >= 0 ? tau[k] : 0.;
+            t[q] = k >= 0 ? tau[k] : 0.;
 #pragma unroll
-            for (int e = 0; e < NE; ++e) { const int i = lane + 64 * e; vv[q][e] = (k >= 0 && i < n && i > k) ? V[i + (size_t)ldv * k] : 0.; }
+            for (int e = 0; e < NE; ++e) { const int i = lane + 64 * e; v[q][e] = (k >= 0 && i < n && i > k) ? V[i + (size_t)ldv * k] : 0.; }
         }
-    };
-    if (nr > 0) fetch(nr - 1, v, t);
-    for (int k0 = nr - 1; k0 >= 0; k0 -= PF) {
-        const bool more = k0 - PF >= 0;
-        if (more) fetch(k0 - PF, vn, tn);
 #pragma unroll
         for (int q = 0; q < PF; ++q) {
             double dot = 0.;
@@ -362,14 +357,6 @@ __global__ __launch_bounds__(64) void k_backtransform(const double* __restrict__
             const double f = t[q] * dot;
 #pragma unroll
             for (int e = 0; e < NE; ++e) z[e] -= f * v[q][e];
-        }
-        if (more) {
-#pragma unroll
-            for (int q = 0; q < PF; ++q) {
-                t[q] = tn[q];
-#pragma unroll
-                for (int e = 0; e < NE; ++e) v[q][e] = vn[q][e];
-            }
         }
     }
 #pragma unroll
