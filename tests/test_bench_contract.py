@@ -34,6 +34,9 @@ def test_bench_json_line_whole_sweep():
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 78.6
     assert r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert r["traffic"] is None                                       # the PMC record belongs to the full workload only
+    rk = d["roofline_kernels"]                                        # every matrix-pipe kernel timed live (toy workloads: the forward kernel only)
+    assert rk and all(v["bound"] == "mfma" and v["frac"] > 0 and v["launches"] > 0 for v in rk.values())
+    assert r.get("dominant_by_ms_per_step") is True and "not a BASELINE configuration" in d["config"]["workload"]
     rs = d["roofline_step"]
     assert rs["achieved"] > 0 and abs(rs["frac"] - rs["achieved"] / rs["peak"]) < 1e-12 and rs["frac"] == rs["frac_executed"]      # the step figure is the EXECUTED one
     assert rs["algorithmic_gflop_per_step"] >= rs["executed_gflop_per_step"] > 0

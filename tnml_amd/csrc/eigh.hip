@@ -52,7 +52,7 @@ static __device__ __forceinline__ void wave_lds_fence() {
 #endif
 #define SVI(i) (V3_PAD ? (i) + ((i) >> 3) : (i))
 #define V3_VLEN (240 + 32)
-#define V3_SMEM_DOUBLES (T8_MAXNB * V3_LD + 2 * V3_VLEN + 2 * 240 + 32)
+#define V3_SMEM_DOUBLES ((T8_MAXNB + 1) * V3_LD + 2 * V3_VLEN + 2 * 240 + 32)
 static __device__ __forceinline__ double lane_bcast(double x, int l) {          // l uniform
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
@@ -61,7 +61,7 @@ static __device__ __forceinline__ double lane_bcast(double x, int l) {          
 __global__ __launch_bounds__(512) void k_sytrd_v3(TriArgs T) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* Y = smem;                                   // [nb][V3_LD]
-    double* s_v = Y + T8_MAXNB * V3_LD;                 // [240] at index SVI(i)
+    double* s_v = Y + (T8_MAXNB + 1) * V3_LD;           // [240] at index SVI(i); (row nb of Y stays zero: phase C reads it instead of branching on a short half)
     double* s_w = s_v + V3_VLEN;                        // [240], padded like s_v
     double* s_xo = s_w + V3_VLEN;                           // [2][240]
     double* s_red = s_xo + 480;                         // [32]: 0..7 v^T A v partials, 8 tau, 9 exact-trace flag, 16..23 trailing-trace partials, 24..31 trace(A) partials
@@ -86,9 +86,15 @@ __global__ __launch_bounds__(512) void k_sytrd_v3(TriArgs T) {
             const int i = i0 + r, j = j0 + cc;
             a[r][cc] = (owner && i < n && j < n) ? T.A[i + (size_t)T.lda * j] : 0.;
         }
+    // the current column lives in the REGISTERS of every live wave as xt = its rows k+2.. (rows lane + 64 e, zero above), its two leading
+    // entries d_k and alpha are broadcast once, by the look-ahead that forms the column (dk_n, alpha_n: uniform values carried to the next
+    // step), so that phase A starts from them instead of two register selects by uniform branches, two broadcasts and eight masked moves
     double x[4], v[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { const int i = lane + 64 * e; x[e] = i < n ? T.A[i] : 0.; v[e] = 0.; }
+    for (int e = 0; e < 4; ++e) { const int i = lane + 64 * e; x[e] = (i >= 2 && i < n) ? T.A[i] : 0.; v[e] = 0.; }
+    double dk_n = lane_bcast(T.A[0], 0), alpha_n = lane_bcast(n > 1 ? T.A[1] : 0., 0);   // (through readlane: the compiler keeps them in scalar registers)
+    //   // d_k and alpha of the coming step (uniform): set by the look-ahead of the step before
+    for (int i = tid; i < V3_LD; i += 512) Y[nb * V3_LD + i] = 0.;      // the row behind the last block column: phase C reads it where a lane's half is one short
     if (tid < V3_VLEN) { s_v[tid] = 0.; s_w[tid] = 0.; }
     if (tid < 240) { s_xo[tid] = 0.; s_xo[240 + tid] = 0.; }
     {   // trace(A) (rank-adaptive early exit below)
@@ -126,6 +132,15 @@ __global__ __launch_bounds__(512) void k_sytrd_v3(TriArgs T) {
     // row-sum duty of phase C: two lanes per row, lane h takes the first / second half of the block columns kb..nb-1
     const int ci = tid >> 1, ch = tid & 1;
     const int cic = ci < 240 ? ci : 239;
+    // d_{k+1} and alpha_{k+1} out of the freshly formed column (row i in register i >> 6 of lane i & 63): uniform selects, two broadcasts
+    auto next_scalars = [&](double v0, double v1, double v2, double v3, int k) {
+        const int i1 = k + 1, i2 = k + 2;
+        const int ea = i1 >> 6, eb = (i2 >> 6) & 3;
+        const double va = ea == 0 ? v0 : (ea == 1 ? v1 : (ea == 2 ? v2 : v3));
+        const double vb = eb == 0 ? v0 : (eb == 1 ? v1 : (eb == 2 ? v2 : v3));
+        dk_n = lane_bcast(va, i1 & 63);
+        alpha_n = i2 < n ? lane_bcast(vb, i2 & 63) : 0.;
+    };
     for (int k = 0; k < n - 1; ++k) {
         const int par = k & 1;
         const int kb = (k + 1) / T8;
@@ -135,16 +150,10 @@ __global__ __launch_bounds__(512) void k_sytrd_v3(TriArgs T) {
         if (live) {
             // ---- A: Householder scalars and v, redundantly per live wave, from the column in registers.  x is zero above
             //      row k; element k is the diagonal entry, element k+1 is alpha.
-            const int e1 = (k + 1) >> 6, l1 = (k + 1) & 63, e0 = k >> 6, l0 = k & 63;
-            double xa, xd;                               // the registers holding alpha and d_k (e1, e0 uniform)
-            switch (e1) { case 0: xa = x[0]; break; case 1: xa = x[1]; break; case 2: xa = x[2]; break; default: xa = x[3]; break; }
-            switch (e0) { case 0: xd = x[0]; break; case 1: xd = x[1]; break; case 2: xd = x[2]; break; default: xd = x[3]; break; }
-            const double alpha = lane_bcast(xa, l1);
-            const bool at0 = lane == l0, at1 = lane == l1;
-            // zero the two leading entries in their registers: what is left is x[k+2:]
+            const double alpha = alpha_n, dk = dk_n;                 // left by the look-ahead of the last step (or the prologue)
             double xt[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) xt[e] = ((e == e0 && at0) || (e == e1 && at1)) ? 0. : x[e];
+            for (int e = 0; e < 4; ++e) xt[e] = x[e];                // rows k+2.. of the column
             double sig = fma(xt[0], xt[0], fma(xt[1], xt[1], fma(xt[2], xt[2], xt[3] * xt[3])));
             sig = wave_sum(sig);
             double beta = alpha, scale = 0.;
@@ -172,10 +181,9 @@ __global__ __launch_bounds__(512) void k_sytrd_v3(TriArgs T) {
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                v[e] = (e == e1 && at1) ? 1. : xt[e] * scale;
+                v[e] = (lane + 64 * e == k + 1) ? 1. : xt[e] * scale;
                 if (e < 3 || lane < 48) s_v[SVI(lane + 64 * e)] = v[e];    // identical values from every live wave
             }
-            const double dk = lane_bcast(xd, l0);
             trem -= dk;                                               // trace of rows k+1.. (before and after this step's update)
             need_exact = T.psd_tol > 0. && trem <= t_screen;
             if (lane == 0) { s_red[8] = tau; s_red[9] = need_exact ? 1. : 0.; }   // for the retired waves
@@ -263,15 +271,15 @@ __global__ __launch_bounds__(512) void k_sytrd_v3(TriArgs T) {
                 for (int w = 0; w < 8; ++w) vAv += s_red[w];
                 const double K = -0.5 * tau * tau * vAv;
                 const int nc = nb - kb, half = (nc + 1) >> 1;         // uniform
-                const int cbeg = kb + ch * half, cnt = ch ? nc - half : half;
+                const int cbeg = kb + ch * half;                      // (lane 1 of a pair: block columns kb + half .. nb - 1, then the zero row)
                 const double* yp = Y + cbeg * V3_LD + cic;
                 double y0 = 0., y1 = 0., y2 = 0.;
                 int u = 0;
-                for (; u + 3 <= half; u += 3) {                       // uniform trip count; the odd lane may run one short
-                    const double t0 = yp[(u < cnt ? u : 0) * V3_LD], t1 = yp[(u + 1 < cnt ? u + 1 : 0) * V3_LD], t2 = yp[(u + 2 < cnt ? u + 2 : 0) * V3_LD];
-                    y0 += u < cnt ? t0 : 0.; y1 += u + 1 < cnt ? t1 : 0.; y2 += u + 2 < cnt ? t2 : 0.;
+                for (; u + 3 <= half; u += 3) {                       // uniform trip count: a lane whose half is one short reads the zero row nb
+                    const double t0 = yp[u * V3_LD], t1 = yp[(u + 1) * V3_LD], t2 = yp[(u + 2) * V3_LD];
+                    y0 += t0; y1 += t1; y2 += t2;
                 }
-                for (; u < half; ++u) { const double t0 = yp[(u < cnt ? u : 0) * V3_LD]; y0 += u < cnt ? t0 : 0.; }
+                for (; u < half; ++u) y0 += yp[u * V3_LD];
                 const double yh = (y0 + y1) + y2;
                 const double yo = dpp_quad<0xB1>(yh);                 // the other half of the row (lane ^ 1)
                 const double y = ch == 0 ? yh + yo : yo + yh;         // first-half part + second-half part on both lanes
@@ -300,14 +308,23 @@ __global__ __launch_bounds__(512) void k_sytrd_v3(TriArgs T) {
                     const int i = lane + 64 * e;
                     const int ic = i < 240 ? i : 239;
                     const double xo = s_xo[par * 240 + ic], wi = s_w[SVI(ic)];
-                    x[e] = (i >= k + 1 && i < n) ? (xo - v[e] * wk1) - wi : 0.;
+                    x[e] = (i < n) ? (xo - v[e] * wk1) - wi : 0.;
                 }
+                next_scalars(x[0], x[1], x[2], x[3], k);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = (lane + 64 * e >= k + 3) ? x[e] : 0.;
             }
             TP3(5);
         } else {                                                      // no reflector: the matrix is unchanged
             if (live) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const int i = lane + 64 * e; const int ic = i < 240 ? i : 239; x[e] = (i >= k + 1 && i < n) ? s_xo[par * 240 + ic] : 0.; }
+                for (int e = 0; e < 4; ++e) {
+                    const int i = lane + 64 * e; const int ic = i < 240 ? i : 239;
+                    x[e] = i < n ? s_xo[par * 240 + ic] : 0.;
+                }
+                next_scalars(x[0], x[1], x[2], x[3], k);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = (lane + 64 * e >= k + 3) ? x[e] : 0.;
             }
             __syncthreads();
         }
@@ -320,9 +337,7 @@ __global__ __launch_bounds__(512) void k_sytrd_v3(TriArgs T) {
         if (tid == 0 && T.nref) T.nref[0] = (double)(kexit + 1);
     } else {
         const int kl = n - 1;
-        double xl;
-        switch (kl >> 6) { case 0: xl = x[0]; break; case 1: xl = x[1]; break; case 2: xl = x[2]; break; default: xl = x[3]; break; }
-        const double dl = lane_bcast(xl, kl & 63);
+        const double dl = dk_n;                                        // d_{n-1}: the look-ahead of the last step (wave 7 is live to the end)
         if (tid == 7 * 64) { T.D[kl] = dl; if (T.nref) T.nref[0] = (double)(n - 1); }   // wave 7 is live to the end
     }
 }

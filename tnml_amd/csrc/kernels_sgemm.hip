@@ -18,9 +18,12 @@ typedef double f64x4s __attribute__((ext_vector_type(4)));
 
 // BMODE 1: op(B) = 1.5 I - 0.5 S with S = the symmetric matrix passed as B (the Newton-Schulz factor of the split's polish step,
 // formed while loading), and dev[0] = max |S - I| by an integer atomic max over non-negative doubles (dev[0] zeroed by the producer of S)
-template <int TA, int TB, int TI, int TJ, int BMODE>
-__global__ __launch_bounds__(64) void k_dgemm_small(SmallGemmArgs P) {
-    const int lane = threadIdx.x, r = lane & 15, g = lane >> 4;
+// KS waves share a tile: wave w takes the blocks of 16 k with index = w (mod KS) and the partial tiles are added in wave order through LDS
+// (a latency chain of 60 MFMAs with their loads becomes 15: the K = 240 products of the split, 10.5 -> ~7 us)
+template <int TA, int TB, int TI, int TJ, int BMODE, int KS>
+__global__ __launch_bounds__(64 * KS) void k_dgemm_small(SmallGemmArgs P) {
+    __shared__ double s_acc[KS > 1 ? (KS - 1) * 64 * 4 * TI * TJ : 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
     const int i0 = blockIdx.x * 16 * TI, j0 = blockIdx.y * 16 * TJ;
     const int M = P.M, N = P.N, K = P.K;
     f64x4s acc[TJ][TI];
@@ -35,7 +38,7 @@ __global__ __launch_bounds__(64) void k_dgemm_small(SmallGemmArgs P) {
 #pragma unroll
     for (int sj = 0; sj < TJ; ++sj) { const int j = j0 + 16 * sj + r; jb[sj] = j < N ? j : N - 1; }
     double dmax = 0.;
-    for (int kb = 0; kb < K; kb += 16) {
+    for (int kb = 16 * wv; kb < K; kb += 16 * KS) {
         double af[TI][4], bf[TJ][4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -66,6 +69,28 @@ __global__ __launch_bounds__(64) void k_dgemm_small(SmallGemmArgs P) {
 #pragma unroll
                 for (int si = 0; si < TI; ++si) acc[sj][si] = __builtin_amdgcn_mfma_f64_16x16x4f64(bf[sj][u], af[si][u], acc[sj][si], 0, 0, 0);
     }
+    if (KS > 1) {
+        if (wv > 0) {
+#pragma unroll
+            for (int sj = 0; sj < TJ; ++sj)
+#pragma unroll
+                for (int si = 0; si < TI; ++si)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s_acc[(((wv - 1) * TJ + sj) * TI + si) * 256 + e * 64 + lane] = acc[sj][si][e];
+        }
+        __syncthreads();
+        if (wv == 0) {
+#pragma unroll
+            for (int w = 1; w < KS; ++w)
+#pragma unroll
+                for (int sj = 0; sj < TJ; ++sj)
+#pragma unroll
+                    for (int si = 0; si < TI; ++si)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[sj][si][e] += s_acc[(((w - 1) * TJ + sj) * TI + si) * 256 + e * 64 + lane];
+        }
+    }
+    if (wv == 0) {
 #pragma unroll
     for (int sj = 0; sj < TJ; ++sj)
 #pragma unroll
@@ -77,7 +102,8 @@ __global__ __launch_bounds__(64) void k_dgemm_small(SmallGemmArgs P) {
                 if (i < M && j < N) P.C[i + (size_t)P.ldc * j] = acc[sj][si][e];
             }
         }
-    if (P.chk_src && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) {
+    }
+    if (P.chk_src && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         // (launched after the polish step: the check values are final) -> pinned host mirror; bad = the test svd_split_device applies
         const double d0 = P.chk_src[0], d1 = P.chk_src[1];
         P.chk_host[0] = d0; P.chk_host[1] = d1; P.chk_host[2] = P.chk_src[2]; P.chk_host[3] = P.chk_src[3];
@@ -88,16 +114,18 @@ __global__ __launch_bounds__(64) void k_dgemm_small(SmallGemmArgs P) {
     if (BMODE == 1 && blockIdx.x == 0) {
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) dmax = fmax(dmax, __shfl_xor(dmax, o));
-        if (lane == 0) atomicMax(reinterpret_cast<unsigned long long*>(P.dev), (unsigned long long)__double_as_longlong(dmax));
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned long long*>(P.dev), (unsigned long long)__double_as_longlong(dmax));      // (every wave of the tile its own share of k)
     }
 }
 
 template <int TA, int TB, int BMODE>
 static void dgemm_small_go(hipStream_t st, const SmallGemmArgs& a) {
-    // 16 x 16 tiles while they fit one wave per CU (latency: a quarter of the MFMA chain of a 32 x 32 tile), 32 x 32 beyond
+    // 16 x 16 tiles while they fit one wave per CU (latency: a quarter of the MFMA chain of a 32 x 32 tile), 32 x 32 beyond; four waves
+    // per tile from a reduction length of 128 on while the tiles are few
     const int t16 = ((a.M + 15) / 16) * ((a.N + 15) / 16);
-    if (t16 <= 512) hipLaunchKernelGGL((k_dgemm_small<TA, TB, 1, 1, BMODE>), dim3((a.M + 15) / 16, (a.N + 15) / 16), dim3(64), 0, st, a);
-    else            hipLaunchKernelGGL((k_dgemm_small<TA, TB, 2, 2, BMODE>), dim3((a.M + 31) / 32, (a.N + 31) / 32), dim3(64), 0, st, a);
+    if (t16 <= 256 && a.K >= 128) hipLaunchKernelGGL((k_dgemm_small<TA, TB, 1, 1, BMODE, 4>), dim3((a.M + 15) / 16, (a.N + 15) / 16), dim3(256), 0, st, a);
+    else if (t16 <= 512)          hipLaunchKernelGGL((k_dgemm_small<TA, TB, 1, 1, BMODE, 1>), dim3((a.M + 15) / 16, (a.N + 15) / 16), dim3(64), 0, st, a);
+    else                          hipLaunchKernelGGL((k_dgemm_small<TA, TB, 2, 2, BMODE, 1>), dim3((a.M + 31) / 32, (a.N + 31) / 32), dim3(64), 0, st, a);
 }
 int launch_dgemm_small(tnml_ctx* c, const SmallGemmArgs& a) {
     if (a.M < 1 || a.N < 1 || a.K < 1) return tnml_fail(c, "dgemm_small: empty product");
