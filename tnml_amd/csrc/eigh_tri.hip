@@ -16,7 +16,7 @@
 //                   processed four at a time from registers (all LDS loads of a group issued before its first use, all stores
 //                   after its last), the interchange flag of a row travels in the last mantissa bit of its multiplier (one
 //                   ulp of a multiplier is the size of the rounding the factorisation carries anyway), the second super-diagonal is re-derived from that flag, the start vector is generated inside the
-//                   first back substitution, and the result leaves through a coalesced write of the whole workgroup.
+//                   first forward sweep, and the result leaves through a coalesced write of the whole workgroup.
 //
 // The vectors are NOT re-orthogonalised against each other (that is what makes LAPACK's dstein sequential): svd.hip puts the kept
 // basis through a Cholesky QR and a Newton-Schulz step, verifies it and falls back to rocSOLVER when the check fails.
@@ -240,18 +240,13 @@ __global__ __launch_bounds__(256) void k_teig_vectors(Teig2Args T) {
             double xscale = 1.;                                     // max-norm scaling of the iterate, applied when the next pass reads it
             double nrm2 = 0.;
             for (int iter = 0; iter < 2; ++iter) {
-                if (iter == 0) {
-                    // first sweep: the pseudo-random vector is taken as (P L)^-1 b itself -- a random right-hand side stays one under the
-                    // forward elimination, so only the back substitution runs (as EISPACK tinvit / LAPACK dstein start): one sweep of four less
-                    for (int kk = lo; kk < hi; ++kk) x[IX(kk)] = rnd();
-                } else {
                 // forward: apply (P L)^-1 (the interchange is a select: the lanes of a wave pivot differently)
-                double xk = x[IX(lo)] * xscale;
+                double xk = iter == 0 ? rnd() : x[IX(lo)] * xscale;
                 k = lo;
                 for (; k + 4 <= hi - 1; k += 4) {
                     double xs[4], ms[4], out[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) { xs[u] = x[IX(k + 1 + u)] * xscale; ms[u] = c[IX(k + u)]; }
+                    for (int u = 0; u < 4; ++u) { xs[u] = iter == 0 ? rnd() : x[IX(k + 1 + u)] * xscale; ms[u] = c[IX(k + u)]; }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const bool sw = teig_flag(ms[u]);
@@ -263,14 +258,13 @@ __global__ __launch_bounds__(256) void k_teig_vectors(Teig2Args T) {
                     for (int u = 0; u < 4; ++u) x[IX(k + u)] = out[u];
                 }
                 for (; k < hi - 1; ++k) {
-                    const double xk1 = x[IX(k + 1)] * xscale, m = c[IX(k)];
+                    const double xk1 = iter == 0 ? rnd() : x[IX(k + 1)] * xscale, m = c[IX(k)];
                     const bool sw = teig_flag(m);
                     const double keep = sw ? xk1 : xk, go = sw ? xk : xk1;
                     x[IX(k)] = keep;
                     xk = go - m * keep;
                 }
                 x[IX(hi - 1)] = xk;
-                }
                 // back substitution with U (second super-diagonal: e_{k+1} where rows k, k+1 were interchanged)
                 double xn1 = 0., xn2 = 0., vmax = 0.;
                 nrm2 = 0.;

@@ -173,7 +173,6 @@ __global__ __launch_bounds__(64 * WR * WC) void k_fgemm64(Fgemm64Args A) {
     constexpr int KS = KT / 4;
     static_assert(KS % 2 == 0, "fragment double buffer assumes an even number of k-steps per chunk");
     double xf[2][RT], mf[2][CT];
-    const int nc = A.Kp / KT;
 
     load_chunk(0);
     store_chunk(lds, lds + KT * XS);
@@ -507,7 +506,7 @@ template <int RT, int CT, int WR, int WC, int FUSE = 0>
 static int bgemm64_go(tnml_ctx* c, const Bgemm64Args& a, double* G, int default_wgs = 768) {
     constexpr int BMr = 16 * RT * WR, BNc = 16 * CT * WC;
     const int tiles = ((a.Kp + BMr - 1) / BMr) * ((a.Np + BNc - 1) / BNc) * a.L;
-    const int target_wgs = default_wgs;
+    const int target_wgs = c->bgemm_wgs > 0 ? c->bgemm_wgs : default_wgs;
     int nsplit = (target_wgs + tiles - 1) / tiles;
     const int chunks = a.NTp / 32;
     if (nsplit > chunks) nsplit = chunks;

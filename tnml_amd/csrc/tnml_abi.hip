@@ -89,6 +89,7 @@ int tnml_set_option(tnml_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "shift_res")) c->shift_res = value;
     else if (!strcmp(name, "res_grid")) c->res_grid = value;
     else if (!strcmp(name, "res_pace")) c->res_pace = value;
+    else if (!strcmp(name, "bgemm_wgs")) c->bgemm_wgs = value;
     else if (!strcmp(name, "sytrd_exit")) c->sytrd_exit = value;
     else if (!strcmp(name, "bgs_chol")) c->bgs_chol = value != 0;
     else if (!strcmp(name, "small_gemm")) c->small_gemm = value != 0;
@@ -245,6 +246,7 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     if (const char* e = getenv("TNML_FWD_RES")) c->fwd_res = atoi(e);
     if (const char* e = getenv("TNML_SHIFT_RES")) c->shift_res = atoi(e);
     if (const char* e = getenv("TNML_RES_PACE")) c->res_pace = atoi(e);
+    if (const char* e = getenv("TNML_BGEMM_WGS")) c->bgemm_wgs = atoi(e);
     if (const char* e = getenv("TNML_BGS_CHOL")) c->bgs_chol = atoi(e) != 0;
     if (const char* e = getenv("TNML_SMALL_GEMM")) c->small_gemm = atoi(e) != 0;
     if (rocblas_create_handle(&c->blas) != rocblas_status_success) return bail(tnml_fail(c, "rocblas_create_handle failed"));
@@ -1223,7 +1225,6 @@ static int exact_device(tnml_ctx* c, double lambda, double pcut) {
     if (c->cfg.nranks > 1) return tnml_fail(c, "exact: one rank only (the design matrix of all images is needed in one place)");
     const BondPlan p = c->plan;
     const PackDesc pd = bond_pack_desc(p);
-    const size_t n = p.msize();
     const int D = p.mL * 4 * p.mR, NT = c->NT;
     // the one-sided Jacobi below costs ~6 min(D, NT)^2 max(D, NT) flops per sweep on ONE host thread and needs up to a few dozen sweeps
     if (D > 4096 || (double)D * NT > 4e8 || (double)std::min(D, NT) * std::min(D, NT) * std::max(D, NT) > 2e10)
