@@ -516,6 +516,7 @@ static int bgemm64_go(tnml_ctx* c, const Bgemm64Args& a, double* G, int default_
     while (nsplit > 1 && (size_t)nsplit * n > cap) --nsplit;
     if ((size_t)nsplit * n > cap) return tnml_fail(c, "bgemm64: slab workspace too small");
     int per = ((chunks + nsplit - 1) / nsplit) * 32;
+    if (c->bgemm_per > 0 && (size_t)((a.NTp + c->bgemm_per * 32 - 1) / (c->bgemm_per * 32)) * n <= cap) per = c->bgemm_per * 32;      // probe knob: images per slab / 32
     nsplit = (a.NTp + per - 1) / per;
     Bgemm64KArgs K{a, (double*)c->slab, nsplit, per, 1};       // non-temporal loads of the Label-carrying environment: +1.3 % (profiles/r01_ab_nt_loads.txt)
     {

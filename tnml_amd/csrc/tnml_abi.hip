@@ -90,6 +90,7 @@ int tnml_set_option(tnml_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "res_grid")) c->res_grid = value;
     else if (!strcmp(name, "res_pace")) c->res_pace = value;
     else if (!strcmp(name, "bgemm_wgs")) c->bgemm_wgs = value;
+    else if (!strcmp(name, "bgemm_per")) c->bgemm_per = value;
     else if (!strcmp(name, "sytrd_exit")) c->sytrd_exit = value;
     else if (!strcmp(name, "bgs_chol")) c->bgs_chol = value != 0;
     else if (!strcmp(name, "small_gemm")) c->small_gemm = value != 0;
@@ -247,6 +248,7 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     if (const char* e = getenv("TNML_SHIFT_RES")) c->shift_res = atoi(e);
     if (const char* e = getenv("TNML_RES_PACE")) c->res_pace = atoi(e);
     if (const char* e = getenv("TNML_BGEMM_WGS")) c->bgemm_wgs = atoi(e);
+    if (const char* e = getenv("TNML_BGEMM_PER")) c->bgemm_per = atoi(e);
     if (const char* e = getenv("TNML_BGS_CHOL")) c->bgs_chol = atoi(e) != 0;
     if (const char* e = getenv("TNML_SMALL_GEMM")) c->small_gemm = atoi(e) != 0;
     if (rocblas_create_handle(&c->blas) != rocblas_status_success) return bail(tnml_fail(c, "rocblas_create_handle failed"));

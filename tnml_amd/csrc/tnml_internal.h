@@ -210,6 +210,7 @@ struct tnml_ctx {
     int fwd_res = 1;                 // forward pass on k_fwd_res (kernels_res.hip): 1 = from 7 680 images per rank on, 0 never, 2 always; option "fwd_res"
     int shift_res = 1;               // Label-carrying environment shift on k_shift_res (kernels_res.hip): 1 = from 7 680 images per rank on, 0 never, 2 always; option "shift_res"
     int res_grid = 0;                // test knob: workgroups of the resident-operand kernels (0: one per CU)
+    int bgemm_per = 0;               // probe knob (TNML_BGEMM_PER): images per slab of the gradient GEMM, in units of 32 (0: derived from bgemm_wgs)
     int bgemm_wgs = 0;               // workgroups the gradient GEMM aims at when it cuts the image range into slabs (0: per-shape default; option "bgemm_wgs")
     unsigned* counters = nullptr;    // [16] device: arrival counters of the "last workgroup reduces" kernels (zero between launches)
     double* Ppart = nullptr;         // [2][10][NTp]: per-half outputs of k_fwd_res
