@@ -121,9 +121,9 @@ __global__ __launch_bounds__(64 * KS) void k_dgemm_small(SmallGemmArgs P) {
 template <int TA, int TB, int BMODE>
 static void dgemm_small_go(hipStream_t st, const SmallGemmArgs& a) {
     // 16 x 16 tiles while they fit one wave per CU (latency: a quarter of the MFMA chain of a 32 x 32 tile), 32 x 32 beyond; four waves
-    // per tile from a reduction length of 128 on while the tiles are few
+    // per tile from a reduction length of 64 on (>= one block of 16 per wave) while the tiles are few
     const int t16 = ((a.M + 15) / 16) * ((a.N + 15) / 16);
-    if (t16 <= 256 && a.K >= 128) hipLaunchKernelGGL((k_dgemm_small<TA, TB, 1, 1, BMODE, 4>), dim3((a.M + 15) / 16, (a.N + 15) / 16), dim3(256), 0, st, a);
+    if (t16 <= 256 && a.K >= 64)  hipLaunchKernelGGL((k_dgemm_small<TA, TB, 1, 1, BMODE, 4>), dim3((a.M + 15) / 16, (a.N + 15) / 16), dim3(256), 0, st, a);
     else if (t16 <= 512)          hipLaunchKernelGGL((k_dgemm_small<TA, TB, 1, 1, BMODE, 1>), dim3((a.M + 15) / 16, (a.N + 15) / 16), dim3(64), 0, st, a);
     else                          hipLaunchKernelGGL((k_dgemm_small<TA, TB, 2, 2, BMODE, 1>), dim3((a.M + 31) / 32, (a.N + 31) / 32), dim3(64), 0, st, a);
 }
