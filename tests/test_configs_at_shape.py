@@ -295,6 +295,34 @@ def test_fused_forward_kernel_matches_the_oracle(NT, kernel):
 
 
 @pytest.mark.gpu
+def test_the_slab_cut_of_the_gradient_gemm_changes_only_the_summation_order():
+    """options bgemm_wgs / bgemm_per (how many image slabs the gradient GEMM is cut into, profiles/r05_sweep_gradient_gemm_slabs.txt):
+    one slab, the default, one slab per 32 images and a ragged cut give the same gradient to rounding, and repeat bit for bit"""
+    from tnml_amd.fixedl import TrainStates
+    from conftest import make_problem
+    N, m, NT = 20, 120, 2100
+    pixels, labels, phi, W = make_problem(N, NT, m, 7, pixel_boost=200.0)
+    ts = TrainStates(labels, N, m, phi=phi)
+    ts.set_mps(W)
+    ts.init()
+    for bb in range(1, 8):
+        ts.shiftE(bb, True)
+    ts.setBond(8)
+    rng = np.random.default_rng(2)
+    B = ts.bond_tensor(8)
+    B = B + 0.05 * rng.standard_normal(B.shape)
+    G0 = ts.gradient(B)
+    assert np.array_equal(G0, ts.gradient(B))
+    for name, val in (("bgemm_wgs", 4), ("bgemm_wgs", 4096), ("bgemm_per", 5), ("bgemm_per", 72)):
+        ts.set_option("bgemm_wgs", 0); ts.set_option("bgemm_per", 0)
+        ts.set_option(name, val)
+        G = ts.gradient(B)
+        assert _rel(G, G0) < 1e-13, (name, val)
+        assert np.array_equal(G, ts.gradient(B)), (name, val)
+    ts.close()
+
+
+@pytest.mark.gpu
 def test_m60_kernel_instantiations_match_the_oracle():
     """bonds that have shrunk to minm = maxm/2 = 60 (the reference default, fixedL.cc:593) run their own tiles: 128 x 128
     feature-GEMM tiles (forced here as for C3: at 60 000 images they are the default), 128 x 64 gradient-GEMM tiles"""
