@@ -512,8 +512,9 @@ __global__ __launch_bounds__(256) void k_chol_rinv_blocked(const double* __restr
     }
     for (int p = 0; p < np; ++p) {
         if (ti == p && tj == p) {
-            // (1) Cholesky of the diagonal tile (lower triangle) ...
-            double dinv[CQ_T];
+            // (1) Cholesky of the diagonal tile (lower triangle), by its one lane: the serial part of a panel.  Published: L_pp below the
+            //     diagonal and the RECIPROCALS of its diagonal on it -- the lanes of phase (2) substitute with L_pp itself, so that the
+            //     inversion of the 8 x 8 triangle (another ~200 dependent instructions of this lane) runs in phase (2), beside them
 #pragma unroll
             for (int k = 0; k < CQ_T; ++k) {
                 double d = a[k][k];
@@ -526,9 +527,7 @@ __global__ __launch_bounds__(256) void k_chol_rinv_blocked(const double* __restr
                 const double dd = fma(-g, g, d); g = fma(dd, h, g);
                 double inv = h + h;
                 const double e1 = fma(-g, inv, 1.0); inv = fma(inv, e1, inv);
-                const double sq = g;
-                dinv[k] = inv;
-                a[k][k] = sq;
+                a[k][k] = inv;                                       // (the diagonal of L itself is not needed again)
 #pragma unroll
                 for (int r = k + 1; r < CQ_T; ++r) a[r][k] *= inv;
 #pragma unroll
@@ -536,70 +535,61 @@ __global__ __launch_bounds__(256) void k_chol_rinv_blocked(const double* __restr
 #pragma unroll
                     for (int r = cc; r < CQ_T; ++r) a[r][cc] = fma(-a[r][k], a[cc][k], a[r][cc]);
             }
-            // ... and its inverse, column by column (forward substitution on the unit vectors)
-            double li[CQ_T][CQ_T];
-#pragma unroll
-            for (int cc = 0; cc < CQ_T; ++cc) {
-#pragma unroll
-                for (int r = 0; r < CQ_T; ++r) {
-                    if (r < cc) li[r][cc] = 0.;
-                    else if (r == cc) li[r][cc] = dinv[cc];
-                    else {
-                        double t = 0.;
-#pragma unroll
-                        for (int k = cc; k < r; ++k) t = fma(a[r][k], li[k][cc], t);
-                        li[r][cc] = -t * dinv[r];
-                    }
-                }
-            }
 #pragma unroll
             for (int r = 0; r < CQ_T; ++r)
 #pragma unroll
-                for (int cc = 0; cc < CQ_T; ++cc) { s_li[r * CQ_T + cc] = li[r][cc]; a[r][cc] = li[r][cc]; }     // X_pp = L_pp^-1 stays in the tile
+                for (int cc = 0; cc < CQ_T; ++cc) { s_li[r * CQ_T + cc] = cc <= r ? a[r][cc] : 0.; a[r][cc] = r == cc ? 1. : 0.; }     // the tile is W_pp = I from here: (2b) turns it into X_pp = L_pp^-1
         }
         __syncthreads();
-        if (tj <= ti && ti >= p && !(ti == p && tj == p) && (tj == p || ti == p)) {
-            double li[CQ_T][CQ_T];
+        if (tj <= ti && ti >= p && (tj == p || ti == p)) {
+            double L[CQ_T][CQ_T];                                    // L_pp below the diagonal, 1 / diag(L_pp) on it
 #pragma unroll
             for (int r = 0; r < CQ_T; ++r)
 #pragma unroll
-                for (int cc = 0; cc < CQ_T; ++cc) li[r][cc] = s_li[r * CQ_T + cc];
+                for (int cc = 0; cc < CQ_T; ++cc) L[r][cc] = s_li[r * CQ_T + cc];
             double t2[CQ_T][CQ_T];
-            if (tj == p) {
-                // (2a) L_ip = A_ip L_pp^-T, published; the tile then becomes W_ip = -L_ip X_pp
+            if (tj == p && ti > p) {
+                // (2a) L_ip = A_ip L_pp^-T (L_ip L_pp^T = A_ip, column by column), published; the tile then becomes
+                //      W_ip = -L_ip L_pp^-1 (W_ip L_pp = -L_ip, from the last column back)
 #pragma unroll
-                for (int r = 0; r < CQ_T; ++r)
+                for (int cc = 0; cc < CQ_T; ++cc)
 #pragma unroll
-                    for (int cc = 0; cc < CQ_T; ++cc) {
-                        double t = 0.;
+                    for (int r = 0; r < CQ_T; ++r) {
+                        double t = a[r][cc];
 #pragma unroll
-                        for (int k = 0; k <= cc; ++k) t = fma(a[r][k], li[cc][k], t);
-                        t2[r][cc] = t;
+                        for (int k = 0; k < cc; ++k) t = fma(-t2[r][k], L[cc][k], t);
+                        t2[r][cc] = t * L[cc][cc];
                     }
                 double* dst = Pl + (size_t)(CQ_T * ti) * CQ_T;
 #pragma unroll
                 for (int r = 0; r < CQ_T; ++r)
 #pragma unroll
                     for (int cc = 0; cc < CQ_T; cc += 2) *reinterpret_cast<double2*>(dst + r * CQ_T + cc) = make_double2(t2[r][cc], t2[r][cc + 1]);
+                // ... and its transpose into column block ti of Px: phase (3) then reads L_jp^T (tiles right of panel p) and X_pj (tiles left
+                // of it) from the same array in the same form -- one update loop instead of two that a wave with tiles of both kinds ran in turn
 #pragma unroll
-                for (int r = 0; r < CQ_T; ++r)
+                for (int k = 0; k < CQ_T; ++k)
 #pragma unroll
-                    for (int cc = 0; cc < CQ_T; ++cc) {
-                        double t = 0.;
+                    for (int r = 0; r < CQ_T; r += 2) *reinterpret_cast<double2*>(Px + (size_t)k * (CQ_NT * CQ_T) + CQ_T * ti + r) = make_double2(t2[r][k], t2[r + 1][k]);
 #pragma unroll
-                        for (int k = cc; k < CQ_T; ++k) t = fma(t2[r][k], li[k][cc], t);
-                        a[r][cc] = -t;
+                for (int cc = CQ_T - 1; cc >= 0; --cc)
+#pragma unroll
+                    for (int r = 0; r < CQ_T; ++r) {
+                        double t = -t2[r][cc];
+#pragma unroll
+                        for (int k = cc + 1; k < CQ_T; ++k) t = fma(-a[r][k], L[k][cc], t);
+                        a[r][cc] = t * L[cc][cc];
                     }
             } else {
-                // (2b) X_pj = L_pp^-1 W_pj, published and final
+                // (2b) X_pj = L_pp^-1 W_pj (forward substitution down the rows), published and final; the diagonal tile (W_pp = I) with them
 #pragma unroll
                 for (int r = 0; r < CQ_T; ++r)
 #pragma unroll
                     for (int cc = 0; cc < CQ_T; ++cc) {
-                        double t = 0.;
+                        double t = a[r][cc];
 #pragma unroll
-                        for (int k = 0; k <= r; ++k) t = fma(li[r][k], a[k][cc], t);
-                        t2[r][cc] = t;
+                        for (int k = 0; k < r; ++k) t = fma(-L[r][k], t2[k][cc], t);
+                        t2[r][cc] = t * L[r][r];
                     }
 #pragma unroll
                 for (int r = 0; r < CQ_T; ++r)
@@ -612,39 +602,22 @@ __global__ __launch_bounds__(256) void k_chol_rinv_blocked(const double* __restr
         }
         __syncthreads();
         if (ti > p && tj <= ti && tj != p) {
-            // (3) A_ij -= L_ip L_jp^T (columns still to be factored) or W_ij -= L_ip X_pj (columns already factored)
+            // (3) A_ij -= L_ip L_jp^T (columns still to be factored) or W_ij -= L_ip X_pj (columns already factored): Px holds L_jp^T / X_pj
             double lrow[CQ_T][CQ_T];
             const double* src = Pl + (size_t)(CQ_T * ti) * CQ_T;
 #pragma unroll
             for (int r = 0; r < CQ_T; ++r)
 #pragma unroll
                 for (int k = 0; k < CQ_T; ++k) lrow[r][k] = src[r * CQ_T + k];
-            if (tj > p) {
-                const double* sc = Pl + (size_t)(CQ_T * tj) * CQ_T;
 #pragma unroll
-                for (int cc = 0; cc < CQ_T; ++cc) {
-                    double lc[CQ_T];
+            for (int k = 0; k < CQ_T; ++k) {
+                double xr[CQ_T];
 #pragma unroll
-                    for (int k = 0; k < CQ_T; ++k) lc[k] = sc[cc * CQ_T + k];
+                for (int cc = 0; cc < CQ_T; ++cc) xr[cc] = Px[(size_t)k * (CQ_NT * CQ_T) + CQ_T * tj + cc];
 #pragma unroll
-                    for (int r = 0; r < CQ_T; ++r) {
-                        double t = a[r][cc];
+                for (int r = 0; r < CQ_T; ++r)
 #pragma unroll
-                        for (int k = 0; k < CQ_T; ++k) t = fma(-lrow[r][k], lc[k], t);
-                        a[r][cc] = t;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < CQ_T; ++k) {
-                    double xr[CQ_T];
-#pragma unroll
-                    for (int cc = 0; cc < CQ_T; ++cc) xr[cc] = Px[(size_t)k * (CQ_NT * CQ_T) + CQ_T * tj + cc];
-#pragma unroll
-                    for (int r = 0; r < CQ_T; ++r)
-#pragma unroll
-                        for (int cc = 0; cc < CQ_T; ++cc) a[r][cc] = fma(-lrow[r][k], xr[cc], a[r][cc]);
-                }
+                    for (int cc = 0; cc < CQ_T; ++cc) a[r][cc] = fma(-lrow[r][k], xr[cc], a[r][cc]);
             }
         }
     }
