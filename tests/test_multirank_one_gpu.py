@@ -439,7 +439,7 @@ def _run_processes(nranks, NT, mode):
                 p.kill()
 
 
-@pytest.mark.parametrize("nranks,NT,mode", [(2, 151, "truncating"), (2, 151, "spec"), (3, 150, "truncating")])
+@pytest.mark.parametrize("nranks,NT,mode", [(2, 151, "truncating"), (2, 151, "spec"), (3, 150, "truncating"), (3, 151, "spec")])
 def test_one_shot_allreduce_across_processes(nranks, NT, mode):
     """the one-shot all-reduce as `bench.py --gpus N --allreduce oneshot` reaches it -- one process per rank,
     receive regions mapped through hipIpcOpenMemHandle, device-side arrival flags, no host barrier (ipc_comm.hip).  Two / three

@@ -60,12 +60,14 @@ __global__ __launch_bounds__(256) void k_os_exchange(OsArgs A) {
         __threadfence_system();                                  // this lane's stores are visible system-wide ...
     }
     __syncthreads();                                             // ... and so are the whole workgroup's
-    if ((A.op == 0 || r == 0) && tid < n) {
+    // (a broadcast posts the flags of EVERY rank too and waits for all of them: a root that waited for nobody could run two collectives
+    // ahead and store into the slot -- same parity -- a slow rank is still reading; the flags make every collective a rendezvous)
+    if (tid < n) {
         unsigned long long* fl = reinterpret_cast<unsigned long long*>(A.peer[tid]) + (size_t)r * A.nbmax + chunk;
         __hip_atomic_store(fl, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    // ---- 2. every contributing rank's chunk has landed here
-    if (tid < n && (A.op == 0 || tid == 0)) {
+    // ---- 2. every rank's chunk (a broadcast: every rank's arrival) has landed here
+    if (tid < n) {
         const unsigned long long* fl = reinterpret_cast<const unsigned long long*>(A.peer[r]) + (size_t)tid * A.nbmax + chunk;
         const long long t0 = wall_clock64();
         while (__hip_atomic_load(fl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < A.seq) {
