@@ -10,7 +10,8 @@
 //     its slot of EVERY rank's region (system-scope stores: all links at once, one hop), fences, raises the chunk's arrival flag
 //     on every rank to the collective's sequence number, then polls its OWN flags of that chunk until every rank's store has landed
 //     and sums the R slots in rank order -- local reads, the same bits on every rank (what the replicated CG scalars and the split
-//     rely on), no host barrier, no event: tnml_bond_update_begin never blocks.  A broadcast is the same kernel with rank 0 the only writer.
+//     rely on), no host barrier, no event: tnml_bond_update_begin never blocks.  A broadcast is the same kernel with rank 0 the only
+//     writer of data; every rank still raises and awaits all flags, so that a broadcast is a rendezvous like a sum (the argument below needs it).
 //   * two parities: rank j can store collective s + 2 only after it finished s + 1, which needs this rank's stores of s + 1, which
 //     this rank's stream orders after its own kernel of s -- so a slot is never overwritten while its owner still reads it, without
 //     acknowledgements.  A poll that sees nothing for `comm_timeout_s` sets a status word and leaves (tnml_synchronize and the next
