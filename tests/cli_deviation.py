@@ -2,7 +2,7 @@
 tests/test_gpu_parity.py::test_fixedl_cli_driver_end_to_end (test infrastructure: prints, asserts nothing)."""
 import os, re, subprocess, sys, tempfile
 import numpy as np
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # (lives under tests/: it calls the oracle)
 sys.path.insert(0, root)
 from oracle import pyoracle
 from tnml_amd import hostlib, synth
