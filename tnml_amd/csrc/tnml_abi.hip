@@ -1592,6 +1592,9 @@ int tnml_bond_update_end(tnml_ctx* c, tnml_bond_report* rep) {
     }
     HIPCK(c, hipEventSynchronize(pr.ev));
     HIPCK(c, hipEventSynchronize(pr.ev2));
+    // a collective of this bond update that gave up waiting for a peer left its buffer unsummed: say so before anything below reads
+    // the sums (it would show up as a failed replica check or a failed split check otherwise)
+    TCK(ipc_comm_check(c));
     double* hq = pend_host(c, slot);
     if (pr.spec) {
         // the deferred check of the speculative split: its verdict came with the carried slots (summed over the ranks: every rank sees the same number)
