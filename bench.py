@@ -243,6 +243,61 @@ def shift_flops(r, NTl, N, single):
 FWD_KERNEL = ["k_fwd_fused"]
 
 
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def second_transport_leg(transport, port, rank, local_rank, world, timeout_s):
+    """This rank's share of the SECOND transport's measurement: the same command as a child process (own rendezvous on `port`, the same
+    RANK / LOCAL_RANK / WORLD_SIZE), --plain.  Returns (json line of the child's rank 0 or None, error text or None).  A child that dies,
+    hangs past `timeout_s` or prints nothing costs an error string, never the parent's line."""
+    import subprocess
+    argv, skip = [], False
+    for a in sys.argv[1:]:
+        if skip:
+            skip = False
+            continue
+        if a in ("--allreduce",):
+            skip = True
+            continue
+        if a.startswith("--allreduce=") or a in ("--leg", "--plain", "--no-cpu-baseline"):
+            continue
+        argv.append(a)
+    cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--allreduce", transport, "--leg", "--plain", "--no-cpu-baseline"]
+    env = dict(os.environ)
+    env.update(RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for k in ("TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS", "GROUP_RANK", "ROLE_RANK"):
+        env.pop(k, None)                                         # the child's rank 0 hosts its own store on `port`
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    try:
+        run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return None, "the %s leg did not finish within %d s (rank %d)" % (transport, timeout_s, rank)
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    if run.returncode != 0:
+        return None, "the %s leg ended with code %d on rank %d: %s" % (transport, run.returncode, rank, (run.stderr or run.stdout)[-600:].replace("\n", " | "))
+    return (lines[-1] if lines else None), None
+
+
+def n1_reference(N, maxm, NT, dtype):
+    """the newest committed one-GPU line of the same workload and window (profiles/r*_bench_driver_form*.json): what `speedup_vs_n1` divides by"""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_driver_form*.json")), reverse=True):
+        try:
+            d = json.loads([ln for ln in open(f).read().splitlines() if ln.startswith("{")][-1])
+        except (OSError, ValueError, IndexError):
+            continue
+        c = d.get("config", {})
+        if d.get("n_gpus") == 1 and d.get("dtype") == dtype and c.get("sites") == N and c.get("maxm") == maxm and c.get("global_images") == NT:
+            return d, "profiles/" + os.path.basename(f)
+    return None, None
+
+
 def read_prof(ts):
     """per-class (launches, ms); the one-launch forward pass is reported under 'fwd_fused' whichever kernel ran it (k_fwd_fused, or
     k_fwd_res + its k_pfinish epilogue launch which the library books under 'p_update')"""
@@ -284,6 +339,12 @@ def main():
     ap.add_argument("--allreduce", default="rccl", choices=["rccl", "oneshot"], help="transport of the library's collectives at --gpus N > 1: RCCL (ncclAllReduce / "
                     "ncclBroadcast), or the one-shot all-reduce across processes (IPC-mapped receive regions, device-side arrival flags, no host barrier: ipc_comm.hip)")
     ap.add_argument("--dry-run", action="store_true", help="control plane only (launcher, rendezvous, shard bounds, max-over-ranks clock): no GPU work")
+    ap.add_argument("--no-second-transport", action="store_true", help="at --gpus N > 1 the same window is timed over BOTH transports in one invocation (the one "
+                    "--allreduce names gives `value`; the other runs afterwards in a child process per rank, so that a failure there cannot "
+                    "take the line with it) and reported side by side under `collectives`; this switch skips the second one")
+    ap.add_argument("--leg", action="store_true", help=argparse.SUPPRESS)          # internal: this process is the second-transport child of a rank
+    ap.add_argument("--share-device", action="store_true", help="test vehicle for one-GPU boxes: every rank uses HIP device 0 (RCCL refuses two ranks on one "
+                    "device, so its block carries that error and `value` comes from the one-shot transport)")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 2 * (args.sites - 1)
@@ -324,10 +385,23 @@ def main():
             gathered = [None] * world
             dist.all_gather_object(gathered, bytes([rank]) * 64)
             assert [g[0] for g in gathered] == list(range(world))
+        # the second transport's leg (a child process per rank with a rendezvous of its own) runs over the same control plane
+        second = None
+        if world > 1 and not args.leg and not args.no_second_transport:
+            other = "oneshot" if args.allreduce == "rccl" else "rccl"
+            port = [free_port() if rank == 0 else None]
+            dist.broadcast_object_list(port, src=0)
+            line, err = second_transport_leg(other, port[0], rank, local_rank, world, 300)
+            errs = [None] * world
+            dist.all_gather_object(errs, err)
+            if rank == 0:
+                bad = [e for e in errs if e]
+                second = {"transport": other, "error": bad[0]} if bad or not line else {"transport": other, "n_gpus": json.loads(line)["n_gpus"],
+                                                                                         "handles_gathered": json.loads(line)["handles_gathered"]}
         if rank == 0:
             print(json.dumps({"dry_run": True, "n_gpus": world, "max_over_ranks": float(t[0]), "images_over_ranks": int(cnt[0]),
                               "shard_of_rank0": [lo, hi], "allreduce": args.allreduce if world > 1 else "none",
-                              "handles_gathered": None if gathered is None else len(gathered)}))
+                              "handles_gathered": None if gathered is None else len(gathered), "second_transport": second}))
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -336,9 +410,13 @@ def main():
     from tnml_amd.fixedl import TrainStates
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    if local_rank >= torch.cuda.device_count():
-        raise SystemExit("bench.py: rank %d needs HIP device %d but only %d are visible" % (rank, local_rank, torch.cuda.device_count()))
-    torch.cuda.set_device(local_rank)
+    dev = 0 if args.share_device else local_rank
+    if dev >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d needs HIP device %d but only %d are visible" % (rank, dev, torch.cuda.device_count()))
+    torch.cuda.set_device(dev)
+    main_tr = args.allreduce
+    if args.share_device and world > 1 and not args.leg:
+        main_tr = "oneshot"                                      # RCCL refuses two ranks on one device: the test vehicle times the one-shot transport
 
     labels = synth.synthetic_labels(NT)
     pixels = synth.synthetic_images(N, labels)
@@ -346,11 +424,11 @@ def main():
     single = args.single_label is not None
     if single:
         W[N // 2 - 1] = W[N // 2 - 1][..., 0] * 3.0             # plain weight MPS: no Label index
-    ts = TrainStates(labels[lo:hi], N, maxm, pixels=pixels[lo:hi], device=local_rank, rank=rank, nranks=world,
+    ts = TrainStates(labels[lo:hi], N, maxm, pixels=pixels[lo:hi], device=dev, rank=rank, nranks=world,
                      NT_total=NT, dtype=args.dtype, single_label=args.single_label)
     del pixels
     comm_ranks = 1
-    if world > 1 and args.allreduce == "oneshot":
+    if world > 1 and main_tr == "oneshot":
         handles = [None] * world                                 # every rank's IPC handle, in rank order, over the gloo control plane
         dist.all_gather_object(handles, ts.oneshot_export())
         ts.oneshot_connect(handles)
@@ -442,6 +520,7 @@ def main():
     gc.disable()
     sync()
     coll0 = ts.collective_stats()
+    split0 = ts.split_stats()
     t0 = time.perf_counter()
     step_marks = []
     for _ in range(args.steps):
@@ -452,6 +531,7 @@ def main():
     elapsed = time.perf_counter() - t0
     gc.enable()
     coll1 = ts.collective_stats()
+    split1 = ts.split_stats()
     if step_marks and rank == 0:
         print("host time at the end of each timed step (ms):", " ".join("%.2f" % (1e3 * t) for t in step_marks), "| total %.2f" % (1e3 * elapsed), file=sys.stderr)
     ts.profile(False)
@@ -563,6 +643,11 @@ def main():
         elapsed = float(t[0])
         elapsed_lit = float(t[1]) if nlit > 0 else None
 
+    out = None
+    shard_sizes = [hi - lo]
+    if world > 1:
+        shard_sizes = [None] * world
+        dist.all_gather_object(shard_sizes, hi - lo)
     if rank == 0:
         timed = reports[n_timed_end - args.steps:n_timed_end]
         NTl = hi - lo
@@ -623,7 +708,7 @@ def main():
                                                                                "whole sweeps" if full_sweeps else
                                                                                ("consecutive interior bonds, Label-carrying shiftE on each" if args.workload == "default" else "consecutive interior bonds of the second sweep"),
                                                                                m_avg),
-                       "global_images": NT, "sites": N, "maxm": maxm, "parallelism": "dp%d (image sharding + %s)" % (world, "RCCL all-reduce" if args.allreduce == "rccl" or world == 1 else "one-shot all-reduce over IPC-mapped regions"),
+                       "global_images": NT, "sites": N, "maxm": maxm, "parallelism": "dp%d (image sharding + %s)" % (world, "RCCL all-reduce" if main_tr == "rccl" or world == 1 else "one-shot all-reduce over IPC-mapped regions"),
                        "rccl_ranks": comm_ranks},
             "roofline": {"bound": "mfma", "kernel": FWD_KERNEL[0] if fused else ("k_fgemm64" if args.dtype in ("f64", "f64_e32") else ("k_fgemm" if args.dtype == "f32" else "k_fgemm_bf16")),
                          "achieved": achieved_tf, "peak": peak, "unit": "TFLOP/s",
@@ -671,6 +756,14 @@ def main():
             "env_host_tier": None if args.env_budget_gb <= 0 else dict(budget_gb=args.env_budget_gb, **ts.env_stats()),
             "last_cost_per_image": timed[-1]["cost"] / NT if timed else None,
             "svd_stats": ts.svd_stats(),
+            "speculative_split": {
+                "splits_in_timed_region": split1["speculative_splits"] - split0["speculative_splits"],
+                "roll_backs_in_timed_region": split1["roll_backs"] - split0["roll_backs"],
+                "roll_back_ms_in_timed_region": split1["roll_back_ms"] - split0["roll_back_ms"],
+                "roll_backs_per_sweep": (split1["roll_backs"] - split0["roll_backs"]) * 2.0 * (N - 1) / args.steps,
+                "ms_per_roll_back": ((split1["roll_back_ms"] - split0["roll_back_ms"]) / (split1["roll_backs"] - split0["roll_backs"])) if split1["roll_backs"] > split0["roll_backs"] else None,
+                "note": "a failed deferred check of a speculative split repeats that bond update with the synchronous split and the one begun after it "
+                        "(tnml_split_stats: device time of the repeated work, inside `value`'s window)"},
             "replica_repairs": ts.replica_repairs(),
             "centre_bond_ms": None if centre_ms is None else {
                 "label_on_B_bond_%d" % (N // 2 - 1): centre_ms[0], "label_on_B_bond_%d" % (N // 2): centre_ms[1],
@@ -680,6 +773,7 @@ def main():
                 "value": rate_8d, "unit": "bond updates/s",
                 "note": "SURVEY.md 8(d) workload: one warm-up sweep from the random-init W with minm = maxm/2, then 60 consecutive interior bonds "
                         "of the second sweep (trained bonds shrink towards maxm/2, so this is NOT the shape of `value`)"},
+            "images_per_rank": shard_sizes,
             "collectives": None if world == 1 else {
                 "allreduces_per_bond_update": (coll1[0] - coll0[0]) / args.steps, "broadcasts_per_bond_update": (coll1[1] - coll0[1]) / args.steps,
                 "allreduce_ms_per_bond_update": kms.get("allreduce", 0.0),
@@ -688,6 +782,20 @@ def main():
                 "note": "sum all-reduces of the packed [scalars | gradient or A p] buffer (merged CG passes, carried after-SVD scalars) and "
                         "broadcasts of rank 0's eigenvalues, per bond update of the timed region; allreduce ms from HIP events on the breakdown steps"},
         }
+        if world > 1:
+            # both transports side by side: this process's own (`value`) now, the other one after its child leg below
+            cm = out["collectives"]
+            cm["value_from"] = main_tr
+            cm[main_tr] = {"value": out["value"], "ms_per_step": ms_per_step, "allreduces_per_bond_update": cm["allreduces_per_bond_update"],
+                           "broadcasts_per_bond_update": cm["broadcasts_per_bond_update"], "allreduce_ms_per_bond_update": cm["allreduce_ms_per_bond_update"],
+                           "ms_per_allreduce": cm["ms_per_allreduce"], "gradient_phase_ms": out["gradient_phase_ms"], "svd_ms": out["svd_ms"], "mode": cm["mode"],
+                           "ranks": comm_ranks}
+            ref, ref_file = n1_reference(N, maxm, NT, args.dtype) if (not full_sweeps and args.workload == "default" and not single) else (None, None)
+            out["speedup_vs_n1"] = None if not ref else {
+                "bond_updates": out["value"] / ref["value"], "gradient_phase": ref["gradient_phase_ms"] / out["gradient_phase_ms"] if out["gradient_phase_ms"] else None,
+                "n1_value": ref["value"], "n1_gradient_phase_ms": ref["gradient_phase_ms"], "n1_svd_ms": ref.get("svd_ms"), "n1_source": ref_file,
+                "note": "against the committed one-GPU line of the same workload and window (same command at --gpus 1 on a box of the same pool, "
+                        "not re-measured in this run); the driver computes scaling efficiency from its own per-N runs"}
         # The three matrix-pipe kernels of a bond update, each from its own HIP events over the TIMED region, with the stamped PMC
         # traffic where it is current; `roofline` is the one with the most time per bond update (the block above describes the forward
         # kernel when that is it).
@@ -731,11 +839,44 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not single:
             ncore = cpu_quota()
             out["cpu_baseline"] = cpu_baseline(maxm, npass, lam, cutoff, min(16, ncore), NT, full=args.cpu_baseline_full)   # paralleldo.h:55-56 caps at 16
+    ts.close()
+    if world > 1 and not args.leg:
+        # ---- the SAME window over the other transport, in this invocation: one child process per rank (own rendezvous), after this
+        # process has released its device memory.  Whatever happens there ends up as a block or an error string under `collectives`.
+        other = "oneshot" if main_tr == "rccl" else "rccl"
+        block = None
+        if args.no_second_transport:
+            block = {"skipped": "--no-second-transport"}
+        elif args.share_device and other == "rccl":
+            block = {"error": "RCCL refuses two ranks on one device (--share-device is the one-GPU test vehicle): not run"}
+        else:
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            port = [free_port() if rank == 0 else None]
+            dist.broadcast_object_list(port, src=0)
+            line, err = second_transport_leg(other, port[0], rank, local_rank, world, int(os.environ.get("TNML_BENCH_LEG_TIMEOUT", "900")))
+            errs = [None] * world
+            dist.all_gather_object(errs, err)
+            if rank == 0:
+                bad = [e for e in errs if e]
+                if bad or not line:
+                    block = {"error": bad[0] if bad else "the %s leg printed no line" % other}
+                else:
+                    d2 = json.loads(line)
+                    c2 = d2.get("collectives") or {}
+                    block = {"value": d2["value"], "ms_per_step": d2["ms_per_step"], "allreduces_per_bond_update": c2.get("allreduces_per_bond_update"),
+                             "broadcasts_per_bond_update": c2.get("broadcasts_per_bond_update"), "allreduce_ms_per_bond_update": c2.get("allreduce_ms_per_bond_update"),
+                             "ms_per_allreduce": c2.get("ms_per_allreduce"), "gradient_phase_ms": d2.get("gradient_phase_ms"), "svd_ms": d2.get("svd_ms"),
+                             "mode": c2.get("mode"), "ranks": (d2.get("config") or {}).get("rccl_ranks"),
+                             "note": "the same command and window in a child process per rank, started after the main measurement had released the devices"}
+        if rank == 0:
+            out["collectives"][other] = block
+    if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    ts.close()
 
 
 if __name__ == "__main__":

@@ -156,6 +156,10 @@ int tnml_comm_init_oneshot(tnml_ctx** ctxs, int n);
 #define TNML_ONESHOT_HANDLE_BYTES 64
 int tnml_oneshot_export(tnml_ctx* ctx, void* handle64);
 int tnml_oneshot_connect(tnml_ctx* ctx, const void* handles /* nranks * TNML_ONESHOT_HANDLE_BYTES, rank order */);
+/* memory kind of this rank's receive region: 1 fine-grained, 2 uncached, 0 no cross-process transport.  (tnml_oneshot_export fails
+   rather than fall back to coarse-grained memory, which is coherent at kernel boundaries only.)  A collective whose device-side wait
+   timed out fills its buffer with NaNs and every later entry point that synchronises with the stream returns an error. */
+int tnml_oneshot_mem_kind(tnml_ctx* ctx);
 /* transport in use: 0 none, 1 RCCL, 2 in-process staging buffer, 3 in-process one-shot, 4 cross-process one-shot */
 int tnml_collective_mode(tnml_ctx* ctx);
 /* Collective.  Verifies that the communicator really spans cfg.nranks ranks (ncclCommCount) and that every rank holds a
@@ -301,6 +305,11 @@ int tnml_set_option(tnml_ctx* ctx, const char* name, int value);
    "noise" (TNML_MODE_SINGLE, fp64 storage: the noise of the sweeps, single.cc:25,222 -- from 1E-14 on tnml_svd_split / tnml_bond_update split
    through the density matrix of site c plus noise * sum_n dr_n dr_n^dag, single.h:648-672: W_c = UU, W_{c+dc} = UU * B) */
 int tnml_set_option_real(tnml_ctx* ctx, const char* name, double value);
+/* The speculative split (minm >= the columns the split may keep: no host synchronisation inside tnml_bond_update_begin): how many splits
+   ran speculatively, how many were ROLLED BACK by tnml_bond_update_end because their deferred orthogonality check failed (each repeats
+   that bond update with the synchronous split, and the one begun after it), and the device time of the repeated work in ms (event-timed;
+   call after tnml_synchronize for the full sum).  fixedL.cc:519-521 has no counterpart: ITensor's svd is synchronous. */
+int tnml_split_stats(tnml_ctx* ctx, int64_t* spec_splits, int64_t* roll_backs, double* roll_back_ms);
 /* health of the in-house eigensolver: number of fallbacks to rocSOLVER so far, number of splits whose kept basis
    held an eigenvalue cluster and was re-orthonormalised by Cholesky QR, and max|Q^T Q - I| of the kept basis
    before the first / second Newton-Schulz polish step of the last split */

@@ -79,13 +79,16 @@ def test_bench_gpus_n_without_a_launcher_starts_n_ranks():
     lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, run.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d == {"dry_run": True, "n_gpus": 2, "max_over_ranks": 2.0, "images_over_ranks": 61, "shard_of_rank0": [0, 30], "allreduce": "rccl", "handles_gathered": None}
+    # ... and the SECOND transport's leg of the same invocation (one child process per rank with a rendezvous of its own, here --dry-run too):
+    # `bench.py --gpus N` times its window over RCCL and over the one-shot all-reduce and reports both under `collectives`
+    assert d == {"dry_run": True, "n_gpus": 2, "max_over_ranks": 2.0, "images_over_ranks": 61, "shard_of_rank0": [0, 30], "allreduce": "rccl", "handles_gathered": None,
+                 "second_transport": {"transport": "oneshot", "n_gpus": 2, "handles_gathered": 2}}
     # --allreduce oneshot: the IPC handles of the cross-process one-shot all-reduce travel over the same gloo control plane
     run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--images", "61", "--allreduce", "oneshot"],
                          capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
     assert run.returncode == 0, (run.stderr + run.stdout)[-2000:]
     d = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][0])
-    assert d["allreduce"] == "oneshot" and d["handles_gathered"] == 2
+    assert d["allreduce"] == "oneshot" and d["handles_gathered"] == 2 and d["second_transport"] == {"transport": "rccl", "n_gpus": 2, "handles_gathered": None}
 
 
 def test_bench_under_the_launcher_form_the_driver_uses():
@@ -97,3 +100,26 @@ def test_bench_under_the_launcher_form_the_driver_uses():
     assert run.returncode == 0, (run.stderr + run.stdout)[-2000:]
     d = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][0])
     assert d["n_gpus"] == 2 and d["images_over_ranks"] == 60000 and d["shard_of_rank0"] == [0, 30000]
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_reports_both_transports_in_one_line():
+    """`bench.py --gpus 2` tells the whole multi-GPU story in ONE line: `collectives` carries a block per transport (RCCL and the
+    cross-process one-shot all-reduce), each with its bond updates/s, ms per all-reduce, gradient-phase and split time; per-rank image
+    counts; the communicator size.  On a one-GPU box both ranks share device 0 (--share-device): RCCL refuses two ranks on one device,
+    so its block carries that as an error string and `value` comes from the one-shot transport -- the second-leg machinery itself
+    (child process per rank, own rendezvous, merge on rank 0) is what test_bench_gpus_n_without_a_launcher_starts_n_ranks covers."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device", "--sites", "24", "--images", "3000", "--maxm", "12",
+                          "--steps", "6", "--warmup", "2", "--plain", "--no-cpu-baseline"], capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
+    assert run.returncode == 0, (run.stderr + run.stdout)[-3000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, run.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["images_per_rank"] == [1500, 1500] and d["config"]["rccl_ranks"] == 2
+    c = d["collectives"]
+    assert c["value_from"] == "oneshot" and "error" in c["rccl"]
+    o = c["oneshot"]
+    assert o["value"] == d["value"] and o["ranks"] == 2 and o["allreduces_per_bond_update"] >= 4 and o["ms_per_allreduce"] > 0
+    assert o["gradient_phase_ms"] > 0 and o["svd_ms"] > 0 and "processes" in o["mode"]
+    assert d["speculative_split"]["splits_in_timed_region"] >= 0 and "roll_backs_per_sweep" in d["speculative_split"]

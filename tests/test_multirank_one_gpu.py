@@ -92,6 +92,41 @@ def test_sweep_on_several_ranks_matches_one_rank_and_the_oracle(nranks, NT, ones
                                rtol=1e-7, atol=1e-8 * ro[0]["cost"])
 
 
+@pytest.mark.parametrize("nranks,oneshot,defer_tail", [(2, False, 1), (3, True, 1), (2, True, 0)])
+def test_roll_back_of_a_speculative_split_on_several_ranks(nranks, oneshot, defer_tail):
+    """minm = maxm: the split runs speculatively on every rank and the verdict of its deferred check travels in the carried tail
+    (slot TNML_SPECSLOT, summed over the ranks), so that every rank rolls back together.  With the test hook debug_fail_split the first,
+    an interior and the last speculative split of a pipelined sweep report a failed check on EVERY rank, and -- the case the sum is
+    there for -- on rank 1 ALONE: all ranks must repeat the bond update (and the one begun after it) with the synchronous split and
+    its collectives, end with bit-identical site tensors, and follow the undisturbed run (tnml_abi.hip: tnml_bond_update_end)."""
+    from tnml_amd.fixedl import mldmrg
+    N, NT, m = 12, 151, 6
+    pixels, labels, phi, W = make_problem(N, NT, m, 5, pixel_boost=200.0)
+    args = (1, m, m, 1e-10, 3, 1e-3, 1e-10)
+
+    def body(fail, only_rank):
+        def run(ts, r):
+            ts.set_option("defer_tail", defer_tail)
+            if fail is not None and (only_rank is None or r == only_rank):
+                ts.set_option("debug_fail_split", fail)
+            ts.init()
+            reps = mldmrg(ts, *args, pipelined=True)
+            ts.replica_check()
+            return dict(reps=reps, W=ts.get_mps(), st=ts.svd_stats())
+        return run
+    clean = _run_ranks(nranks, labels, phi, W, N, m, body(None, None), oneshot=oneshot)
+    for fail, only_rank in ((0, None), (4, None), (17, None), (5, 1)):
+        redo = _run_ranks(nranks, labels, phi, W, N, m, body(fail, only_rank), oneshot=oneshot)
+        for x in redo:
+            assert x["st"]["fallbacks"] >= clean[0]["st"]["fallbacks"] + 1, (fail, only_rank, x["st"], clean[0]["st"])   # EVERY rank repeated the bond update
+            assert [r["cost"] for r in x["reps"]] == [r["cost"] for r in redo[0]["reps"]]
+            assert all(np.array_equal(a, b) for a, b in zip(x["W"], redo[0]["W"]))
+            assert [r["bond"] for r in x["reps"]] == [r["bond"] for r in clean[0]["reps"]]
+            assert [r["newm"] for r in x["reps"]] == [r["newm"] for r in clean[0]["reps"]]
+            assert [r["ncorrect"] for r in x["reps"]] == [r["ncorrect"] for r in clean[0]["reps"]]
+        np.testing.assert_allclose([r["cost"] for r in redo[0]["reps"]], [r["cost"] for r in clean[0]["reps"]], rtol=1e-8)
+
+
 def test_two_ranks_at_m120_share_the_truncation_decision():
     """m = 120: the in-house eigensolver path with the eigenvalues broadcast from rank 0; two ranks of 300 images"""
     N, NT, m = 20, 600, 120
@@ -473,3 +508,19 @@ def test_one_shot_allreduce_across_processes(nranks, NT, mode):
         assert outs[0]["bcasts"] <= 4, outs[0]["bcasts"]         # only the four 2 x 2 chain-end splits still broadcast eigenvalues
     else:
         assert outs[0]["bcasts"] == nb
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_one_shot_allreduce_across_processes_at_m120(nranks):
+    """The cross-process one-shot all-reduce at the HEADLINE payload: [48 scalars | G], G = 240 x 240 doubles = 461 KB = 29 chunks of
+    k_os_exchange (the m = 6 test above moves one chunk).  Two and three PROCESSES on the one GPU, m = 120, pipelined bond updates with
+    the speculative split, strict replica check (a mismatch is an error); the parent holds the ranks at a start barrier until every one
+    of them has its context, data and peers (tools/oneshot_processes_m120.py).  Every rank must hold the same bits: six all-reduced
+    gradients, the cost of each of 8 bond updates, every site tensor at the end."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import oneshot_processes_m120 as osp
+    outs, errs = osp.run(nranks, NT=1536, nbonds=8, repair=0, timeout=420)
+    osp.check(outs, nranks)
+    assert all(o["mem_kind"] in (1, 2) for o in outs)
+    assert outs[0]["allreduces"] >= 6 + 5 * 8

@@ -35,7 +35,7 @@ struct IpcComm {
     char* peer[OS_MAXR] = {nullptr};      // every rank's region as mapped here (peer[r] = region)
     bool opened[OS_MAXR] = {false};
     unsigned long long seq = 0;           // collectives entered so far
-    int mem_kind = 0;                     // 1 fine-grained, 2 uncached, 3 plain hipMalloc
+    int mem_kind = 0;                     // 1 fine-grained, 2 uncached (coarse-grained memory is refused)
     unsigned long long* h_status = nullptr;   // pinned: the kernels' time-out word, mirrored
 };
 
@@ -77,8 +77,13 @@ __global__ __launch_bounds__(256) void k_os_exchange(OsArgs A) {
         }
     }
     __syncthreads();
-    if (s_bad) {                                                 // a peer never arrived: report, leave the buffer as it is
+    if (s_bad) {
+        // a peer never arrived: report, and POISON this chunk -- the stream carries on (pack kernels, CG vector kernels, the split), and
+        // whatever consumes the buffer before the host looks at the status word must not see a plausible unsummed value: NaNs spread
+        // into every cost, norm and fingerprint downstream, and every checked host synchronisation (SYNCK) fails on the status word
         if (tid == 0) { __hip_atomic_store(A.h_status, A.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+        const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+        for (size_t i = lo + tid; i < hi; i += 256) A.buf[i] = qnan;
         return;
     }
     __threadfence_system();                                      // (acquire for the lanes that did not poll)
@@ -114,8 +119,15 @@ int tnml_oneshot_export(tnml_ctx* c, void* handle64) {
     void* p = nullptr;
     if (hipExtMallocWithFlags(&p, ic->region_bytes, hipDeviceMallocFinegrained) == hipSuccess) ic->mem_kind = 1;
     else if ((void)hipGetLastError(), hipExtMallocWithFlags(&p, ic->region_bytes, hipDeviceMallocUncached) == hipSuccess) ic->mem_kind = 2;
-    else if ((void)hipGetLastError(), hipMalloc(&p, ic->region_bytes) == hipSuccess) ic->mem_kind = 3;
-    else { (void)hipGetLastError(); delete ic; return tnml_fail(c, "tnml_oneshot_export: cannot allocate %zu bytes for the receive region", ic->region_bytes); }
+    else {
+        // (no plain hipMalloc fallback: coarse-grained memory is coherent at kernel boundaries only -- a peer's stores and flags
+        // could sit unseen in this GPU's L2 while the polling kernel runs)
+        (void)hipGetLastError();
+        const size_t want = ic->region_bytes;
+        delete ic;
+        return tnml_fail(c, "tnml_oneshot_export: cannot allocate %zu bytes of fine-grained (or uncached) device memory for the receive region; "
+                            "the one-shot transport does not run on coarse-grained memory -- use tnml_comm_init (RCCL)", want);
+    }
     ic->region = static_cast<char*>(p);
     if (hipMemset(p, 0, ic->recv_off) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); delete ic; return tnml_fail(c, "tnml_oneshot_export: memset failed"); }
     hipIpcMemHandle_t h;
@@ -161,6 +173,7 @@ void ipc_comm_release(tnml_ctx* c) {
     delete ic;
 }
 int ipc_comm_mem_kind(const tnml_ctx* c) { return c->ipc ? c->ipc->mem_kind : 0; }
+int tnml_oneshot_mem_kind(tnml_ctx* c) { return c ? ipc_comm_mem_kind(c) : 0; }
 
 // op: 0 = sum of doubles, 1 = copy of rank 0's values; in stream order, never blocks the host
 int ipc_comm_exchange(tnml_ctx* c, double* buf, size_t count, int op) {

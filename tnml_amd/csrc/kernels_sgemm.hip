@@ -107,7 +107,7 @@ __global__ __launch_bounds__(64 * KS) void k_dgemm_small(SmallGemmArgs P) {
         // (launched after the polish step: the check values are final) -> pinned host mirror; bad = the test svd_split_device applies
         const double d0 = P.chk_src[0], d1 = P.chk_src[1];
         P.chk_host[0] = d0; P.chk_host[1] = d1; P.chk_host[2] = P.chk_src[2]; P.chk_host[3] = P.chk_src[3];
-        const double bad = (P.chk_force_bad || !(d0 < 1e-6) || d1 != 0.) ? 1. : 0.;
+        const double bad = (!(d0 < 1e-6) || d1 != 0.) ? 1. : 0.;
         P.chk_host[4] = bad;
         if (P.chk_bad) P.chk_bad[0] = bad;
     }
@@ -142,17 +142,17 @@ int launch_dgemm_small(tnml_ctx* c, const SmallGemmArgs& a) {
 }
 
 // the side job alone (the product it would have ridden in went to rocBLAS)
-__global__ void k_split_check_mirror(const double* __restrict__ src, double* __restrict__ host, double* __restrict__ bad, int force_bad) {
+__global__ void k_split_check_mirror(const double* __restrict__ src, double* __restrict__ host, double* __restrict__ bad) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         const double d0 = src[0], d1 = src[1];
         host[0] = d0; host[1] = d1; host[2] = src[2]; host[3] = src[3];
-        const double b = (force_bad || !(d0 < 1e-6) || d1 != 0.) ? 1. : 0.;
+        const double b = (!(d0 < 1e-6) || d1 != 0.) ? 1. : 0.;
         host[4] = b;
         if (bad) bad[0] = b;
     }
 }
-int launch_split_check_mirror(tnml_ctx* c, const double* src, double* host, double* bad, int force_bad) {
-    hipLaunchKernelGGL(k_split_check_mirror, dim3(1), dim3(64), 0, c->stream, src, host, bad, force_bad);
+int launch_split_check_mirror(tnml_ctx* c, const double* src, double* host, double* bad) {
+    hipLaunchKernelGGL(k_split_check_mirror, dim3(1), dim3(64), 0, c->stream, src, host, bad);
     HIPCK(c, hipGetLastError());
     return 0;
 }

@@ -103,13 +103,13 @@ __global__ void k_mc_flag(const unsigned long long* __restrict__ status, double*
 int split_gemm(tnml_ctx* c, bool ta, bool tb, int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* C, int ldc, int strips, const SmallGemmArgs* chk) {
     if (c->small_gemm && K <= 1024 && (double)M * N * K <= 4.0e7) {   // (tools/probe/probe_sgemm.hip: 8.7-9.9 us against 19 at 240^3, 17 against 25 at 300 x 300 x 600; loses from ~6e7 on)
         SmallGemmArgs g{A, lda, B, ldb, C, ldc, M, N, K, ta ? 1 : 0, tb ? 1 : 0};
-        if (chk) { g.chk_src = chk->chk_src; g.chk_host = chk->chk_host; g.chk_bad = chk->chk_bad; g.chk_force_bad = chk->chk_force_bad; }
+        if (chk) { g.chk_src = chk->chk_src; g.chk_host = chk->chk_host; g.chk_bad = chk->chk_bad; }
         return launch_dgemm_small(c, g);
     }
     const rocblas_status st = dgemm_strips(c->blas, ta ? rocblas_operation_transpose : rocblas_operation_none, tb ? rocblas_operation_transpose : rocblas_operation_none,
                                            M, N, K, A, lda, B, ldb, C, ldc, strips);
     if (st != rocblas_status_success) return tnml_fail(c, "split_gemm: rocblas dgemm failed (%d)", (int)st);
-    if (chk) return launch_split_check_mirror(c, chk->chk_src, chk->chk_host, chk->chk_bad, chk->chk_force_bad);
+    if (chk) return launch_split_check_mirror(c, chk->chk_src, chk->chk_host, chk->chk_bad);
     return 0;
 }
 
@@ -249,7 +249,7 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
                 S.a = pool.back(); pool.pop_back();
             }
         } else spec = false;
-        if (spec) { pr.spec = true; pr.split_n = n; pr.split_mk = mk; c->spec_splits += 1; }
+        if (spec) { pr.spec = true; pr.split_n = n; pr.split_mk = mk; c->spec_splits += 1; c->spec_splits_total += 1; }
         else hmir = nullptr;
     }
     if (tri) {
@@ -342,7 +342,9 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
     if (spec) {
         // m = mk; the eigenvalues are on their way to hmir[0..n) (k_teig_vectors), the check values follow with the factor product
         chk.chk_src = dv; chk.chk_host = hmir + n; chk.chk_bad = c->tail + TNML_SPECSLOT;
-        chk.chk_force_bad = (c->debug_fail_split >= 0 && c->spec_splits - 1 == c->debug_fail_split) ? 1 : 0;
+        // test hook (option debug_fail_split): the k-th speculative split reports a failed check -- by spoiling the check VALUE in stream
+        // order before the product that mirrors it, so that no product kernel carries a test switch
+        if (c->debug_fail_split >= 0 && c->spec_splits - 1 == c->debug_fail_split) TCK(launch_fill_f64(c, dv + 1, 1.0, 1));
         chkp = &chk;
         if (truncerr) *truncerr = 0.;                      // tnml_bond_update_end computes it from the mirrored eigenvalues
         if (newm) *newm = m;
@@ -365,7 +367,7 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
     double* h_mc = h + n + 8;
     *h_mc = 0.;
     if (mc) HIPCK(c, hipMemcpyAsync(h_mc, mcflag, 8, hipMemcpyDeviceToHost, st));
-    HIPCK(c, hipStreamSynchronize(st));
+    SYNCK(c, st);
     if (mc && *h_mc != 0.) {
         // the workgroup cluster gave up waiting for a peer (a workgroup that never got a CU): nothing it wrote is used.  Redo this
         // split with the stock solver: Gram matrix again (sG may have served as workspace), dsyevd, eigenvalues to the host.
@@ -378,7 +380,7 @@ int svd_split_device(tnml_ctx* c, const double* B_it, int b, int ha, double cuto
         evals = c->sD; own_eig = false; stock = true; Q = c->sF; direct_left = false;
         TCK(bcast_rank0(c, const_cast<double*>(evals), n));
         HIPCK(c, hipMemcpyAsync(h, evals, sizeof(double) * n, hipMemcpyDeviceToHost, st));
-        HIPCK(c, hipStreamSynchronize(st));
+        SYNCK(c, st);
     }
     if (own_eig) { hd[0] = h[n]; hd[1] = h[n + 1]; hd[2] = h[n + 2]; }
     if (c->svd_print >= 0) {                                                   // debugging aid (option svd_print = k): the spectrum of the k-th split of this context

@@ -112,6 +112,21 @@ int tnml_set_option(tnml_ctx* c, const char* name, int value) {
 int tnml_synchronize(tnml_ctx* c) { HIPCK(c, hipStreamSynchronize(c->stream)); if (c->copy_stream) HIPCK(c, hipStreamSynchronize(c->copy_stream)); return ipc_comm_check(c); }
 int64_t tnml_device_bytes(tnml_ctx* c) { return c->bytes; }
 int64_t tnml_replica_repairs(tnml_ctx* c) { return c->replica_repairs; }
+int tnml_split_stats(tnml_ctx* c, int64_t* spec_splits, int64_t* roll_backs, double* roll_back_ms) {
+    // resolves the event pairs of the roll-backs that have finished (call after tnml_synchronize for the full sum)
+    for (size_t k = 0; k < c->redo_events.size();) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->redo_events[k].first, c->redo_events[k].second) == hipSuccess) {
+            c->redo_ms += ms;
+            (void)hipEventDestroy(c->redo_events[k].first); (void)hipEventDestroy(c->redo_events[k].second);
+            c->redo_events.erase(c->redo_events.begin() + k);
+        } else { (void)hipGetLastError(); ++k; }
+    }
+    if (spec_splits) *spec_splits = c->spec_splits_total;
+    if (roll_backs) *roll_backs = c->spec_redos;
+    if (roll_back_ms) *roll_back_ms = c->redo_ms;
+    return 0;
+}
 int tnml_svd_stats(tnml_ctx* c, int64_t* fallbacks, int64_t* cluster_repairs, double* d0, double* d1) {
     if (fallbacks) *fallbacks = c->svd_fallbacks;
     if (cluster_repairs) *cluster_repairs = c->svd_cholqr;
@@ -366,6 +381,7 @@ int tnml_destroy(tnml_ctx* c) {
     for (int k = 0; k < 2; ++k) { if (c->pend[k].ev) (void)hipEventDestroy(c->pend[k].ev); if (c->pend[k].ev2) (void)hipEventDestroy(c->pend[k].ev2); }
     for (auto& p : c->prof_pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     for (auto e : c->prof_free) (void)hipEventDestroy(e);
+    for (auto& p : c->redo_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     void* ptrs[] = {c->phi, c->label, c->ones, c->U, c->P, c->dP, c->Pp, c->Zp, c->Mf, c->slab, c->partials, c->partials2, c->vB, c->vR, c->vP,
                     c->arbuf, c->locals, c->scal, c->vpart, c->counters, c->Ppart, c->tB, c->tB2, c->sM, c->sG, c->sD, c->sE, c->sF, c->sInfo, c->sE2, c->sTau, c->sV, c->sC, c->sW, c->sScr, c->sS, c->sCm, c->sQ1, c->sDev, c->mc_xbuf, c->fprint, c->noise_ws};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -487,7 +503,7 @@ int tnml_replica_check(tnml_ctx* c, int* nranks_in_comm) {
     TCK(allreduce(c, c->tail + TNML_FPSLOT, 8));
     double h[8];
     HIPCK(c, hipMemcpyAsync(h, c->tail + TNML_FPSLOT, sizeof h, hipMemcpyDeviceToHost, c->stream));
-    HIPCK(c, hipStreamSynchronize(c->stream));
+    SYNCK(c, c->stream);
     if (!fingerprint_agrees(h, c->cfg.nranks)) return tnml_fail(c, "replicas of the weight MPS differ between ranks");
     return 0;
 }
@@ -557,7 +573,7 @@ int tnml_site_dims(tnml_ctx* c, int j, int* ml, int* mr, int* has_label) {
 int tnml_get_site(tnml_ctx* c, int j, double* A) {
     if (j < 1 || j > c->N || !c->W[j].set) return tnml_fail(c, "tnml_get_site: site %d not set", j);
     const SiteT& s = c->W[j];
-    HIPCK(c, hipStreamSynchronize(c->stream));
+    SYNCK(c, c->stream);
     HIPCK(c, hipMemcpy(A, s.a, sizeof(double) * (size_t)s.ml * 2 * s.mr * s.L, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -622,7 +638,7 @@ static int env_spill(tnml_ctx* c, int j) {
     } else {
         if (e.ev_pending) { HIPCK(c, hipStreamWaitEvent(c->stream, e.ev, 0)); }
         HIPCK(c, hipMemcpyAsync(e.host, e.ptr, bytes, hipMemcpyDeviceToHost, c->stream));
-        if (!e.host_pinned) HIPCK(c, hipStreamSynchronize(c->stream));
+        if (!e.host_pinned) SYNCK(c, c->stream);
     }
     e.ev_pending = false;                               // (a copy back that was still in flight is ordered before this one: same stream, or waited for above)
     sl.mask &= (e.unit < 0) ? 0u : ~(1u << e.unit);
@@ -706,7 +722,7 @@ static int env_fetch(tnml_ctx* c, int j) {
         e.ev_pending = true;
     } else {
         HIPCK(c, hipMemcpyAsync(e.ptr, e.host, bytes, hipMemcpyHostToDevice, c->stream));
-        if (!e.host_pinned) HIPCK(c, hipStreamSynchronize(c->stream));
+        if (!e.host_pinned) SYNCK(c, c->stream);
     }
     c->env_fetches += 1;
     return 0;
@@ -841,7 +857,7 @@ int tnml_get_env(tnml_ctx* c, int j, double* E) {
     const EnvSlot& e = c->env[j];
     const size_t ne = (size_t)e.L * e.m * c->NTp;
     std::vector<char> h(ne * c->eesz());
-    HIPCK(c, hipStreamSynchronize(c->stream));
+    SYNCK(c, c->stream);
     HIPCK(c, hipMemcpy(h.data(), e.ptr, h.size(), hipMemcpyDeviceToHost));
     for (int i = 0; i < c->NT; ++i)
         for (int l = 0; l < e.L; ++l)
@@ -888,7 +904,7 @@ int tnml_classify(tnml_ctx* c, double* weights, int32_t* pred, int64_t count[TNM
     if (rc) return rc;
     std::vector<char> h((size_t)TNML_NL * c->NTp * c->esz());
     std::vector<int> lab(c->NTp);
-    HIPCK(c, hipStreamSynchronize(c->stream));
+    SYNCK(c, c->stream);
     HIPCK(c, hipMemcpy(h.data(), c->P, h.size(), hipMemcpyDeviceToHost));
     HIPCK(c, hipMemcpy(lab.data(), c->label, sizeof(int) * c->NTp, hipMemcpyDeviceToHost));
     HIPCK(c, hipMemsetAsync(tail, 0, sizeof(double) * TNML_NSCAL_AR, c->stream));
@@ -987,7 +1003,7 @@ int tnml_bond_tensor(tnml_ctx* c, int b, double* B) {
     int mL, mR, lab; TCK(tnml_bond_dims(c, b, &mL, &mR, &lab));
     if (c->W[b].mr != c->W[b + 1].ml) return tnml_fail(c, "bond %d: link dimensions differ", b);
     TCK(launch_bond_form(c, c->W[b], c->W[b + 1], c->tB));
-    HIPCK(c, hipStreamSynchronize(c->stream));
+    SYNCK(c, c->stream);
     HIPCK(c, hipMemcpy(B, c->tB, sizeof(double) * bond_elems(c, b), hipMemcpyDeviceToHost));
     return 0;
 }
@@ -1082,7 +1098,7 @@ static int read_scal(tnml_ctx* c, const double* dev, int count, double* host_out
     double* h = c->h_scal + 2 * c->svd_n + 64;
     if (count > SC_N + 4 * TNML_MAX_PASS) return tnml_fail(c, "read_scal: count too large");
     HIPCK(c, hipMemcpyAsync(h, dev, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
-    HIPCK(c, hipStreamSynchronize(c->stream));
+    SYNCK(c, c->stream);
     memcpy(host_out, h, sizeof(double) * count);
     return 0;
 }
@@ -1156,7 +1172,7 @@ static void cgrad_trace_parse(tnml_ctx* c, int npass, tnml_cg_trace* tr, int slo
 static int cgrad_fetch_trace(tnml_ctx* c, int npass, tnml_cg_trace* tr) {
     if (!tr) return 0;
     TCK(cgrad_trace_enqueue(c));
-    HIPCK(c, hipStreamSynchronize(c->stream));
+    SYNCK(c, c->stream);
     cgrad_trace_parse(c, npass, tr);
     return 0;
 }
@@ -1241,7 +1257,7 @@ static int exact_device(tnml_ctx* c, double lambda, double pcut) {
         TCK(forward_pass(c, c->vP, LD_MODE_PAP, c->tail, true));      // Pp[n] = v_n . e_j
         HIPCK(c, hipMemcpyAsync(Pt.data() + (size_t)NT * j, c->Pp, sizeof(double) * (size_t)NT, hipMemcpyDeviceToHost, c->stream));
     }
-    HIPCK(c, hipStreamSynchronize(c->stream));
+    SYNCK(c, c->stream);
     std::vector<double> hB((size_t)D, 0.);
     const int tgt = c->target();
     if (NT >= D) {                                                      // Phi^T = U S V^T: columns u_j s_j (images), V in tensor space
@@ -1274,7 +1290,7 @@ static int exact_device(tnml_ctx* c, double lambda, double pcut) {
     }
     HIPCK(c, hipMemcpyAsync(c->tB, hB.data(), sizeof(double) * D, hipMemcpyHostToDevice, c->stream));
     TCK(launch_pack(c, pd, c->tB, c->vB, nullptr));
-    HIPCK(c, hipStreamSynchronize(c->stream));                          // hB is a local
+    SYNCK(c, c->stream);                          // hB is a local
     return 0;
 }
 
@@ -1289,7 +1305,7 @@ static int download_bond(tnml_ctx* c, const double* Mvec, double* B) {   // M-la
     const BondPlan& p = c->plan;
     const size_t ne = (size_t)p.mL * 4 * p.mR * p.LB;
     TCK(launch_unpack(c, bond_pack_desc(p), Mvec, c->tB2));
-    HIPCK(c, hipStreamSynchronize(c->stream));
+    SYNCK(c, c->stream);
     HIPCK(c, hipMemcpy(B, c->tB2, sizeof(double) * ne, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -1301,7 +1317,7 @@ int tnml_forward(tnml_ctx* c, const double* B, double* P) {
     TCK(forward_pass(c, c->vB, LD_MODE_COST, c->tail, true));
     const size_t ne = (size_t)TNML_NL * c->NTp;
     std::vector<char> h(ne * c->esz());
-    HIPCK(c, hipStreamSynchronize(c->stream));
+    SYNCK(c, c->stream);
     HIPCK(c, hipMemcpy(h.data(), c->P, h.size(), hipMemcpyDeviceToHost));
     const int nl = c->nl();                                // [NT][10], or [NT] in the per-label variant
     for (int i = 0; i < c->NT; ++i)
@@ -1374,7 +1390,7 @@ int tnml_pinv(tnml_ctx* c, const double* V0, int r, int npass, double lambda, do
             TCK(forward_pass(c, c->vP, LD_MODE_PAP, c->tail, true));   // Pp[n] = V_k . v_n
             if (want_yus) {
                 HIPCK(c, hipMemcpyAsync(hp.data(), c->Pp, sizeof(double) * c->NTp, hipMemcpyDeviceToHost, c->stream));
-                HIPCK(c, hipStreamSynchronize(c->stream));
+                SYNCK(c, c->stream);
                 double t = 0.; for (int n = 0; n < NT; ++n) if (lab[n] == c->target()) t += hp[n];
                 yus[k] = t;
             } else {
@@ -1530,7 +1546,7 @@ int tnml_bond_update_begin(tnml_ctx* c, int b, int ha, const tnml_sweep_params* 
             TCK(allreduce(c, c->tail + TNML_FPSLOT, 8));
             double* hf = pend_host(c, slot) + 48;
             HIPCK(c, hipMemcpyAsync(hf, c->tail + TNML_FPSLOT, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-            HIPCK(c, hipStreamSynchronize(c->stream));
+            SYNCK(c, c->stream);
             if (!fingerprint_agrees(hf, c->cfg.nranks)) {             // every rank sees the same sums: every rank takes this branch together
                 for (int j = b; j <= b + 1; ++j) { SiteT& sT = c->W[j]; TCK(bcast_rank0(c, sT.a, (size_t)sT.ml * 2 * sT.mr * sT.L)); }
                 c->replica_repairs += 1;
@@ -1606,7 +1622,7 @@ int tnml_bond_update_end(tnml_ctx* c, tnml_bond_report* rep) {
             // and its rocSOLVER fallback.  Rare (a few per sweep), so the repeat may cost what it costs.
             const bool had_next = c->pend_count == 2;
             PendingReport& nx = c->pend[slot ^ 1];
-            HIPCK(c, hipStreamSynchronize(c->stream));
+            SYNCK(c, c->stream);
             if (c->copy_stream) HIPCK(c, hipStreamSynchronize(c->copy_stream));
             const int b1 = nx.b, ha1 = nx.ha; const tnml_sweep_params sp1 = nx.sp;
             const int b0 = pr.b, ha0 = pr.ha; const tnml_sweep_params sp0 = pr.sp;
@@ -1615,11 +1631,15 @@ int tnml_bond_update_end(tnml_ctx* c, tnml_bond_report* rep) {
             c->pend_count = 0; c->carry_slot = -1; c->p_valid = false; c->currb = -1;
             HIPCK(c, hipMemsetAsync(c->tail + TNML_CARRY, 0, sizeof(double) * TNML_CARRYN, c->stream));
             c->spec_redos += 1; c->svd_fallbacks += 1;
+            // what a roll-back costs = the device time of the work enqueued again (tnml_split_stats reports count and sum)
+            hipEvent_t re0 = nullptr, re1 = nullptr;
+            if (hipEventCreate(&re0) == hipSuccess && hipEventCreate(&re1) == hipSuccess) (void)hipEventRecord(re0, c->stream);
             c->force_safe = true;
             int rc = tnml_bond_update_begin(c, b0, ha0, &sp0);        // lands in `slot` again (pend_tail has not moved)
             c->force_safe = false;
             if (rc) return rc;
             if (had_next) TCK(tnml_bond_update_begin(c, b1, ha1, &sp1));
+            if (re0 && re1) { (void)hipEventRecord(re1, c->stream); c->redo_events.push_back({re0, re1}); }
             return tnml_bond_update_end(c, rep);
         }
         spec_commit(c, pr);

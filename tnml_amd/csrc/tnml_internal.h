@@ -23,6 +23,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/tnml.h"
@@ -221,6 +222,7 @@ struct tnml_ctx {
     // check values are mirrored into pinned host memory by the kernels that produce them and read by tnml_bond_update_end.  The new site
     // tensors go to spare buffers; a failed check rolls the sites back and repeats the bond update with the synchronous split.
     int spec_split = 1; bool force_safe = false; long spec_redos = 0, spec_splits = 0; int debug_fail_split = -1;
+    long spec_splits_total = 0; double redo_ms = 0.; std::vector<std::pair<hipEvent_t, hipEvent_t>> redo_events;   // tnml_split_stats
     std::vector<double*> spare_small, spare_big;   // spare site-tensor buffers (capacity 2 maxm^2, x 10 for the Label site)
     double* hrep = nullptr;                        // pinned: [2 slots][hrep_stride] = eigenvalues + check values of a speculative split | CG scalars + trace | norm partials | after-SVD scalars
     double* hmir = nullptr;                        // != nullptr while a bond update is being enqueued: the [scal | trace] mirror of its slot (the CG step kernels write it)
@@ -263,6 +265,10 @@ void prof_resolve(tnml_ctx* c);
 
 #define HIPCK(c, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return tnml_fail((c), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 #define TCK(expr) do { int r_ = (expr); if (r_) return r_; } while (0)
+// a host synchronisation with the stream, then the transport's verdict: a collective of the cross-process one-shot transport that timed
+// out on the device has left NaNs in its buffer (never unsummed values) and a status word -- whatever the host reads after this
+// line has either been summed over every rank or the call fails here
+#define SYNCK(c, st) do { HIPCK((c), hipStreamSynchronize(st)); TCK(ipc_comm_check(c)); } while (0)
 
 // RAII-less profiling bracket around a group of launches of one kernel class
 struct ProfScope {
@@ -433,10 +439,10 @@ struct SmallGemmArgs {
     int M, N, K; int ta, tb;
     int bmode = 0; double* dev = nullptr;      // bmode 1: op(B) = 1.5 I - 0.5 B (B symmetric, K == N), dev[0] = max |B - I| (atomic max: zero it first)
     // a side job of tile (0, 0) (speculative split): the four check values of the split to their pinned host mirror, and bad[0] = 1 when they fail
-    const double* chk_src = nullptr; double* chk_host = nullptr; double* chk_bad = nullptr; int chk_force_bad = 0;
+    const double* chk_src = nullptr; double* chk_host = nullptr; double* chk_bad = nullptr;
 };
 int launch_dgemm_small(tnml_ctx* c, const SmallGemmArgs& a);
-int launch_split_check_mirror(tnml_ctx* c, const double* src, double* host, double* bad, int force_bad);
+int launch_split_check_mirror(tnml_ctx* c, const double* src, double* host, double* bad);
 // C = op(A) op(B) at the sizes of the split: the in-house kernel up to 4e7 multiply-adds, rocBLAS (as `strips` column strips) beyond
 int split_gemm(tnml_ctx* c, bool ta, bool tb, int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* C, int ldc, int strips, const SmallGemmArgs* chk = nullptr);   // chk: its chk_* fields ride along (or get a launch of their own)
 

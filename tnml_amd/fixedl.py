@@ -101,6 +101,10 @@ class TrainStates:
         assert len(blob) == 64 * self.nranks, (len(blob), self.nranks)
         self._ck(self._L.tnml_oneshot_connect(self._h, C.create_string_buffer(blob, len(blob))))
 
+    def oneshot_mem_kind(self):
+        """memory kind of the receive region of the cross-process one-shot transport: 1 fine-grained, 2 uncached, 0 none"""
+        return self._L.tnml_oneshot_mem_kind(self._h)
+
     def collective_mode(self):
         """0 none (one rank), 1 RCCL, 2 in-process staging buffer, 3 in-process one-shot peer write, 4 cross-process one-shot (IPC)"""
         return self._L.tnml_collective_mode(self._h)
@@ -144,6 +148,12 @@ class TrainStates:
         fb, cr, d0, d1 = C.c_int64(), C.c_int64(), C.c_double(), C.c_double()
         self._ck(self._L.tnml_svd_stats(self._h, C.byref(fb), C.byref(cr), C.byref(d0), C.byref(d1)))
         return dict(fallbacks=fb.value, cluster_repairs=cr.value, dev_before_polish=d0.value, dev_after_first_polish=d1.value)
+
+    def split_stats(self):
+        """speculative splits so far, how many tnml_bond_update_end rolled back (failed deferred check), device ms of the repeated work"""
+        a, b, ms = C.c_int64(), C.c_int64(), C.c_double()
+        self._ck(self._L.tnml_split_stats(self._h, C.byref(a), C.byref(b), C.byref(ms)))
+        return dict(speculative_splits=a.value, roll_backs=b.value, roll_back_ms=ms.value)
 
     def device_bytes(self):
         return self._L.tnml_device_bytes(self._h)
