@@ -55,12 +55,14 @@ def main():
         ts.set_option("check_replicas", 2)                       # a replica mismatch after a split is repaired (and counted), not an error
     b, ha = 8, 1
     costs, inflight = [], 0
-    for k in range(nbonds):                                      # pipelined like the sweep drivers: bond k + 1 is enqueued before the report of bond k is read
+    depth = int(os.environ.get("TNML_T_DEPTH", "2"))             # 2: pipelined like the sweep drivers (bond k + 1 is enqueued before the report of bond k is read)
+    for k in range(nbonds):
         ts.bond_update_begin(b, ha, m, m, 1e-10, 4, 1e-3, 1e-10)
         inflight += 1
-        if inflight == 2:
+        if inflight == depth:
             costs.append(ts.bond_update_end()["cost"])
             inflight -= 1
+            note("bond update %d reported" % len(costs))
         b, ha = lib.sweepnext(b, ha, N)
     while inflight:
         costs.append(ts.bond_update_end()["cost"])

@@ -19,6 +19,7 @@
 // On one GPU the same code runs between two PROCESSES sharing the device (IPC handles open on the exporting device too): that is how
 // it is tested on a one-GPU box (tests/test_multirank_one_gpu.py).  Ranks that are threads of one process keep local_comm.hip.
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 
 #include "tnml_internal.h"
@@ -47,52 +48,69 @@ struct OsArgs {
 static __device__ __forceinline__ void st_sys(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 static __device__ __forceinline__ double ld_sys(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
+// At most OS_MAXWG workgroups per collective, each walking the chunks blockIdx.x, blockIdx.x + gridDim.x, ... in the same order on every
+// rank: first it hands out ALL its chunks (stores, fence, flags -- nothing to wait for), then it collects them (poll, ordered sum).
+// Why the cap: a workgroup that polls holds a wave on every SIMD of its CU.  The 461 KB buffer of an ordinary bond is 29 chunks, but the
+// two Label-on-B bonds move 4.6 MB = 282 chunks, and 282 polling workgroups put a wave on every SIMD of EVERY CU; where ranks share a GPU
+// (the one-GPU test vehicle) a 768-lane workgroup of the peer's preceding kernel -- 3 waves of 168 registers per SIMD -- then fits
+// nowhere, the peer never reaches its collective and both sides wait for ever (seen as "collective 30 timed out", the second all-reduce
+// of the first Label-on-B bond: profiles/r06_oneshot_processes_root_cause.txt).  32 workgroups keep >= 7/8 of the chip free whatever
+// the payload, and still move 4.6 MB in tens of microseconds.
+#define OS_MAXWG 32
 __global__ __launch_bounds__(256) void k_os_exchange(OsArgs A) {
     __shared__ int s_bad;
-    const int tid = threadIdx.x, chunk = blockIdx.x, n = A.n, r = A.r;
-    const size_t lo = (size_t)chunk * OS_CHUNK, hi = lo + OS_CHUNK < A.count ? lo + OS_CHUNK : A.count;
+    const int tid = threadIdx.x, n = A.n, r = A.r;
+    const int nb = (int)((A.count + OS_CHUNK - 1) / OS_CHUNK);
     if (tid == 0) s_bad = 0;
-    // ---- 1. this rank's chunk into its slot of every rank's region (a broadcast: rank 0 alone writes)
-    if (A.op == 0 || r == 0) {
-        for (int j = 0; j < n; ++j) {
-            double* dst = reinterpret_cast<double*>(A.peer[j] + A.recv_off) + ((size_t)A.parity * n + r) * A.cap;
-            for (size_t i = lo + tid; i < hi; i += 256) st_sys(dst + i, A.buf[i]);
+    // ---- 1. this rank's chunks into its slot of every rank's region (a broadcast: rank 0 alone writes), then the chunk's flag on every rank
+    for (int chunk = blockIdx.x; chunk < nb; chunk += gridDim.x) {
+        const size_t lo = (size_t)chunk * OS_CHUNK, hi = lo + OS_CHUNK < A.count ? lo + OS_CHUNK : A.count;
+        if (A.op == 0 || r == 0) {
+            for (int j = 0; j < n; ++j) {
+                double* dst = reinterpret_cast<double*>(A.peer[j] + A.recv_off) + ((size_t)A.parity * n + r) * A.cap;
+                for (size_t i = lo + tid; i < hi; i += 256) st_sys(dst + i, A.buf[i]);
+            }
+            __threadfence_system();                              // this lane's stores are visible system-wide ...
         }
-        __threadfence_system();                                  // this lane's stores are visible system-wide ...
-    }
-    __syncthreads();                                             // ... and so are the whole workgroup's
-    // (a broadcast posts the flags of EVERY rank too and waits for all of them: a root that waited for nobody could run two collectives
-    // ahead and store into the slot -- same parity -- a slow rank is still reading; the flags make every collective a rendezvous)
-    if (tid < n) {
-        unsigned long long* fl = reinterpret_cast<unsigned long long*>(A.peer[tid]) + (size_t)r * A.nbmax + chunk;
-        __hip_atomic_store(fl, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    // ---- 2. every rank's chunk (a broadcast: every rank's arrival) has landed here
-    if (tid < n) {
-        const unsigned long long* fl = reinterpret_cast<const unsigned long long*>(A.peer[r]) + (size_t)tid * A.nbmax + chunk;
-        const long long t0 = wall_clock64();
-        while (__hip_atomic_load(fl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < A.seq) {
-            __builtin_amdgcn_s_sleep(8);
-            if (wall_clock64() - t0 > A.timeout_ticks) { s_bad = 1; break; }
+        __syncthreads();                                         // ... and so are the whole workgroup's
+        // (a broadcast posts the flags of EVERY rank too and waits for all of them: a root that waited for nobody could run two collectives
+        // ahead and store into the slot -- same parity -- a slow rank is still reading; the flags make every collective a rendezvous)
+        if (tid < n) {
+            unsigned long long* fl = reinterpret_cast<unsigned long long*>(A.peer[tid]) + (size_t)r * A.nbmax + chunk;
+            __hip_atomic_store(fl, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
-    __syncthreads();
-    if (s_bad) {
-        // a peer never arrived: report, and POISON this chunk -- the stream carries on (pack kernels, CG vector kernels, the split), and
-        // whatever consumes the buffer before the host looks at the status word must not see a plausible unsummed value: NaNs spread
-        // into every cost, norm and fingerprint downstream, and every checked host synchronisation (SYNCK) fails on the status word
-        if (tid == 0) { __hip_atomic_store(A.h_status, A.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-        const double qnan = __longlong_as_double(0x7ff8000000000000ll);
-        for (size_t i = lo + tid; i < hi; i += 256) A.buf[i] = qnan;
-        return;
-    }
-    __threadfence_system();                                      // (acquire for the lanes that did not poll)
-    // ---- 3. ordered local sum (rank order: the same bits on every rank) / copy of rank 0's values
-    const double* src = reinterpret_cast<const double*>(A.peer[r] + A.recv_off) + (size_t)A.parity * n * A.cap;
-    for (size_t i = lo + tid; i < hi; i += 256) {
-        double s = ld_sys(src + i);
-        if (A.op == 0) for (int j = 1; j < n; ++j) s += ld_sys(src + (size_t)j * A.cap + i);
-        A.buf[i] = s;
+    // ---- 2. every rank's chunk (a broadcast: every rank's arrival) has landed here: ordered local sum (rank order: the same bits on
+    //         every rank) / copy of rank 0's values
+    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+    for (int chunk = blockIdx.x; chunk < nb; chunk += gridDim.x) {
+        const size_t lo = (size_t)chunk * OS_CHUNK, hi = lo + OS_CHUNK < A.count ? lo + OS_CHUNK : A.count;
+        if (tid < n && !s_bad) {
+            const unsigned long long* fl = reinterpret_cast<const unsigned long long*>(A.peer[r]) + (size_t)tid * A.nbmax + chunk;
+            const long long t0 = wall_clock64();
+            while (__hip_atomic_load(fl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < A.seq) {
+                __builtin_amdgcn_s_sleep(8);
+                if (wall_clock64() - t0 > A.timeout_ticks) { s_bad = 1; break; }
+            }
+        }
+        __syncthreads();
+        if (s_bad) {
+            // a peer never arrived: report, and POISON this chunk (and, without waiting again, every later one of this workgroup) -- the
+            // stream carries on (pack kernels, CG vector kernels, the split), and whatever consumes the buffer before the host looks at the
+            // status word must not see a plausible unsummed value: NaNs spread into every cost, norm and fingerprint downstream, and
+            // every checked host synchronisation (SYNCK) fails on the status word
+            if (tid == 0) { __hip_atomic_store(A.h_status, A.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+            for (size_t i = lo + tid; i < hi; i += 256) A.buf[i] = qnan;
+            continue;                                            // (s_bad stays set: uniform over the workgroup from here on)
+        }
+        __threadfence_system();                                  // (acquire for the lanes that did not poll)
+        const double* src = reinterpret_cast<const double*>(A.peer[r] + A.recv_off) + (size_t)A.parity * n * A.cap;
+        for (size_t i = lo + tid; i < hi; i += 256) {
+            double s = ld_sys(src + i);
+            if (A.op == 0) for (int j = 1; j < n; ++j) s += ld_sys(src + (size_t)j * A.cap + i);
+            A.buf[i] = s;
+        }
+        __syncthreads();                                         // (s_bad is read above by every lane before any lane of the next round may set it)
     }
 }
 
@@ -189,7 +207,9 @@ int ipc_comm_exchange(tnml_ctx* c, double* buf, size_t count, int op) {
     a.recv_off = ic->recv_off; a.h_status = ic->h_status;
     a.timeout_ticks = (long long)c->comm_timeout_s * 100000000ll;       // wall_clock64: 100 MHz
     const int nb = (int)((count + OS_CHUNK - 1) / OS_CHUNK);
-    hipLaunchKernelGGL(k_os_exchange, dim3(nb), dim3(256), 0, c->stream, a);
+    static const bool trace = getenv("TNML_IPC_TRACE") != nullptr;       // debugging aid: the host-side sequence of collectives of every rank
+    if (trace) fprintf(stderr, "[ipc rank %d] seq %llu op %d count %zu chunks %d\n", ic->r, a.seq, op, count, nb);
+    hipLaunchKernelGGL(k_os_exchange, dim3(nb < OS_MAXWG ? nb : OS_MAXWG), dim3(256), 0, c->stream, a);
     HIPCK(c, hipGetLastError());
     return 0;
 }

@@ -541,6 +541,7 @@ void launch_slab_reduce64(tnml_ctx* c, const double* slab, double* G, size_t n, 
 int launch_bgemm64(tnml_ctx* c, const Bgemm64Args& a, double* G) {
     // Tile choices: the winners of the tuning runs recorded under profiles/ (r01 tune_bgemm, r02_tune_m60.txt, r03_tune_m300.txt,
     // r03_tune_bgemm_wide_tiles.txt, r03_ab_bgemm_double_buffer_and_ablation.txt); the losing instantiations are gone.
+    if (grad_quad_applies(c, a)) return launch_grad_quad(c, a, G);
     if (a.EL) {                                             // fused Z build: >= 320 lanes per workgroup
         if (a.Kp % 240 == 0 && a.Np % 240 == 0) return bgemm64_go<5, 1, 3, 4, 1>(c, a, G, 256 * a.L);   // 240 x 64, 12 waves: 181 us vs 153 + 90 unfused
         if (a.Kp % 80 == 0 && a.Np % 80 == 0)   return bgemm64_go<1, 5, 5, 1, 1>(c, a, G);               // 80 x 80, 5 waves

@@ -211,6 +211,8 @@ struct tnml_ctx {
     int fwd_res = 1;                 // forward pass on k_fwd_res (kernels_res.hip): 1 = from 7 680 images per rank on, 0 never, 2 always; option "fwd_res"
     int shift_res = 1;               // Label-carrying environment shift on k_shift_res (kernels_res.hip): 1 = from 7 680 images per rank on, 0 never, 2 always; option "shift_res"
     int res_grid = 0;                // test knob: workgroups of the resident-operand kernels (0: one per CU)
+    int grad_quad = 1;               // gradient GEMM on k_grad_quad (kernels_grad.hip; m = 120, fp64 storage, Label on an environment): 1 = from 4 096 images per rank on, 0 never, 2 always; option "grad_quad", env TNML_GRAD_QUAD
+    bool attr_gq = false;
     int bgemm_per = 0;               // probe knob (TNML_BGEMM_PER): images per slab of the gradient GEMM, in units of 32 (0: derived from bgemm_wgs)
     int bgemm_wgs = 0;               // workgroups the gradient GEMM aims at when it cuts the image range into slabs (0: per-shape default; option "bgemm_wgs")
     unsigned* counters = nullptr;    // [16] device: arrival counters of the "last workgroup reduces" kernels (zero between launches)
@@ -324,6 +326,9 @@ struct Bgemm64Args {
 };
 int launch_bgemm64(tnml_ctx* c, const Bgemm64Args& a, double* G);
 void launch_slab_reduce64(tnml_ctx* c, const double* slab, double* G, size_t n, int nsplit);
+// ---- kernels_grad.hip: the gradient GEMM with the accumulators resident in a quad of workgroups, three MFMA-issuing waves per SIMD ----
+bool grad_quad_applies(const tnml_ctx* c, const Bgemm64Args& a);
+int launch_grad_quad(tnml_ctx* c, const Bgemm64Args& a, double* G);
 
 // ---- kernels_stream.hip -------------------------------------------------------------------
 enum { LD_MODE_COST = 0, LD_MODE_PAP = 1, LD_MODE_FWD = 2 };

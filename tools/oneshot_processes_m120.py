@@ -35,14 +35,17 @@ def run(nranks, NT=1536, nbonds=8, repair=0, timeout=420, verbose=False):
         for p in procs:                                            # the start barrier: every rank has its context, data and peers
             p.stdin.write("GO\n")
             p.stdin.flush()
-        outs, errs = [], []
+        outs, errs, bad = [], [], []
         t_end = time.time() + timeout
-        for p in procs:
+        for r, p in enumerate(procs):
             so, se = p.communicate(timeout=max(1.0, t_end - time.time()))
             errs.append(se)
             res = [ln for ln in so.splitlines() if ln.startswith("RESULT ")]
-            assert p.returncode == 0 and res, "rank failed (rc %s):\n%s" % (p.returncode, se[-3000:])
-            outs.append(json.loads(res[-1][7:]))
+            if p.returncode != 0 or not res:
+                bad.append("rank %d failed (rc %s):\n%s" % (r, p.returncode, se[-2500:]))
+            else:
+                outs.append(json.loads(res[-1][7:]))
+        assert not bad, "\n".join(bad)
         if verbose:
             for se in errs:
                 sys.stderr.write(se)
