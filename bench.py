@@ -48,7 +48,7 @@ def kernel_source_sha16():
     """fingerprint of the kernel sources a PMC measurement belongs to"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("kernels_gemm.hip", "kernels_stream.hip", "kernels_fused.hip", "kernels_res.hip"):
+    for f in ("kernels_gemm.hip", "kernels_stream.hip", "kernels_fused.hip", "kernels_res.hip", "kernels_grad.hip"):
         h.update(open(os.path.join(ROOT, "tnml_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -241,6 +241,7 @@ def shift_flops(r, NTl, N, single):
 
 
 FWD_KERNEL = ["k_fwd_fused"]
+GRAD_KERNEL = ["k_bgemm64 (gradient GEMM dP*dag(t.v), Z built while staging)"]
 
 
 def free_port():
@@ -307,6 +308,11 @@ def read_prof(ts):
         FWD_KERNEL[0] = "k_fwd_res"
         n0, ms0 = pr.get("fwd_fused", (0, 0.0))
         pr["fwd_fused"] = (n0 + n, ms0 + ms)
+    n, ms = pr.pop("grad_quad", (0, 0.0))                     # the gradient GEMM is reported under 'bgemm' whichever kernel ran it
+    if n:
+        GRAD_KERNEL[0] = "k_grad_quad (gradient GEMM dP*dag(t.v): accumulators resident in a quad of workgroups, four MFMA waves per SIMD)"
+        n0, ms0 = pr.get("bgemm", (0, 0.0))
+        pr["bgemm"] = (n0 + n, ms0 + ms)
     return pr
 
 
@@ -509,7 +515,7 @@ def main():
     # random-init and 14-27 later in a long window -- so it is taken inside the timed region, not on the breakdown steps after it)
     # (the gradient GEMM and the shift are timed live as well -- roofline_kernels -- where a bond update is GPU-bound; on toy workloads, where
     # it is bound by the host's launch rate, ten more event records per bond update would move the figure being measured)
-    live = "fgemm_fwd,fwd_fused,fwd_res,svd" + (",bgemm,fgemm_shift" if (hi - lo) * maxm * maxm >= 1e8 else "")
+    live = "fgemm_fwd,fwd_fused,fwd_res,svd" + (",bgemm,grad_quad,fgemm_shift" if (hi - lo) * maxm * maxm >= 1e8 else "")
     ts.profile(os.environ.get("TNML_BENCH_NOPROF", "0") != "1", only=live)
     ts.profile_reset()
     # no cyclic garbage collection inside the timed region: a generation-2 pass over this process's heap takes ~40 ms -- the time of
@@ -804,7 +810,7 @@ def main():
             rk = {}
             for cls, kname, per_step_flops, alg_bytes in (
                     ("fwd_fused" if fused else "fgemm_fwd", out["roofline"]["kernel"], flops_per_pass, float(np.mean([NTl * (11 * min(r["mL"], r["mR"]) * 8 + 2 * 2 * 8 + 4) for r in timed])) if timed else None),
-                    ("bgemm", "k_bgemm64 (gradient GEMM dP*dag(t.v), Z built while staging)", flops_per_pass, float(np.mean([NTl * (11 * min(r["mL"], r["mR"]) * 8 + 2 * 2 * 8 + 10 * 8) for r in timed])) if timed else None),
+                    ("bgemm", GRAD_KERNEL[0], flops_per_pass, float(np.mean([NTl * (11 * min(r["mL"], r["mR"]) * 8 + 2 * 2 * 8 + 10 * 8) for r in timed])) if timed else None),
                     ("fgemm_shift", "k_shift_res / k_fgemm64 (shiftE)", sh,
                      float(np.mean([NTl * 8.0 * ((r["mL"] if r["half"] == 1 else r["mR"]) + r["newm"]) * (shift_flops(r, NTl, N, single) / (2.0 * NTl * 2 * (r["mL"] if r["half"] == 1 else r["mR"]) * r["newm"])) + NTl * 16.0
                                     for r in timed])) if timed else None)):

@@ -323,6 +323,63 @@ def test_the_slab_cut_of_the_gradient_gemm_changes_only_the_summation_order():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("NT,wgs", [(300, 0), (1100, 12), (2100, 8), (2100, 0)])
+def test_gradient_quad_kernel_matches_the_oracle(NT, wgs):
+    """k_grad_quad (kernels_grad.hip; option "grad_quad"): the gradient GEMM dP*dag(t.v) (fixedL.cc:379,418) of the BASELINE config 3 shape
+    with the 240 x 240 accumulators resident in a quad of workgroups -- from 4 096 images per rank on it is the kernel every CG pass of
+    an m = 120 bond with the Label index on an environment runs, forced here (grad_quad = 2) at oracle-sized image counts.  300 images = 16
+    chunks of 32 on 16 quads (ONE stage each: prologue and epilogue only), 1 100 images = 40 chunks on 3 quads (option bgemm_wgs = 12:
+    14 + 14 + 12 stages, ragged), 2 100 images = 72 chunks on 2 quads (36 stages each) and on 64 quads (2 stages on 8 of them, 1 on the others).
+    Gradient against the oracle for both bond kinds the kernel serves, bit-identical repeats, the same sums as k_bgemm64 to rounding,
+    the CG that runs on it, and a whole bond update."""
+    from oracle import pyoracle
+    from tnml_amd.fixedl import TrainStates
+    from conftest import make_problem
+    N, m = 20, 120
+    pixels, labels, phi, W = make_problem(N, NT, m, 7, pixel_boost=200.0)
+    ts = TrainStates(labels, N, m, phi=phi)
+    ts.set_option("grad_quad", 2)
+    if wgs:
+        ts.set_option("bgemm_wgs", wgs)
+    ts.set_mps(W)
+    ts.init()
+    o = pyoracle.Oracle(phi, labels, W, nthread=min(8, os.cpu_count() or 1))
+    o.init()
+    rng = np.random.default_rng(1)
+    at = 1
+    for b, kind in ((8, "Label on RE"), (12, "Label on LE")):
+        for bb in range(at, b):
+            ts.shiftE(bb, True); o.shiftE(bb, True)
+        at = b
+        ts.setBond(b); o.set_bond(b)
+        B = o.bond_tensor(b)
+        B = B + 0.05 * rng.standard_normal(B.shape)
+        ts.profile(True, only="bgemm,grad_quad")
+        ts.profile_reset()
+        G = ts.gradient(B)
+        ts.profile(False)
+        pr = ts.profile_read()
+        assert pr["grad_quad"][0] == 1 and pr.get("bgemm", (0, 0))[0] == 0      # the kernel under test really ran
+        assert _rel(G, o.gradient(B)) < 1e-9, kind
+        assert np.array_equal(G, ts.gradient(B)), kind                # fixed summation order: the same bits every time
+        ts.set_option("grad_quad", 0)
+        assert _rel(G, ts.gradient(B)) < 1e-13, kind                   # k_bgemm64: another summation order, the same sums
+        ts.set_option("grad_quad", 2)
+        Bg, tg = ts.cgrad(B, 3, 1e-3, 1e-10)
+        Bo, to = o.cgrad(B, 3, 1e-3, 1e-10)
+        np.testing.assert_allclose(tg["cost"], to["cost"], rtol=1e-9, err_msg=kind)
+        np.testing.assert_allclose(tg["alpha"], to["alpha"], rtol=1e-5, err_msg=kind)
+        assert _rel(Bg, Bo) < 1e-5, kind
+    r = ts.bond_update(12, 1, m, m // 2, 1e-10, 3, 1e-3, 1e-10)
+    o.set_bond(12)
+    B, _ = o.cgrad(o.bond_tensor(12), 3, 1e-3, 1e-10)
+    newm, te, _ = o.svd_split(B, 12, 1, 1e-10, m, m // 2)
+    C, lc, cr, nc = o.quadcost(o.bond_tensor(12), 1e-3)
+    assert r["newm"] == newm and r["ncorrect"] == nc and r["cost"] == pytest.approx(C, rel=1e-8)
+    ts.close()
+
+
+@pytest.mark.gpu
 def test_m60_kernel_instantiations_match_the_oracle():
     """bonds that have shrunk to minm = maxm/2 = 60 (the reference default, fixedL.cc:593) run their own tiles: 128 x 128
     feature-GEMM tiles (forced here as for C3: at 60 000 images they are the default), 128 x 64 gradient-GEMM tiles"""

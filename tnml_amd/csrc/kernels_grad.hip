@@ -1,22 +1,31 @@
 // kernels_grad.hip -- k_grad_quad: the gradient GEMM dP*dag(t.v) (fixedL.cc:379,418) at m = 120, fp64 storage, Label index on an environment:
 //
-//   G[2a + s][2q + t] = sum_n  E_n[a] phiI_n[s]  *  phiO_n[t] Z_n[q],      Z_n[q] = sum_l EL_n[l][q] dP_n[l]
+//   G[2a + s][2q + t] = sum_n  E_n[a] * ( phiI_n[s] phiO_n[t] Z_n[q] ),      Z_n[q] = sum_l EL_n[l][q] dP_n[l]
 //
 // (E the Label-free, EL the Label-carrying environment; the dense t.v of the reference is never formed).  The reduction runs over the
 // IMAGES, so both MFMA operands change every k-step and neither can live in registers the way the bond matrix does in k_fwd_res; what can
-// live in registers is the RESULT.  The shape follows the counters of round 5 (profiles/r05_grad_pmc_by_variant.txt): every earlier form
-// kept two MFMA-issuing waves per SIMD (128 accumulator registers per wave, or 157 KB of LDS) and sat at 3/4 of the matrix pipe with
-// nothing else running; a wave that only loads or only does VALU work is starved by the MFMA waves of its SIMD.  Here
+// live in registers is the RESULT.  The shape follows two measurements:
+//   (1) profiles/r05_grad_pmc_by_variant.txt: every earlier form kept two MFMA-issuing waves per SIMD (128 accumulator registers per
+//       wave, or 157 KB of LDS) and sat at 3/4 of the matrix pipe with nothing else running; a wave that only loads or only does VALU work
+//       is starved by the MFMA waves of its SIMD;
+//   (2) profiles/r06_grad_quad_v1_first_run.txt: with three MFMA waves per SIMD and BOTH site features applied to the fragments (12
+//       multiplies per 10 MFMAs) the compute side alone still reached only 0.61 of the pipe -- a VALU instruction is issued only while
+//       no MFMA of any wave waits at the SIMD's issue port, so the waves fall into step: MFMA phases, then VALU phases with the pipe idle.
+// Hence:
 //   * a QUAD of workgroups (one XCD: blocks b, b + 8, b + 16, b + 24) owns the 240 x 240 accumulators for one slab of images; workgroup h
-//     of the quad owns the output links q in [30 h, 30 h + 30), i.e. 60 of the 240 columns (4 column tiles, the last one 3/4 full), and
-//     therefore streams only ITS quarter of the Label-carrying environment -- the 577 MB stream is read exactly once;
-//   * 12 UNIFORM waves per workgroup = THREE MFMA-issuing waves per SIMD, 5 row tiles x 1 column tile = 40 accumulator registers each;
-//     every wave also does 1/12 of the staging (loads into registers one stage ahead, LDS writes, the ten FMAs per element of Z), and the
-//     three waves of a SIMD do that part after DIFFERENT MFMA blocks of a stage, so that at any time two of them feed the matrix pipe;
-//   * the site features are applied to the FRAGMENTS (one multiply per fragment element), so the Label-free rows go to LDS raw and are
-//     staged once per workgroup for both values of s: 46 KB of LDS per 32-image stage, two stages, ONE barrier per stage;
-//   * row stride 36 doubles: the 16-byte fragment reads of 16 consecutive rows fall on 16 different bank quads (stride 34, as in
-//     k_bgemm64, makes two lanes of each ds_read_b128 group collide -- its 12 % bank-conflict time).
+//     of the quad owns the output links q in [30 h, 30 h + 30), i.e. 60 of the 240 columns 2q + t (4 column tiles, the last one 3/4 full),
+//     and therefore streams only ITS quarter of the Label-carrying environment -- the 577 MB stream is read exactly once;
+//   * 16 UNIFORM waves per workgroup = FOUR MFMA-issuing waves per SIMD, 4 row tiles x 1 column tile = 32 accumulator registers each;
+//   * the A operand is the RAW Label-free environment: rows are taken s-major (8 row tiles of a = 0..127 per value of s, rows 120..127
+//     zero), so a wave's row tiles share one s and both site features move to the B side as ONE weight w_st[n] = phiI_n[s] phiO_n[t],
+//     tabulated per stage: 2 multiplies per 8 MFMAs, and the Label-free rows go to LDS untouched, once for both values of s.  Price: 16 row
+//     tiles instead of 15 (6.7 % more MFMAs);
+//   * every wave does 1/16 of the staging (loads into registers one stage ahead, LDS writes, the ten FMAs per element of Z), and the four
+//     waves of a SIMD do that part after DIFFERENT MFMA blocks of a stage; 46 KB of LDS per 32-image stage, two stages, ONE barrier per stage;
+//   * fragments are read one k-step (4 images, ds_read_b64) at a time and ONE K-STEP AHEAD of the MFMAs that use them: the four waves
+//     of a SIMD share the pipe round-robin and therefore stay in step -- with the reads of a block at its top (the 16-byte form) all four
+//     waited for LDS at the same moments and the pipe idled ~20 % of every block (profiles/r06_grad_quad_steps.txt, "no staging");
+//   * row stride 34 doubles: the 8-byte fragment reads of 16 consecutive rows x 2 k-slots fall on 32 different bank pairs.
 // Deterministic: every element is accumulated over its slab's images in a fixed order; the slabs are summed in slab order by the
 // consumer (the CG vector kernel, or k_slab_reduce64), exactly like k_bgemm64's.
 #include "tnml_internal.h"
@@ -24,13 +33,12 @@
 typedef double f64x4g __attribute__((ext_vector_type(4)));
 
 #define GQ_TI 32                       // images per stage
-#define GQ_RS 36                       // doubles between staged rows
+#define GQ_RS 34                       // doubles between staged rows
 #define GQ_Q 30                        // output links per workgroup
-#define GQ_E_D (120 * GQ_RS)           // doubles per stage buffer: Label-free rows
+#define GQ_E_D (128 * GQ_RS)           // doubles per stage buffer: Label-free rows 0..119 + 8 rows of zeros
 #define GQ_Z_D (31 * GQ_RS)            // Z rows of this workgroup + one row of zeros (the padding columns of the last column tile)
-#define GQ_P_D (4 * GQ_TI)             // phiI[0..1], phiO[0..1]
-#define GQ_D_D (TNML_NL * GQ_TI)       // dP rows
-#define GQ_LDS_DOUBLES (2 * (GQ_E_D + GQ_Z_D + GQ_P_D + GQ_D_D))
+#define GQ_W_D (4 * GQ_RS)             // w[2 s + t][n] = phiI[s][n] phiO[t][n]
+#define GQ_LDS_DOUBLES (2 * (GQ_E_D + GQ_Z_D + GQ_W_D))
 
 struct GradQuadArgs {
     const double* EI; const double* phiI; const double* phiO;      // [120][NTp], [2][NTp], [2][NTp]
@@ -48,14 +56,14 @@ static __device__ __forceinline__ void gq_barrier() {
     asm volatile("" ::: "memory");
 }
 
-// ABL (probe builds): 1 = no loads of the Label-carrying environment (compute side alone), 2 = no MFMAs (stream side alone)
+// ABL (the ablations of the record under profiles/): 1 = no loads of the Label-carrying environment (compute side alone),
+// 3 = no staging at all inside the loop (the MFMA loop with its fragment reads and the barrier per stage)
 template <int ABL>
-__global__ __launch_bounds__(768) void k_grad_quad(GradQuadArgs A) {
+__global__ __launch_bounds__(1024) void k_grad_quad(GradQuadArgs A) {
     extern __shared__ __attribute__((aligned(16))) double gq_lds[];
-    double* const Es = gq_lds;                         // [2][120][36]
+    double* const Es = gq_lds;                         // [2][128][36]
     double* const Zs = Es + 2 * GQ_E_D;                // [2][31][36]
-    double* const Ph = Zs + 2 * GQ_Z_D;                // [2][4][32]
-    double* const Ds = Ph + 2 * GQ_P_D;                // [2][10][32]
+    double* const Ws = Zs + 2 * GQ_Z_D;                // [2][4][32]
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x;
     const int h = (b >> 3) & 3, grp = (b & 7) + 8 * (b >> 5);
@@ -65,147 +73,144 @@ __global__ __launch_bounds__(768) void k_grad_quad(GradQuadArgs A) {
     const int nch = min(A.per, A.nchunks - c0);        // >= 1 (the launcher sizes ngroups)
     auto n_of = [&](int k) { return (size_t)(c0 + (k < nch ? k : nch - 1)) * GQ_TI; };      // (beyond the slab: the last chunk again, never consumed)
 
-    // ---- staging pieces: 16 bytes per lane, 4 rows x 32 images per wave instruction.  Every wave moves the Label-free rows 4w .. 4w + 3
-    //      and 4w + 48 .. 4w + 51 of the NEXT stage; its third piece is, by wave: 0..5 the rows 4w + 96 .., 6 the four feature rows (both
-    //      of the next stage), 7..9 the dP rows 4 (w - 7) .. of the stage AFTER next, 10..11 nothing
+    // ---- staging pieces: 16 bytes per lane, 4 rows x 32 images per wave instruction (addresses as uniform base + 32-bit lane offset: one
+    //      SGPR pair per request instead of a VGPR pair), requested one stage ahead.  Slot 0: the Label-free rows 4w .. 4w + 3; slot 1:
+    //      waves 0..13 the rows 4w + 64 .., wave 14 the four feature rows, from which it tabulates the weights w[2 s + t][n]
     const int rho = lane >> 4, x2 = 2 * (lane & 15);
-    double2 pc[3];
-    // (addresses as uniform base + 32-bit lane offset: one SGPR pair per request instead of a VGPR pair)
+    double2 pc[2];
     const unsigned pvoff = (unsigned)(((size_t)rho * NTp + x2) * sizeof(double));
     auto ld16 = [&](const double* ubase, unsigned voff) { return *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(ubase) + voff); };
-    // third piece: uniform base (at image 0) + lane offset, its LDS place (doubles) = dst2 + (buffer or slot) * st2
-    const double* ub2; unsigned voff2 = pvoff;
-    int dst2, st2;
-    bool ok2 = true, dp2 = false;
-    if (w < 6)       { ub2 = A.EI + (size_t)(4 * (w + 24)) * NTp; dst2 = (4 * (w + 24) + rho) * GQ_RS + x2; st2 = GQ_E_D; }
-    else if (w == 6) {                                 // rows phiI[0], phiI[1], phiO[0], phiO[1] (two sites of one feature array: the second base as an offset from the first)
-        const double* f1 = A.phiO - 2 * (size_t)NTp;
-        ub2 = A.phiI < f1 ? A.phiI : f1;
-        voff2 = pvoff + (unsigned)(((rho < 2 ? A.phiI : f1) - ub2) * (ptrdiff_t)sizeof(double));
-        dst2 = 2 * (GQ_E_D + GQ_Z_D) + rho * GQ_TI + x2; st2 = GQ_P_D;
-    } else {
-        const int row = 4 * (w - 7) + rho;
-        ok2 = w < 10 && row < TNML_NL; dp2 = true;
-        ub2 = A.dP + (size_t)(w < 10 ? 4 * (w - 7) : 0) * NTp;
-        dst2 = 2 * (GQ_E_D + GQ_Z_D + GQ_P_D) + row * GQ_TI + x2; st2 = GQ_D_D;
-    }
+    const bool e1 = w < 14;                            // slot 1 is a Label-free piece
+    // (wave 14: rows phiI[0], phiI[1], phiO[0], phiO[1] -- two sites of one feature array: the second base as an offset from the first)
+    const double* fO = A.phiO - 2 * (size_t)NTp;
+    const double* fb = A.phiI < fO ? A.phiI : fO;
+    const unsigned fvoff = pvoff + (unsigned)(((rho < 2 ? A.phiI : fO) - fb) * (ptrdiff_t)sizeof(double));
+    // (the lane offsets pass through an empty asm where they are used: their zero extension then sits next to the load and folds into its
+    // address mode -- hoisted out of the loop it becomes a 64-bit VGPR add per request, 30 registers of addresses alive across the MFMAs)
+    auto piece_load = [&](size_t nE) {
+        unsigned vo = pvoff, vf = fvoff;
+        asm volatile("" : "+v"(vo), "+v"(vf));
+        pc[0] = ld16(A.EI + (size_t)(4 * w) * NTp + nE, vo);
+        if (e1) pc[1] = ld16(A.EI + (size_t)(4 * (w + 16)) * NTp + nE, vo);
+        else if (w == 14) pc[1] = ld16(fb + nE, vf);
+    };
     const int dst0 = (4 * w + rho) * GQ_RS + x2;
-    auto piece_load = [&](size_t nE, size_t nD) {
-        pc[0] = ld16(A.EI + (size_t)(4 * w) * NTp + nE, pvoff);
-        pc[1] = ld16(A.EI + (size_t)(4 * (w + 12)) * NTp + nE, pvoff);
-        pc[2] = ok2 ? ld16(ub2 + (dp2 ? nD : nE), voff2) : make_double2(0., 0.);
-    };
-    auto piece_store = [&](int bufE, int slotD) {
+    auto piece_store = [&](int bufE) {
         *reinterpret_cast<double2*>(Es + bufE * GQ_E_D + dst0) = pc[0];
-        *reinterpret_cast<double2*>(Es + bufE * GQ_E_D + dst0 + 48 * GQ_RS) = pc[1];
-        if (ok2) *reinterpret_cast<double2*>(gq_lds + dst2 + (dp2 ? slotD : bufE) * st2) = pc[2];
-    };
-    // ---- Z units: one output link x 32 images per wave instruction, the ten labels dealt to the two lane halves (labels 5 qs .. 5 qs + 4:
-    //      five loads per lane and unit, the halves added by one cross-half exchange); unit ids w, w + 12, w + 24 (< 30)
-    const int img = lane & 31, qs = lane >> 5;
-    double el[3][5];
-    const unsigned elvoff = (unsigned)(((size_t)(5 * qs) * A.EL_lstride + img) * sizeof(double));      // < 4 GB (checked by the launcher)
-    const bool u3 = w < 6;                              // this wave has a third unit
-    auto el_load = [&](size_t n0) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const double* ub = A.EL + (size_t)(GQ_Q * h + w + 12 * j) * NTp + n0;       // uniform
-#pragma unroll
-            for (int l = 0; l < 5; ++l)
-                el[j][l] = ((j < 2 || u3) && ABL != 1) ? __builtin_nontemporal_load(reinterpret_cast<const double*>(reinterpret_cast<const char*>(ub + (size_t)l * A.EL_lstride) + elvoff)) : 1.0;
+        if (e1) *reinterpret_cast<double2*>(Es + bufE * GQ_E_D + dst0 + 64 * GQ_RS) = pc[1];
+        else if (w == 14) {                            // lane (2 s + t, image pair): phiI[s] from lane row s, phiO[t] from lane row 2 + t
+            const int lI = 16 * (rho >> 1) + (lane & 15), lO = 16 * (2 + (rho & 1)) + (lane & 15);
+            const double ix = __shfl(pc[1].x, lI), iy = __shfl(pc[1].y, lI), ox = __shfl(pc[1].x, lO), oy = __shfl(pc[1].y, lO);
+            *reinterpret_cast<double2*>(Ws + bufE * GQ_W_D + rho * GQ_RS + x2) = make_double2(ix * ox, iy * oy);
         }
     };
-    auto z_build = [&](int bufZ, int slotD) {
-        const double* dp = Ds + slotD * GQ_D_D + 5 * qs * GQ_TI + img;
-        double d[5];
+    // ---- Z units: one output link x 32 images per wave instruction, the ten labels dealt to the two lane halves (labels 5 qs .. 5 qs + 4:
+    //      five loads per lane and unit + the five dP values of the lane's image, the halves added by one cross-half exchange); unit ids
+    //      w, w + 16 (< 30)
+    const int img = lane & 31, qs = lane >> 5;
+    double el[2][5], dpv[5];
+    const unsigned elvoff = (unsigned)(((size_t)(5 * qs) * A.EL_lstride + img) * sizeof(double));      // < 4 GB (checked by the launcher)
+    const unsigned dpvoff = (unsigned)(((size_t)(5 * qs) * NTp + img) * sizeof(double));
+    const bool u2 = w < 14;                             // this wave has a second unit
+    auto el_load = [&](size_t n0) {
+        unsigned elvo = elvoff, dpvo = dpvoff;
+        asm volatile("" : "+v"(elvo), "+v"(dpvo));
 #pragma unroll
-        for (int l = 0; l < 5; ++l) d[l] = dp[l * GQ_TI];
+        for (int l = 0; l < 5; ++l) dpv[l] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(A.dP + (size_t)l * NTp + n0) + dpvo);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
+        for (int j = 0; j < 2; ++j) {
+            const double* ub = A.EL + (size_t)(GQ_Q * h + w + 16 * j) * NTp + n0;       // uniform
+#pragma unroll
+            for (int l = 0; l < 5; ++l)
+                el[j][l] = ((j < 1 || u2) && ABL != 1) ? *reinterpret_cast<const double*>(reinterpret_cast<const char*>(ub + (size_t)l * A.EL_lstride) + elvo) : 1.0;      // (default cache policy: non-temporal loads measured 4-7 % slower here)
+        }
+    };
+    auto z_build = [&](int bufZ) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
             double z = 0.;
 #pragma unroll
-            for (int l = 0; l < 5; ++l) z = fma(el[j][l], d[l], z);
+            for (int l = 0; l < 5; ++l) z = fma(el[j][l], dpv[l], z);
             const double zo = __shfl_xor(z, 32);
-            if (qs == 0 && (j < 2 || u3)) Zs[bufZ * GQ_Z_D + (w + 12 * j) * GQ_RS + img] = z + zo;       // (labels 0..4) + (labels 5..9)
+            if (qs == 0 && (j < 1 || u2)) Zs[bufZ * GQ_Z_D + (w + 16 * j) * GQ_RS + img] = z + zo;       // (labels 0..4) + (labels 5..9)
         }
     };
 
-    // ---- MFMA roles: wave (rg, J) = row tiles 5 rg .. 5 rg + 4 of the M-layout rows 2a + s, column tile J of this workgroup's 60 columns
-    //      2q + t.  Rows 2a, 2a + 1 share the staged row a (two lanes read the same 16 bytes: a broadcast), so one feature fragment
-    //      serves all five row tiles and a row tile is 8 consecutive staged rows: offsets differ by compile-time constants.
-    const int rg = w >> 2, J = w & 3;
+    // ---- MFMA roles: wave (rgp, J): rgp = 2 s + half -> the row tiles a = 64 half + 16 r + i (r = 0..3) of site-index value s; J = column
+    //      tile of this workgroup's 60 columns 2q + t (lane i: q' = c >> 1, t = c & 1; the padding columns read a row of zeros)
+    const int rgp = w >> 2, J = w & 3;
     const int li = lane & 15, g = lane >> 4;
-    const int eoff = (8 * 5 * rg + (li >> 1)) * GQ_RS + 2 * g;             // + 8 r GQ_RS for row tile r
-    const int poff = (li & 1) * GQ_TI + 2 * g;
-    const int cc = 16 * J + li;                                             // column 60 h + cc
-    const int zoff = (cc < 2 * GQ_Q ? (cc >> 1) : GQ_Q) * GQ_RS + 2 * g;    // padding columns read the row of zeros
-    const int ooff = (2 + (cc & 1)) * GQ_TI + 2 * g;
-    f64x4g acc[5];
+    const int sI = rgp >> 1, a0 = 64 * (rgp & 1);
+    const int eoff = (a0 + li) * GQ_RS + g;                               // + 16 r GQ_RS for row tile r, + 4 ks for k-step ks (lane group g: image 4 ks + g)
+    const int cc = 16 * J + li;                                            // column 60 h + cc
+    const int zoff = (cc < 2 * GQ_Q ? (cc >> 1) : GQ_Q) * GQ_RS + g;
+    const int woff = (2 * sI + (cc & 1)) * GQ_RS + g;
+    f64x4g acc[4];
 #pragma unroll
-    for (int r = 0; r < 5; ++r) acc[r] = f64x4g{0., 0., 0., 0.};
+    for (int r = 0; r < 4; ++r) acc[r] = f64x4g{0., 0., 0., 0.};
 
     // ---- prologue
     if (tid < 2 * GQ_RS) Zs[(tid / GQ_RS) * GQ_Z_D + GQ_Q * GQ_RS + (tid % GQ_RS)] = 0.;
-    piece_load(n_of(0), n_of(0));
-    piece_store(0, 0);
-    piece_load(n_of(0), n_of(1));                      // (the first stage's rows once more, harmlessly: what is wanted is dP of the second stage)
-    piece_store(0, 1);
+    if (tid < 2 * 8 * GQ_RS) Es[(tid / (8 * GQ_RS)) * GQ_E_D + 120 * GQ_RS + (tid % (8 * GQ_RS))] = 0.;
+    piece_load(n_of(0));
     el_load(n_of(0));
-    gq_barrier();
-    z_build(0, 0);
-    piece_load(n_of(1), n_of(2));
+    piece_store(0);
+    z_build(0);
+    piece_load(n_of(1));
     el_load(n_of(1));
     gq_barrier();
 
+    double en[4], zn, on;                              // the fragments of the NEXT k-step
+    auto frag_load = [&](int buf, int ks) {
+        const double* Eb = Es + buf * GQ_E_D + eoff + 4 * ks;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) en[r] = Eb[16 * r * GQ_RS];
+        zn = Zs[buf * GQ_Z_D + zoff + 4 * ks];
+        on = Ws[buf * GQ_W_D + woff + 4 * ks];
+    };
+    frag_load(0, 0);
     for (int k = 0; k < nch; ++k) {
         const int cur = k & 1, nxt = cur ^ 1;
-        const double* Eb = Es + cur * GQ_E_D;
-        const double* Zb = Zs + cur * GQ_Z_D;
-        const double* Pb = Ph + cur * GQ_P_D;
 #pragma unroll
-        for (int blk = 0; blk < 4; ++blk) {
-            const int kk = 8 * blk;
-            double a0[5], a1[5];
-            const double2 p = *reinterpret_cast<const double2*>(Pb + poff + kk);
-#pragma unroll
-            for (int r = 0; r < 5; ++r) {
-                const double2 e = *reinterpret_cast<const double2*>(Eb + eoff + 8 * r * GQ_RS + kk);
-                a0[r] = e.x * p.x; a1[r] = e.y * p.y;
-            }
-            const double2 z = *reinterpret_cast<const double2*>(Zb + zoff + kk);
-            const double2 o = *reinterpret_cast<const double2*>(Pb + ooff + kk);
-            const double b0 = z.x * o.x, b1 = z.y * o.y;
-            if (ABL != 2) {
-#pragma unroll
-                for (int r = 0; r < 5; ++r) acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[r], b0, acc[r], 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 5; ++r) acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[r], b1, acc[r], 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 5; ++r) acc[r][0] += a0[r] * b0 + a1[r] * b1;
-            }
-            // the staging share of this wave, after the block whose number is its place on the SIMD (waves w, w + 4, w + 8 share one):
-            // what was requested one stage ago goes to the other buffers, the next requests go out
-            __builtin_amdgcn_sched_barrier(0);       // (no fragment reads of later blocks hoisted over this one's MFMAs: they would cost their registers for the whole stage)
-            if (blk == rg) {
-                piece_store(nxt, cur);                 // E / features of chunk k + 1 -> buffers nxt; dP of chunk k + 2 -> slot (k + 2) & 1 = cur
-                z_build(nxt, nxt);                     // Z of chunk k + 1 from dP slot (k + 1) & 1
-                piece_load(n_of(k + 2), n_of(k + 3));
+        for (int ks = 0; ks < 8; ++ks) {
+            // the staging share of this wave, at the place in the stage that is its place on the SIMD (waves w, w + 4, w + 8, w + 12 share
+            // one): before k-step 0, 2, 4 or 6 -- never after the last one, where no other wave would have MFMAs left to run beside it and
+            // the whole workgroup would wait for it at the barrier.  What was requested one stage ago goes to the other buffers, the next
+            // requests go out.
+            if (ABL != 3 && ks == 2 * rgp) {
+                __builtin_amdgcn_s_setprio(3);         // few instructions beside the MFMAs of three other waves: issue them ahead (2 % of the launch)
+                piece_store(nxt);                      // E / weights of chunk k + 1
+                z_build(nxt);                          // Z of chunk k + 1
+                piece_load(n_of(k + 2));
                 el_load(n_of(k + 2));
+                __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            double ec[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ec[r] = en[r];
+            const double bc = zn * on;
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks < 7) frag_load(cur, ks + 1);        // (the first k-step of the next stage is read behind the barrier)
+            __builtin_amdgcn_sched_barrier(0);       // reads of the next k-step FIRST, then this one's MFMAs: left alone the scheduler issues the MFMAs first
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(ec[r], bc, acc[r], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);       // (keeps the order stated: reads of the next k-step, then this one's MFMAs)
         }
         gq_barrier();
+        frag_load(nxt, 0);
     }
 
     // ---- epilogue: the quad's partial G, M-layout rows 2a + s, columns 2q + t
     double* out = A.slab + (size_t)grp * 240 * 240;
     if (cc < 2 * GQ_Q) {
 #pragma unroll
-        for (int r = 0; r < 5; ++r)
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                out[(size_t)(16 * (5 * rg + r) + g + 4 * e) * 240 + 2 * GQ_Q * h + cc] = acc[r][e];
+            for (int e4 = 0; e4 < 4; ++e4) {
+                const int a = a0 + 16 * r + g + 4 * e4;
+                if (a < 120) out[(size_t)(2 * a + sI) * 240 + 2 * GQ_Q * h + cc] = acc[r][e4];
+            }
     }
 }
 
@@ -235,17 +240,17 @@ int launch_grad_quad(tnml_ctx* c, const Bgemm64Args& a, double* G) {
     if (!c->attr_gq) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_grad_quad<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_grad_quad<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k_grad_quad<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_grad_quad<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return tnml_fail(c, "grad_quad: cannot reserve %zu bytes of LDS", lds);
         c->attr_gq = true;
     }
     const int grid = 32 * ((K.ngroups + 7) / 8);                 // blocks b, b + 8, b + 16, b + 24 of a run of 32 = one quad on one XCD
     {
-        ProfScope ps(c, KC_BGEMM);
-        // (grad_quad = 3 / 4: the ablations of the record under profiles/ -- compute side alone / stream side alone; wrong results by construction)
-        if (c->grad_quad == 3)      hipLaunchKernelGGL(k_grad_quad<1>, dim3(grid), dim3(768), lds, c->stream, K);
-        else if (c->grad_quad == 4) hipLaunchKernelGGL(k_grad_quad<2>, dim3(grid), dim3(768), lds, c->stream, K);
-        else                        hipLaunchKernelGGL(k_grad_quad<0>, dim3(grid), dim3(768), lds, c->stream, K);
+        ProfScope ps(c, KC_GRAD_QUAD);
+        // (grad_quad = 3 / 5: the ablations of the record under profiles/ -- compute side alone / the MFMA loop alone; wrong results by construction)
+        if (c->grad_quad == 3)      hipLaunchKernelGGL(k_grad_quad<1>, dim3(grid), dim3(1024), lds, c->stream, K);
+        else if (c->grad_quad == 5) hipLaunchKernelGGL(k_grad_quad<3>, dim3(grid), dim3(1024), lds, c->stream, K);
+        else                        hipLaunchKernelGGL(k_grad_quad<0>, dim3(grid), dim3(1024), lds, c->stream, K);
     }
     const size_t n = (size_t)240 * 240;
     if (c->defer_slab) c->slab_pending = K.ngroups;            // the CG vector kernel that consumes G sums the slabs itself (slab order: the same bits)

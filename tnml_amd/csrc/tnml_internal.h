@@ -32,11 +32,11 @@
 
 enum KClass {
     KC_FGEMM_FWD = 0, KC_FGEMM_SHIFT, KC_LABELDOT, KC_ZPRIME, KC_BGEMM, KC_SLABRED, KC_PACK, KC_VEC,
-    KC_SMALLGEMM, KC_SVD, KC_ALLREDUCE, KC_PUPDATE, KC_FWD_FUSED, KC_FWD_RES, KC_COUNT
+    KC_SMALLGEMM, KC_SVD, KC_ALLREDUCE, KC_PUPDATE, KC_FWD_FUSED, KC_FWD_RES, KC_GRAD_QUAD, KC_COUNT
 };
 static const char* const kclass_names[KC_COUNT] = {
     "fgemm_fwd", "fgemm_shift", "labeldot", "zprime", "bgemm", "slab_reduce", "pack", "cg_vec",
-    "small_gemm", "svd", "allreduce", "p_update", "fwd_fused", "fwd_res"};
+    "small_gemm", "svd", "allreduce", "p_update", "fwd_fused", "fwd_res", "grad_quad"};
 
 struct EnvSlot {
     void* ptr = nullptr;    // [L][m][NTp], fp32 or fp64 elements (tnml_ctx::env64); null while the environment is spilled to the host

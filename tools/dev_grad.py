@@ -30,12 +30,12 @@ def main():
     rng = np.random.default_rng(3)
     B = B + 0.05 * rng.standard_normal(B.shape)
     out = {}
-    modes = (0, 2) + ((3, 4) if os.environ.get("TNML_DEV_ABL") else ())
+    modes = (0, 2) + ((3, 5) if os.environ.get("TNML_DEV_ABL") else ())
     for mode in modes:
         ts.set_option("grad_quad", mode)
         G = ts.gradient(B)
         G2 = ts.gradient(B)
-        ts.profile(True, only="bgemm,slab_reduce")
+        ts.profile(True, only="bgemm,grad_quad,slab_reduce")
         ts.profile_reset()
         t0 = time.time()
         for _ in range(reps):
@@ -44,11 +44,11 @@ def main():
         dt = time.time() - t0
         ts.profile(False)
         pr = ts.profile_read()
-        out[mode] = (G, np.array_equal(G, G2), pr.get("bgemm"), pr.get("slab_reduce"), dt / reps)
+        out[mode] = (G, np.array_equal(G, G2), pr.get("grad_quad") if pr.get("grad_quad", (0, 0))[0] else pr.get("bgemm"), pr.get("slab_reduce"), dt / reps)
     G0, G1 = out[0][0], out[2][0]
     print("images %d: max |G_quad - G_bgemm64| / max |G| = %.3e   (repeats bit-identical: bgemm64 %s, quad %s)" % (
         NT, np.abs(G1 - G0).max() / np.abs(G0).max(), out[0][1], out[2][1]))
-    for mode, name in ((0, "k_bgemm64"), (2, "k_grad_quad"), (3, "quad, no EL loads"), (4, "quad, no MFMAs")):
+    for mode, name in ((0, "k_bgemm64"), (2, "k_grad_quad"), (3, "quad, no EL loads"), (5, "quad, no staging")):
         if mode not in out:
             continue
         bg, sr = out[mode][2], out[mode][3]
