@@ -160,6 +160,9 @@ int tnml_oneshot_connect(tnml_ctx* ctx, const void* handles /* nranks * TNML_ONE
    rather than fall back to coarse-grained memory, which is coherent at kernel boundaries only.)  A collective whose device-side wait
    timed out fills its buffer with NaNs and every later entry point that synchronises with the stream returns an error. */
 int tnml_oneshot_mem_kind(tnml_ctx* ctx);
+/* bytes of the receive region tnml_oneshot_export will allocate for this configuration ([2 parities][nranks][10 Kmax^2 + 48] doubles + flags);
+   tnml_estimate_bytes / tnml_plan_maxm do not know the transport and do not count it: subtract it from the budget when planning maxm */
+int64_t tnml_oneshot_region_bytes(const tnml_config* cfg);
 /* transport in use: 0 none, 1 RCCL, 2 in-process staging buffer, 3 in-process one-shot, 4 cross-process one-shot */
 int tnml_collective_mode(tnml_ctx* ctx);
 /* Collective.  Verifies that the communicator really spans cfg.nranks ranks (ncclCommCount) and that every rank holds a

@@ -81,3 +81,21 @@ def test_sweepnext_and_shards():
     # ParallelDo chunking (paralleldo.h:32-43): equal chunks, last takes the remainder
     assert [lib.shard_bounds(60000, 8, r) for r in range(8)] == [(7500 * r, 7500 * (r + 1)) for r in range(8)]
     assert [lib.shard_bounds(10, 3, r) for r in range(3)] == [(0, 3), (3, 6), (6, 10)]
+
+
+def test_oneshot_region_bytes_is_what_the_planner_has_to_subtract():
+    """tnml_oneshot_region_bytes: [2 parities][nranks][10 Kmax^2 + 48] doubles + flags -- the receive region of the cross-process
+    one-shot all-reduce, which tnml_estimate_bytes does not count (no GPU needed: pure arithmetic)"""
+    import ctypes as C
+    from tnml_amd import lib
+    L = lib.load()
+    def cfg(maxm, nranks):
+        c = lib.Config()
+        c.device, c.rank, c.nranks, c.N, c.NT_local, c.maxm, c.dtype = 0, 0, nranks, 784, 7500, maxm, lib.DTYPES["f64"] if hasattr(lib, "DTYPES") else 1
+        return c
+    b120 = L.tnml_oneshot_region_bytes(C.byref(cfg(120, 8)))
+    b300 = L.tnml_oneshot_region_bytes(C.byref(cfg(300, 8)))
+    cap120 = 10 * 240 * 240 + 48
+    assert 2 * 8 * cap120 * 8 <= b120 <= 2 * 8 * cap120 * 8 + 65536
+    assert 4.4e8 < b300 < 4.8e8                                       # ~460 MB per rank at maxm = 300 with 8 ranks
+    assert L.tnml_oneshot_region_bytes(None) == -1

@@ -121,6 +121,18 @@ static size_t os_region_bytes(int n, size_t cap, int nbmax, size_t* recv_off) {
     return off + sizeof(double) * 2 * (size_t)n * cap;
 }
 
+// size of the receive region tnml_oneshot_export allocates for a context of this configuration: [2 parities][nranks slots][mcap + tail]
+// doubles + flags -- 37 MB per rank at maxm = 120 with 8 ranks, 460 MB at maxm = 300; NOT part of tnml_estimate_bytes (which does not know the
+// transport): a driver that plans maxm against free memory (tnml_plan_maxm) subtracts it from its budget
+int64_t tnml_oneshot_region_bytes(const tnml_config* cfg) {
+    if (!cfg || cfg->nranks < 1 || cfg->maxm < 1) return -1;
+    const bool bf = cfg->dtype == TNML_BF16 || cfg->dtype == TNML_BF16X3;
+    const size_t Kmax = bf ? (size_t)(2 * cfg->maxm + 31) / 32 * 32 : (size_t)(2 * cfg->maxm + 15) / 16 * 16;      // (as tnml_create pads it)
+    const size_t cap = (size_t)TNML_NL * Kmax * Kmax + TNML_TAILN;
+    size_t off;
+    return (int64_t)os_region_bytes(cfg->nranks, cap, (int)((cap + OS_CHUNK - 1) / OS_CHUNK), &off);
+}
+
 int tnml_oneshot_export(tnml_ctx* c, void* handle64) {
     if (!c || !handle64) return tnml_fail(c, "tnml_oneshot_export: null argument");
     if (c->comm || c->local || c->ipc) return tnml_fail(c, "tnml_oneshot_export: context already has a communicator");
@@ -134,6 +146,15 @@ int tnml_oneshot_export(tnml_ctx* c, void* handle64) {
     ic->region_bytes = os_region_bytes(ic->n, ic->cap, ic->nbmax, &ic->recv_off);
     // fine-grained memory: peer stores over xGMI must become visible to this GPU's loads without a kernel boundary (coarse-grained
     // hipMalloc memory is only coherent at kernel boundaries); RCCL allocates its communication buffers the same way
+    {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr < ic->region_bytes) {
+            const size_t want = ic->region_bytes;
+            delete ic;
+            return tnml_fail(c, "tnml_oneshot_export: the receive region needs %zu bytes, %zu are free on device %d -- tnml_estimate_bytes / tnml_plan_maxm do not "
+                                "count it: plan maxm with tnml_oneshot_region_bytes subtracted from the budget", want, fr, c->cfg.device);
+        }
+    }
     void* p = nullptr;
     if (hipExtMallocWithFlags(&p, ic->region_bytes, hipDeviceMallocFinegrained) == hipSuccess) ic->mem_kind = 1;
     else if ((void)hipGetLastError(), hipExtMallocWithFlags(&p, ic->region_bytes, hipDeviceMallocUncached) == hipSuccess) ic->mem_kind = 2;

@@ -101,6 +101,10 @@ class TrainStates:
         assert len(blob) == 64 * self.nranks, (len(blob), self.nranks)
         self._ck(self._L.tnml_oneshot_connect(self._h, C.create_string_buffer(blob, len(blob))))
 
+    def oneshot_region_bytes(self):
+        """bytes of the receive region oneshot_export allocates (not part of estimate_bytes)"""
+        return int(self._L.tnml_oneshot_region_bytes(C.byref(self._cfg)))
+
     def oneshot_mem_kind(self):
         """memory kind of the receive region of the cross-process one-shot transport: 1 fine-grained, 2 uncached, 0 none"""
         return self._L.tnml_oneshot_mem_kind(self._h)

@@ -27,7 +27,7 @@ EXPORTS = [
     "tnml_shard_bounds", "tnml_profile_enable", "tnml_profile_select", "tnml_profile_count", "tnml_profile_get",
     "tnml_profile_reset", "tnml_synchronize", "tnml_device_bytes", "tnml_svd_stats", "tnml_classify", "tnml_replica_check",
     "tnml_estimate_bytes", "tnml_device_memory", "tnml_plan_maxm", "tnml_set_option", "tnml_comm_init_local", "tnml_comm_init_oneshot", "tnml_collective_mode", "tnml_bond_update_begin", "tnml_bond_update_end", "tnml_replica_repairs", "tnml_pAp", "tnml_collective_stats", "tnml_last_warning",
-    "tnml_exact", "tnml_set_option_real", "tnml_pinv", "tnml_env_stats", "tnml_oneshot_export", "tnml_oneshot_connect", "tnml_oneshot_mem_kind", "tnml_split_stats",
+    "tnml_exact", "tnml_set_option_real", "tnml_pinv", "tnml_env_stats", "tnml_oneshot_export", "tnml_oneshot_connect", "tnml_oneshot_mem_kind", "tnml_split_stats", "tnml_oneshot_region_bytes",
 ]
 
 
@@ -131,6 +131,8 @@ def load():
     L.tnml_set_option.argtypes = [vp, C.c_char_p, C.c_int]
     L.tnml_estimate_bytes.argtypes = [C.POINTER(Config)]
     L.tnml_estimate_bytes.restype = C.c_int64
+    L.tnml_oneshot_region_bytes.argtypes = [C.POINTER(Config)]
+    L.tnml_oneshot_region_bytes.restype = C.c_int64
     L.tnml_device_memory.argtypes = [C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.tnml_plan_maxm.argtypes = [C.POINTER(Config), C.c_int, C.c_int, C.c_int64]
     _lib = L
