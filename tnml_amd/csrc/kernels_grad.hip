@@ -87,7 +87,7 @@ __global__ __launch_bounds__(1024) void k_grad_quad(GradQuadArgs A) {
     const unsigned fvoff = pvoff + (unsigned)(((rho < 2 ? A.phiI : fO) - fb) * (ptrdiff_t)sizeof(double));
     // (the lane offsets pass through an empty asm where they are used: their zero extension then sits next to the load and folds into its
     // address mode -- hoisted out of the loop it becomes a 64-bit VGPR add per request, 30 registers of addresses alive across the MFMAs)
-    auto piece_load = [&](size_t nE) {
+    auto piece_load = [&](size_t nE, double2 (&pc)[2]) {
         unsigned vo = pvoff, vf = fvoff;
         asm volatile("" : "+v"(vo), "+v"(vf));
         pc[0] = ld16(A.EI + (size_t)(4 * w) * NTp + nE, vo);
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(1024) void k_grad_quad(GradQuadArgs A) {
         else if (w == 14) pc[1] = ld16(fb + nE, vf);
     };
     const int dst0 = (4 * w + rho) * GQ_RS + x2;
-    auto piece_store = [&](int bufE) {
+    auto piece_store = [&](int bufE, const double2 (&pc)[2]) {
         *reinterpret_cast<double2*>(Es + bufE * GQ_E_D + dst0) = pc[0];
         if (e1) *reinterpret_cast<double2*>(Es + bufE * GQ_E_D + dst0 + 64 * GQ_RS) = pc[1];
         else if (w == 14) {                            // lane (2 s + t, image pair): phiI[s] from lane row s, phiO[t] from lane row 2 + t
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(1024) void k_grad_quad(GradQuadArgs A) {
     const unsigned elvoff = (unsigned)(((size_t)(5 * qs) * A.EL_lstride + img) * sizeof(double));      // < 4 GB (checked by the launcher)
     const unsigned dpvoff = (unsigned)(((size_t)(5 * qs) * NTp + img) * sizeof(double));
     const bool u2 = w < 14;                             // this wave has a second unit
-    auto el_load = [&](size_t n0) {
+    auto el_load = [&](size_t n0, double (&el)[2][5], double (&dpv)[5]) {
         unsigned elvo = elvoff, dpvo = dpvoff;
         asm volatile("" : "+v"(elvo), "+v"(dpvo));
 #pragma unroll
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(1024) void k_grad_quad(GradQuadArgs A) {
                 el[j][l] = ((j < 1 || u2) && ABL != 1) ? *reinterpret_cast<const double*>(reinterpret_cast<const char*>(ub + (size_t)l * A.EL_lstride) + elvo) : 1.0;      // (default cache policy: non-temporal loads measured 4-7 % slower here)
         }
     };
-    auto z_build = [&](int bufZ) {
+    auto z_build = [&](int bufZ, const double (&el)[2][5], const double (&dpv)[5]) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             double z = 0.;
@@ -145,21 +145,23 @@ __global__ __launch_bounds__(1024) void k_grad_quad(GradQuadArgs A) {
     const int cc = 16 * J + li;                                            // column 60 h + cc
     const int zoff = (cc < 2 * GQ_Q ? (cc >> 1) : GQ_Q) * GQ_RS + g;
     const int woff = (2 * sI + (cc & 1)) * GQ_RS + g;
-    f64x4g acc[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = f64x4g{0., 0., 0., 0.};
-
     // ---- prologue
     if (tid < 2 * GQ_RS) Zs[(tid / GQ_RS) * GQ_Z_D + GQ_Q * GQ_RS + (tid % GQ_RS)] = 0.;
     if (tid < 2 * 8 * GQ_RS) Es[(tid / (8 * GQ_RS)) * GQ_E_D + 120 * GQ_RS + (tid % (8 * GQ_RS))] = 0.;
-    piece_load(n_of(0));
-    el_load(n_of(0));
-    piece_store(0);
-    z_build(0);
-    piece_load(n_of(1));
-    el_load(n_of(1));
+    {   // the first TWO chunks are requested together (the accumulators are not live yet: their registers hold the first chunk's requests)
+        double2 pc0[2]; double el0[2][5], dpv0[5];
+        piece_load(n_of(0), pc0);
+        el_load(n_of(0), el0, dpv0);
+        piece_load(n_of(1), pc);
+        el_load(n_of(1), el, dpv);
+        piece_store(0, pc0);
+        z_build(0, el0, dpv0);
+    }
     gq_barrier();
 
+    f64x4g acc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = f64x4g{0., 0., 0., 0.};
     double en[4], zn, on;                              // the fragments of the NEXT k-step
     auto frag_load = [&](int buf, int ks) {
         const double* Eb = Es + buf * GQ_E_D + eoff + 4 * ks;
@@ -179,10 +181,10 @@ __global__ __launch_bounds__(1024) void k_grad_quad(GradQuadArgs A) {
             // requests go out.
             if (ABL != 3 && ks == 2 * rgp) {
                 __builtin_amdgcn_s_setprio(3);         // few instructions beside the MFMAs of three other waves: issue them ahead (2 % of the launch)
-                piece_store(nxt);                      // E / weights of chunk k + 1
-                z_build(nxt);                          // Z of chunk k + 1
-                piece_load(n_of(k + 2));
-                el_load(n_of(k + 2));
+                piece_store(nxt, pc);                  // E / weights of chunk k + 1
+                z_build(nxt, el, dpv);                 // Z of chunk k + 1
+                piece_load(n_of(k + 2), pc);
+                el_load(n_of(k + 2), el, dpv);
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
             }
