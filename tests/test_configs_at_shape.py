@@ -380,6 +380,47 @@ def test_gradient_quad_kernel_matches_the_oracle(NT, wgs):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("m", [64, 96, 104, 128])
+def test_gradient_quad_kernel_at_other_bond_dimensions(m):
+    """k_grad_quad serves every bond dimension up to 128 (its 256 x 256 tile grid is fixed; rows and links beyond the bond dimensions are
+    staged as zeros and come out as the zero padding of the M-layout): bonds that have shrunk below maxm (fixedL.cc:593) and unequal left /
+    right dimensions (bond 7 of a 20-site chain: 64 x m).  Unforced it takes bonds from m = 104 on; forced here (grad_quad = 2)."""
+    from oracle import pyoracle
+    from tnml_amd.fixedl import TrainStates
+    from conftest import make_problem
+    N, NT = 20, 300
+    pixels, labels, phi, W = make_problem(N, NT, m, 9, pixel_boost=200.0)
+    ts = TrainStates(labels, N, m, phi=phi)
+    ts.set_option("grad_quad", 2)
+    ts.set_mps(W)
+    ts.init()
+    o = pyoracle.Oracle(phi, labels, W, nthread=min(8, os.cpu_count() or 1))
+    o.init()
+    rng = np.random.default_rng(4)
+    at = 1
+    for b, kind in ((7, "Label on RE, 64 x m"), (8, "Label on RE"), (12, "Label on LE"), (13, "Label on LE, m x 64")):
+        for bb in range(at, b):
+            ts.shiftE(bb, True); o.shiftE(bb, True)
+        at = b
+        ts.setBond(b); o.set_bond(b)
+        B = o.bond_tensor(b)
+        B = B + 0.05 * rng.standard_normal(B.shape)
+        ts.profile(True, only="bgemm,grad_quad")
+        ts.profile_reset()
+        G = ts.gradient(B)
+        ts.profile(False)
+        pr = ts.profile_read()
+        assert pr["grad_quad"][0] == 1 and pr.get("bgemm", (0, 0))[0] == 0, kind
+        assert _rel(G, o.gradient(B)) < 1e-9, kind
+        assert np.array_equal(G, ts.gradient(B)), kind
+        Bg, tg = ts.cgrad(B, 3, 1e-3, 1e-10)                          # the CG's norms run over the PADDED M-layout: the padding must be zeros
+        Bo, to = o.cgrad(B, 3, 1e-3, 1e-10)
+        np.testing.assert_allclose(tg["cost"], to["cost"], rtol=1e-9, err_msg=kind)
+        np.testing.assert_allclose(tg["alpha"], to["alpha"], rtol=1e-5, err_msg=kind)
+    ts.close()
+
+
+@pytest.mark.gpu
 def test_m60_kernel_instantiations_match_the_oracle():
     """bonds that have shrunk to minm = maxm/2 = 60 (the reference default, fixedL.cc:593) run their own tiles: 128 x 128
     feature-GEMM tiles (forced here as for C3: at 60 000 images they are the default), 128 x 64 gradient-GEMM tiles"""

@@ -1,4 +1,5 @@
-// kernels_grad.hip -- k_grad_quad: the gradient GEMM dP*dag(t.v) (fixedL.cc:379,418) at m = 120, fp64 storage, Label index on an environment:
+// kernels_grad.hip -- k_grad_quad: the gradient GEMM dP*dag(t.v) (fixedL.cc:379,418) for bond dimensions up to 128 (BASELINE config 3: m = 120), fp64
+// storage, Label index on an environment:
 //
 //   G[2a + s][2q + t] = sum_n  E_n[a] * ( phiI_n[s] phiO_n[t] Z_n[q] ),      Z_n[q] = sum_l EL_n[l][q] dP_n[l]
 //
@@ -12,12 +13,13 @@
 //       multiplies per 10 MFMAs) the compute side alone still reached only 0.61 of the pipe -- a VALU instruction is issued only while
 //       no MFMA of any wave waits at the SIMD's issue port, so the waves fall into step: MFMA phases, then VALU phases with the pipe idle.
 // Hence:
-//   * a QUAD of workgroups (one XCD: blocks b, b + 8, b + 16, b + 24) owns the 240 x 240 accumulators for one slab of images; workgroup h
-//     of the quad owns the output links q in [30 h, 30 h + 30), i.e. 60 of the 240 columns 2q + t (4 column tiles, the last one 3/4 full),
-//     and therefore streams only ITS quarter of the Label-carrying environment -- the 577 MB stream is read exactly once;
+//   * a QUAD of workgroups (one XCD: blocks b, b + 8, b + 16, b + 24) owns the accumulators of the whole gradient (up to 256 x 256; 240 x 240 at
+//     m = 120) for one slab of images; workgroup h of the quad owns the output links q in [32 h, 32 h + 32), i.e. 64 columns 2q + t = 4 column
+//     tiles (at m = 120 the last workgroup holds 24 links), and therefore streams only ITS share of the Label-carrying environment -- the
+//     577 MB stream is read exactly once;
 //   * 16 UNIFORM waves per workgroup = FOUR MFMA-issuing waves per SIMD, 4 row tiles x 1 column tile = 32 accumulator registers each;
-//   * the A operand is the RAW Label-free environment: rows are taken s-major (8 row tiles of a = 0..127 per value of s, rows 120..127
-//     zero), so a wave's row tiles share one s and both site features move to the B side as ONE weight w_st[n] = phiI_n[s] phiO_n[t],
+//   * the A operand is the RAW Label-free environment: rows are taken s-major (8 row tiles of a = 0..127 per value of s, rows from the bond
+//     dimension on zero), so a wave's row tiles share one s and both site features move to the B side as ONE weight w_st[n] = phiI_n[s] phiO_n[t],
 //     tabulated per stage: 2 multiplies per 8 MFMAs, and the Label-free rows go to LDS untouched, once for both values of s.  Price: 16 row
 //     tiles instead of 15 (6.7 % more MFMAs);
 //   * every wave does 1/16 of the staging (loads into registers one stage ahead, LDS writes, the ten FMAs per element of Z), and the four
@@ -34,18 +36,19 @@ typedef double f64x4g __attribute__((ext_vector_type(4)));
 
 #define GQ_TI 32                       // images per stage
 #define GQ_RS 34                       // doubles between staged rows
-#define GQ_Q 30                        // output links per workgroup
-#define GQ_E_D (128 * GQ_RS)           // doubles per stage buffer: Label-free rows 0..119 + 8 rows of zeros
-#define GQ_Z_D (31 * GQ_RS)            // Z rows of this workgroup + one row of zeros (the padding columns of the last column tile)
+#define GQ_Q 32                        // output links per workgroup
+#define GQ_E_D (128 * GQ_RS)           // doubles per stage buffer: Label-free rows 0..mI-1, zeros up to 127
+#define GQ_Z_D (GQ_Q * GQ_RS)          // Z rows of this workgroup (zeros for links beyond the bond dimension)
 #define GQ_W_D (4 * GQ_RS)             // w[2 s + t][n] = phiI[s][n] phiO[t][n]
 #define GQ_LDS_DOUBLES (2 * (GQ_E_D + GQ_Z_D + GQ_W_D))
 
 struct GradQuadArgs {
-    const double* EI; const double* phiI; const double* phiO;      // [120][NTp], [2][NTp], [2][NTp]
-    const double* EL; size_t EL_lstride;                          // [10][120][NTp]
+    const double* EI; const double* phiI; const double* phiO;      // [mI][NTp], [2][NTp], [2][NTp]
+    const double* EL; size_t EL_lstride;                          // [10][mO][NTp]
     const double* dP;                                             // [10][NTp]
     int NTp;
-    double* slab;                                                 // [ngroups][240][240], M-layout
+    int mI, mO, Kp, Np;                                           // bond dimensions (<= 128) and the padded M-layout extents of G
+    double* slab;                                                 // [ngroups][Kp][Np], M-layout
     int ngroups, per, nchunks;                                    // quads, 32-image chunks per quad, chunks in all
 };
 
@@ -74,44 +77,45 @@ __global__ __launch_bounds__(1024) void k_grad_quad(GradQuadArgs A) {
     auto n_of = [&](int k) { return (size_t)(c0 + (k < nch ? k : nch - 1)) * GQ_TI; };      // (beyond the slab: the last chunk again, never consumed)
 
     // ---- staging pieces: 16 bytes per lane, 4 rows x 32 images per wave instruction (addresses as uniform base + 32-bit lane offset: one
-    //      SGPR pair per request instead of a VGPR pair), requested one stage ahead.  Slot 0: the Label-free rows 4w .. 4w + 3; slot 1:
-    //      waves 0..13 the rows 4w + 64 .., wave 14 the four feature rows, from which it tabulates the weights w[2 s + t][n]
+    //      SGPR pair per request instead of a VGPR pair), requested one stage ahead.  Slot 0: the Label-free rows 4w .. 4w + 3; slot 1: the
+    //      rows 4w + 64 .. (rows from mI on are written as zeros); slot 2, wave 15 alone: the four feature rows, from which it tabulates the
+    //      weights w[2 s + t][n]
     const int rho = lane >> 4, x2 = 2 * (lane & 15);
-    double2 pc[2];
+    double2 pc[3];
     const unsigned pvoff = (unsigned)(((size_t)rho * NTp + x2) * sizeof(double));
     auto ld16 = [&](const double* ubase, unsigned voff) { return *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(ubase) + voff); };
-    const bool e1 = w < 14;                            // slot 1 is a Label-free piece
-    // (wave 14: rows phiI[0], phiI[1], phiO[0], phiO[1] -- two sites of one feature array: the second base as an offset from the first)
+    const bool v0 = 4 * w + rho < A.mI, v1 = 64 + 4 * w + rho < A.mI;     // this lane's rows exist
+    // (wave 15: rows phiI[0], phiI[1], phiO[0], phiO[1] -- two sites of one feature array: the second base as an offset from the first)
     const double* fO = A.phiO - 2 * (size_t)NTp;
     const double* fb = A.phiI < fO ? A.phiI : fO;
     const unsigned fvoff = pvoff + (unsigned)(((rho < 2 ? A.phiI : fO) - fb) * (ptrdiff_t)sizeof(double));
     // (the lane offsets pass through an empty asm where they are used: their zero extension then sits next to the load and folds into its
     // address mode -- hoisted out of the loop it becomes a 64-bit VGPR add per request, 30 registers of addresses alive across the MFMAs)
-    auto piece_load = [&](size_t nE, double2 (&pc)[2]) {
+    auto piece_load = [&](size_t nE, double2 (&pc)[3]) {
         unsigned vo = pvoff, vf = fvoff;
         asm volatile("" : "+v"(vo), "+v"(vf));
-        pc[0] = ld16(A.EI + (size_t)(4 * w) * NTp + nE, vo);
-        if (e1) pc[1] = ld16(A.EI + (size_t)(4 * (w + 16)) * NTp + nE, vo);
-        else if (w == 14) pc[1] = ld16(fb + nE, vf);
+        pc[0] = v0 ? ld16(A.EI + (size_t)(4 * w) * NTp + nE, vo) : make_double2(0., 0.);
+        pc[1] = v1 ? ld16(A.EI + (size_t)(4 * (w + 16)) * NTp + nE, vo) : make_double2(0., 0.);
+        if (w == 15) pc[2] = ld16(fb + nE, vf);
     };
     const int dst0 = (4 * w + rho) * GQ_RS + x2;
-    auto piece_store = [&](int bufE, const double2 (&pc)[2]) {
+    auto piece_store = [&](int bufE, const double2 (&pc)[3]) {
         *reinterpret_cast<double2*>(Es + bufE * GQ_E_D + dst0) = pc[0];
-        if (e1) *reinterpret_cast<double2*>(Es + bufE * GQ_E_D + dst0 + 64 * GQ_RS) = pc[1];
-        else if (w == 14) {                            // lane (2 s + t, image pair): phiI[s] from lane row s, phiO[t] from lane row 2 + t
+        *reinterpret_cast<double2*>(Es + bufE * GQ_E_D + dst0 + 64 * GQ_RS) = pc[1];
+        if (w == 15) {                                 // lane (2 s + t, image pair): phiI[s] from lane row s, phiO[t] from lane row 2 + t
             const int lI = 16 * (rho >> 1) + (lane & 15), lO = 16 * (2 + (rho & 1)) + (lane & 15);
-            const double ix = __shfl(pc[1].x, lI), iy = __shfl(pc[1].y, lI), ox = __shfl(pc[1].x, lO), oy = __shfl(pc[1].y, lO);
+            const double ix = __shfl(pc[2].x, lI), iy = __shfl(pc[2].y, lI), ox = __shfl(pc[2].x, lO), oy = __shfl(pc[2].y, lO);
             *reinterpret_cast<double2*>(Ws + bufE * GQ_W_D + rho * GQ_RS + x2) = make_double2(ix * ox, iy * oy);
         }
     };
     // ---- Z units: one output link x 32 images per wave instruction, the ten labels dealt to the two lane halves (labels 5 qs .. 5 qs + 4:
     //      five loads per lane and unit + the five dP values of the lane's image, the halves added by one cross-half exchange); unit ids
-    //      w, w + 16 (< 30)
+    //      w, w + 16 = the links 32 h + w, 32 h + w + 16 (links from mO on: zeros, nothing loaded)
     const int img = lane & 31, qs = lane >> 5;
     double el[2][5], dpv[5];
     const unsigned elvoff = (unsigned)(((size_t)(5 * qs) * A.EL_lstride + img) * sizeof(double));      // < 4 GB (checked by the launcher)
     const unsigned dpvoff = (unsigned)(((size_t)(5 * qs) * NTp + img) * sizeof(double));
-    const bool u2 = w < 14;                             // this wave has a second unit
+    const bool uv[2] = {GQ_Q * h + w < A.mO, GQ_Q * h + w + 16 < A.mO};                                // uniform
     auto el_load = [&](size_t n0, double (&el)[2][5], double (&dpv)[5]) {
         unsigned elvo = elvoff, dpvo = dpvoff;
         asm volatile("" : "+v"(elvo), "+v"(dpvo));
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(1024) void k_grad_quad(GradQuadArgs A) {
             const double* ub = A.EL + (size_t)(GQ_Q * h + w + 16 * j) * NTp + n0;       // uniform
 #pragma unroll
             for (int l = 0; l < 5; ++l)
-                el[j][l] = ((j < 1 || u2) && ABL != 1) ? *reinterpret_cast<const double*>(reinterpret_cast<const char*>(ub + (size_t)l * A.EL_lstride) + elvo) : 1.0;      // (default cache policy: non-temporal loads measured 4-7 % slower here)
+                el[j][l] = !uv[j] ? 0. : (ABL == 1 ? 1.0 : *reinterpret_cast<const double*>(reinterpret_cast<const char*>(ub + (size_t)l * A.EL_lstride) + elvo));      // (default cache policy: non-temporal loads measured 4-7 % slower here)
         }
     };
     auto z_build = [&](int bufZ, const double (&el)[2][5], const double (&dpv)[5]) {
@@ -132,24 +136,22 @@ __global__ __launch_bounds__(1024) void k_grad_quad(GradQuadArgs A) {
 #pragma unroll
             for (int l = 0; l < 5; ++l) z = fma(el[j][l], dpv[l], z);
             const double zo = __shfl_xor(z, 32);
-            if (qs == 0 && (j < 1 || u2)) Zs[bufZ * GQ_Z_D + (w + 16 * j) * GQ_RS + img] = z + zo;       // (labels 0..4) + (labels 5..9)
+            if (qs == 0) Zs[bufZ * GQ_Z_D + (w + 16 * j) * GQ_RS + img] = z + zo;       // (labels 0..4) + (labels 5..9)
         }
     };
 
     // ---- MFMA roles: wave (rgp, J): rgp = 2 s + half -> the row tiles a = 64 half + 16 r + i (r = 0..3) of site-index value s; J = column
-    //      tile of this workgroup's 60 columns 2q + t (lane i: q' = c >> 1, t = c & 1; the padding columns read a row of zeros)
+    //      tile of this workgroup's 64 columns 2q' + t (lane i: q' = c >> 1, t = c & 1)
     const int rgp = w >> 2, J = w & 3;
     const int li = lane & 15, g = lane >> 4;
     const int sI = rgp >> 1, a0 = 64 * (rgp & 1);
     const int eoff = (a0 + li) * GQ_RS + g;                               // + 16 r GQ_RS for row tile r, + 4 ks for k-step ks (lane group g: image 4 ks + g)
-    const int cc = 16 * J + li;                                            // column 60 h + cc
-    const int zoff = (cc < 2 * GQ_Q ? (cc >> 1) : GQ_Q) * GQ_RS + g;
+    const int cc = 16 * J + li;                                            // column 64 h + cc
+    const int zoff = (cc >> 1) * GQ_RS + g;
     const int woff = (2 * sI + (cc & 1)) * GQ_RS + g;
     // ---- prologue
-    if (tid < 2 * GQ_RS) Zs[(tid / GQ_RS) * GQ_Z_D + GQ_Q * GQ_RS + (tid % GQ_RS)] = 0.;
-    if (tid < 2 * 8 * GQ_RS) Es[(tid / (8 * GQ_RS)) * GQ_E_D + 120 * GQ_RS + (tid % (8 * GQ_RS))] = 0.;
     {   // the first TWO chunks are requested together (the accumulators are not live yet: their registers hold the first chunk's requests)
-        double2 pc0[2]; double el0[2][5], dpv0[5];
+        double2 pc0[3]; double el0[2][5], dpv0[5];
         piece_load(n_of(0), pc0);
         el_load(n_of(0), el0, dpv0);
         piece_load(n_of(1), pc);
@@ -203,25 +205,29 @@ __global__ __launch_bounds__(1024) void k_grad_quad(GradQuadArgs A) {
         frag_load(nxt, 0);
     }
 
-    // ---- epilogue: the quad's partial G, M-layout rows 2a + s, columns 2q + t
-    double* out = A.slab + (size_t)grp * 240 * 240;
-    if (cc < 2 * GQ_Q) {
+    // ---- epilogue: the quad's partial G, M-layout rows 2a + s, columns 2q + t, out to the padded extents (rows and columns beyond the bond
+    //      dimensions come out as the zeros the consumer expects there)
+    double* out = A.slab + (size_t)grp * A.Kp * A.Np;
+    const int col = 2 * GQ_Q * h + cc;
+    if (col < A.Np) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int e4 = 0; e4 < 4; ++e4) {
-                const int a = a0 + 16 * r + g + 4 * e4;
-                if (a < 120) out[(size_t)(2 * a + sI) * 240 + 2 * GQ_Q * h + cc] = acc[r][e4];
+                const int row = 2 * (a0 + 16 * r + g + 4 * e4) + sI;
+                if (row < A.Kp) out[(size_t)row * A.Np + col] = acc[r][e4];
             }
     }
 }
 
 bool grad_quad_applies(const tnml_ctx* c, const Bgemm64Args& a) {
     if (!c->grad_quad || !a.EL || !a.env64 || a.L != 1 || a.w) return false;
-    if (a.Kp != 240 || a.Np != 240 || a.mI != 120 || a.mO != 120 || a.NTp % GQ_TI) return false;
-    if (c->grad_quad == 1 && a.NTp < 4096) return false;
+    if (a.mI < 1 || a.mO < 1 || a.mI > 128 || a.mO > 128 || a.Kp < 2 * a.mI || a.Np < 2 * a.mO || a.Kp > 256 || a.Np > 256 || a.NTp % GQ_TI) return false;
+    // unforced: from 4 096 images per rank on, and only where most of its fixed 256 x 256 tile grid is gradient (m >= 104: two thirds);
+    // smaller bonds keep the tiles of k_bgemm64 that fit them
+    if (c->grad_quad == 1 && (a.NTp < 4096 || a.mI < 104 || a.mO < 104)) return false;
     if ((size_t)TNML_NL * a.EL_lstride * sizeof(double) >= ((size_t)1 << 32)) return false;      // 32-bit lane offsets
-    return c->slab_bytes >= (size_t)64 * 240 * 240 * sizeof(double);
+    return c->slab_bytes >= (size_t)64 * a.Kp * a.Np * sizeof(double);
 }
 
 int launch_grad_quad(tnml_ctx* c, const Bgemm64Args& a, double* G) {
@@ -229,10 +235,11 @@ int launch_grad_quad(tnml_ctx* c, const Bgemm64Args& a, double* G) {
     GradQuadArgs K;
     K.EI = static_cast<const double*>(a.EI); K.phiI = static_cast<const double*>(a.phiI); K.phiO = static_cast<const double*>(a.phiO);
     K.EL = static_cast<const double*>(a.EL); K.EL_lstride = a.EL_lstride; K.dP = a.dPz; K.NTp = a.NTp;
+    K.mI = a.mI; K.mO = a.mO; K.Kp = a.Kp; K.Np = a.Np;
     K.slab = static_cast<double*>(c->slab);
     K.nchunks = a.NTp / GQ_TI;
     int quads = c->cu_count / 4;                                   // one workgroup per CU
-    const int cap = (int)(c->slab_bytes / ((size_t)240 * 240 * sizeof(double)));
+    const int cap = (int)(c->slab_bytes / ((size_t)a.Kp * a.Np * sizeof(double)));
     if (quads > cap) quads = cap;
     if (c->bgemm_wgs > 0 && c->bgemm_wgs / 4 < quads) quads = c->bgemm_wgs / 4 > 0 ? c->bgemm_wgs / 4 : 1;      // test knob: fewer quads -> more stages each
     if (quads > K.nchunks) quads = K.nchunks;
@@ -254,7 +261,7 @@ int launch_grad_quad(tnml_ctx* c, const Bgemm64Args& a, double* G) {
         else if (c->grad_quad == 5) hipLaunchKernelGGL(k_grad_quad<3>, dim3(grid), dim3(1024), lds, c->stream, K);
         else                        hipLaunchKernelGGL(k_grad_quad<0>, dim3(grid), dim3(1024), lds, c->stream, K);
     }
-    const size_t n = (size_t)240 * 240;
+    const size_t n = (size_t)a.Kp * a.Np;
     if (c->defer_slab) c->slab_pending = K.ngroups;            // the CG vector kernel that consumes G sums the slabs itself (slab order: the same bits)
     else {
         ProfScope ps(c, KC_SLABRED);
