@@ -223,9 +223,10 @@ __global__ __launch_bounds__(1024) void k_grad_quad(GradQuadArgs A) {
 bool grad_quad_applies(const tnml_ctx* c, const Bgemm64Args& a) {
     if (!c->grad_quad || !a.EL || !a.env64 || a.L != 1 || a.w) return false;
     if (a.mI < 1 || a.mO < 1 || a.mI > 128 || a.mO > 128 || a.Kp < 2 * a.mI || a.Np < 2 * a.mO || a.Kp > 256 || a.Np > 256 || a.NTp % GQ_TI) return false;
-    // unforced: from 4 096 images per rank on, and only where most of its fixed 256 x 256 tile grid is gradient (m >= 104: two thirds);
-    // smaller bonds keep the tiles of k_bgemm64 that fit them
-    if (c->grad_quad == 1 && (a.NTp < 4096 || a.mI < 104 || a.mO < 104)) return false;
+    // unforced: from 4 096 images per rank on and from mI mO >= 72^2 on -- its 256 x 256 tile grid is fixed (155-160 us at 60 000 images whatever
+    // the bond), but the tiles k_bgemm64 has for other sizes than 120 are far from it: 192 / 203 / 210 / 376 / 387 / 273 us at m = 72 / 88 / 96 /
+    // 104 / 112 / 128 (profiles/r06_grad_quad_by_bond_dimension.txt); bonds of 64 and below keep the 128 x 64 tiles made for them
+    if (c->grad_quad == 1 && (a.NTp < 4096 || a.mI * a.mO < 72 * 72)) return false;
     if ((size_t)TNML_NL * a.EL_lstride * sizeof(double) >= ((size_t)1 << 32)) return false;      // 32-bit lane offsets
     return c->slab_bytes >= (size_t)64 * a.Kp * a.Np * sizeof(double);
 }
