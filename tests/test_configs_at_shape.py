@@ -380,11 +380,13 @@ def test_gradient_quad_kernel_matches_the_oracle(NT, wgs):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("m", [64, 96, 104, 128])
+@pytest.mark.parametrize("m", [40, 61, 64, 96, 104, 128])
 def test_gradient_quad_kernel_at_other_bond_dimensions(m):
     """k_grad_quad serves every bond dimension up to 128 (its 256 x 256 tile grid is fixed; rows and links beyond the bond dimensions are
     staged as zeros and come out as the zero padding of the M-layout): bonds that have shrunk below maxm (fixedL.cc:593) and unequal left /
-    right dimensions (bond 7 of a 20-site chain: 64 x m).  Unforced it takes bonds from m = 104 on; forced here (grad_quad = 2)."""
+    right dimensions (bond 7 of a 20-site chain: 64 x m), dimensions that are multiples of nothing (61).  Unforced it takes bonds from
+    72 x 72 on (a one-workgroup form for bonds up to 64 x 64 measured 120 us against the 75 of k_bgemm64's 128 x 64 tiles at m = 60: twice the
+    Label-carrying rows per workgroup and stage; not kept); forced here (grad_quad = 2)."""
     from oracle import pyoracle
     from tnml_amd.fixedl import TrainStates
     from conftest import make_problem
@@ -417,6 +419,59 @@ def test_gradient_quad_kernel_at_other_bond_dimensions(m):
         Bo, to = o.cgrad(B, 3, 1e-3, 1e-10)
         np.testing.assert_allclose(tg["cost"], to["cost"], rtol=1e-9, err_msg=kind)
         np.testing.assert_allclose(tg["alpha"], to["alpha"], rtol=1e-5, err_msg=kind)
+    ts.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,NT,grid", [(61, 300, 0), (64, 300, 0), (90, 1100, 16), (96, 300, 0), (104, 300, 0), (110, 2100, 16), (120, 300, 0)])
+def test_resident_forward_and_shift_kernels_at_other_bond_dimensions(m, NT, grid):
+    """k_fwd_res / k_shift_res (kernels_res.hip) serve input dimensions 33..120 -- one instantiation per reduction length, rows from the bond
+    dimension on staged from valid rows against zero rows of the packed matrix -- and every output dimension their tile grid holds (2..15
+    column tiles of 8 links on the pair of workgroups of k_fwd_res; up to 8 column tiles of 16 on the waves of k_shift_res, with at most four
+    of them every wave takes one 32-image half): trained bonds shrink towards minm = maxm/2 (fixedL.cc:593) and are not multiples of
+    anything (61, 90, 110), left and right dimensions differ (bonds 7 and 13 of a 20-site chain: 64 x m, m x 64).  Forced (options
+    fwd_res / shift_res = 2; m = 120: fwd_res = 3, the general form on the benchmark's own bond); grid caps make several rounds per workgroup."""
+    from oracle import pyoracle
+    from tnml_amd.fixedl import TrainStates
+    from conftest import make_problem
+    N = 20
+    pixels, labels, phi, W = make_problem(N, NT, m, 11, pixel_boost=200.0)
+    ts = TrainStates(labels, N, m, phi=phi)
+    ts.set_option("fwd_res", 3 if m == 120 else 2)
+    ts.set_option("shift_res", 2)
+    if grid:
+        ts.set_option("res_grid", grid)
+    ts.set_mps(W)
+    ts.profile(True, only="fgemm_shift,fwd_res,fgemm_fwd,labeldot")
+    ts.init()
+    o = pyoracle.Oracle(phi, labels, W, nthread=min(8, os.cpu_count() or 1))
+    o.init()
+    for j in (5, 7, 8, 9, 10):                                # right environments carrying the Label index (64 -> m at site 8, m -> m below)
+        assert _rel(ts.env(j), o.env(j)) < 1e-12, j
+    rng = np.random.default_rng(6)
+    at = 1
+    for b, kind in ((7, "Label on RE, 64 x m"), (8, "Label on RE"), (12, "Label on LE"), (13, "Label on LE, m x 64")):
+        for bb in range(at, b):
+            ts.shiftE(bb, True); o.shiftE(bb, True)
+            if bb >= 10:
+                assert _rel(ts.env(bb), o.env(bb)) < 1e-12, bb        # left environments carrying the Label index, built by shiftE
+        at = b
+        ts.setBond(b); o.set_bond(b)
+        B = o.bond_tensor(b)
+        B = B + 0.05 * rng.standard_normal(B.shape)
+        ts.profile_reset()
+        Pg = ts.forward(B)
+        pr = ts.profile_read()
+        assert pr["fwd_res"][0] == 1 and pr.get("fgemm_fwd", (0, 0))[0] == 0 and pr.get("labeldot", (0, 0))[0] == 0, (kind, pr)
+        assert _rel(Pg, o.forward(B)) < 1e-11, kind
+        Cg, lg, _, ng = ts.quadcost(B, 1e-3)
+        Co, lo, _, no = o.quadcost(B, 1e-3)
+        assert Cg == pytest.approx(Co, rel=1e-11) and ng == no, kind
+        Bg, tg = ts.cgrad(B, 3, 1e-3, 1e-10)
+        Bo, to = o.cgrad(B, 3, 1e-3, 1e-10)
+        np.testing.assert_allclose(tg["cost"], to["cost"], rtol=1e-9, err_msg=kind)
+        np.testing.assert_allclose(tg["alpha"], to["alpha"], rtol=1e-5, err_msg=kind)
+    ts.profile(False)
     ts.close()
 
 

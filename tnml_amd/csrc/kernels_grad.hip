@@ -50,6 +50,7 @@ struct GradQuadArgs {
     int mI, mO, Kp, Np;                                           // bond dimensions (<= 128) and the padded M-layout extents of G
     double* slab;                                                 // [ngroups][Kp][Np], M-layout
     int ngroups, per, nchunks;                                    // quads, 32-image chunks per quad, chunks in all
+    long long* dbg = nullptr;                                     // ABL 5 (tools/probe/probe_fixed.hip): four 100 MHz stamps per workgroup
 };
 
 // workgroup barrier without the vmcnt(0) of __syncthreads(): the loads for the stage after next stay in flight across it
@@ -60,7 +61,8 @@ static __device__ __forceinline__ void gq_barrier() {
 }
 
 // ABL (the ablations of the record under profiles/): 1 = no loads of the Label-carrying environment (compute side alone),
-// 3 = no staging at all inside the loop (the MFMA loop with its fragment reads and the barrier per stage)
+// 3 = no staging at all inside the loop (the MFMA loop with its fragment reads and the barrier per stage), 5 = the kernel as shipped + time
+// stamps of every workgroup (entry, prologue done, loop done, stores done)
 template <int ABL>
 __global__ __launch_bounds__(1024) void k_grad_quad(GradQuadArgs A) {
     extern __shared__ __attribute__((aligned(16))) double gq_lds[];
@@ -69,6 +71,7 @@ __global__ __launch_bounds__(1024) void k_grad_quad(GradQuadArgs A) {
     double* const Ws = Zs + 2 * GQ_Z_D;                // [2][4][32]
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x;
+    const long long ts0 = ABL == 5 ? (long long)wall_clock64() : 0;
     const int h = (b >> 3) & 3, grp = (b & 7) + 8 * (b >> 5);
     if (grp >= A.ngroups) return;
     const int NTp = A.NTp;
@@ -160,6 +163,7 @@ __global__ __launch_bounds__(1024) void k_grad_quad(GradQuadArgs A) {
         z_build(0, el0, dpv0);
     }
     gq_barrier();
+    const long long ts1 = ABL == 5 ? (long long)wall_clock64() : 0;
 
     f64x4g acc[4];
 #pragma unroll
@@ -207,6 +211,7 @@ __global__ __launch_bounds__(1024) void k_grad_quad(GradQuadArgs A) {
 
     // ---- epilogue: the quad's partial G, M-layout rows 2a + s, columns 2q + t, out to the padded extents (rows and columns beyond the bond
     //      dimensions come out as the zeros the consumer expects there)
+    const long long ts2 = ABL == 5 ? (long long)wall_clock64() : 0;
     double* out = A.slab + (size_t)grp * A.Kp * A.Np;
     const int col = 2 * GQ_Q * h + cc;
     if (col < A.Np) {
@@ -217,6 +222,11 @@ __global__ __launch_bounds__(1024) void k_grad_quad(GradQuadArgs A) {
                 const int row = 2 * (a0 + 16 * r + g + 4 * e4) + sI;
                 if (row < A.Kp) out[(size_t)row * A.Np + col] = acc[r][e4];
             }
+    }
+    if (ABL == 5 && A.dbg) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) { long long* d = A.dbg + 4 * (size_t)b; d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = (long long)wall_clock64(); }
     }
 }
 

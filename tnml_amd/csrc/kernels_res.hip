@@ -24,10 +24,12 @@
 typedef double f64x4r __attribute__((ext_vector_type(4)));
 
 #define FR_TI 32                       // images per tile
-#define FR_NK 60                       // MFMA k-steps over the reduction length 240
-#define FR_ROWS 124                    // rows of the staged image operand: 120 environment rows, phiI[0..1], phiO[0..1]
-#define FR_EIS (FR_ROWS * FR_TI)       // doubles per buffer
-#define FR_LDS_DOUBLES (2 * FR_EIS + 2 * 64 * FR_TI + 2 * 4 * TNML_NL * FR_TI)
+// NKA = MFMA k-steps over the rows a of the input environment (4 each; 30 at m = 120); rows of the staged image operand: 4 NKA environment
+// rows, phiI[0..1], phiO[0..1]
+#define FR_ROWS(NKA) (4 * (NKA) + 4)
+#define FR_EIS(NKA) (FR_ROWS(NKA) * FR_TI)       // doubles per buffer
+#define FR_LDS_DOUBLES_N(NKA) (2 * FR_EIS(NKA) + 2 * 64 * FR_TI + 2 * 4 * TNML_NL * FR_TI)
+#define FR_LDS_DOUBLES FR_LDS_DOUBLES_N(30)
 
 // workgroup barrier WITHOUT the vmcnt(0) that __syncthreads() carries: the streaming waves keep four rows of the Label-carrying
 // environment in flight across it.  LDS writes of this wave are complete (lgkmcnt(0)); what else has to have landed is stated at the call.
@@ -47,18 +49,31 @@ static __device__ __forceinline__ void fr_barrier() {
 // (tools/probe/probe_valu_mfma.hip: ten FMAs of a third wave take 8 300 cycles instead of 80, fp64, fp32 and integer alike) -- the
 // streaming wave's FMAs, and with them its next loads, would wait for stalls of the GEMM waves.  The pauses are those stalls, made on purpose.
 // ABL (probe builds only): 1 = no label-dot loads (GEMM role alone), 2 = no MFMAs (streaming role alone), 5 = per-wave cycle counters
-template <int PS, int PK, int ABL>
+// Other bond dimensions than 120 x 120 (trained bonds shrink towards minm = maxm/2, fixedL.cc:593): NKA = ceil(mI / 4) rounded up to the next
+// instantiation built (rows from mI on are staged from valid rows and meet zero rows of M); the T = Np / 16 column tiles of M (8 output links
+// each; links from mO on: zero columns of M, rows of the Label-carrying environment taken from valid ones) are dealt ceil(T / 2) + floor(T / 2)
+// to the two workgroups of a pair; the streaming waves always run their eight steps -- a step beyond the half's tiles re-reads the
+// environment's first rows (cache hits) and weighs them zero, so that the hand-counted waits hold on every path.
+// GEN = false: the 120 x 120 bond of the benchmark with its extents as constants (NKA = 30).
+// NST = steps of the streaming waves per tile: 8, or 4 where no half has more than four column tiles (mO <= 64).
+template <int PS, int PK, int ABL, int NKA = 30, bool GEN = false, int NST = 8>
 __global__ __launch_bounds__(768) void k_fwd_res(FwdResArgs A) {
+    static_assert(GEN || NKA == 30, "the constant-extent form is the 120 x 120 bond");
+    static_assert(NST == 8 || (NST == 4 && GEN), "four or eight streaming steps per tile");
+    constexpr int EIS = FR_EIS(NKA);
+    const int mI = GEN ? A.mI : 120, mO = GEN ? A.mO : 120, Kp = GEN ? A.Kp : 240, Np = GEN ? A.Np : 240;
     extern __shared__ __attribute__((aligned(16))) double fr_lds[];
-    double* EIs = fr_lds;                        // [2][124][32]
-    double* Us = EIs + 2 * FR_EIS;               // [2][64][32]: U[q - 64 half][image]
+    double* EIs = fr_lds;                        // [2][4 NKA + 4][32]
+    double* Us = EIs + 2 * EIS;                  // [2][64][32]: U[q - first link of the half][image]
     double* red = Us + 2 * 64 * FR_TI;           // [2][4][10][32]
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x;
     // workgroups b and b + 8 land on the same XCD (round-robin dispatch over 8 XCDs): the pair shares its image operand in one L2
     const int half = (b >> 3) & 1, pair = (b & 7) + 8 * (b >> 4), npairs = gridDim.x >> 1;
     const int NTp = A.NTp;
-    const int nq = half ? 56 : 64;               // output links of this half
+    const int T = Np >> 4, T0 = (T + 1) >> 1;
+    const int Th = half ? T - T0 : T0;           // column tiles (of 8 output links) of this half: 8 + 7 at m = 120
+    const int qb = half ? 8 * T0 : 0;            // its first output link
     const int niter = (A.ntiles - pair + npairs - 1) / npairs;      // >= 1 (launch_fwd_res sizes the grid)
 
     if (wid < 8) {
@@ -67,9 +82,9 @@ __global__ __launch_bounds__(768) void k_fwd_res(FwdResArgs A) {
         // accumulators per image group share ONE environment fragment per k-step (half the LDS reads) and the site feature is applied
         // once, in the epilogue, instead of once per MFMA.
         const int w = wid;
-        const bool act = 8 * w < nq;             // half 1 has 7 column tiles
-        const int ct = 8 * half + w;
-        double me[FR_NK / 2], mo[FR_NK / 2];     // M[2 (4 ks + g) + s][16 ct + i], s = 0 / 1
+        const bool act = w < Th;
+        const int ct = (half ? T0 : 0) + w;
+        double me[NKA], mo[NKA];                 // M[2 (4 ks + g) + s][16 ct + i], s = 0 / 1
         {
             // MFMA row i of this wave's tile is column j = 2 q + t of M with q = 8 ct + (i & 7), t = i >> 3: a lane's accumulator rows
             // g, g + 4 (t = 0) and g + 8, g + 12 (t = 1) are then BOTH site-index values of the output links 8 ct + g, 8 ct + g + 4,
@@ -77,9 +92,10 @@ __global__ __launch_bounds__(768) void k_fwd_res(FwdResArgs A) {
             const int g = lane >> 4, i = lane & 15;
             const int col = 2 * (8 * ct + (i & 7)) + (i >> 3);
 #pragma unroll
-            for (int ks = 0; ks < FR_NK / 2; ++ks) {
-                me[ks] = act ? A.M[(size_t)(2 * (4 * ks + g)) * 240 + col] : 0.;
-                mo[ks] = act ? A.M[(size_t)(2 * (4 * ks + g) + 1) * 240 + col] : 0.;
+            for (int ks = 0; ks < NKA; ++ks) {
+                const bool in = act && 2 * (4 * ks + g) + 1 < Kp;            // (Kp is even: both rows or neither)
+                me[ks] = in ? A.M[(size_t)(2 * (4 * ks + g)) * Np + col] : 0.;
+                mo[ks] = in ? A.M[(size_t)(2 * (4 * ks + g) + 1) * Np + col] : 0.;
             }
         }
         fr_barrier();                            // prologue: the first tile's image operand is in X[0]
@@ -89,7 +105,7 @@ __global__ __launch_bounds__(768) void k_fwd_res(FwdResArgs A) {
             const long long c0 = ABL == 5 ? clock64() : 0;
             long long c1 = c0, c2 = c0;
             if (it < niter && act) {
-                const double* Eb = EIs + (it & 1) * FR_EIS;
+                const double* Eb = EIs + (it & 1) * EIS;
                 double* Ub = Us + (it & 1) * 64 * FR_TI;
                 // (the lane index passes through an empty asm before the MFMA loop and again before the epilogue: everything derived
                 // from it is then recomputed where it is used instead of living -- spilled -- across the 120 MFMAs)
@@ -109,10 +125,10 @@ __global__ __launch_bounds__(768) void k_fwd_res(FwdResArgs A) {
                 double a0 = ep0[0], b0 = ep1[0], a1 = ep0[4 * FR_TI], b1 = ep1[4 * FR_TI];
                 __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
-                for (int ks = 0; ks < (ABL == 2 ? 1 : FR_NK / 2); ++ks) {
+                for (int ks = 0; ks < (ABL == 2 ? 1 : NKA); ++ks) {
                     const double xa = a0, xb = b0;
                     a0 = a1; b0 = b1;
-                    if (ks + 2 < FR_NK / 2) { a1 = ep0[4 * (ks + 2) * FR_TI]; b1 = ep1[4 * (ks + 2) * FR_TI]; __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
+                    if (ks + 2 < NKA) { a1 = ep0[4 * (ks + 2) * FR_TI]; b1 = ep1[4 * (ks + 2) * FR_TI]; __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
                     ce0 = __builtin_amdgcn_mfma_f64_16x16x4f64(me[ks], xa, ce0, 0, 0, 0);
                     co0 = __builtin_amdgcn_mfma_f64_16x16x4f64(mo[ks], xa, co0, 0, 0, 0);
                     ce1 = __builtin_amdgcn_mfma_f64_16x16x4f64(me[ks], xb, ce1, 0, 0, 0);
@@ -127,8 +143,8 @@ __global__ __launch_bounds__(768) void k_fwd_res(FwdResArgs A) {
                 g = ln >> 4; i = ln & 15;
 #pragma unroll
                 for (int grp = 0; grp < 2; ++grp) {
-                    const double pI0 = Eb[120 * FR_TI + 16 * grp + i], pI1 = Eb[121 * FR_TI + 16 * (grp ^ 1) + i];
-                    const double pO0 = Eb[122 * FR_TI + 16 * grp + i], pO1 = Eb[123 * FR_TI + 16 * (grp ^ 1) + i];
+                    const double pI0 = Eb[(4 * NKA) * FR_TI + 16 * grp + i], pI1 = Eb[(4 * NKA + 1) * FR_TI + 16 * (grp ^ 1) + i];
+                    const double pO0 = Eb[(4 * NKA + 2) * FR_TI + 16 * grp + i], pO1 = Eb[(4 * NKA + 3) * FR_TI + 16 * (grp ^ 1) + i];
                     const f64x4r ce = grp ? ce1 : ce0, co = grp ? co1 : co0;
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
@@ -151,39 +167,64 @@ __global__ __launch_bounds__(768) void k_fwd_res(FwdResArgs A) {
         __builtin_amdgcn_s_setprio(3);          // few instructions, all of them latency critical: issue ahead of the GEMM waves of this SIMD
         const int sw = wid - 8;
         const int img = lane & 31, qs = lane >> 5;
-        const int nk = nq >> 3;                                  // 8 rows of q per step over the 4 waves x 2 lane halves
+        const int nk = Th;                                       // 8 rows of q per step over the 4 waves x 2 lane halves: one step per column tile
         // staging of a tile's image operand straight into LDS (no staging registers): one global_load_lds_dwordx4 moves 4 rows of
-        // 32 images (1 KB; lane -> row lane >> 4, images 2 (lane & 15) ...): environment rows 4 grp .., grp = sw, sw + 4, ... < 30;
-        // the four feature rows (phiI[0..1], phiO[0..1]) are group 30, taken by wave 10.  Every wave issues exactly 8 pieces (wave 11
-        // repeats a group -- same bytes to the same place) so that the counts below hold on every path.
+        // 32 images (1 KB; lane -> row lane >> 4, images 2 (lane & 15) ...): NKA groups of environment rows 4 grp .. and the four feature
+        // rows (phiI[0..1], phiO[0..1]) as group NKA; every wave issues exactly 8 pieces (groups sw, sw + 4, ...; slots beyond the last group
+        // repeat groups -- same bytes to the same place) so that the counts below hold on every path.  Rows from mI on only have to be finite
+        // (they meet zero rows of M): the group that straddles mI repeats its last valid row, the groups beyond it take rows 0..3.
         const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)fr_lds);
         const int xcol = 2 * ((lane & 15) ^ (((lane >> 4) & 1) << 3));      // source images of this lane's 16 bytes: odd rows swap their halves
         const double* const phr = ((lane >> 4) < 2 ? A.phiI : A.phiO) + (size_t)((lane >> 4) & 1) * NTp + xcol;
         const double* const eir = A.EI + (size_t)(lane >> 4) * NTp + xcol;
+        const int gb = GEN ? (mI - 1) >> 2 : NKA;                           // the last group with a valid row (constant extents: every group is whole)
+        const int rb = 4 * gb + (lane >> 4) < mI ? 4 * gb + (lane >> 4) : mI - 1;
+        const double* const eib = A.EI + (size_t)rb * NTp + xcol;
         auto x_stage = [&](int tile, int buf) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                const int grp = r < 7 ? sw + 4 * r : (sw < 2 ? sw + 28 : (sw == 2 ? 30 : 3));       // uniform
-                const double* src = (grp == 30 ? phr : eir + (size_t)(4 * grp) * NTp) + (size_t)tile * FR_TI;
-                const unsigned dst = lds0 + (unsigned)((buf * FR_EIS + 4 * grp * FR_TI) * sizeof(double));
+                int grp = sw + 4 * r;                                               // uniform
+                const double* src;
+                if constexpr (GEN) {
+                    if (grp > NKA) grp -= NKA + 1;
+                    if (grp > NKA) grp -= NKA + 1;
+                    src = (grp == NKA ? phr : (grp < gb ? eir + (size_t)(4 * grp) * NTp : (grp == gb ? eib : eir))) + (size_t)tile * FR_TI;
+                } else {
+                    grp = r < 7 ? sw + 4 * r : (sw < 2 ? sw + 28 : (sw == 2 ? 30 : 3));
+                    src = (grp == 30 ? phr : eir + (size_t)(4 * grp) * NTp) + (size_t)tile * FR_TI;
+                }
+                const unsigned dst = lds0 + (unsigned)((buf * EIS + 4 * grp * FR_TI) * sizeof(double));
                 unsigned keep;
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                              : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
             }
         };
-        const double* ELw = A.EL + (size_t)(64 * half + 2 * sw) * NTp;          // uniform part of this wave's rows
+        const double* ELw = A.EL + (size_t)(qb + 2 * sw) * NTp;                   // uniform part of this wave's rows
         const unsigned eoff = (unsigned)(((size_t)qs * NTp + img) * sizeof(double));  // lane part (bytes)
         const unsigned uoff = (unsigned)((2 * sw + qs) * FR_TI + img);                // lane part of a U read (doubles)
-        const size_t k7 = nk > 7 ? (size_t)56 * NTp : 0;                              // half 1 has 7 steps: its 8th re-reads row 0 and weighs it 0
+        // row offset (doubles, from ELw) and lane part of the eight steps: step k < nk reads the links qb + 8 k + 2 sw + (0, 1); a step beyond
+        // the half's tiles reads the links 2 sw + (0, 1) of the environment's first rows and is weighed zero; links from mO on (the last tile
+        // of all, mO not a multiple of 8) meet U = 0 (zero columns of M): a pair that straddles mO takes its valid row twice, a pair beyond
+        // it the first rows again
+        size_t roff[8]; bool same[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int q0 = qb + 8 * k + 2 * sw;
+            const bool real = k < nk && q0 < mO;
+            roff[k] = real ? (size_t)(8 * k) * NTp : (size_t)0 - (size_t)qb * NTp;
+            same[k] = GEN && real && q0 + 1 >= mO;
+        }
+        const unsigned eoff0 = (unsigned)(img * sizeof(double));
         // four rows (of 10 labels) of the Label-carrying environment in flight per lane, as a ring that runs on across the tiles
         // and across the barriers: while row k of a tile is consumed, row k + 4 (of this tile or the next) is requested
         double ea[TNML_NL], eb[TNML_NL], ec[TNML_NL], ed[TNML_NL];
-        auto s_load = [&](int tile, size_t rowoff, double (&e)[TNML_NL]) {
+        auto s_load = [&](int tile, int k, double (&e)[TNML_NL]) {
+            const unsigned vo = same[k] ? eoff0 : eoff;
 #pragma unroll
             for (int l = 0; l < TNML_NL; ++l) {
-                const double* bp = ELw + (size_t)tile * FR_TI + (size_t)l * A.EL_lstride + rowoff;      // uniform: an SGPR pair
+                const double* bp = ELw + (size_t)tile * FR_TI + (size_t)l * A.EL_lstride + roff[k];      // uniform: an SGPR pair
                 if (ABL == 1) e[l] = 1.0;
-                else asm volatile("global_load_dwordx2 %0, %1, %2 nt" : "=v"(e[l]) : "v"(eoff), "s"(bp) : "memory");
+                else asm volatile("global_load_dwordx2 %0, %1, %2 nt" : "=v"(e[l]) : "v"(vo), "s"(bp) : "memory");
             }
         };
 #define FR_WAIT(N, e) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6]), "+v"(e[7]), "+v"(e[8]), "+v"(e[9]) :: "memory")
@@ -203,16 +244,26 @@ __global__ __launch_bounds__(768) void k_fwd_res(FwdResArgs A) {
 #define FR_FENCE() do { asm volatile("" : "+v"(px[0]), "+v"(px[1]), "+v"(px[2]), "+v"(px[3]), "+v"(px[4]), "+v"(px[5]), "+v"(px[6]), "+v"(px[7]), "+v"(px[8]), "+v"(px[9]) :: "memory"); \
                         __builtin_amdgcn_sched_barrier(0); } while (0)
             // outstanding behind row 0: rows 1..3 = 30 loads, and so on down the ring
-            FR_WAIT(30, ea); s_use(0, ea, true); FR_FENCE(); s_load(tile, (size_t)32 * NTp, ea);
-            FR_WAIT(30, eb); s_use(1, eb, true); FR_FENCE(); s_load(tile, (size_t)40 * NTp, eb);
-            FR_WAIT(30, ec); s_use(2, ec, true); FR_FENCE(); s_load(tile, (size_t)48 * NTp, ec);
-            FR_WAIT(30, ed); s_use(3, ed, true); FR_FENCE(); s_load(tile, k7, ed);
-            mid();
-            // behind row 4: rows 5..7 (30) + the 8 pieces (+ 5 stores on wave 8: the wait is then stricter than needed, never weaker)
-            FR_WAIT(38, ea); s_use(4, ea, true); FR_FENCE(); s_load(ntile, 0, ea);
-            FR_WAIT(38, eb); s_use(5, eb, true); FR_FENCE(); s_load(ntile, (size_t)8 * NTp, eb);
-            FR_WAIT(38, ec); s_use(6, ec, true); FR_FENCE(); s_load(ntile, (size_t)16 * NTp, ec);
-            FR_WAIT(38, ed); s_use(7, ed, nk > 7); FR_FENCE(); s_load(ntile, (size_t)24 * NTp, ed);
+            if constexpr (NST == 8) {
+                FR_WAIT(30, ea); s_use(0, ea, nk > 0); FR_FENCE(); s_load(tile, 4, ea);
+                FR_WAIT(30, eb); s_use(1, eb, nk > 1); FR_FENCE(); s_load(tile, 5, eb);
+                FR_WAIT(30, ec); s_use(2, ec, nk > 2); FR_FENCE(); s_load(tile, 6, ec);
+                FR_WAIT(30, ed); s_use(3, ed, nk > 3); FR_FENCE(); s_load(tile, 7, ed);
+                mid();
+                // behind row 4: rows 5..7 (30) + the 8 pieces (+ 5 stores on wave 8: the wait is then stricter than needed, never weaker)
+                FR_WAIT(38, ea); s_use(4, ea, nk > 4); FR_FENCE(); s_load(ntile, 0, ea);
+                FR_WAIT(38, eb); s_use(5, eb, nk > 5); FR_FENCE(); s_load(ntile, 1, eb);
+                FR_WAIT(38, ec); s_use(6, ec, nk > 6); FR_FENCE(); s_load(ntile, 2, ec);
+                FR_WAIT(38, ed); s_use(7, ed, nk > 7); FR_FENCE(); s_load(ntile, 3, ed);
+            } else {
+                // four steps per tile: every step requests its row of the NEXT tile.  Behind row 0 in the first round: rows 1..3 (30); later:
+                // row 1, the 8 pieces, rows 2, 3 (38) -- 30 is never weaker; behind rows 2, 3: 38 in every round
+                FR_WAIT(30, ea); s_use(0, ea, nk > 0); FR_FENCE(); s_load(ntile, 0, ea);
+                FR_WAIT(30, eb); s_use(1, eb, nk > 1); FR_FENCE(); s_load(ntile, 1, eb);
+                mid();
+                FR_WAIT(38, ec); s_use(2, ec, nk > 2); FR_FENCE(); s_load(ntile, 2, ec);
+                FR_WAIT(38, ed); s_use(3, ed, nk > 3); FR_FENCE(); s_load(ntile, 3, ed);
+            }
 #undef FR_FENCE
 #pragma unroll
             for (int l = 0; l < TNML_NL; ++l) {
@@ -236,7 +287,7 @@ __global__ __launch_bounds__(768) void k_fwd_res(FwdResArgs A) {
         fr_barrier();                                            // prologue: the first tile's image operand is in X[0]
         // round 0: nothing to contract yet; open the ring with rows 0..3 of the first tile
         x_stage(niter > 1 ? pair + npairs : pair, 1);
-        s_load(pair, 0, ea); s_load(pair, (size_t)8 * NTp, eb); s_load(pair, (size_t)16 * NTp, ec); s_load(pair, (size_t)24 * NTp, ed);
+        s_load(pair, 0, ea); s_load(pair, 1, eb); s_load(pair, 2, ec); s_load(pair, 3, ed);
         asm volatile("s_waitcnt vmcnt(40)" ::: "memory");        // the staged tile has landed (issued before the 40 row loads)
         fr_barrier();
         long long t_dot = 0, t_bar = 0;
@@ -247,7 +298,9 @@ __global__ __launch_bounds__(768) void k_fwd_res(FwdResArgs A) {
                 x_stage(it + 1 < niter ? pair + (it + 1) * npairs : tile, (it + 1) & 1);      // (no next tile: this one again, into the idle buffer)
                 if (it >= 2) finalize(pair + (it - 2) * npairs, red + ((it - 1) & 1) * 4 * TNML_NL * FR_TI);
             });
-            asm volatile("s_waitcnt vmcnt(40)" ::: "memory");    // all but the 40 row loads just requested: the staged tile has landed
+            // all but the row loads requested behind the pieces (rows 0..3 / rows 2, 3 of the next tile): the staged tile has landed
+            if constexpr (NST == 8) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+            else                    asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
             const long long c1 = ABL == 5 ? clock64() : 0;
             fr_barrier();
             if (ABL == 5) { const long long c2 = clock64(); t_dot += c1 - c0; t_bar += c2 - c1; }
@@ -261,19 +314,24 @@ __global__ __launch_bounds__(768) void k_fwd_res(FwdResArgs A) {
 }
 
 // ==========================================================================================================================
-// k_shift_res -- the Label-carrying environment shift (TrainStates::shiftE / init, fixedL.cc:142-149,221-228), m = 120:
-//   E'[l][y][n] = sum_{a,s} E[l][a][n] phi[s][n] A[a,s,y]  =  phi[0] (E M_even) + phi[1] (E M_odd),  M = the packed site matrix [240][128].
-// M (245 KB) fits the registers of ONE workgroup: 8 waves, wave w keeps column tile w (120 VGPRs) for the whole launch and the
-// workgroup walks 64-image tiles of the 10 x NTp rows.  No second role: every wave issues its share of the next tile's LDS-DMA
-// pieces at the top of a round, so nothing but MFMAs, LDS fragment reads and stores runs beside the matrix pipe.  The second half of a
-// tile's outputs is stored at the top of the NEXT round: the wait that lands the DMA pieces at the end of a round (vmcnt counts loads
-// and stores alike) then finds only stores that are half a round old.  One barrier per tile.
+// k_shift_res -- the Label-carrying environment shift (TrainStates::shiftE / init, fixedL.cc:142-149,221-228), bond dimensions up to 120 x 128:
+//   E'[l][y][n] = sum_{a,s} E[l][a][n] phi[s][n] A[a,s,y]  =  phi[0] (E M_even) + phi[1] (E M_odd),  M = the packed site matrix [Kp][Np].
+// M (245 KB at m = 120) fits the registers of ONE workgroup: 8 waves, a wave keeps ONE 16-column tile for the whole reduction length (4 NKS
+// rows of the input environment, NKS = the template parameter: 2 NKS doubles per lane) for the whole launch and the workgroup walks 64-image
+// tiles of the 10 x NTp rows.  No second role: every wave issues its share of the next tile's LDS-DMA pieces at the top of a round, so nothing
+// but MFMAs, LDS fragment reads and stores runs beside the matrix pipe.  The second half of a tile's outputs is stored at the top of the NEXT
+// round: the wait that lands the DMA pieces at the end of a round (vmcnt counts loads and stores alike) then finds only stores that are half a
+// round old.  One barrier per tile.
+// Other bond dimensions than 120 (trained bonds shrink towards minm = maxm/2, fixedL.cc:593): the input dimension picks the instantiation
+// (NKS = ceil(mI / 4) rounded up to the next one built; rows from mI on are staged from a valid row and meet zero rows of M); with at most four
+// column tiles (mO <= 64) the eight waves take one 32-image half of the tile each, so all of them keep issuing MFMAs.
 // ==========================================================================================================================
 #define SR_TI 64
-#define SR_ROWS 122                                // 120 environment rows, phi[0], phi[1]
-#define SR_LDS_DOUBLES (2 * SR_ROWS * SR_TI)
 
+template <int NKS>
 __global__ __launch_bounds__(512) void k_shift_res(ShiftResArgs A) {
+    constexpr int ROWS = 4 * NKS + 2;                  // 4 NKS environment rows, phi[0], phi[1]
+    constexpr int NP = 2 * NKS + 1;                    // DMA pieces of 2 rows per tile (the last one: the two feature rows)
     extern __shared__ __attribute__((aligned(16))) double sr_lds[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NTp = A.NTp, tpl = NTp / SR_TI;
@@ -285,24 +343,37 @@ __global__ __launch_bounds__(512) void k_shift_res(ShiftResArgs A) {
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff), "s"(dst), "s"(base) : "memory");
     };
-    // tile t = rows n0 .. n0 + 63 of label l; 61 pieces of 2 rows (piece 60: the two feature rows); 8 per wave, the last slots repeat pieces
+    // tile t = rows n0 .. n0 + 63 of label l; NP pieces of 2 rows; 8 per wave, the last slots repeat pieces (same bytes to the same place).
+    // Rows from mI on (mI odd, or below the instantiation's 4 NKS) meet zero rows of M and only have to be finite: a piece that straddles
+    // mI takes its last valid row twice (lane offset without the row part), a piece beyond it takes rows 0 and 1
+    const unsigned doff0 = (unsigned)((2 * (lane & 31)) * sizeof(double));
     auto stage = [&](int t, int buf) {
         const int l = t / tpl, n0 = (t - l * tpl) * SR_TI;
         const double* eb = A.EI + (size_t)l * A.EI_lstride + n0;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             int p = w + 8 * r;
-            if (p > 60) p -= 61;
-            dma16(p == 60 ? A.phiI + n0 : eb + (size_t)(2 * p) * NTp, doff, lds0 + (unsigned)((buf * SR_ROWS * SR_TI + 2 * p * SR_TI) * sizeof(double)));
+            if (p >= NP) p -= NP;
+            if (p >= NP) p -= NP;
+            const int r0 = 2 * p < A.mI ? 2 * p : 0;
+            dma16(p == NP - 1 ? A.phiI + n0 : eb + (size_t)r0 * NTp, (p != NP - 1 && 2 * p == A.mI - 1) ? doff0 : doff, lds0 + (unsigned)((buf * ROWS * SR_TI + 2 * p * SR_TI) * sizeof(double)));
         }
     };
-    double me[30], mo[30];
+    // wave -> column tile and image halves: more than four column tiles: wave w keeps tile w and runs both 32-image halves of a tile;
+    // up to four: waves w and w + 4 keep tile w & 3 and run one half each
+    const int CT = A.Np >> 4;
+    const bool split = CT <= 4;
+    const int ct = split ? (w & 3) : w;
+    const bool act = ct < CT;
+    const bool do0 = !split || w < 4, do1 = !split || w >= 4;
+    double me[NKS], mo[NKS];
     {
         const int g = lane >> 4, i = lane & 15;
 #pragma unroll
-        for (int ks = 0; ks < 30; ++ks) {
-            me[ks] = A.M[(size_t)(2 * (4 * ks + g)) * 128 + 16 * w + i];
-            mo[ks] = A.M[(size_t)(2 * (4 * ks + g) + 1) * 128 + 16 * w + i];
+        for (int ks = 0; ks < NKS; ++ks) {
+            const bool in = act && 2 * (4 * ks + g) + 1 < A.Kp;          // (Kp is even: both rows or neither)
+            me[ks] = in ? A.M[(size_t)(2 * (4 * ks + g)) * A.Np + 16 * ct + i] : 0.;
+            mo[ks] = in ? A.M[(size_t)(2 * (4 * ks + g) + 1) * A.Np + 16 * ct + i] : 0.;
         }
     }
     if (niter > 0) stage(blockIdx.x, 0);
@@ -318,75 +389,97 @@ __global__ __launch_bounds__(512) void k_shift_res(ShiftResArgs A) {
         int g = ln >> 4, i = ln & 15;
         if (obp) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { const int y = 16 * w + g + 4 * (q & 3); if (y < A.mO) obp[(size_t)(4 * (q & 3)) * NTp + 16 * (q >> 2)] = ob[q]; }
+            for (int q = 0; q < 8; ++q) { const int y = 16 * ct + g + 4 * (q & 3); if (y < A.mO) obp[(size_t)(4 * (q & 3)) * NTp + 16 * (q >> 2)] = ob[q]; }
         }
         if (it + 1 < niter) stage(t + G, (it + 1) & 1);
-        const double* Eb = sr_lds + (it & 1) * SR_ROWS * SR_TI;
-        double* op = A.out + (size_t)l * A.out_lstride + (size_t)(16 * w + g) * NTp + n0 + i;
+        const double* Eb = sr_lds + (it & 1) * ROWS * SR_TI;
+        double* op = A.out + (size_t)l * A.out_lstride + (size_t)(16 * ct + g) * NTp + n0 + i;
+        if (act) {
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            const double* ep0 = Eb + g * SR_TI + 32 * pass + i;            // E[4 ks + g][32 pass + i], [.. + 16 + i]
-            const double* ep1 = ep0 + 16;
-            f64x4r ce0 = {0., 0., 0., 0.}, co0 = {0., 0., 0., 0.}, ce1 = {0., 0., 0., 0.}, co1 = {0., 0., 0., 0.};
-            double a0 = ep0[0], b0 = ep1[0], a1 = ep0[4 * SR_TI], b1 = ep1[4 * SR_TI];
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            for (int pass = 0; pass < 2; ++pass) {
+                if (pass == 0 ? !do0 : !do1) continue;                         // uniform
+                const double* ep0 = Eb + g * SR_TI + 32 * pass + i;            // E[4 ks + g][32 pass + i], [.. + 16 + i]
+                const double* ep1 = ep0 + 16;
+                f64x4r ce0 = {0., 0., 0., 0.}, co0 = {0., 0., 0., 0.}, ce1 = {0., 0., 0., 0.}, co1 = {0., 0., 0., 0.};
+                double a0 = ep0[0], b0 = ep1[0], a1 = ep0[4 * SR_TI], b1 = ep1[4 * SR_TI];
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
-            for (int ks = 0; ks < 30; ++ks) {
-                const double xa = a0, xb = b0;
-                a0 = a1; b0 = b1;
-                if (ks + 2 < 30) { a1 = ep0[4 * (ks + 2) * SR_TI]; b1 = ep1[4 * (ks + 2) * SR_TI]; __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
-                ce0 = __builtin_amdgcn_mfma_f64_16x16x4f64(me[ks], xa, ce0, 0, 0, 0);
-                co0 = __builtin_amdgcn_mfma_f64_16x16x4f64(mo[ks], xa, co0, 0, 0, 0);
-                ce1 = __builtin_amdgcn_mfma_f64_16x16x4f64(me[ks], xb, ce1, 0, 0, 0);
-                co1 = __builtin_amdgcn_mfma_f64_16x16x4f64(mo[ks], xb, co1, 0, 0, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            }
-            // lane (g, i) holds output links y = 16 w + g + 4 e of images 32 pass + 16 grp + i
-            ln = lane;
-            asm volatile("" : "+v"(ln));
-            g = ln >> 4; i = ln & 15;
-#pragma unroll
-            for (int grp = 0; grp < 2; ++grp) {
-                const double pI0 = Eb[120 * SR_TI + 32 * pass + 16 * grp + i], pI1 = Eb[121 * SR_TI + 32 * pass + 16 * grp + i];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const double v = fma(pI1, grp ? co1[e] : co0[e], pI0 * (grp ? ce1[e] : ce0[e]));
-                    if (pass == 0) { if (16 * w + g + 4 * e < A.mO) op[(size_t)(4 * e) * NTp + 16 * grp] = v; }
-                    else ob[4 * grp + e] = v;
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const double xa = a0, xb = b0;
+                    a0 = a1; b0 = b1;
+                    if (ks + 2 < NKS) { a1 = ep0[4 * (ks + 2) * SR_TI]; b1 = ep1[4 * (ks + 2) * SR_TI]; __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
+                    ce0 = __builtin_amdgcn_mfma_f64_16x16x4f64(me[ks], xa, ce0, 0, 0, 0);
+                    co0 = __builtin_amdgcn_mfma_f64_16x16x4f64(mo[ks], xa, co0, 0, 0, 0);
+                    ce1 = __builtin_amdgcn_mfma_f64_16x16x4f64(me[ks], xb, ce1, 0, 0, 0);
+                    co1 = __builtin_amdgcn_mfma_f64_16x16x4f64(mo[ks], xb, co1, 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
                 }
+                // lane (g, i) holds output links y = 16 ct + g + 4 e of images 32 pass + 16 grp + i
+                ln = lane;
+                asm volatile("" : "+v"(ln));
+                g = ln >> 4; i = ln & 15;
+#pragma unroll
+                for (int grp = 0; grp < 2; ++grp) {
+                    const double pI0 = Eb[(4 * NKS) * SR_TI + 32 * pass + 16 * grp + i], pI1 = Eb[(4 * NKS + 1) * SR_TI + 32 * pass + 16 * grp + i];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const double v = fma(pI1, grp ? co1[e] : co0[e], pI0 * (grp ? ce1[e] : ce0[e]));
+                        if (pass == 0) { if (16 * ct + g + 4 * e < A.mO) op[(size_t)(4 * e) * NTp + 16 * grp] = v; }
+                        else ob[4 * grp + e] = v;
+                    }
+                }
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
             }
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
+            if (do1) obp = op + 32;
         }
-        obp = op + 32;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next tile's pieces have landed (the stores still counted are half a round old)
         fr_barrier();
     }
     if (obp) {
         const int g = lane >> 4;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { const int y = 16 * w + g + 4 * (q & 3); if (y < A.mO) obp[(size_t)(4 * (q & 3)) * NTp + 16 * (q >> 2)] = ob[q]; }
+        for (int q = 0; q < 8; ++q) { const int y = 16 * ct + g + 4 * (q & 3); if (y < A.mO) obp[(size_t)(4 * (q & 3)) * NTp + 16 * (q >> 2)] = ob[q]; }
     }
 }
 
+// the instantiations built: input dimensions up to 4 NKS
+static const int sr_nks_list[] = {12, 16, 18, 20, 22, 24, 26, 28, 30};
+static int sr_nks_for(int mI) {
+    for (int v : sr_nks_list) if (4 * v >= mI) return v;
+    return 0;
+}
+bool shift_res_applies(int mI, int mO) { return mI >= 33 && sr_nks_for(mI) != 0 && mO >= 1 && mO <= 128; }      // (mI >= 2: a piece is two rows)
+
+template <int NKS>
+static int shift_res_go(tnml_ctx* c, const ShiftResArgs& a, int grid) {
+    const size_t lds = sizeof(double) * 2 * (4 * NKS + 2) * SR_TI;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_shift_res<NKS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return tnml_fail(c, "shift_res: cannot reserve %zu bytes of LDS", lds);
+    ProfScope ps(c, KC_FGEMM_SHIFT);
+    hipLaunchKernelGGL(k_shift_res<NKS>, dim3(grid), dim3(512), lds, c->stream, a);
+    return 0;
+}
 int launch_shift_res(tnml_ctx* c, const ShiftResArgs& a_in) {
     ShiftResArgs a = a_in;
     if (a.NTp % SR_TI) return tnml_fail(c, "shift_res: image count not a multiple of %d", SR_TI);
     if (((size_t)a.L * a.EI_lstride) * sizeof(double) >= ((size_t)1 << 32)) return tnml_fail(c, "shift_res: environment larger than 4 GB (32-bit lane offsets)");
+    if (!shift_res_applies(a.mI, a.mO) || a.Np % 16 || a.Np < a.mO || a.Np > 128) return tnml_fail(c, "shift_res: bond dimensions %d x %d (packed %d) not served", a.mI, a.mO, a.Np);
     if (!c->cu_count) { hipDeviceProp_t pr; c->cu_count = hipGetDeviceProperties(&pr, c->cfg.device) == hipSuccess ? pr.multiProcessorCount : 256; }
     a.ntiles = a.L * (a.NTp / SR_TI);
     int grid = c->cu_count;
     if (c->res_grid > 0 && c->res_grid < grid) grid = c->res_grid;
     if (grid > a.ntiles) grid = a.ntiles;
-    const size_t lds = sizeof(double) * SR_LDS_DOUBLES;
-    if (!c->attr_res) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_shift_res), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return tnml_fail(c, "shift_res: cannot reserve %zu bytes of LDS", lds);
-        c->attr_res = true;
-    }
-    {
-        ProfScope ps(c, KC_FGEMM_SHIFT);
-        hipLaunchKernelGGL(k_shift_res, dim3(grid), dim3(512), lds, c->stream, a);
+    switch (sr_nks_for(a.mI)) {
+        case 12: TCK((shift_res_go<12>(c, a, grid))); break;
+        case 16: TCK((shift_res_go<16>(c, a, grid))); break;
+        case 18: TCK((shift_res_go<18>(c, a, grid))); break;
+        case 20: TCK((shift_res_go<20>(c, a, grid))); break;
+        case 22: TCK((shift_res_go<22>(c, a, grid))); break;
+        case 24: TCK((shift_res_go<24>(c, a, grid))); break;
+        case 26: TCK((shift_res_go<26>(c, a, grid))); break;
+        case 28: TCK((shift_res_go<28>(c, a, grid))); break;
+        default: TCK((shift_res_go<30>(c, a, grid))); break;
     }
     HIPCK(c, hipGetLastError());
     return 0;
@@ -452,31 +545,67 @@ __global__ __launch_bounds__(256) void k_pfinish(PfinishArgs A) {
     res_wave_partials(val, lab, cor, A.mode == LD_MODE_PAP, A.partials + ((size_t)blockIdx.x * 4 + (tid >> 6)) * 12, lane);
 }
 
-template <int PS, int PK>
+template <int PS, int PK, int NKA, bool GEN, int NST = 8>
 static int fwd_res_go(tnml_ctx* c, const FwdResArgs& a, int grid) {
-    const size_t lds = sizeof(double) * FR_LDS_DOUBLES;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_res<PS, PK, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    const size_t lds = sizeof(double) * FR_LDS_DOUBLES_N(NKA);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_res<PS, PK, 0, NKA, GEN, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return tnml_fail(c, "fwd_res: cannot reserve %zu bytes of LDS", lds);
     ProfScope ps(c, KC_FWD_RES);
-    hipLaunchKernelGGL((k_fwd_res<PS, PK, 0>), dim3(grid), dim3(768), lds, c->stream, a);
+    hipLaunchKernelGGL((k_fwd_res<PS, PK, 0, NKA, GEN, NST>), dim3(grid), dim3(768), lds, c->stream, a);
     return 0;
 }
+// the instantiations built for other bonds than 120 x 120: input dimensions up to 4 NKA
+static const int fr_nka_list[] = {12, 16, 18, 20, 22, 24, 26, 28, 30};
+static int fr_nka_for(int mI) {
+    for (int v : fr_nka_list) if (4 * v >= mI) return v;
+    return 0;
+}
+// bond dimensions k_fwd_res serves: input 33..120 (one instantiation per reduction length), output 16..120 (2..15 column tiles of 8 links on a
+// pair of workgroups)
+bool fwd_res_applies(int mI, int mO) { return mI >= 33 && fr_nka_for(mI) != 0 && mO >= 16 && mO <= 120; }
 int launch_fwd_res(tnml_ctx* c, const FwdResArgs& a) {
     if (a.NTp % 256) return tnml_fail(c, "fwd_res: image count not a multiple of 256");
     if ((size_t)TNML_NL * a.EL_lstride * sizeof(double) >= ((size_t)1 << 32)) return tnml_fail(c, "fwd_res: environment larger than 4 GB (32-bit lane offsets)");
+    if (!fwd_res_applies(a.mI, a.mO) || a.Np % 16 || a.Np < 2 * a.mO || a.Np > 240 || a.Kp < 2 * a.mI) return tnml_fail(c, "fwd_res: bond %d x %d (packed %d x %d) not served", a.mI, a.mO, a.Kp, a.Np);
     if (!c->cu_count) { hipDeviceProp_t pr; c->cu_count = hipGetDeviceProperties(&pr, c->cfg.device) == hipSuccess ? pr.multiProcessorCount : 256; }
     int grid = c->cu_count / 16 * 16;
     if (c->res_grid > 0 && c->res_grid < grid) grid = c->res_grid / 16 * 16;      // test knob: fewer workgroups -> more rounds each
     if (grid < 16) grid = 16;
     while (grid > 16 && (grid / 2) > a.ntiles) grid -= 16;                        // every pair of workgroups has at least one tile
     // pacing of the GEMM waves (see k_fwd_res): 384 cycles every 8 MFMAs measured best (tools/probe/kbench_res.hip,
-    // profiles/r04_probe_fwd_res.txt); option "res_pace" selects the others
-    switch (c->res_pace) {
-        case 1:  TCK((fwd_res_go<0, 1>(c, a, grid))); break;      // no pauses
-        case 2:  TCK((fwd_res_go<4, 2>(c, a, grid))); break;
-        case 3:  TCK((fwd_res_go<6, 3>(c, a, grid))); break;
-        case 4:  TCK((fwd_res_go<4, 1>(c, a, grid))); break;
-        default: TCK((fwd_res_go<6, 2>(c, a, grid))); break;
+    // profiles/r04_probe_fwd_res.txt); option "res_pace" selects the others (120 x 120 bonds only)
+    if (a.mI == 120 && a.mO == 120 && a.Kp == 240 && a.Np == 240 && c->fwd_res != 3) {
+        switch (c->res_pace) {
+            case 1:  TCK((fwd_res_go<0, 1, 30, false>(c, a, grid))); break;      // no pauses
+            case 2:  TCK((fwd_res_go<4, 2, 30, false>(c, a, grid))); break;
+            case 3:  TCK((fwd_res_go<6, 3, 30, false>(c, a, grid))); break;
+            case 4:  TCK((fwd_res_go<4, 1, 30, false>(c, a, grid))); break;
+            default: TCK((fwd_res_go<6, 2, 30, false>(c, a, grid))); break;
+        }
+    } else if (a.Np <= 128) {                                                       // mO <= 64: at most four column tiles per half, four streaming steps per tile
+        switch (fr_nka_for(a.mI)) {
+            case 12: TCK((fwd_res_go<6, 2, 12, true, 4>(c, a, grid))); break;
+            case 16: TCK((fwd_res_go<6, 2, 16, true, 4>(c, a, grid))); break;
+            case 18: TCK((fwd_res_go<6, 2, 18, true, 4>(c, a, grid))); break;
+            case 20: TCK((fwd_res_go<6, 2, 20, true, 4>(c, a, grid))); break;
+            case 22: TCK((fwd_res_go<6, 2, 22, true, 4>(c, a, grid))); break;
+            case 24: TCK((fwd_res_go<6, 2, 24, true, 4>(c, a, grid))); break;
+            case 26: TCK((fwd_res_go<6, 2, 26, true, 4>(c, a, grid))); break;
+            case 28: TCK((fwd_res_go<6, 2, 28, true, 4>(c, a, grid))); break;
+            default: TCK((fwd_res_go<6, 2, 30, true, 4>(c, a, grid))); break;
+        }
+    } else {                                                                        // (fwd_res = 3: the general form on a 120 x 120 bond too -- tests)
+        switch (fr_nka_for(a.mI)) {
+            case 12: TCK((fwd_res_go<6, 2, 12, true>(c, a, grid))); break;
+            case 16: TCK((fwd_res_go<6, 2, 16, true>(c, a, grid))); break;
+            case 18: TCK((fwd_res_go<6, 2, 18, true>(c, a, grid))); break;
+            case 20: TCK((fwd_res_go<6, 2, 20, true>(c, a, grid))); break;
+            case 22: TCK((fwd_res_go<6, 2, 22, true>(c, a, grid))); break;
+            case 24: TCK((fwd_res_go<6, 2, 24, true>(c, a, grid))); break;
+            case 26: TCK((fwd_res_go<6, 2, 26, true>(c, a, grid))); break;
+            case 28: TCK((fwd_res_go<6, 2, 28, true>(c, a, grid))); break;
+            default: TCK((fwd_res_go<6, 2, 30, true>(c, a, grid))); break;
+        }
     }
     HIPCK(c, hipGetLastError());
     return 0;

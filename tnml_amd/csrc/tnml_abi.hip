@@ -304,7 +304,7 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     if ((rc = dmalloc(c, &c->partials2, (size_t)c->partial_cap * 12))) return bail(rc);
     if ((rc = dmalloc(c, &c->counters, 16))) return bail(rc);
     if (hipMemsetAsync(c->counters, 0, 16 * sizeof(unsigned), c->stream) != hipSuccess) return bail(tnml_fail(c, "memset failed"));
-    if (cfg->dtype == TNML_F64 && cfg->mode == TNML_MODE_FIXEDL && c->maxm >= 120 && (rc = dmalloc(c, &c->Ppart, (size_t)2 * TNML_NL * NTp))) return bail(rc);   // k_fwd_res
+    if (cfg->dtype == TNML_F64 && cfg->mode == TNML_MODE_FIXEDL && c->maxm >= 33 && (rc = dmalloc(c, &c->Ppart, (size_t)2 * TNML_NL * NTp))) return bail(rc);   // k_fwd_res (input dimensions 33..120)
     if ((rc = dmalloc(c, &c->vB, c->mcap))) return bail(rc);
     if ((rc = dmalloc(c, &c->vR, c->mcap))) return bail(rc);
     if ((rc = dmalloc(c, &c->vP, c->mcap))) return bail(rc);
@@ -784,11 +784,11 @@ static int shift_core(tnml_ctx* c, int cs, bool from_left, const void* src, int 
         f.phiO = nullptr;
         f.out = (double*)dst; f.out_lstride = (size_t)m_out * c->NTp; f.mO = m_out;
         f.NTp = c->NTp; f.L = Lout; f.env64 = c->env64(); f.out32 = !c->env64() && !acc_out;
-        // the Label-carrying shift at m = 120 with the site matrix resident in registers (kernels_res.hip)
-        if (c->shift_res && c->env64() && !acc_out && src && Le == TNML_NL && A.L == 1 && m_in == 120 && m_out == 120 && d.Kp == 240 && d.Np == 128 &&
+        // the Label-carrying shift with the site matrix resident in registers (kernels_res.hip): input dimensions 33..120, output up to 128
+        if (c->shift_res && c->env64() && !acc_out && src && Le == TNML_NL && A.L == 1 && shift_res_applies(m_in, m_out) && d.Np <= 128 &&
             (c->shift_res >= 2 || c->NTp >= 7680) &&
             (size_t)TNML_NL * m_in * c->NTp * sizeof(double) < ((size_t)1 << 32)) {      // (32-bit lane offsets: beyond ~447 000 images per rank the generic kernel takes over)
-            ShiftResArgs sa{(const double*)src, (size_t)m_in * c->NTp, (const double*)phi_site(c, cs), c->sM, (double*)dst, (size_t)m_out * c->NTp, m_out, c->NTp, Lout};
+            ShiftResArgs sa{(const double*)src, (size_t)m_in * c->NTp, (const double*)phi_site(c, cs), c->sM, (double*)dst, (size_t)m_out * c->NTp, m_out, c->NTp, Lout, m_in, d.Kp, d.Np};
             return launch_shift_res(c, sa);
         }
         return launch_fgemm64(c, f);
@@ -1030,10 +1030,10 @@ static int forward_pass(tnml_ctx* c, const double* vec, int mode, double* tail, 
         f.NTp = c->NTp; f.L = p.LB; f.env64 = c->env64();
         // the bond matrix resident in the registers of a pair of workgroups (kernels_res.hip): from 7 680 images per rank on (the 7 500-image
         // shard of an 8-GPU run: 0.162 ms per bond update against 0.250 for the feature GEMM + label dot pair, profiles/r04_shard7500_res_kernels.txt)
-        if (c->fwd_res && c->Ppart && c->env64() && !c->single() && p.kind != 2 && p.Kp == 240 && p.Np == 240 && p.mI == 120 && p.mO == 120 &&
+        if (c->fwd_res && c->Ppart && c->env64() && !c->single() && p.kind != 2 && fwd_res_applies(p.mI, p.mO) &&
             (c->fwd_res >= 2 || c->NTp >= 7680) &&
             (size_t)TNML_NL * ustride * sizeof(double) < ((size_t)1 << 32)) {           // (32-bit lane offsets of k_fwd_res: larger shards fall through to the kernels below)
-            FwdResArgs fr{(const double*)p.EI, (const double*)p.phiI, vec, (const double*)p.phiO, (const double*)p.EX, ustride, c->NTp, c->NTp / 32, c->Ppart};
+            FwdResArgs fr{(const double*)p.EI, (const double*)p.phiI, vec, (const double*)p.phiO, (const double*)p.EX, ustride, c->NTp, c->NTp / 32, c->Ppart, p.mI, p.mO, p.Kp, p.Np};
             TCK(launch_fwd_res(c, fr));
             PfinishArgs pf{2, c->Ppart, nullptr, nullptr, nullptr, nullptr, c->label, c->NTp, (double*)a.P, (double*)a.dP, mode, c->partials, c->counters, tail, mode == LD_MODE_PAP ? 1 : 0};
             TCK(launch_pfinish(c, pf));

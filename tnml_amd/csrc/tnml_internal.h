@@ -377,8 +377,10 @@ struct FwdResArgs {
     const double* EL; size_t EL_lstride;              // Label-carrying environment [10][120][NTp]
     int NTp, ntiles;                                  // ntiles = NTp / 32
     double* Ppart;                                    // out: [2][10][NTp], the label dot over the output links of each half
+    int mI = 120, mO = 120, Kp = 240, Np = 240;       // bond dimensions and the M-layout extents Kp = ru16(2 mI), Np = ru16(2 mO)
     long long* dbg = nullptr;                         // probe builds: per-wave cycle counters of workgroup 0
 };
+bool fwd_res_applies(int mI, int mO);
 int launch_fwd_res(tnml_ctx* c, const FwdResArgs& a);
 struct PfinishArgs {
     int npart;                                        // 2: P = Ppart[0] + Ppart[1]; 0: P = P + alpha Pp (fast CG update)
@@ -394,13 +396,15 @@ struct PfinishArgs {
 };
 int launch_pfinish(tnml_ctx* c, const PfinishArgs& a);
 struct ShiftResArgs {
-    const double* EI; size_t EI_lstride;              // Label-carrying input environment [L][120][NTp]
+    const double* EI; size_t EI_lstride;              // Label-carrying input environment [L][mI][NTp]
     const double* phiI;                               // features of the absorbed site [2][NTp]
-    const double* M;                                  // packed site matrix [240][128] (k = 2 x + s, j = y), zero padded
+    const double* M;                                  // packed site matrix [Kp][Np] (k = 2 x + s, j = y), zero padded
     double* out; size_t out_lstride; int mO;          // [L][mO][NTp]
     int NTp, L;
+    int mI, Kp, Np;                                   // input bond dimension (33..120) and the packed extents: Kp = ru16(2 mI), Np = ru16(mO) <= 128
     int ntiles = 0;                                   // set by the launcher: L * NTp / 64
 };
+bool shift_res_applies(int mI, int mO);
 int launch_shift_res(tnml_ctx* c, const ShiftResArgs& a);
 
 // ---- kernels_small.hip --------------------------------------------------------------------
