@@ -1510,9 +1510,9 @@ def test_a_sweep_over_bonds_of_unequal_dimensions_in_lockstep(dims, maxm, minm):
     ts.close()
 
 
-@pytest.mark.parametrize("m", [121, 123, 124, 125, 127, 128, 129, 160, 161, 200, 224, 225, 240, 256, 257, 300, 319, 320])
+@pytest.mark.parametrize("m", [121, 123, 124, 125, 127, 128, 129, 160, 161, 200, 224, 225, 240, 256, 257, 300, 319, 320, 321, 384, 385, 400, 448, 500, 512])
 def test_split_at_every_size_between_the_one_workgroup_kernel_and_the_cluster_limit(m):
-    """every Gram side n = 2m from 242 to 640 takes some combination of the cluster tridiagonalisation's workgroup count (4..14), the
+    """every Gram side n = 2m from 242 to 1 024 (round 6: 642..1 024, 17..32 workgroups) takes some combination of the cluster tridiagonalisation's workgroup count (4..32), the
     inverse iteration's vectors per workgroup (16 / 8 / 4, with or without byte flags) and the back transformation's reflectors per pass:
     the singular values of a random bond tensor against numpy at the sizes on either side of each switch (n = 256 once fell into a gap
     between two LDS layouts and failed in the middle of a sweep)."""
@@ -1531,7 +1531,7 @@ def test_split_at_every_size_between_the_one_workgroup_kernel_and_the_cluster_li
     sv = np.linalg.svd(Bn.reshape(2 * m, 2 * m), compute_uv=False)
     # above 128 kept columns the Cholesky QR of the basis is a block Gram-Schmidt over <= 128-column blocks (2 blocks up to 256, 3 above);
     # bgs_chol = 0 is the stock dpotrf + dtrsm it replaced -- both at the sizes either side of a block-count switch
-    for bgs in ((1, 0) if m in (129, 256, 257, 300) else (1,)):
+    for bgs in ((1, 0) if m in (129, 256, 257, 300, 385) else (1,)):
         ts.set_option("bgs_chol", bgs)
         mg, teg, svg = ts.svd_split(Bn, b, 1, 1e-12, m, m)
         assert mg == m

@@ -401,7 +401,8 @@ int eigh_backtransform(tnml_ctx* c, const double* V, const double* tau, int n, c
     if (n <= 256)      hipLaunchKernelGGL((k_backtransform<4, 8>), dim3(ncols), dim3(64), 0, st, V, n, tau, n, Z, ldz, U, ldu, tau + (n - 1));
     else if (n <= 384) hipLaunchKernelGGL((k_backtransform<6, 6>), dim3(ncols), dim3(64), 0, st, V, n, tau, n, Z, ldz, U, ldu, tau + (n - 1));
     else if (n <= 640) hipLaunchKernelGGL((k_backtransform<10, 4>), dim3(ncols), dim3(64), 0, st, V, n, tau, n, Z, ldz, U, ldu, tau + (n - 1));
-    else return tnml_fail(c, "eigh_backtransform: n=%d exceeds 640", n);
+    else if (n <= 1024) hipLaunchKernelGGL((k_backtransform<16, 4>), dim3(ncols), dim3(64), 0, st, V, n, tau, n, Z, ldz, U, ldu, tau + (n - 1));
+    else return tnml_fail(c, "eigh_backtransform: n=%d exceeds 1024", n);
     HIPCK(c, hipGetLastError());
     return 0;
 }

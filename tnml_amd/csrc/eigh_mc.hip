@@ -1,4 +1,4 @@
-// eigh_mc.hip -- Householder tridiagonalisation of the split's Gram matrix for 240 < n <= 640 (maxm up to 320) on a
+// eigh_mc.hip -- Householder tridiagonalisation of the split's Gram matrix for 240 < n <= 1024 (maxm up to 512) on a
 // small CLUSTER of workgroups, the matrix resident in registers.
 //
 // Why: the re-split of a bond tensor at maxm = 300 (BASELINE config 5) needs the eigen-decomposition of a 600 x 600 Gram
@@ -7,7 +7,7 @@
 // ONE CU, which holds 240 x 240 and no more.
 //
 // Here the FULL symmetric matrix is cut into 8 x 8 blocks (one lane per block, as in k_sytrd_v3) and the block ROWS are dealt
-// cyclically to P <= 16 workgroups of 512 lanes (13 at n = 600).  With whole rows at home y_i = (A v)_i is a local sum, so a
+// cyclically to P <= 32 workgroups of 512 lanes (13 at n = 600, 20 at n = 800, 32 at n = 1 024: a workgroup holds at most 512 blocks).  With whole rows at home y_i = (A v)_i is a local sum, so a
 // Householder step costs ONE exchange between the workgroups, and there is no grid barrier (4-5 us each) in it: the payload is
 // written as 16-byte granules {lo32, tag, hi32, tag} by one write-through store (global_store_dwordx4 sc0 sc1), the tag encodes
 // (launch, step), and a consumer polls the granule itself with agent-scope loads until both tags are the current step's
@@ -36,9 +36,9 @@
 #include "tnml_internal.h"
 
 #define MC_T 8
-#define MC_MAXN 640
+#define MC_MAXN 1024
 #define MC_MAXNB (MC_MAXN / MC_T)
-#define MC_PMAX 16
+#define MC_PMAX 32                        // workgroups (their scalars are polled by the lanes 0 .. MC_PMAX - 1 of every wave, y of row k + 1 by lane MC_PMAX)
 #define MC_THREADS 512
 #define MC_LD 66                          // stride of the partial table between block columns (64 local rows + 2)
 #define MC_SMEM_DOUBLES (MC_MAXNB * MC_LD + 8 * MC_MAXN + 2 * MC_MAXN + 8 * 64 + 64)
@@ -359,12 +359,13 @@ __global__ __launch_bounds__(MC_THREADS) void k_sytrd_mc(McArgs T) {
 #endif
             if (first) {                                             // the lanes of the wave have reconverged: every lane's granules are in
                 const double qv = (lsc || ly1) ? MC_G2D(ga) : 0.;
-                double qs = lsc ? qv : 0., ds = lsc ? MC_G2D(gb) : 0.;   // lanes 0..15: a fixed tree over the row of 16 lanes, the same in every wave of every workgroup
+                double qs = lsc ? qv : 0., ds = lsc ? MC_G2D(gb) : 0.;   // lanes 0..31: a fixed tree over two rows of 16 lanes, the same in every wave of every workgroup
                 qs += dpp_quad<0xB1>(qs); ds += dpp_quad<0xB1>(ds);
                 qs += dpp_quad<0x4E>(qs); ds += dpp_quad<0x4E>(ds);
                 qs += dpp_quad<0x141>(qs); ds += dpp_quad<0x141>(ds);
                 qs += dpp_quad<0x140>(qs); ds += dpp_quad<0x140>(ds);
-                vAv = mc_bcast(qs, 0); te = mc_bcast(ds, 0);
+                // (workgroups 0..15) + (workgroups 16..31): up to 16 workgroups the second row holds zeros -- the bits of rounds 3-5
+                vAv = mc_bcast(qs, 0) + mc_bcast(qs, 16); te = mc_bcast(ds, 0) + mc_bcast(ds, 16);
                 const double yk1 = mc_bcast(qv, MC_PMAX);
                 K = -0.5 * tau * tau * vAv;
                 wk1 = tau * yk1 + K;                                  // v_{k+1} = 1
@@ -456,7 +457,7 @@ int eigh_mc_max_n() { return MC_MAXN; }
 
 // A (n x n symmetric, device) -> D, E, tau (tau[n-1] = number of reflectors), V on `st`.  xbuf: eigh_mc_xbuf_bytes() of device memory,
 // zeroed once at allocation; *epoch is advanced per launch.  The kernel reports through xbuf's status word (eigh_mc_status_ptr).
-// All P <= 16 workgroups must be resident at the same time (they wait for each other): P CUs with 100 KB of LDS each.
+// All P <= 32 workgroups must be resident at the same time (they wait for each other): P CUs with 151 KB of LDS each.
 int eigh_mc_tridiagonalize(tnml_ctx* c, hipStream_t st, const double* A, int n, double* D, double* E, double* tau, double* V, double psd_tol,
                            void* xbuf, unsigned* epoch, long long* dbg, int xp, int spin_max) {
     if (n > MC_MAXN || n < 3) return tnml_fail(c, "eigh_mc_tridiagonalize: n=%d outside 3..%d", n, MC_MAXN);

@@ -23,7 +23,7 @@
 #include "tnml_internal.h"
 
 #ifndef TEIG_MAXN
-#define TEIG_MAXN 640
+#define TEIG_MAXN 1024
 #endif
 
 struct Teig2Args {

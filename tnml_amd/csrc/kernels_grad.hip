@@ -71,7 +71,7 @@ __global__ __launch_bounds__(1024) void k_grad_quad(GradQuadArgs A) {
     double* const Ws = Zs + 2 * GQ_Z_D;                // [2][4][32]
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x;
-    const long long ts0 = ABL == 5 ? (long long)wall_clock64() : 0;
+    const long long ts0 = (ABL == 5 || ABL == 6) ? (long long)wall_clock64() : 0;
     const int h = (b >> 3) & 3, grp = (b & 7) + 8 * (b >> 5);
     if (grp >= A.ngroups) return;
     const int NTp = A.NTp;
@@ -157,13 +157,13 @@ __global__ __launch_bounds__(1024) void k_grad_quad(GradQuadArgs A) {
         double2 pc0[3]; double el0[2][5], dpv0[5];
         piece_load(n_of(0), pc0);
         el_load(n_of(0), el0, dpv0);
-        piece_load(n_of(1), pc);
-        el_load(n_of(1), el, dpv);
+        if (ABL != 6) { piece_load(n_of(1), pc); el_load(n_of(1), el, dpv); }
         piece_store(0, pc0);
         z_build(0, el0, dpv0);
+        if (ABL == 6) { piece_load(n_of(1), pc); el_load(n_of(1), el, dpv); }      // (probe: the second chunk requested when the first has landed)
     }
     gq_barrier();
-    const long long ts1 = ABL == 5 ? (long long)wall_clock64() : 0;
+    const long long ts1 = (ABL == 5 || ABL == 6) ? (long long)wall_clock64() : 0;
 
     f64x4g acc[4];
 #pragma unroll
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(1024) void k_grad_quad(GradQuadArgs A) {
 
     // ---- epilogue: the quad's partial G, M-layout rows 2a + s, columns 2q + t, out to the padded extents (rows and columns beyond the bond
     //      dimensions come out as the zeros the consumer expects there)
-    const long long ts2 = ABL == 5 ? (long long)wall_clock64() : 0;
+    const long long ts2 = (ABL == 5 || ABL == 6) ? (long long)wall_clock64() : 0;
     double* out = A.slab + (size_t)grp * A.Kp * A.Np;
     const int col = 2 * GQ_Q * h + cc;
     if (col < A.Np) {
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(1024) void k_grad_quad(GradQuadArgs A) {
                 if (row < A.Kp) out[(size_t)row * A.Np + col] = acc[r][e4];
             }
     }
-    if (ABL == 5 && A.dbg) {
+    if ((ABL == 5 || ABL == 6) && A.dbg) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) { long long* d = A.dbg + 4 * (size_t)b; d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = (long long)wall_clock64(); }

@@ -461,8 +461,8 @@ int eigh_tridiag_eig(tnml_ctx* c, const double* D, const double* E, int n, doubl
 int eigh_ns_matrix(tnml_ctx* c, const double* S, double* Cm, int m, double* dev);
 int eigh_chol_rinv(tnml_ctx* c, const double* S, int m, double* Rinv, double* flag, int zero_prev = 0);   // m <= 128; zero_prev: also clears flag[-1]
 #define TNML_CHOL_MAXM 128
-#define TEIG_SCRATCH_DOUBLES 4096        // eigh_tridiag_eig scratch
-// ---- eigh_mc.hip: tridiagonalisation on a cluster of workgroups, 240 < n <= 640
+#define TEIG_SCRATCH_DOUBLES 5120        // eigh_tridiag_eig scratch (n <= 1 024)
+// ---- eigh_mc.hip: tridiagonalisation on a cluster of workgroups, 240 < n <= 1 024
 size_t eigh_mc_xbuf_bytes();
 int eigh_mc_max_n();
 int eigh_mc_tridiagonalize(tnml_ctx* c, hipStream_t st, const double* A, int n, double* D, double* E, double* tau, double* V, double psd_tol,

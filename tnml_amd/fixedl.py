@@ -25,8 +25,9 @@ class TrainStates:
     """Training set + environments + W replica of one rank (TrainStates + MPS W of fixedL.cc)."""
 
     def __init__(self, labels, N, maxm, pixels=None, phi=None, device=0, rank=0, nranks=1, NT_total=None, dtype="f64",
-                 single_label=None):
-        """single_label = L selects the per-label variant (single.cc): plain weight MPS, target y_n = [l_n == L]"""
+                 single_label=None, svd_backend=0):
+        """single_label = L selects the per-label variant (single.cc): plain weight MPS, target y_n = [l_n == L];
+        svd_backend = 1: the split on stock rocsolver_dsyevd (TNML_SVD_ROCSOLVER) instead of the in-house eigensolver"""
         self._L = _lib.load()
         self._h = C.c_void_p()
         labels = np.ascontiguousarray(labels, dtype=np.int32)
@@ -39,7 +40,7 @@ class TrainStates:
         self.rank, self.nranks = rank, nranks
         self.NT_total = int(NT_total if NT_total is not None else self.NT)
         self.dtype = dtype
-        cfg = _lib.Config(device, rank, nranks, self.N, self.NT, self.NT_total, self.maxm, _lib.DTYPES[dtype], 0,
+        cfg = _lib.Config(device, rank, nranks, self.N, self.NT, self.NT_total, self.maxm, _lib.DTYPES[dtype], int(svd_backend),
                           1 if self.single else 0, int(single_label) if self.single else 0)
         self._cfg = cfg
         rc = self._L.tnml_create(C.byref(self._h), C.byref(cfg))

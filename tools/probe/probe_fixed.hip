@@ -104,6 +104,19 @@ int main(int argc, char** argv) {
             printf("    wg %3d: entry +%.2f, prologue %.2f, loop %.2f, stores %.2f, exit +%.2f\n", b, 0.01 * (d[0] - e0), 0.01 * (d[1] - d[0]), 0.01 * (d[2] - d[1]), 0.01 * (d[3] - d[2]), 0.01 * (d[3] - e0));
         }
     }
+    {
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_grad_quad<6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const float t6 = time_it([&]() { hipLaunchKernelGGL(k_grad_quad<6>, dim3(grid), dim3(1024), lds, g_st, K); });
+        CK(hipStreamSynchronize(g_st));
+        CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+        double pro = 0, loop = 0, epi = 0; int nw = 0;
+        for (int b = 0; b < grid; ++b) {
+            if ((b & 7) + 8 * (b >> 5) >= K.ngroups) continue;
+            const long long* d = &h[4 * (size_t)b];
+            pro += d[1] - d[0]; loop += d[2] - d[1]; epi += d[3] - d[2]; ++nw;
+        }
+        printf("  second chunk requested AFTER the first has landed: %.2f us per launch; prologue %.2f us, loop %.2f us, stores %.2f us\n", t6, 0.01 * pro / nw, 0.01 * loop / nw, 0.01 * epi / nw);
+    }
     const float t_e = time_it([&]() { hipLaunchKernelGGL(k_empty, dim3(grid), dim3(1024), lds, g_st, (double*)nullptr); });
     const float t_e0 = time_it([&]() { hipLaunchKernelGGL(k_empty, dim3(grid), dim3(64), 0, g_st, (double*)nullptr); });
     const float t_s = time_it([&]() { hipLaunchKernelGGL(k_store_only, dim3(grid), dim3(1024), 0, g_st, (double*)c->slab, Kp, Np, K.ngroups); });
