@@ -476,6 +476,58 @@ def test_resident_forward_and_shift_kernels_at_other_bond_dimensions(m, NT, grid
 
 
 @pytest.mark.gpu
+def test_a_truncating_sweep_on_the_resident_kernels_in_lockstep_with_the_oracle():
+    """Trained bonds shrink towards minm (fixedL.cc:593) to whatever the spectrum leaves: one whole sweep (both halves) of a 24-site chain that
+    starts at m = 100 with maxm = 100, minm = 40 and a cutoff that bites, every bond update compared with the oracle's (new bond dimension,
+    cost, #correct, CG trace) and then set to the oracle's state.  The resident kernels are forced (fwd_res / shift_res / grad_quad = 2), so the
+    forward pass, the gradient GEMM and the Label-carrying shifts meet the pairs of unequal, odd bond dimensions a real run produces -- the
+    instantiations by reduction length, the zero-padded M-layout, clamped rows and links -- not only the hand-picked ones of the tests above."""
+    from oracle import pyoracle
+    from tnml_amd import lib
+    from tnml_amd.fixedl import TrainStates
+    from conftest import make_problem
+    N, NT, m = 24, 200, 100
+    maxm, minm, cutoff, npass, lam, cconv = 100, 40, 3e-4, 3, 1e-3, 1e-10
+    pixels, labels, phi, W = make_problem(N, NT, m, 13, pixel_boost=200.0)
+    ts = TrainStates(labels, N, maxm, phi=phi)
+    for k in ("fwd_res", "shift_res", "grad_quad"):
+        ts.set_option(k, 2)
+    ts.set_mps(W)
+    ts.init()
+    o = pyoracle.Oracle(phi, labels, W, nthread=min(8, os.cpu_count() or 1))
+    o.init()
+    dims = set()
+    ts.profile(True, only="fwd_res,fgemm_fwd,grad_quad,bgemm")
+    b, ha, n = 1, 1, 0
+    while ha <= 2:
+        r = ts.bond_update(b, ha, maxm, minm, cutoff, npass, lam, cconv)
+        o.set_bond(b)
+        B, tr = o.cgrad(o.bond_tensor(b), npass, lam, cconv)
+        newm, te, _ = o.svd_split(B, b, ha, cutoff, maxm, minm)
+        C, lc, cr, nc = o.quadcost(o.bond_tensor(b), lam)
+        o.shiftE(b, ha == 1)
+        assert r["newm"] == newm, (b, ha, r["newm"], newm)
+        assert r["cost"] == pytest.approx(C, rel=1e-8), (b, ha)
+        assert r["ncorrect"] == nc, (b, ha)
+        np.testing.assert_allclose(r["cg"]["cost"], tr["cost"], rtol=1e-8, err_msg="bond %d half %d" % (b, ha))
+        dims.add((r["mL"], r["mR"], newm))
+        ts.set_site(b, o.get_site(b))
+        ts.set_site(b + 1, o.get_site(b + 1))
+        ts.shiftE(b, ha == 1)
+        n += 1
+        b, ha = lib.sweepnext(b, ha, N)
+    ts.profile(False)
+    pr = ts.profile_read()
+    assert n == 2 * (N - 1)
+    shrunk = sorted(d for d in dims if d[2] < 100 and d[2] > 33)
+    print("bond updates %d; (mL, mR, newm) met: %s" % (n, sorted(dims)))
+    print("launches: %s" % {k: v[0] for k, v in pr.items() if v[0]})
+    assert len({d[2] for d in shrunk}) >= 3, shrunk                       # the sweep really produced several truncated dimensions between 33 and 100
+    assert pr["fwd_res"][0] >= 50 and pr["grad_quad"][0] >= 50            # (chain ends below 33 x 16 and the two Label-on-B bonds run the generic kernels)
+    ts.close()
+
+
+@pytest.mark.gpu
 def test_m60_kernel_instantiations_match_the_oracle():
     """bonds that have shrunk to minm = maxm/2 = 60 (the reference default, fixedL.cc:593) run their own tiles: 128 x 128
     feature-GEMM tiles (forced here as for C3: at 60 000 images they are the default), 128 x 64 gradient-GEMM tiles"""
