@@ -97,6 +97,7 @@ int tnml_set_option(tnml_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "spec_split")) c->spec_split = value != 0;
     else if (!strcmp(name, "debug_fail_split")) { c->debug_fail_split = value; c->spec_splits = 0; }
     else if (!strcmp(name, "bf16_grad")) c->bf16_grad = value != 0;
+    else if (!strcmp(name, "bf16_once")) c->bf16_once = value != 0;
     else if (!strcmp(name, "env_async")) c->env_async = value != 0;
     else if (!strcmp(name, "env_budget_mb")) { if (value < 0) return tnml_fail(c, "env_budget_mb must be >= 0"); c->env_budget_bytes = (long)value << 20; }
     else if (!strcmp(name, "comm_timeout_s")) { if (value < 1) return tnml_fail(c, "comm_timeout_s must be >= 1"); c->comm_timeout_s = value; local_comm_set_timeout(c, value); }
@@ -305,6 +306,10 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     if ((rc = dmalloc(c, &c->counters, 16))) return bail(rc);
     if (hipMemsetAsync(c->counters, 0, 16 * sizeof(unsigned), c->stream) != hipSuccess) return bail(tnml_fail(c, "memset failed"));
     if (cfg->dtype == TNML_F64 && cfg->mode == TNML_MODE_FIXEDL && c->maxm >= 33 && (rc = dmalloc(c, &c->Ppart, (size_t)2 * TNML_NL * NTp))) return bail(rc);   // k_fwd_res (input dimensions 33..120)
+    if (c->bf16()) {                                    // bf16 copies of the forward pass's operands (kernels_bf16e.hip)
+        c->ebt_cap = bf16e_env_elems(c->maxm, NTp, c->bf16() == 2); c->mbt_cap = bf16e_m_elems(c->maxm, c->bf16() == 2);
+        if ((rc = dmalloc(c, &c->ebt, c->ebt_cap)) || (rc = dmalloc(c, &c->mbt, c->mbt_cap))) return bail(rc);
+    }
     if ((rc = dmalloc(c, &c->vB, c->mcap))) return bail(rc);
     if ((rc = dmalloc(c, &c->vR, c->mcap))) return bail(rc);
     if ((rc = dmalloc(c, &c->vP, c->mcap))) return bail(rc);
@@ -385,7 +390,7 @@ int tnml_destroy(tnml_ctx* c) {
     for (auto e : c->prof_free) (void)hipEventDestroy(e);
     for (auto& p : c->redo_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     void* ptrs[] = {c->phi, c->label, c->ones, c->U, c->P, c->dP, c->Pp, c->Zp, c->Mf, c->slab, c->partials, c->partials2, c->vB, c->vR, c->vP,
-                    c->arbuf, c->locals, c->scal, c->vpart, c->counters, c->Ppart, c->tB, c->tB2, c->sM, c->sG, c->sD, c->sE, c->sF, c->sInfo, c->sE2, c->sTau, c->sV, c->sC, c->sW, c->sScr, c->sS, c->sCm, c->sQ1, c->sDev, c->mc_xbuf, c->fprint, c->noise_ws};
+                    c->arbuf, c->locals, c->scal, c->vpart, c->counters, c->Ppart, c->tB, c->tB2, c->sM, c->sG, c->sD, c->sE, c->sF, c->sInfo, c->sE2, c->sTau, c->sV, c->sC, c->sW, c->sScr, c->sS, c->sCm, c->sQ1, c->sDev, c->mc_xbuf, c->fprint, c->noise_ws, c->ebt, c->mbt};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     // (site tensors and spares have changed places during speculative splits: every buffer is in exactly one of the two sets)
     for (auto& s : c->W) if (s.a) (void)hipFree(s.a);
@@ -711,6 +716,7 @@ static int env_fetch(tnml_ctx* c, int j) {
     const int m = e.m, L = e.L;
     const size_t bytes = (size_t)L * m * c->NTp * c->eesz();
     const bool async = c->env_async && e.host_pinned;
+    c->env_epoch += 1;
     if (async) TCK(env_copy_stream(c));
     TCK(slot_acquire(c, e, m, L, async ? c->copy_stream : c->stream));     // (clears on_host; the host copy stays valid until the copy below has read it)
     if (async) {
@@ -767,6 +773,7 @@ static int shift_core(tnml_ctx* c, int cs, bool from_left, const void* src, int 
     if (Le == TNML_NL && A.L == TNML_NL) return tnml_fail(c, "shift: Label index on both env and site");
     const int Lout = A.L > Le ? A.L : Le;
     if (Lout_p) *Lout_p = Lout;
+    c->env_epoch += 1;                                  // an environment is about to be written: bf16 copies made from environments are stale
     PackDesc d;
     d.TO = 1; d.L = A.L; d.st = 0; d.ss = A.ml; d.sl = (long)2 * A.ml * A.mr;
     if (from_left) { d.nx = A.ml; d.sx = 1; d.ny = A.mr; d.sy = 2 * A.ml; }
@@ -1053,14 +1060,18 @@ static int forward_pass(tnml_ctx* c, const double* vec, int mode, double* tail, 
         }
         TCK(launch_fgemm64(c, f));
     } else {
-        TCK(launch_cvt(c, vec, c->Mf, p.msize()));
-        FgemmArgs f;
-        f.EI = (const float*)p.EI; f.EI_lstride = 0; f.mI = p.mI; f.phiI = (const float*)p.phiI;
-        f.M = c->Mf; f.M_lstride = p.kind == 2 ? (size_t)p.Kp * p.Np : 0; f.Kp = p.Kp; f.Np = p.Np;
-        f.phiO = (const float*)p.phiO;
-        f.out = (float*)c->U; f.out_lstride = ustride; f.mO = p.mO;
-        f.NTp = c->NTp; f.L = p.LB;
-        TCK(launch_fgemm(c, f));
+        if (c->bf16() && c->bf16_once && c->ebt && p.kind != 2) {        // operands converted once per bond / per launch (kernels_bf16e.hip)
+            TCK(launch_fgemm_bf16e(c, (const float*)p.EI, p.mI, (const float*)p.phiI, vec, p.Kp, p.Np, (const float*)p.phiO, (float*)c->U, p.mO));
+        } else {
+            TCK(launch_cvt(c, vec, c->Mf, p.msize()));
+            FgemmArgs f;
+            f.EI = (const float*)p.EI; f.EI_lstride = 0; f.mI = p.mI; f.phiI = (const float*)p.phiI;
+            f.M = c->Mf; f.M_lstride = p.kind == 2 ? (size_t)p.Kp * p.Np : 0; f.Kp = p.Kp; f.Np = p.Np;
+            f.phiO = (const float*)p.phiO;
+            f.out = (float*)c->U; f.out_lstride = ustride; f.mO = p.mO;
+            f.NTp = c->NTp; f.L = p.LB;
+            TCK(launch_fgemm(c, f));
+        }
     }
     return launch_labeldot(c, a, tail, reduce);
 }

@@ -153,6 +153,10 @@ struct tnml_ctx {
     hipStream_t copy_stream = nullptr;   // host tier: evictions and prefetches run beside the compute stream
     hipEvent_t ev_compute = nullptr;     // "everything enqueued on the compute stream so far" (recorded before an eviction starts)
     int env_async = 1;                   // option env_async: 0 = every copy of the host tier on the compute stream (the simple form)
+    int bf16_once = 1;                   // option bf16_once: the bf16 modes' forward feature GEMM with its operands converted once per bond / per launch (kernels_bf16e.hip; 0: k_fgemm_bf16, which rounds while staging)
+    unsigned short* ebt = nullptr; unsigned short* mbt = nullptr; size_t ebt_cap = 0, mbt_cap = 0;   // bf16 copies of the Label-free environment [planes][NTp][KH] and of the bond vector [planes][2][2][QP][KH]
+    const void* ebt_src = nullptr; int ebt_m = 0; unsigned long ebt_epoch = 0, env_epoch = 1;        // what the environment copy was made from; env_epoch advances with every write of an environment
+    bool attr_bf16e = false;
     int bf16_grad = 1;                   // option bf16_grad: in the bf16 modes the gradient GEMM runs on the bf16 pipe too (0: the fp32 kernel, as through round 3)
     int small_gemm = 1;                  // option small_gemm: the split's products on k_dgemm_small (0: rocBLAS, as through round 4)
     int bgs_chol = 1;                    // option bgs_chol: block Gram-Schmidt Cholesky QR for 128 < kept columns <= 384 (0: rocSOLVER dpotrf + dtrsm)
@@ -290,6 +294,10 @@ struct FgemmArgs {
     int NTp; int L;
 };
 int launch_fgemm(tnml_ctx* c, const FgemmArgs& a);
+// ---- kernels_bf16e.hip: the forward feature GEMM of the bf16 modes with operands converted once ----
+size_t bf16e_env_elems(int maxm, int NTp, int split);
+size_t bf16e_m_elems(int maxm, int split);
+int launch_fgemm_bf16e(tnml_ctx* c, const float* EI, int mI, const float* phiI, const double* vec, int Kp, int Np, const float* phiO, float* out, int mO);
 
 struct BgemmArgs {
     const float* EI; int mI; const float* phiI;      // A operand rows: X[n][2a+s]
