@@ -1588,6 +1588,38 @@ def test_gradient_gemm_on_the_bf16_pipe(dtype, gate_on, gate_off):
     ts.close()
 
 
+@pytest.mark.parametrize("dtype,gate", [("bf16x3", 2e-4), ("bf16", 3e-2)])
+@pytest.mark.parametrize("m", [24, 61, 150])
+def test_forward_gemm_of_the_bf16_modes_with_operands_converted_once(dtype, gate, m):
+    """B*t.v (fixedL.cc:318,377,399,416) in the bf16 study modes with k_fgemm_bf16e (round 6: the Label-free environment converted to bf16
+    once per bond, the bond vector once per launch, both site features applied to the fp32 accumulators) against the oracle and against
+    the round-5 kernel that rounds E * phi while staging (option bf16_once = 0): both within the operand precision of the oracle, close
+    to each other, and not the same code path.  Bond dimensions that fill their last reduction chunk / link tile (24 -> 32 of 32, 64 of 64
+    unused), that are odd (61) and that need several of each (150); the copy of the environment must follow every shift."""
+    NT = 300 if m <= 61 else 130
+    ts, o = _pair(N=24, NT=NT, m=m, dtype=dtype)
+    at = 1
+    rng = np.random.default_rng(m)
+    for b, kind in ((8, "Label on RE"), (9, "Label on RE, next bond"), (15, "Label on LE")):
+        for bb in range(at, b):
+            ts.shiftE(bb, True); o.shiftE(bb, True)
+        at = b
+        ts.setBond(b); o.set_bond(b)
+        B = o.bond_tensor(b)
+        B = B + 0.05 * np.abs(B).max() * rng.standard_normal(B.shape)
+        Po = o.forward(B)
+        ts.set_option("bf16_once", 1)
+        P1 = ts.forward(B)
+        assert np.array_equal(P1, ts.forward(B)), kind                    # the cached copy of the environment gives the same bits
+        ts.set_option("bf16_once", 0)
+        P0 = ts.forward(B)
+        e1, e0, d = _relmax(P1, Po), _relmax(P0, Po), _relmax(P1, P0)
+        print(dtype, m, kind, "forward error converted once %.2e, rounding while staging %.2e, between them %.2e" % (e1, e0, d))
+        assert e1 < gate and e0 < gate, kind
+        assert 0 < d < 2 * gate, kind
+    ts.close()
+
+
 def test_environments_spill_to_host_memory_and_the_sweep_does_not_notice():
     """the host tier of the environments (the reference's Nbatch / proj_images spill, fixedL.cc:115-120,153,177-178,216,231): with
     env_budget_mb the environment slabs on the device are capped, slabs farthest from the current bond are copied to host memory and
