@@ -31,6 +31,8 @@ def main():
     B = B + 0.05 * rng.standard_normal(B.shape)
     out = {}
     modes = (0, 2) + ((3, 5) if os.environ.get("TNML_DEV_ABL") else ())
+    if os.environ.get("TNML_DEV_WGS"):
+        ts.set_option("bgemm_wgs", int(os.environ["TNML_DEV_WGS"]))      # workgroups the gradient GEMM aims at (slab count)
     for mode in modes:
         ts.set_option("grad_quad", mode)
         G = ts.gradient(B)
