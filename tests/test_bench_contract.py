@@ -123,3 +123,22 @@ def test_bench_gpus_2_reports_both_transports_in_one_line():
     assert o["value"] == d["value"] and o["ranks"] == 2 and o["allreduces_per_bond_update"] >= 4 and o["ms_per_allreduce"] > 0
     assert o["gradient_phase_ms"] > 0 and o["svd_ms"] > 0 and "processes" in o["mode"]
     assert d["speculative_split"]["splits_in_timed_region"] >= 0 and "roll_backs_per_sweep" in d["speculative_split"]
+
+
+@pytest.mark.gpu
+def test_bench_gpus_8_runs_eight_ranks_over_the_one_shot_transport():
+    """the shape of the driver's 8-GPU run (BASELINE config 3 = 8 shards) as far as a one-GPU box can take it: `bench.py --gpus 8` starts eight
+    ranks, each a process with its own context, the cross-process one-shot all-reduce joins them (eight receive slots per rank, 7 peers written
+    per collective), the line reports eight image counts and the communicator size.  All ranks share device 0 (--share-device), so the
+    rate means nothing; that every rank finishes the same bond updates with the same bits is checked inside the library (check_replicas)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--share-device", "--sites", "24", "--images", "8000", "--maxm", "12",
+                          "--steps", "6", "--warmup", "2", "--plain", "--no-cpu-baseline"], capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
+    assert run.returncode == 0, (run.stderr + run.stdout)[-3000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, run.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["images_per_rank"] == [1000] * 8 and d["config"]["rccl_ranks"] == 8
+    o = d["collectives"]["oneshot"]
+    assert o["ranks"] == 8 and o["value"] == d["value"] and o["allreduces_per_bond_update"] >= 4
+    assert d.get("replica_repairs", 0) == 0
