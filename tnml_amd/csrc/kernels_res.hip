@@ -454,8 +454,11 @@ bool shift_res_applies(int mI, int mO) { return mI >= 33 && sr_nks_for(mI) != 0 
 template <int NKS>
 static int shift_res_go(tnml_ctx* c, const ShiftResArgs& a, int grid) {
     const size_t lds = sizeof(double) * 2 * (4 * NKS + 2) * SR_TI;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_shift_res<NKS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return tnml_fail(c, "shift_res: cannot reserve %zu bytes of LDS", lds);
+    if (!c->attr_sr[NKS]) {                           // (function attributes are per device: remembered per context)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_shift_res<NKS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return tnml_fail(c, "shift_res: cannot reserve %zu bytes of LDS", lds);
+        c->attr_sr[NKS] = true;
+    }
     ProfScope ps(c, KC_FGEMM_SHIFT);
     hipLaunchKernelGGL(k_shift_res<NKS>, dim3(grid), dim3(512), lds, c->stream, a);
     return 0;
@@ -548,8 +551,12 @@ __global__ __launch_bounds__(256) void k_pfinish(PfinishArgs A) {
 template <int PS, int PK, int NKA, bool GEN, int NST = 8>
 static int fwd_res_go(tnml_ctx* c, const FwdResArgs& a, int grid) {
     const size_t lds = sizeof(double) * FR_LDS_DOUBLES_N(NKA);
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_res<PS, PK, 0, NKA, GEN, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return tnml_fail(c, "fwd_res: cannot reserve %zu bytes of LDS", lds);
+    bool& done = c->attr_fr[2 * (GEN ? 1 : 0) + (NST == 4 ? 1 : 0)][NKA];
+    if (!done || !GEN) {                              // (the constant-extent form has one slot for its five pacings: set every time, as before)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fwd_res<PS, PK, 0, NKA, GEN, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return tnml_fail(c, "fwd_res: cannot reserve %zu bytes of LDS", lds);
+        done = true;
+    }
     ProfScope ps(c, KC_FWD_RES);
     hipLaunchKernelGGL((k_fwd_res<PS, PK, 0, NKA, GEN, NST>), dim3(grid), dim3(768), lds, c->stream, a);
     return 0;

@@ -210,7 +210,7 @@ struct tnml_ctx {
     void* mc_xbuf = nullptr;   // exchange buffer of the multi-workgroup tridiagonalisation (eigh_mc.hip), contexts with maxm > 120 only
     unsigned mc_epoch = 0;
     int mc_spin_max = -1;      // polls before a waiting thread of k_sytrd_mc gives up (-1: default; option "mc_spin_max", 0 in the fallback test)
-    bool attr_res = false;           // kernels_res.hip
+    bool attr_sr[32] = {false}, attr_fr[4][32] = {{false}};   // LDS attribute set (per device = per context) for k_shift_res<NKS> / k_fwd_res<.., NKA, GEN, NST>: [2 GEN + (NST == 4)][NKA]
     int res_pace = 0;                // pacing of the GEMM waves of k_fwd_res (0: default; option "res_pace")
     int fwd_res = 1;                 // forward pass on k_fwd_res (kernels_res.hip): 1 = from 7 680 images per rank on, 0 never, 2 always; option "fwd_res"
     int shift_res = 1;               // Label-carrying environment shift on k_shift_res (kernels_res.hip): 1 = from 7 680 images per rank on, 0 never, 2 always; option "shift_res"
