@@ -822,10 +822,19 @@ def main():
                 fl_launch = per_step_flops if cls != "fgemm_shift" else sh / max(launches_per_step, 1e-9)
                 tr_, src_ = pmc_traffic(cls) if pmc_ok else (None, None)
                 ach = fl_launch / (per_launch_ms * 1e-3) / 1e12
+                # both roofs of the same launch: below the ridge (peak flops / peak bytes per second) the HBM stream is the binding one --
+                # the trained bonds of the 8(d) workload (m = 59-60: 5.5 flop/B against a ridge of 9.8) -- at m = 120 (10.9 flop/B) the matrix pipe
+                hbm_gbs = (alg_bytes / (per_launch_ms * 1e-3) / 1e9) if alg_bytes else None
+                ai = (fl_launch / alg_bytes) if alg_bytes else None
+                ridge = peak * 1e12 / (HBM_PEAK_GBS * 1e9)
                 rk[cls] = {"kernel": kname, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                            "avg_launch_ms": per_launch_ms, "launches": nl_, "ms_per_step": ms_ / args.steps, "flops_per_launch": fl_launch,
                            "algorithmic_bytes_per_launch": alg_bytes, "traffic": tr_,
-                           "traffic_over_algorithmic": (tr_ / alg_bytes) if (tr_ and alg_bytes) else None, "traffic_source": src_}
+                           "traffic_over_algorithmic": (tr_ / alg_bytes) if (tr_ and alg_bytes) else None, "traffic_source": src_,
+                           "hbm_achieved_gbs": hbm_gbs, "hbm_frac": (hbm_gbs / HBM_PEAK_GBS) if hbm_gbs else None,
+                           "flop_per_byte": ai, "ridge_flop_per_byte": ridge,
+                           "binding_roof": None if ai is None else ("hbm" if ai < ridge else "mfma"),
+                           "frac_of_binding_roof": None if ai is None else ((hbm_gbs / HBM_PEAK_GBS) if ai < ridge else ach / peak)}
             out["roofline_kernels"] = rk
             if rk:
                 dom = max(rk, key=lambda k: rk[k]["ms_per_step"])
