@@ -50,6 +50,9 @@ def one_case(rng, idx):
         NT = max(NT, 33)
     tol = {"f64": 1e-7, "f64_e32": 2e-3, "f32": 5e-2}[dtype]
     desc = dict(case=idx, N=N, dims=dims, NT=NT, boost=boost, dtype=dtype, maxm=maxm, minm=minm, cutoff=cutoff, npass=npass, lam=lam)
+    only = os.environ.get("FUZZ_ONLY")                                # FUZZ_ONLY=i,j,...: draw every case (the generator advances) but run only these
+    if only and idx not in [int(x) for x in only.split(",")]:
+        return desc, 0.0, []
     pixels, labels, phi, _ = make_problem(N, NT, 2, 5 + idx, pixel_boost=boost)
     W = _mps_with_dims(dims, 100 + idx)
     ts = TrainStates(labels, N, max(max(dims), maxm), phi=phi, dtype=dtype)
@@ -57,7 +60,7 @@ def one_case(rng, idx):
     o3 = pyoracle.Oracle(phi, labels, W, nthread=3)
     ts.set_mps(W); o.init(); o3.init(); ts.init()
     tl = None
-    if os.environ.get("FUZZ_TRACE") == str(idx):                       # a second HIP context in the literal evaluation order (no P recurrence, no carried outputs)
+    if str(idx) in os.environ.get("FUZZ_TRACE", "").split(","):             # a second HIP context in the literal evaluation order (no P recurrence, no carried outputs)
         tl = TrainStates(labels, N, max(max(dims), maxm), phi=phi, dtype=dtype)
         tl.set_option("fast_cg", 0); tl.set_option("reuse_p", 0)
         tl.set_mps(W); tl.init()
@@ -66,7 +69,7 @@ def one_case(rng, idx):
         r = ts.bond_update(b, ha, maxm, minm, cutoff, npass, lam, 1e-10)
         o.set_bond(b)
         B, tr = o.cgrad(o.bond_tensor(b), npass, lam, 1e-10)
-        trace = os.environ.get("FUZZ_TRACE") == str(idx)
+        trace = str(idx) in os.environ.get("FUZZ_TRACE", "").split(",")
         newm, te, sv = o.svd_split(B, b, ha, cutoff, maxm, minm)
         C, lc, cr, nc = o.quadcost(o.bond_tensor(b), lam)
         o.shiftE(b, ha == 1)
