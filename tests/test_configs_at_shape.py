@@ -380,20 +380,26 @@ def test_gradient_quad_kernel_matches_the_oracle(NT, wgs):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("m", [40, 61, 64, 96, 104, 128])
-def test_gradient_quad_kernel_at_other_bond_dimensions(m):
-    """k_grad_quad serves every bond dimension up to 128 (its 256 x 256 tile grid is fixed; rows and links beyond the bond dimensions are
-    staged as zeros and come out as the zero padding of the M-layout): bonds that have shrunk below maxm (fixedL.cc:593) and unequal left /
-    right dimensions (bond 7 of a 20-site chain: 64 x m), dimensions that are multiples of nothing (61).  Unforced it takes bonds from
-    72 x 72 on (a one-workgroup form for bonds up to 64 x 64 measured 120 us against the 75 of k_bgemm64's 128 x 64 tiles at m = 60: twice the
-    Label-carrying rows per workgroup and stage; not kept); forced here (grad_quad = 2)."""
+@pytest.mark.parametrize("m,NT,pair,wgs", [(40, 300, 1, 0), (40, 1100, 1, 6), (40, 300, 0, 0), (61, 300, 1, 0), (64, 2100, 1, 4), (64, 300, 0, 0),
+                                           (96, 300, 1, 0), (104, 300, 1, 0), (128, 300, 1, 0)])
+def test_gradient_quad_kernel_at_other_bond_dimensions(m, NT, pair, wgs):
+    """k_grad_quad serves every bond dimension up to 128 (the 256 x 256 tile grid of its quad form is fixed; rows and links beyond the bond
+    dimensions are staged as zeros and come out as the zero padding of the M-layout): bonds that have shrunk below maxm (fixedL.cc:593) and
+    unequal left / right dimensions (bond 7 of a 20-site chain: 64 x m), dimensions that are multiples of nothing (61).  Bonds up to 64 x 64 run
+    its PAIR form (option grad_pair = 1, the default: 128 x 128 tile grid on two workgroups, two row tiles per wave) -- here with one stage per pair
+    (300 images), with 12 + 12 + 11 stages on three pairs (1 100 images, bgemm_wgs = 6) and with 36 stages on each of two pairs (2 100 images,
+    bgemm_wgs = 4) -- or, with grad_pair = 0, the quad form.  Unforced the quad form takes bonds from 72 x 72 on and the pair form 33^2 <= mI mO
+    <= 56^2 from 15 360 images on; forced here (grad_quad = 2)."""
     from oracle import pyoracle
     from tnml_amd.fixedl import TrainStates
     from conftest import make_problem
-    N, NT = 20, 300
+    N = 20
     pixels, labels, phi, W = make_problem(N, NT, m, 9, pixel_boost=200.0)
     ts = TrainStates(labels, N, m, phi=phi)
     ts.set_option("grad_quad", 2)
+    ts.set_option("grad_pair", pair)
+    if wgs:
+        ts.set_option("bgemm_wgs", wgs)
     ts.set_mps(W)
     ts.init()
     o = pyoracle.Oracle(phi, labels, W, nthread=min(8, os.cpu_count() or 1))
@@ -415,6 +421,9 @@ def test_gradient_quad_kernel_at_other_bond_dimensions(m):
         assert pr["grad_quad"][0] == 1 and pr.get("bgemm", (0, 0))[0] == 0, kind
         assert _rel(G, o.gradient(B)) < 1e-9, kind
         assert np.array_equal(G, ts.gradient(B)), kind
+        ts.set_option("grad_quad", 0)
+        assert _rel(G, ts.gradient(B)) < 1e-13, kind                   # k_bgemm64: another summation order, the same sums
+        ts.set_option("grad_quad", 2)
         Bg, tg = ts.cgrad(B, 3, 1e-3, 1e-10)                          # the CG's norms run over the PADDED M-layout: the padding must be zeros
         Bo, to = o.cgrad(B, 3, 1e-3, 1e-10)
         np.testing.assert_allclose(tg["cost"], to["cost"], rtol=1e-9, err_msg=kind)

@@ -37,10 +37,11 @@ typedef double f64x4g __attribute__((ext_vector_type(4)));
 #define GQ_TI 32                       // images per stage
 #define GQ_RS 34                       // doubles between staged rows
 #define GQ_Q 32                        // output links per workgroup
-#define GQ_E_D (128 * GQ_RS)           // doubles per stage buffer: Label-free rows 0..mI-1, zeros up to 127
+#define GQ_E_D_N(NR) (32 * (NR) * GQ_RS) // doubles per stage buffer: Label-free rows 0..mI-1, zeros up to 32 NR - 1 (NR = row tiles per wave: 4 quad form, 2 pair form)
 #define GQ_Z_D (GQ_Q * GQ_RS)          // Z rows of this workgroup (zeros for links beyond the bond dimension)
 #define GQ_W_D (4 * GQ_RS)             // w[2 s + t][n] = phiI[s][n] phiO[t][n]
-#define GQ_LDS_DOUBLES (2 * (GQ_E_D + GQ_Z_D + GQ_W_D))
+#define GQ_LDS_DOUBLES_N(NR) (2 * (GQ_E_D_N(NR) + GQ_Z_D + GQ_W_D))
+#define GQ_LDS_DOUBLES GQ_LDS_DOUBLES_N(4)
 
 struct GradQuadArgs {
     const double* EI; const double* phiI; const double* phiO;      // [mI][NTp], [2][NTp], [2][NTp]
@@ -63,16 +64,22 @@ static __device__ __forceinline__ void gq_barrier() {
 // ABL (the ablations of the record under profiles/): 1 = no loads of the Label-carrying environment (compute side alone),
 // 3 = no staging at all inside the loop (the MFMA loop with its fragment reads and the barrier per stage), 5 = the kernel as shipped + time
 // stamps of every workgroup (entry, prologue done, loop done, stores done)
-template <int ABL>
+// NR = row tiles per wave.  4: the QUAD form above (bond dimensions up to 128 x 128).  2: the PAIR form for bonds up to 64 x 64 (the trained bonds of
+// a network with minm = maxm / 2, fixedL.cc:593: m = 59-60 at config 3) -- a pair of workgroups (blocks b, b + 8 of a run of 16) owns the 128 x 128
+// tile grid, workgroup h the output links [32 h, 32 h + 32), a wave 2 row tiles x 1 column tile; 64 staged rows instead of 128, everything else
+// as in the quad form.  At these sizes the launch is bound by the 320 MB it streams, not by the matrix pipe: half the MFMAs per staged byte.
+template <int ABL, int NR = 4>
 __global__ __launch_bounds__(1024) void k_grad_quad(GradQuadArgs A) {
+    static_assert(NR == 4 || NR == 2, "quad form or pair form");
+    constexpr int GQ_E_D = GQ_E_D_N(NR);
     extern __shared__ __attribute__((aligned(16))) double gq_lds[];
-    double* const Es = gq_lds;                         // [2][128][36]
-    double* const Zs = Es + 2 * GQ_E_D;                // [2][31][36]
+    double* const Es = gq_lds;                         // [2][32 NR][34]
+    double* const Zs = Es + 2 * GQ_E_D;                // [2][32][34]
     double* const Ws = Zs + 2 * GQ_Z_D;                // [2][4][32]
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x;
     const long long ts0 = (ABL == 5 || ABL == 6) ? (long long)wall_clock64() : 0;
-    const int h = (b >> 3) & 3, grp = (b & 7) + 8 * (b >> 5);
+    const int h = (b >> 3) & (NR - 1), grp = (b & 7) + 8 * (NR == 4 ? b >> 5 : b >> 4);
     if (grp >= A.ngroups) return;
     const int NTp = A.NTp;
     const int c0 = grp * A.per;
@@ -87,7 +94,7 @@ __global__ __launch_bounds__(1024) void k_grad_quad(GradQuadArgs A) {
     double2 pc[3];
     const unsigned pvoff = (unsigned)(((size_t)rho * NTp + x2) * sizeof(double));
     auto ld16 = [&](const double* ubase, unsigned voff) { return *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(ubase) + voff); };
-    const bool v0 = 4 * w + rho < A.mI, v1 = 64 + 4 * w + rho < A.mI;     // this lane's rows exist
+    const bool v0 = 4 * w + rho < A.mI, v1 = NR == 4 && 64 + 4 * w + rho < A.mI;     // this lane's rows exist
     // (wave 15: rows phiI[0], phiI[1], phiO[0], phiO[1] -- two sites of one feature array: the second base as an offset from the first)
     const double* fO = A.phiO - 2 * (size_t)NTp;
     const double* fb = A.phiI < fO ? A.phiI : fO;
@@ -98,13 +105,13 @@ __global__ __launch_bounds__(1024) void k_grad_quad(GradQuadArgs A) {
         unsigned vo = pvoff, vf = fvoff;
         asm volatile("" : "+v"(vo), "+v"(vf));
         pc[0] = v0 ? ld16(A.EI + (size_t)(4 * w) * NTp + nE, vo) : make_double2(0., 0.);
-        pc[1] = v1 ? ld16(A.EI + (size_t)(4 * (w + 16)) * NTp + nE, vo) : make_double2(0., 0.);
+        if (NR == 4) pc[1] = v1 ? ld16(A.EI + (size_t)(4 * (w + 16)) * NTp + nE, vo) : make_double2(0., 0.);
         if (w == 15) pc[2] = ld16(fb + nE, vf);
     };
     const int dst0 = (4 * w + rho) * GQ_RS + x2;
     auto piece_store = [&](int bufE, const double2 (&pc)[3]) {
         *reinterpret_cast<double2*>(Es + bufE * GQ_E_D + dst0) = pc[0];
-        *reinterpret_cast<double2*>(Es + bufE * GQ_E_D + dst0 + 64 * GQ_RS) = pc[1];
+        if (NR == 4) *reinterpret_cast<double2*>(Es + bufE * GQ_E_D + dst0 + 64 * GQ_RS) = pc[1];
         if (w == 15) {                                 // lane (2 s + t, image pair): phiI[s] from lane row s, phiO[t] from lane row 2 + t
             const int lI = 16 * (rho >> 1) + (lane & 15), lO = 16 * (2 + (rho & 1)) + (lane & 15);
             const double ix = __shfl(pc[2].x, lI), iy = __shfl(pc[2].y, lI), ox = __shfl(pc[2].x, lO), oy = __shfl(pc[2].y, lO);
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(1024) void k_grad_quad(GradQuadArgs A) {
     //      tile of this workgroup's 64 columns 2q' + t (lane i: q' = c >> 1, t = c & 1)
     const int rgp = w >> 2, J = w & 3;
     const int li = lane & 15, g = lane >> 4;
-    const int sI = rgp >> 1, a0 = 64 * (rgp & 1);
+    const int sI = rgp >> 1, a0 = 16 * NR * (rgp & 1);
     const int eoff = (a0 + li) * GQ_RS + g;                               // + 16 r GQ_RS for row tile r, + 4 ks for k-step ks (lane group g: image 4 ks + g)
     const int cc = 16 * J + li;                                            // column 64 h + cc
     const int zoff = (cc >> 1) * GQ_RS + g;
@@ -165,14 +172,14 @@ __global__ __launch_bounds__(1024) void k_grad_quad(GradQuadArgs A) {
     gq_barrier();
     const long long ts1 = (ABL == 5 || ABL == 6) ? (long long)wall_clock64() : 0;
 
-    f64x4g acc[4];
+    f64x4g acc[NR];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = f64x4g{0., 0., 0., 0.};
-    double en[4], zn, on;                              // the fragments of the NEXT k-step
+    for (int r = 0; r < NR; ++r) acc[r] = f64x4g{0., 0., 0., 0.};
+    double en[NR], zn, on;                             // the fragments of the NEXT k-step
     auto frag_load = [&](int buf, int ks) {
         const double* Eb = Es + buf * GQ_E_D + eoff + 4 * ks;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) en[r] = Eb[16 * r * GQ_RS];
+        for (int r = 0; r < NR; ++r) en[r] = Eb[16 * r * GQ_RS];
         zn = Zs[buf * GQ_Z_D + zoff + 4 * ks];
         on = Ws[buf * GQ_W_D + woff + 4 * ks];
     };
@@ -194,15 +201,15 @@ __global__ __launch_bounds__(1024) void k_grad_quad(GradQuadArgs A) {
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            double ec[4];
+            double ec[NR];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ec[r] = en[r];
+            for (int r = 0; r < NR; ++r) ec[r] = en[r];
             const double bc = zn * on;
             __builtin_amdgcn_sched_barrier(0);
             if (ks < 7) frag_load(cur, ks + 1);        // (the first k-step of the next stage is read behind the barrier)
             __builtin_amdgcn_sched_barrier(0);       // reads of the next k-step FIRST, then this one's MFMAs: left alone the scheduler issues the MFMAs first
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(ec[r], bc, acc[r], 0, 0, 0);
+            for (int r = 0; r < NR; ++r) acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(ec[r], bc, acc[r], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);       // (keeps the order stated: reads of the next k-step, then this one's MFMAs)
         }
         gq_barrier();
@@ -216,7 +223,7 @@ __global__ __launch_bounds__(1024) void k_grad_quad(GradQuadArgs A) {
     const int col = 2 * GQ_Q * h + cc;
     if (col < A.Np) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < NR; ++r)
 #pragma unroll
             for (int e4 = 0; e4 < 4; ++e4) {
                 const int row = 2 * (a0 + 16 * r + g + 4 * e4) + sI;
@@ -230,48 +237,66 @@ __global__ __launch_bounds__(1024) void k_grad_quad(GradQuadArgs A) {
     }
 }
 
+static inline bool gq_pair_form(const Bgemm64Args& a) { return a.mI <= 64 && a.mO <= 64 && a.Kp <= 128 && a.Np <= 128; }
+
 bool grad_quad_applies(const tnml_ctx* c, const Bgemm64Args& a) {
     if (!c->grad_quad || !a.EL || !a.env64 || a.L != 1 || a.w) return false;
     if (a.mI < 1 || a.mO < 1 || a.mI > 128 || a.mO > 128 || a.Kp < 2 * a.mI || a.Np < 2 * a.mO || a.Kp > 256 || a.Np > 256 || a.NTp % GQ_TI) return false;
     // unforced: from 4 096 images per rank on and from mI mO >= 72^2 on -- its 256 x 256 tile grid is fixed (155-160 us at 60 000 images whatever
     // the bond), but the tiles k_bgemm64 has for other sizes than 120 are far from it: 192 / 203 / 210 / 376 / 387 / 273 us at m = 72 / 88 / 96 /
-    // 104 / 112 / 128 (profiles/r06_grad_quad_by_bond_dimension.txt); bonds of 64 and below keep the 128 x 64 tiles made for them
-    if (c->grad_quad == 1 && (a.NTp < 4096 || a.mI * a.mO < 72 * 72)) return false;
+    // 104 / 112 / 128 (profiles/r06_grad_quad_by_bond_dimension.txt).  Bonds up to 64 x 64 have the PAIR form (128 x 128 tile grid): unforced
+    // for 33^2 <= mI mO <= 56^2 from 15 360 images per rank on -- 59 / 60 / 63 us at m = 33 / 40 / 48 against 73 / 79 / 70 of k_bgemm64's 128 x 64
+    // tiles; at m = 60-64 both stream their 320 MB at ~5 TB/s (67-76 against 71-74 us, box by box) and at 7 500 images k_bgemm64 is ahead
+    // (19.3 against 20.3 us): those stay where they were (profiles/r06_grad_pair_form.txt)
+    if (c->grad_quad == 1) {
+        if (gq_pair_form(a)) {
+            const int mm = a.mI * a.mO;
+            if (!c->grad_pair || a.NTp < 15360 || mm < c->grad_pair_min * c->grad_pair_min || mm > c->grad_pair_max * c->grad_pair_max) return false;
+        } else if (a.NTp < 4096 || a.mI * a.mO < 72 * 72) return false;
+    }
     if ((size_t)TNML_NL * a.EL_lstride * sizeof(double) >= ((size_t)1 << 32)) return false;      // 32-bit lane offsets
     return c->slab_bytes >= (size_t)64 * a.Kp * a.Np * sizeof(double);
 }
 
+template <int NR>
+static int grad_quad_go(tnml_ctx* c, const GradQuadArgs& K, int grid) {
+    const size_t lds = sizeof(double) * GQ_LDS_DOUBLES_N(NR);
+    bool& done = NR == 4 ? c->attr_gq : c->attr_gp;
+    if (!done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_grad_quad<0, NR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_grad_quad<1, NR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_grad_quad<3, NR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return tnml_fail(c, "grad_quad: cannot reserve %zu bytes of LDS", lds);
+        done = true;
+    }
+    ProfScope ps(c, KC_GRAD_QUAD);
+    // (grad_quad = 3 / 5: the ablations of the record under profiles/ -- compute side alone / the MFMA loop alone; wrong results by construction)
+    if (c->grad_quad == 3)      hipLaunchKernelGGL((k_grad_quad<1, NR>), dim3(grid), dim3(1024), lds, c->stream, K);
+    else if (c->grad_quad == 5) hipLaunchKernelGGL((k_grad_quad<3, NR>), dim3(grid), dim3(1024), lds, c->stream, K);
+    else                        hipLaunchKernelGGL((k_grad_quad<0, NR>), dim3(grid), dim3(1024), lds, c->stream, K);
+    return 0;
+}
+
 int launch_grad_quad(tnml_ctx* c, const Bgemm64Args& a, double* G) {
     if (!c->cu_count) { hipDeviceProp_t pr; c->cu_count = hipGetDeviceProperties(&pr, c->cfg.device) == hipSuccess ? pr.multiProcessorCount : 256; }
+    const bool pair = gq_pair_form(a) && c->grad_pair != 0;          // (grad_pair = 0: the quad form for every bond -- tests, A/B)
+    const int nwg = pair ? 2 : 4;                                  // workgroups per group
     GradQuadArgs K;
     K.EI = static_cast<const double*>(a.EI); K.phiI = static_cast<const double*>(a.phiI); K.phiO = static_cast<const double*>(a.phiO);
     K.EL = static_cast<const double*>(a.EL); K.EL_lstride = a.EL_lstride; K.dP = a.dPz; K.NTp = a.NTp;
     K.mI = a.mI; K.mO = a.mO; K.Kp = a.Kp; K.Np = a.Np;
     K.slab = static_cast<double*>(c->slab);
     K.nchunks = a.NTp / GQ_TI;
-    int quads = c->cu_count / 4;                                   // one workgroup per CU
+    int groups = c->cu_count / nwg;                                // one workgroup per CU
     const int cap = (int)(c->slab_bytes / ((size_t)a.Kp * a.Np * sizeof(double)));
-    if (quads > cap) quads = cap;
-    if (c->bgemm_wgs > 0 && c->bgemm_wgs / 4 < quads) quads = c->bgemm_wgs / 4 > 0 ? c->bgemm_wgs / 4 : 1;      // test knob: fewer quads -> more stages each
-    if (quads > K.nchunks) quads = K.nchunks;
-    K.per = (K.nchunks + quads - 1) / quads;
+    if (groups > cap) groups = cap;
+    if (c->bgemm_wgs > 0 && c->bgemm_wgs / nwg < groups) groups = c->bgemm_wgs / nwg > 0 ? c->bgemm_wgs / nwg : 1;      // test knob: fewer groups -> more stages each
+    if (groups > K.nchunks) groups = K.nchunks;
+    K.per = (K.nchunks + groups - 1) / groups;
     K.ngroups = (K.nchunks + K.per - 1) / K.per;
-    const size_t lds = sizeof(double) * GQ_LDS_DOUBLES;
-    if (!c->attr_gq) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_grad_quad<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k_grad_quad<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k_grad_quad<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return tnml_fail(c, "grad_quad: cannot reserve %zu bytes of LDS", lds);
-        c->attr_gq = true;
-    }
-    const int grid = 32 * ((K.ngroups + 7) / 8);                 // blocks b, b + 8, b + 16, b + 24 of a run of 32 = one quad on one XCD
-    {
-        ProfScope ps(c, KC_GRAD_QUAD);
-        // (grad_quad = 3 / 5: the ablations of the record under profiles/ -- compute side alone / the MFMA loop alone; wrong results by construction)
-        if (c->grad_quad == 3)      hipLaunchKernelGGL(k_grad_quad<1>, dim3(grid), dim3(1024), lds, c->stream, K);
-        else if (c->grad_quad == 5) hipLaunchKernelGGL(k_grad_quad<3>, dim3(grid), dim3(1024), lds, c->stream, K);
-        else                        hipLaunchKernelGGL(k_grad_quad<0>, dim3(grid), dim3(1024), lds, c->stream, K);
-    }
+    const int grid = 8 * nwg * ((K.ngroups + 7) / 8);             // blocks b, b + 8, (b + 16, b + 24) of a run of 8 nwg = one group on one XCD
+    if (pair) TCK(grad_quad_go<2>(c, K, grid));
+    else      TCK(grad_quad_go<4>(c, K, grid));
     const size_t n = (size_t)a.Kp * a.Np;
     if (c->defer_slab) c->slab_pending = K.ngroups;            // the CG vector kernel that consumes G sums the slabs itself (slab order: the same bits)
     else {

@@ -106,6 +106,9 @@ int tnml_set_option(tnml_ctx* c, const char* name, int value) {
     else if (!strcmp(name, "mc_spin_max")) c->mc_spin_max = value;
     else if (!strcmp(name, "svd_print")) { c->svd_print = value; c->svd_calls = 0; }
     else if (!strcmp(name, "grad_quad")) c->grad_quad = value;
+    else if (!strcmp(name, "grad_pair")) c->grad_pair = value;
+    else if (!strcmp(name, "grad_pair_min")) c->grad_pair_min = value;
+    else if (!strcmp(name, "grad_pair_max")) c->grad_pair_max = value;
     else if (!strcmp(name, "fg64_cfg")) c->opt_fg64_cfg = value;
     else if (!strcmp(name, "ldot_cfg")) c->opt_ldot_cfg = value;
     else return tnml_fail(c, "tnml_set_option: unknown option %s", name);
@@ -266,6 +269,9 @@ int tnml_create(tnml_ctx** out, const tnml_config* cfg) {
     if (const char* e = getenv("TNML_RES_PACE")) c->res_pace = atoi(e);
     if (const char* e = getenv("TNML_BGEMM_WGS")) c->bgemm_wgs = atoi(e);
     if (const char* e = getenv("TNML_GRAD_QUAD")) c->grad_quad = atoi(e);
+    if (const char* e = getenv("TNML_GRAD_PAIR")) c->grad_pair = atoi(e);
+    if (const char* e = getenv("TNML_GRAD_PAIR_MIN")) c->grad_pair_min = atoi(e);
+    if (const char* e = getenv("TNML_GRAD_PAIR_MAX")) c->grad_pair_max = atoi(e);
     if (const char* e = getenv("TNML_BGEMM_PER")) c->bgemm_per = atoi(e);
     if (const char* e = getenv("TNML_BGS_CHOL")) c->bgs_chol = atoi(e) != 0;
     if (const char* e = getenv("TNML_SMALL_GEMM")) c->small_gemm = atoi(e) != 0;

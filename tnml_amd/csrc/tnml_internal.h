@@ -216,7 +216,9 @@ struct tnml_ctx {
     int shift_res = 1;               // Label-carrying environment shift on k_shift_res (kernels_res.hip): 1 = from 7 680 images per rank on, 0 never, 2 always; option "shift_res"
     int res_grid = 0;                // test knob: workgroups of the resident-operand kernels (0: one per CU)
     int grad_quad = 1;               // gradient GEMM on k_grad_quad (kernels_grad.hip; m = 120, fp64 storage, Label on an environment): 1 = from 4 096 images per rank on, 0 never, 2 always; option "grad_quad", env TNML_GRAD_QUAD
-    bool attr_gq = false;
+    bool attr_gq = false, attr_gp = false;
+    int grad_pair = 1;               // bonds up to 64 x 64: the pair form of k_grad_quad (128 x 128 tile grid, two workgroups): 1 = for grad_pair_min^2 <= mI mO <= grad_pair_max^2 (and whenever grad_quad = 2 forces the kernel), 0 = never (the quad form when forced)
+    int grad_pair_min = 33, grad_pair_max = 56;      // sqrt(mI mO) range the pair form takes unforced
     int bgemm_per = 0;               // probe knob (TNML_BGEMM_PER): images per slab of the gradient GEMM, in units of 32 (0: derived from bgemm_wgs)
     int bgemm_wgs = 0;               // workgroups the gradient GEMM aims at when it cuts the image range into slabs (0: per-shape default; option "bgemm_wgs")
     unsigned* counters = nullptr;    // [16] device: arrival counters of the "last workgroup reduces" kernels (zero between launches)

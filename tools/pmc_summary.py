@@ -43,7 +43,7 @@ for f in ("kernels_gemm.hip", "kernels_stream.hip", "kernels_fused.hip", "kernel
     h.update(open(os.path.join(root, "tnml_amd", "csrc", f), "rb").read())
 # (the first pattern that matches a kernel of the run: the resident-operand kernels of round 4 where they ran, else the tiled ones)
 classes = {"fgemm_fwd": ["k_fgemm64<2, 5, 4, 3, 16, double, 2>"], "fgemm_shift": ["k_shift_res", "k_fgemm64<2, 4, 4, 2, 8, double, 1>"],
-           "labeldot": ["k_labeldot<4, 2, 10, double, double, double"], "bgemm": ["k_grad_quad<0>", "k_bgemm64<5, 1, 3, 4, 1, double>"],
+           "labeldot": ["k_labeldot<4, 2, 10, double, double, double"], "bgemm": ["k_grad_quad<0, 4>", "k_grad_quad<0", "k_bgemm64<5, 1, 3, 4, 1, double>"],
            "fwd_fused": ["k_fwd_res", "k_fwd_fused"]}
 rec = {"kernels_src_sha16": h.hexdigest()[:16], "commit": os.environ.get("TNML_COMMIT", "unknown"),
        "workload": "bench.py default (BASELINE config 3, 60000 images, maxm 120, fp64)", "kernels": {}}
