@@ -35,6 +35,12 @@
 typedef double f64x4g __attribute__((ext_vector_type(4)));
 
 #define GQ_TI 32                       // images per stage
+#ifndef GQ_SLOT
+#define GQ_SLOT(rgp) (2 * (rgp))       // the k-step before which the waves of row group rgp do their staging share (tuning builds override it)
+#endif
+#ifndef GQ_PRIO
+#define GQ_PRIO 3                      // issue priority of a wave while it stages
+#endif
 #define GQ_RS 34                       // doubles between staged rows
 #define GQ_Q 32                        // output links per workgroup
 #define GQ_E_D_N(NR) (32 * (NR) * GQ_RS) // doubles per stage buffer: Label-free rows 0..mI-1, zeros up to 32 NR - 1 (NR = row tiles per wave: 4 quad form, 2 pair form)
@@ -192,8 +198,8 @@ __global__ __launch_bounds__(1024) void k_grad_quad(GradQuadArgs A) {
             // one): before k-step 0, 2, 4 or 6 -- never after the last one, where no other wave would have MFMAs left to run beside it and
             // the whole workgroup would wait for it at the barrier.  What was requested one stage ago goes to the other buffers, the next
             // requests go out.
-            if (ABL != 3 && ks == 2 * rgp) {
-                __builtin_amdgcn_s_setprio(3);         // few instructions beside the MFMAs of three other waves: issue them ahead (2 % of the launch)
+            if (ABL != 3 && ks == GQ_SLOT(rgp)) {
+                __builtin_amdgcn_s_setprio(GQ_PRIO);         // few instructions beside the MFMAs of three other waves: issue them ahead (2 % of the launch)
                 piece_store(nxt, pc);                  // E / weights of chunk k + 1
                 z_build(nxt, el, dpv);                 // Z of chunk k + 1
                 piece_load(n_of(k + 2), pc);
